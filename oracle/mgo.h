@@ -1,0 +1,144 @@
+/*
+ * mgo.h -- CPU ORACLE for the multigrid V-cycle hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker.  The product path
+ * (multigrid_petsc_amd/csrc) never links or calls it.
+ *
+ * What it is: a plain-C restatement of the algorithm the reference
+ * (SyamVangara/multigrid-petsc) executes for `-cycle 0`, each function citing
+ * the reference file:line it follows (paths relative to /root/reference).
+ *
+ * PARITY PINNING STATUS
+ *  - integer half (index maps, ranges): pinned against the reference outputs
+ *    recorded in SURVEY.md section 8(c2) (tests/golden/survey_c2.json).
+ *  - floating-point half: the arithmetic lives in PETSc (third party, version
+ *    unpinned, not installed, not vendored) and the reference ships no tests
+ *    or golden vectors => "parity unpinned" by the reference.  It is pinned
+ *    instead by (i) the closed-form discrete-eigenvector known answer,
+ *    (ii) bit-equality of two independent restatements in this file
+ *    (assembled-CSR path that follows solver.c's MatSetValue loops, and a
+ *    matrix-free stencil path), see tests/test_oracle.py.
+ *  - 3-D has no reference implementation at all (DIMENSION is 2,
+ *    include/mesh.h:17); the 3-D branches extend the 2-D semantics by analogy
+ *    and are marked "3-D extension".
+ *
+ * PETSc semantics assumed (PETSc source is not in the tree):
+ *   MatMult(AIJ):        y_i = sum_k a_ik*x_k, k ascending in column, sum starts at 0.0,
+ *                        separate multiply and add (no FMA contraction)
+ *   KSPRICHARDSON/NONE:  r = b (zero guess) or b - A x; repeat maxit times
+ *                        { z = B r; x = x + scale*z; r = b - A x unless last }
+ *   PCJACOBI:            z = r * (1/diag(A))
+ *   KSPBuildResidual:    t = A x; r = b - t
+ *   KSPSolve zero-fills x when the initial-guess-nonzero flag is false
+ *   VecNorm(NORM_2):     sqrt(sum x_i^2)   (evaluated here with long-double
+ *                        block accumulation so the oracle value is accurate
+ *                        to ~1 ulp; the reduction order is not part of parity)
+ */
+#ifndef MGO_H
+#define MGO_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGO_PI 3.14159265358979323846   /* include/problem.h:13 */
+
+/* ---------------- integer half: src/matbuild.c ---------------- */
+int  mgo_ipow(int base, int exp);                                  /* matbuild.c:10-25 */
+void mgo_get_ranges(int totaln, int procs, int *ranges);           /* matbuild.c:120-144 */
+/* grids per level and grid ids (matbuild.c:27-47). gridId_out holds `grids` ints laid level after level;
+ * ngrids_out[l] = grids in level l. returns total grids. */
+int  mgo_grid_ids(int totalGrids, int levels, int *ngrids_out, int *gridId_out);
+/* unknowns per side of grid g: (npts-1)/2^g - 1  (matbuild.c:62-67) */
+int  mgo_grid_n(int npts, int g);
+/* number of unknowns in level l (sum over its grids), 2-D (matbuild.c:58-70) */
+int  mgo_level_total_2d(int npts, int totalGrids, int levels, int l);
+/* Build the maps of level l (2-D, reference semantics), style 0/1/2 (matbuild.c:146-323).
+ *   global_out: total*3 ints (i,j,g);  grid_out: the level's grid->global maps concatenated in lg order;
+ *   ranges_out: procs+1 ints.  returns 0 or -1 on bad style. */
+int  mgo_mapping_2d(int npts, int totalGrids, int levels, int style, int procs, int l,
+                    int *global_out, int *grid_out, int *ranges_out);
+/* 3x3 transfer stencils (matbuild.c:398-431) */
+void mgo_restriction_stencil(double w[9]);
+void mgo_prolongation_stencil(double w[9]);
+
+/* ---------------- mesh / problem: src/mesh.c, src/problem.c ---------------- */
+/* coords along one axis for the uniform mesh, npts entries (mesh.c:140-171: repeated addition) */
+void   mgo_coords_uniform(int npts, int axis, double *c);
+double mgo_mesh_h(int dim, int npts);                              /* mesh.c:189-193 */
+void   mgo_opA(const double *metrics, const double *h, double *As);/* problem.c:3-22 */
+/* constant stencil of level l: 2-D As[5] = {(i-1),(j-1),C,(j+1),(i+1)}; 3-D As[7] = {(k-1),(i-1),(j-1),C,(j+1),(i+1),(k+1)} */
+void   mgo_level_stencil(int dim, int npts, int l, double *As, double *h_out);
+double mgo_ffunc(int dim, double x, double y, double z);           /* problem.c:24-28 */
+double mgo_solfunc(int dim, double x, double y, double z);         /* problem.c:30-34 */
+void   mgo_rhs(int dim, int npts, double *b);                      /* solver.c:558-620 (g0==g1 branch) */
+void   mgo_error_norms(int dim, int npts, const double *u, double err[3]); /* solver.c:1211-1237 */
+
+/* ---------------- assembled (AIJ) path: src/solver.c ---------------- */
+typedef struct mgo_csr {
+    long nrows, ncols, nnz;
+    long *rowptr; int *col; double *val;
+} mgo_csr;
+void     mgo_csr_free(mgo_csr *m);
+mgo_csr *mgo_build_A(int dim, int npts, int l);      /* solver.c:185-253,489-510 via MatSetValue(ADD_VALUES) semantics */
+mgo_csr *mgo_build_R(int dim, int npts, int l);      /* solver.c:1035-1094: level l -> l+1 */
+mgo_csr *mgo_build_P(int dim, int npts, int l);      /* solver.c:1096-1154: level l+1 -> l */
+void     mgo_csr_mult(const mgo_csr *m, const double *x, double *y);   /* MatMult */
+long     mgo_csr_nrows(const mgo_csr *m);
+long     mgo_csr_ncols(const mgo_csr *m);
+long     mgo_csr_nnz(const mgo_csr *m);
+void     mgo_csr_row(const mgo_csr *m, long row, int *ncols, int *cols, double *vals);
+void     mgo_csr_diag_inv(const mgo_csr *m, double *dinv);
+
+/* smoothers on an assembled operator (PETSc semantics, see header comment) */
+void mgo_richardson_csr(const mgo_csr *A, const double *dinv, const double *b, double *x,
+                        int maxit, double scale, int guess_nonzero, double *work /*2*n*/);
+void mgo_chebyshev_csr(const mgo_csr *A, const double *dinv, const double *b, double *x,
+                       int maxit, double emin, double emax, int guess_nonzero, double *work /*4*n*/);
+void mgo_residual_csr(const mgo_csr *A, const double *b, const double *x, double *r);
+
+/* ---------------- matrix-free path (same bits as the assembled path) ---------------- */
+/* Arrays are compact lexicographic: index (k*n+i)*n+j (3-D), i*n+j (2-D); nz is the number of
+ * local planes (nz==n for the whole grid; 2-D uses nz=1).  zlo/zhi: optional ghost planes
+ * (n*n doubles) standing for plane -1 / nz of a z-slab, NULL = homogeneous Dirichlet. */
+void mgo_st_apply(int dim, int n, int nz, const double *As, const double *x,
+                  const double *zlo, const double *zhi, double *y);
+void mgo_st_jacobi(int dim, int n, int nz, const double *As, double scale, const double *b,
+                   const double *u, const double *zlo, const double *zhi, double *unew, int zero_guess);
+void mgo_st_cheby_step(int dim, int n, int nz, const double *As, const double *b,
+                       const double *pk, const double *zlo, const double *zhi, const double *pkm1,
+                       double c_km1, double c_k, double c_z, double *pkp1);
+void mgo_st_residual(int dim, int n, int nz, const double *As, const double *b, const double *u,
+                     const double *zlo, const double *zhi, double *r);
+/* restriction fine(nf, nzf planes) -> coarse(nc=(nf-1)/2, nzc planes); fine plane index of coarse
+ * plane kc is 2*kc + {0,1,2}; fzhi = optional fine ghost plane nzf (slab case) */
+void mgo_st_restrict(int dim, int nf, int nzf, int nzc, const double *rf, const double *fzhi, double *bc);
+/* uf += P uc ; czlo/czhi = optional coarse ghost planes -1 / nzc */
+void mgo_st_prolong_add(int dim, int nf, int nzf, int nzc, const double *uc,
+                        const double *czlo, const double *czhi, double *uf);
+double mgo_norm2(const double *x, long n);
+double mgo_sumsq(const double *x, long n);
+
+/* ---------------- the V-cycle: src/solver.c:1414-1575 ---------------- */
+typedef struct mgo_vcycle_cfg {
+    int dim, npts, levels;
+    int v0, v1;            /* -v v0,v1 (solver.c:1474,1507) */
+    int maxiter;           /* -iter */
+    int ksp_type;          /* 0 richardson, 1 chebyshev */
+    double scale;          /* -ksp_richardson_scale (PETSc default 1.0) */
+    double emin, emax;     /* -ksp_chebyshev_eigenvalues */
+    int use_csr;           /* 1: assembled AIJ path, 0: matrix-free path */
+    int fixed_cycles;      /* >0: run exactly this many cycles, ignore the stopping test */
+    double rtol;           /* stopping factor, reference uses 1.e-7 (solver.c:1530) */
+} mgo_vcycle_cfg;
+/* rnorm_raw: maxiter+1 doubles, absolute ||r|| per cycle (solver.c:1520,1549); u_out: N0 doubles or NULL.
+ * returns number of cycles done (solver->numIter, solver.c:1558); bnorm_out = ||b0||. */
+int mgo_vcycle(const mgo_vcycle_cfg *cfg, double *rnorm_raw, double *u_out, double *bnorm_out,
+               double *solve_seconds);
+int mgo_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
