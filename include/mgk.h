@@ -1,0 +1,132 @@
+/*
+ * mgk.h -- kernel-level C ABI of the MI355X multigrid V-cycle hot path.
+ *
+ * This is the drop-in boundary UNDER the PETSc-surface shim (include/petscksp.h):
+ * plain C, opaque context, device pointers and sizes, no C++/torch types.
+ * One entry point per PETSc operation that the reference executes inside
+ * MultigridVcycle (src/solver.c:1414-1575); the reference call each one
+ * replaces is cited at its declaration (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - every function returns 0 on success, otherwise a nonzero code
+ *     (hipError_t value or MGK_E*), never throws, never allocates on the hot
+ *     path; mgk_last_error() returns a static description of the last failure.
+ *   - `stream` is a hipStream_t passed as void*; NULL selects the context's
+ *     compute stream.  Kernels are asynchronous on their stream.
+ *   - device arrays use the padded layout described by mgk_geom (below).
+ *   - arithmetic: IEEE fp64, no fused multiply-add, terms summed in ascending
+ *     column order of the assembled row (see DESIGN.md "canonical arithmetic").
+ *
+ * Device layout of a level field (one rank's slab)
+ *   interior unknown (k,i,j), k plane (z), i row (y), j column (x):
+ *       offset = org + k*plane + i*pitch + j
+ *   with one ghost row / plane on every side (i=-1, i=ny, k=-1, k=nz) and the
+ *   x ghosts inside the row padding (j=-1, j=nx).  Ghosts of a global boundary
+ *   hold 0 (homogeneous Dirichlet, src/solver.c:239-251 drops those
+ *   neighbours); ghost planes of an internal slab boundary hold halo data.
+ *   The row starts 128-byte aligned; j=0 sits at column MGK_XOFF so that the
+ *   nx+1 = 2^m doubles (interior + right ghost) of a row are whole 128-B lines.
+ */
+#ifndef MGK_H
+#define MGK_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGK_XOFF 16          /* column of interior x=0 inside a padded row */
+#define MGK_EINVAL  10001    /* bad argument / shape */
+#define MGK_ENOGPU  10002    /* no usable HIP device: the product path never falls back to the CPU */
+#define MGK_ECOMM   10003    /* RCCL failure */
+
+typedef struct mgk_ctx mgk_ctx;
+
+typedef struct mgk_geom {
+    int  dim;            /* 2 or 3 */
+    int  nx, ny, nz;     /* local interior unknowns per axis (2-D: nz = 1, no ghost planes) */
+    int  pitch;          /* doubles per padded row */
+    long plane;          /* doubles per padded plane = pitch*(ny+2) */
+    long org;            /* offset of interior (0,0,0) */
+    long total;          /* doubles to allocate */
+} mgk_geom;
+
+/* host helper: fill a geometry for nx x ny (x nz) local unknowns.  returns 0 or MGK_EINVAL. */
+int  mgk_geom_init(mgk_geom *g, int dim, int nx, int ny, int nz);
+
+/* ---- context, memory, streams (thin wrappers so that host code stays C) ---- */
+int  mgk_device_count(void);
+int  mgk_ctx_create(mgk_ctx **ctx, int device);
+void mgk_ctx_destroy(mgk_ctx *ctx);
+const char *mgk_last_error(void);
+void *mgk_stream_compute(mgk_ctx *ctx);
+void *mgk_stream_comm(mgk_ctx *ctx);
+int  mgk_malloc(mgk_ctx *ctx, void **dptr, size_t bytes);          /* zero-filled */
+int  mgk_free(mgk_ctx *ctx, void *dptr);
+int  mgk_memset0(mgk_ctx *ctx, void *dptr, size_t bytes, void *stream);   /* VecSet(x,0.0) solver.c:1514 */
+int  mgk_h2d(mgk_ctx *ctx, void *dst, const void *src, size_t bytes);     /* synchronous */
+int  mgk_d2h(mgk_ctx *ctx, void *dst, const void *src, size_t bytes);     /* synchronous */
+int  mgk_d2d(mgk_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream);
+int  mgk_sync(mgk_ctx *ctx, void *stream);                         /* NULL: whole device */
+/* stream-ordered event timing for bench.py's roofline leg */
+int  mgk_timer_create(mgk_ctx *ctx, void **timer);
+int  mgk_timer_start(mgk_ctx *ctx, void *timer, void *stream);
+int  mgk_timer_stop(mgk_ctx *ctx, void *timer, void *stream);
+int  mgk_timer_elapsed_ms(mgk_ctx *ctx, void *timer, double *ms);  /* synchronises on the stop event */
+void mgk_timer_destroy(mgk_ctx *ctx, void *timer);
+/* cross-stream dependency: work queued later on `waiter` starts after everything queued so far on `signaller` */
+int  mgk_stream_wait(mgk_ctx *ctx, void *waiter, void *signaller);
+
+/* compact lexicographic (k*ny+i)*nx+j  <->  padded layout (VecGetArray/VecSetValue side, src/solver.c:588-617,1255) */
+int  mgk_pack_f64(mgk_ctx *ctx, const mgk_geom *g, const double *compact_dev, double *padded_dev, void *stream);
+int  mgk_unpack_f64(mgk_ctx *ctx, const mgk_geom *g, const double *padded_dev, double *compact_dev, void *stream);
+
+/* ---- K1: KSPSolve, KSPRICHARDSON + PCJACOBI, one sweep (src/solver.c:1531,1536,1542) ----
+ * coef: ascending-column stencil, 2-D {(i-1),(j-1),C,(j+1),(i+1)}  (OpA, src/problem.c:3-22;
+ *       row fill src/solver.c:239-251), 3-D {(k-1),(i-1),(j-1),C,(j+1),(i+1),(k+1)}.
+ * unew = u + scale*((b - A u)*dinv);  u and unew must be different buffers. */
+int  mgk_jacobi_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale,
+                    const double *b, const double *u, double *unew, void *stream);
+/* first sweep after KSPSolve zero-filled the guess: unew = scale*(b*dinv), u is not read */
+int  mgk_jacobi_zero_f64(mgk_ctx *ctx, const mgk_geom *g, double dinv, double scale,
+                         const double *b, double *unew, void *stream);
+/* KSPCHEBYSHEV recurrence step: pkp1 = (c_km1*pkm1 + c_k*pk) + c_z*((b - A pk)*dinv) */
+int  mgk_cheby_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv,
+                   double c_km1, double c_k, double c_z,
+                   const double *b, const double *pk, const double *pkm1, double *pkp1, void *stream);
+
+/* ---- K2/K5: KSPBuildResidual / MatMult+VecAXPY (src/solver.c:1516-1517,1534,1545): r = b - A u ---- */
+int  mgk_residual_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef,
+                      const double *b, const double *u, double *r, void *stream);
+/* K2+K6 fused: sum over the slab of (b - A u)^2, r is not written.  *sumsq_host is valid after return. */
+int  mgk_residual_sumsq_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef,
+                            const double *b, const double *u, double *sumsq_host, void *stream);
+
+/* ---- K3: MatMult(res[l], r, b[l+1]) full weighting (src/solver.c:1535, matrix :1071-1092) ----
+ * coarse (kc,ic,jc) gathers fine (2kc+dk, 2ic+di, 2jc+dj), d in {0,1,2}.  gc->nz coarse planes are
+ * produced from fine planes 0..2*gc->nz (plane gf->nz is the fine ghost plane in the slab case). */
+int  mgk_restrict_fw_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc,
+                         const double *rf, double *bc, void *stream);
+
+/* ---- K4: MatMult(pro[l], u[l+1], rv) + VecAXPY(u[l],1.0,rv) (src/solver.c:1540-1541, matrix :1131-1152) ---- */
+int  mgk_prolong_add_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc,
+                         const double *uc, double *uf, void *stream);
+
+/* ---- K6: VecNorm(NORM_2) (src/solver.c:1512,1518,1546): returns sum of squares of the interior ---- */
+int  mgk_sumsq_f64(mgk_ctx *ctx, const mgk_geom *g, const double *x, double *sumsq_host, void *stream);
+
+/* ---- setup-side device helpers ---- */
+/* b(k,i,j) = (cx[j]*sy[i])*sz[k]  (levelvecb + Ffunc, src/solver.c:586-594, src/problem.c:24-28);
+ * cx/sy/sz are device arrays of nx/ny/nz doubles (2-D: sz unused) */
+int  mgk_fill_separable_f64(mgk_ctx *ctx, const mgk_geom *g, const double *cx, const double *sy,
+                            const double *sz, double *out, void *stream);
+/* GetError (src/solver.c:1211-1237) against sol = (sx[j]*sy[i])*sz[k]: err3_host = {max|e|, sum|e|, sum e^2} */
+int  mgk_error_sums_f64(mgk_ctx *ctx, const mgk_geom *g, const double *u, const double *sx,
+                        const double *sy, const double *sz, double *err3_host, void *stream);
+
+/* tuning knob for the marching stencil kernel (profiling only): <=0 keeps the built-in choice */
+void mgk_set_tuning(int variant, int zchunk);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

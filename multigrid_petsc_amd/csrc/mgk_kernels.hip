@@ -1,0 +1,855 @@
+// mgk_kernels.hip -- hand-written gfx950 (MI355X, CDNA4) kernels of the multigrid V-cycle hot path
+// and their C ABI (include/mgk.h).  HBM-bound fp64 stencil work: no MFMA; 64-wide wavefronts,
+// 16-byte-per-lane coalesced HBM access, LDS-staged plane tiles, register marching along the
+// slowest axis, wavefront-shuffle reductions.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off   (NO fast-math: results must be
+// bit-identical to the canonical arithmetic restated in oracle/mgo.c).
+//
+// Reference operations replaced (paths relative to /root/reference):
+//   k_stencil<MODE 0>  KSPSolve Richardson+Jacobi sweep        src/solver.c:1531,1536,1542
+//   k_stencil<MODE 1>  KSPBuildResidual / MatMult+VecAXPY      src/solver.c:1516-1517,1534,1545
+//   k_stencil<MODE 2>  KSPChebyshev recurrence step            (KSPSetFromOptions, src/solver.c:1476)
+//   k_stencil<MODE 3>  KSPBuildResidual fused with VecNorm     src/solver.c:1545-1546
+//   k_restrict*        MatMult(res[l],r,b[l+1])                src/solver.c:1535 (matrix :1071-1092)
+//   k_prolong*         MatMult(pro[l],u,rv)+VecAXPY            src/solver.c:1540-1541 (matrix :1131-1152)
+//   k_sumsq            VecNorm(NORM_2)                         src/solver.c:1512,1518,1546
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include "mgk.h"
+
+// ------------------------------------------------------------------------------------------
+// error handling / context
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "ok";
+static int fail(int code, const char *what) {
+    snprintf(g_err, sizeof(g_err), "%s (code %d%s%s)", what, code,
+             code < 10000 ? ": " : "", code < 10000 ? hipGetErrorString((hipError_t)code) : "");
+    return code;
+}
+#define HIPCHK(call)                                                             \
+    do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail((int)e_, #call); } while (0)
+
+struct mgk_ctx {
+    int device;
+    hipStream_t compute, comm;
+    double *partials;      // reduction scratch (device)
+    double *result_dev;    // 8 doubles (device)
+    double *result_host;   // 8 doubles (pinned host)
+    int max_partials;
+};
+
+extern "C" const char *mgk_last_error(void) { return g_err; }
+
+extern "C" int mgk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int mgk_ctx_create(mgk_ctx **out, int device) {
+    if (!out) return fail(MGK_EINVAL, "mgk_ctx_create: null out");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(MGK_ENOGPU, "mgk_ctx_create: no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(MGK_EINVAL, "mgk_ctx_create: device index out of range");
+    HIPCHK(hipSetDevice(device));
+    mgk_ctx *c = new mgk_ctx();
+    c->device = device;
+    HIPCHK(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->comm, hipStreamNonBlocking));
+    c->max_partials = 16384;
+    HIPCHK(hipMalloc(&c->partials, sizeof(double) * 3 * c->max_partials));
+    HIPCHK(hipMalloc(&c->result_dev, sizeof(double) * 8));
+    HIPCHK(hipHostMalloc(&c->result_host, sizeof(double) * 8, hipHostMallocDefault));
+    *out = c;
+    return 0;
+}
+
+extern "C" void mgk_ctx_destroy(mgk_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(c->partials);
+    (void)hipFree(c->result_dev);
+    (void)hipHostFree(c->result_host);
+    (void)hipStreamDestroy(c->compute);
+    (void)hipStreamDestroy(c->comm);
+    delete c;
+}
+
+extern "C" void *mgk_stream_compute(mgk_ctx *c) { return (void *)c->compute; }
+extern "C" void *mgk_stream_comm(mgk_ctx *c) { return (void *)c->comm; }
+static inline hipStream_t S(mgk_ctx *c, void *s) { return s ? (hipStream_t)s : c->compute; }
+
+extern "C" int mgk_malloc(mgk_ctx *c, void **dptr, size_t bytes) {
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMalloc(dptr, bytes ? bytes : 8));
+    HIPCHK(hipMemsetAsync(*dptr, 0, bytes ? bytes : 8, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    return 0;
+}
+extern "C" int mgk_free(mgk_ctx *c, void *dptr) { (void)c; HIPCHK(hipFree(dptr)); return 0; }
+extern "C" int mgk_memset0(mgk_ctx *c, void *dptr, size_t bytes, void *stream) {
+    HIPCHK(hipMemsetAsync(dptr, 0, bytes, S(c, stream)));
+    return 0;
+}
+extern "C" int mgk_h2d(mgk_ctx *c, void *dst, const void *src, size_t bytes) {
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    return 0;
+}
+extern "C" int mgk_d2h(mgk_ctx *c, void *dst, const void *src, size_t bytes) {
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    return 0;
+}
+extern "C" int mgk_d2d(mgk_ctx *c, void *dst, const void *src, size_t bytes, void *stream) {
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, S(c, stream)));
+    return 0;
+}
+extern "C" int mgk_sync(mgk_ctx *c, void *stream) {
+    if (stream) HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    else { HIPCHK(hipSetDevice(c->device)); HIPCHK(hipDeviceSynchronize()); }
+    return 0;
+}
+
+struct mgk_timer { hipEvent_t a, b; };
+extern "C" int mgk_timer_create(mgk_ctx *c, void **t) {
+    (void)c;
+    mgk_timer *x = new mgk_timer();
+    HIPCHK(hipEventCreate(&x->a));
+    HIPCHK(hipEventCreate(&x->b));
+    *t = x;
+    return 0;
+}
+extern "C" int mgk_timer_start(mgk_ctx *c, void *t, void *s) { HIPCHK(hipEventRecord(((mgk_timer *)t)->a, S(c, s))); return 0; }
+extern "C" int mgk_timer_stop(mgk_ctx *c, void *t, void *s) { HIPCHK(hipEventRecord(((mgk_timer *)t)->b, S(c, s))); return 0; }
+extern "C" int mgk_timer_elapsed_ms(mgk_ctx *c, void *t, double *ms) {
+    (void)c;
+    mgk_timer *x = (mgk_timer *)t;
+    HIPCHK(hipEventSynchronize(x->b));
+    float f = 0.f;
+    HIPCHK(hipEventElapsedTime(&f, x->a, x->b));
+    *ms = (double)f;
+    return 0;
+}
+extern "C" void mgk_timer_destroy(mgk_ctx *c, void *t) {
+    (void)c;
+    mgk_timer *x = (mgk_timer *)t;
+    if (!x) return;
+    (void)hipEventDestroy(x->a);
+    (void)hipEventDestroy(x->b);
+    delete x;
+}
+extern "C" int mgk_stream_wait(mgk_ctx *c, void *waiter, void *signaller) {
+    hipEvent_t ev;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ev, S(c, signaller)));
+    HIPCHK(hipStreamWaitEvent(S(c, waiter), ev, 0));
+    HIPCHK(hipEventDestroy(ev));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// geometry
+// ------------------------------------------------------------------------------------------
+extern "C" int mgk_geom_init(mgk_geom *g, int dim, int nx, int ny, int nz) {
+    if (!g || (dim != 2 && dim != 3) || nx < 1 || ny < 1 || nz < 1 || (nx & 1) == 0)
+        return fail(MGK_EINVAL, "mgk_geom_init: need dim in {2,3}, odd nx >= 1, ny,nz >= 1");
+    if (dim == 2) nz = 1;
+    g->dim = dim; g->nx = nx; g->ny = ny; g->nz = nz;
+    g->pitch = ((MGK_XOFF + nx + 1 + 15) / 16) * 16;
+    g->plane = (long)g->pitch * (ny + 2);
+    if (dim == 3) { g->org = g->plane + g->pitch + MGK_XOFF; g->total = g->plane * (nz + 2) + g->pitch; }
+    else { g->org = g->pitch + MGK_XOFF; g->total = g->plane + g->pitch; }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double2 ld2(const double *p, bool ok) {
+    return ok ? *reinterpret_cast<const double2 *>(p) : make_double2(0.0, 0.0);
+}
+__device__ __forceinline__ double ld1(const double *p, bool ok) { return ok ? *p : 0.0; }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+// block-wide sum, result valid in thread 0.  red: >= 16 doubles of LDS
+__device__ __forceinline__ double block_sum(double v, double *red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0) for (int q = 0; q < nw; q++) s += red[q];
+    return s;
+}
+__device__ __forceinline__ double block_max(double v, double *red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0) for (int q = 0; q < nw; q++) s = fmax(s, red[q]);
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------
+// the marching stencil kernel
+// ------------------------------------------------------------------------------------------
+// A block owns an (x,y) tile of TX = 128*WX by TY = WY*RY unknowns and marches along z (3-D) or
+// along y (2-D) over `zc` planes.  Each lane owns one aligned pair of x-neighbours (16-byte
+// loads: a wave row is 1 KiB contiguous) for RY consecutive rows.  Planes z-1, z, z+1 of the
+// own points live in registers (plus z+2 in flight); the plane being processed is staged in a
+// double-buffered LDS tile from which the x neighbours and the y neighbours owned by other
+// waves are read.  y halos across tile borders go straight from global memory to the consuming
+// lane; x halos across tile borders are fetched by the two edge lanes of a row.
+// Each u plane is read from HBM once per tile column (+ halo lines that neighbouring tiles also
+// touch: L2 / Infinity-Cache hits), b once, the output written once: 24 B per unknown.
+struct StArgs {
+    const double *u, *b, *aux;
+    double *out;
+    double *partials;
+    int nx, ny, nm;       // nm: number of marching planes (nz in 3-D, ny in 2-D)
+    long rs, ms;          // row stride (3-D: pitch), marching stride (3-D: plane, 2-D: pitch)
+    int zc, ntx, nty;
+    double a0, a1, a2, a3, a4, a5, a6;   // (m-1), S, W, C, E, N, (m+1); 2-D: S and N unused
+    double dinv, scale, ckm1, ck, cz;
+};
+
+enum { MODE_JACOBI = 0, MODE_RESIDUAL = 1, MODE_CHEBY = 2, MODE_RESNORM = 3 };
+
+template <int DIM, int WX, int WY, int RY, int MODE>
+__global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs a) {
+    constexpr int TX = 128 * WX;
+    constexpr int TY = (DIM == 3) ? WY * RY : 1;
+    constexpr int LW = TX + 4;
+    static_assert(DIM == 3 || (WY == 1 && RY == 1), "2-D marches along y: one row per tile");
+    __shared__ __attribute__((aligned(16))) double lds[2][TY][LW];
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wx = w % WX, wy = w / WX;
+
+    // XCD-aware block remap: blocks b and b+8 share an XCD (L2); give every XCD a contiguous
+    // range of tiles so that halo lines shared by neighbouring tiles hit in its L2.
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int tx = bid % a.ntx;
+    const int t2 = bid / a.ntx;
+    const int ty = t2 % a.nty, tz = t2 / a.nty;
+
+    const int xl = wx * 128 + 2 * lane;          // local x of the own pair
+    const int x0 = tx * TX + xl;                 // global x (even)
+    const int yb = (DIM == 3) ? ty * TY + wy * RY : 0;
+    const int lrow = (DIM == 3) ? wy * RY : 0;   // first own row inside the LDS tile
+    const int z0 = tz * a.zc;
+    const int z1 = min(z0 + a.zc, a.nm);
+    if (z0 >= z1) return;
+
+    const bool xok = x0 < a.nx;                  // pair in bounds (x0+1 <= nx: right ghost at most)
+    const bool lastpair = (x0 + 1 == a.nx);      // .y is the right ghost: must stay 0
+    bool rok[RY];
+#pragma unroll
+    for (int r = 0; r < RY; r++) rok[r] = xok && (DIM == 2 || yb + r < a.ny);
+
+    const bool isW = (lane == 0 && wx == 0), isE = (lane == 63 && wx == WX - 1);
+    const int xh = isW ? tx * TX - 1 : tx * TX + TX;
+    const bool xhok = (isW || isE) && xh <= a.nx;
+    const int xhl = isW ? 1 : TX + 2;            // LDS column of the halo cell
+
+    const long rowoff = (DIM == 3) ? (long)yb * a.rs : 0;
+    const double *up_ = a.u + rowoff + x0;       // own pair, row 0, plane 0
+    const double *bp_ = a.b + rowoff + x0;
+    const double *ap_ = (MODE == MODE_CHEBY) ? a.aux + rowoff + x0 : nullptr;
+    const double *hp_ = a.u + rowoff + xh;       // x-halo cell, row 0, plane 0
+    // y halos across the tile border (3-D only)
+    const bool needS = (DIM == 3) && (wy == 0);
+    const bool needN = (DIM == 3) && (wy == WY - 1);
+    const bool okS = needS && xok;                              // row yb-1 >= -1 always exists
+    const bool okN = needN && xok && (yb + RY <= a.ny);         // ghost row ny is the last one
+
+    double2 um[RY], uc[RY], up[RY], uq[RY], bc[RY], bn[RY], ac[RY], an[RY];
+    double xp[RY], xq[RY];
+    double2 hS = make_double2(0, 0), hN = hS, hSn = hS, hNn = hS;
+
+    // ---- prologue: planes z0-1, z0, z0+1; stage plane z0 in LDS ----
+#pragma unroll
+    for (int r = 0; r < RY; r++) {
+        const long ro = (long)r * a.rs;
+        um[r] = ld2(up_ + (long)(z0 - 1) * a.ms + ro, rok[r]);
+        uc[r] = ld2(up_ + (long)z0 * a.ms + ro, rok[r]);
+        up[r] = ld2(up_ + (long)(z0 + 1) * a.ms + ro, rok[r]);
+        bc[r] = ld2(bp_ + (long)z0 * a.ms + ro, rok[r]);
+        if (MODE == MODE_CHEBY) ac[r] = ld2(ap_ + (long)z0 * a.ms + ro, rok[r]);
+        const bool hok = xhok && (DIM == 2 || yb + r < a.ny);
+        double xc = ld1(hp_ + (long)z0 * a.ms + ro, hok);
+        xp[r] = ld1(hp_ + (long)(z0 + 1) * a.ms + ro, hok);
+        *reinterpret_cast<double2 *>(&lds[0][lrow + r][xl + 2]) = uc[r];
+        if (isW || isE) lds[0][lrow + r][xhl] = xc;
+    }
+    if (DIM == 3) {
+        hS = ld2(up_ + (long)z0 * a.ms - a.rs, okS);
+        hN = ld2(up_ + (long)z0 * a.ms + (long)RY * a.rs, okN);
+    }
+
+    double acc = 0.0;   // MODE_RESNORM
+
+    for (int z = z0; z < z1; z++) {
+        const int buf = (z - z0) & 1;
+        const bool more = (z + 1 < z1);
+        // ---- issue the loads consumed in the NEXT step ----
+        if (more) {
+#pragma unroll
+            for (int r = 0; r < RY; r++) {
+                const long ro = (long)r * a.rs;
+                uq[r] = ld2(up_ + (long)(z + 2) * a.ms + ro, rok[r]);
+                bn[r] = ld2(bp_ + (long)(z + 1) * a.ms + ro, rok[r]);
+                if (MODE == MODE_CHEBY) an[r] = ld2(ap_ + (long)(z + 1) * a.ms + ro, rok[r]);
+                const bool hok = xhok && (DIM == 2 || yb + r < a.ny);
+                xq[r] = ld1(hp_ + (long)(z + 2) * a.ms + ro, hok);
+            }
+            if (DIM == 3) {
+                hSn = ld2(up_ + (long)(z + 1) * a.ms - a.rs, okS);
+                hNn = ld2(up_ + (long)(z + 1) * a.ms + (long)RY * a.rs, okN);
+            }
+        }
+        __syncthreads();   // lds[buf] (plane z) complete
+
+        // ---- neighbours of plane z ----
+        double Wn[RY], En[RY];
+#pragma unroll
+        for (int r = 0; r < RY; r++) {
+            Wn[r] = lds[buf][lrow + r][xl + 1];
+            En[r] = lds[buf][lrow + r][xl + 4];
+        }
+        double2 Sn = hS, Nn = hN;
+        if (DIM == 3 && WY > 1) {
+            if (wy > 0) Sn = *reinterpret_cast<const double2 *>(&lds[buf][lrow - 1][xl + 2]);
+            if (wy < WY - 1) Nn = *reinterpret_cast<const double2 *>(&lds[buf][lrow + RY][xl + 2]);
+        }
+
+        // ---- compute + store plane z ----
+#pragma unroll
+        for (int r = 0; r < RY; r++) {
+            double2 s2 = (r == 0) ? Sn : uc[r > 0 ? r - 1 : 0];
+            double2 n2 = (r == RY - 1) ? Nn : uc[r < RY - 1 ? r + 1 : r];
+            double tx_, ty_;
+            if (DIM == 3) {
+                tx_ = a.a0 * um[r].x;           ty_ = a.a0 * um[r].y;
+                tx_ = tx_ + a.a1 * s2.x;        ty_ = ty_ + a.a1 * s2.y;
+                tx_ = tx_ + a.a2 * Wn[r];       ty_ = ty_ + a.a2 * uc[r].x;
+                tx_ = tx_ + a.a3 * uc[r].x;     ty_ = ty_ + a.a3 * uc[r].y;
+                tx_ = tx_ + a.a4 * uc[r].y;     ty_ = ty_ + a.a4 * En[r];
+                tx_ = tx_ + a.a5 * n2.x;        ty_ = ty_ + a.a5 * n2.y;
+                tx_ = tx_ + a.a6 * up[r].x;     ty_ = ty_ + a.a6 * up[r].y;
+            } else {
+                tx_ = a.a0 * um[r].x;           ty_ = a.a0 * um[r].y;
+                tx_ = tx_ + a.a2 * Wn[r];       ty_ = ty_ + a.a2 * uc[r].x;
+                tx_ = tx_ + a.a3 * uc[r].x;     ty_ = ty_ + a.a3 * uc[r].y;
+                tx_ = tx_ + a.a4 * uc[r].y;     ty_ = ty_ + a.a4 * En[r];
+                tx_ = tx_ + a.a6 * up[r].x;     ty_ = ty_ + a.a6 * up[r].y;
+            }
+            double rx = bc[r].x - tx_, ry = bc[r].y - ty_;
+            double2 o;
+            if (MODE == MODE_JACOBI) {
+                double zx = rx * a.dinv, zy = ry * a.dinv;
+                o.x = uc[r].x + a.scale * zx;
+                o.y = uc[r].y + a.scale * zy;
+            } else if (MODE == MODE_CHEBY) {
+                double zx = rx * a.dinv, zy = ry * a.dinv;
+                o.x = (a.ckm1 * ac[r].x + a.ck * uc[r].x) + a.cz * zx;
+                o.y = (a.ckm1 * ac[r].y + a.ck * uc[r].y) + a.cz * zy;
+            } else {
+                o.x = rx; o.y = ry;
+            }
+            if (lastpair) o.y = 0.0;
+            if (rok[r]) {
+                if (MODE == MODE_RESNORM) acc += o.x * o.x + o.y * o.y;
+                else *reinterpret_cast<double2 *>(a.out + rowoff + x0 + (long)z * a.ms + (long)r * a.rs) = o;
+            }
+        }
+
+        // ---- stage plane z+1 and rotate ----
+        if (more) {
+#pragma unroll
+            for (int r = 0; r < RY; r++) {
+                *reinterpret_cast<double2 *>(&lds[buf ^ 1][lrow + r][xl + 2]) = up[r];
+                if (isW || isE) lds[buf ^ 1][lrow + r][xhl] = xp[r];
+                um[r] = uc[r]; uc[r] = up[r]; up[r] = uq[r];
+                bc[r] = bn[r]; xp[r] = xq[r];
+                if (MODE == MODE_CHEBY) ac[r] = an[r];
+            }
+            hS = hSn; hN = hNn;
+        }
+    }
+
+    if (MODE == MODE_RESNORM) {
+        __shared__ double red[16];
+        double s = block_sum(acc, red);
+        if (threadIdx.x == 0) a.partials[blockIdx.x] = s;
+    }
+}
+
+// sum `n` partials in a fixed order (one block) -> out[slot]
+__global__ void __launch_bounds__(256) k_finish_sum(const double *partials, int n, double *out, int slot) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int q = threadIdx.x; q < n; q += 256) s += partials[q];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[slot] = s;
+}
+__global__ void __launch_bounds__(256) k_finish_max(const double *partials, int n, double *out, int slot) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int q = threadIdx.x; q < n; q += 256) s = fmax(s, partials[q]);
+    s = block_max(s, red);
+    if (threadIdx.x == 0) out[slot] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// launch of the marching kernel
+// ------------------------------------------------------------------------------------------
+static int g_variant = -1, g_zchunk = -1;
+extern "C" void mgk_set_tuning(int variant, int zchunk) { g_variant = variant; g_zchunk = zchunk; }
+
+template <int DIM, int WX, int WY, int RY, int MODE>
+static int launch_st(mgk_ctx *c, StArgs &a, int nrows, hipStream_t s, int *nblocks_out) {
+    constexpr int TX = 128 * WX, TY = (DIM == 3) ? WY * RY : 1;
+    a.ntx = (a.nx + 1 + TX - 1) / TX;
+    a.nty = (DIM == 3) ? (nrows + TY - 1) / TY : 1;
+    long tiles = (long)a.ntx * a.nty;
+    int zc = g_zchunk;
+    if (zc <= 0) {
+        // aim at >= ~4096 blocks (256 CUs x several resident blocks x 2+ rounds), chunks >= 16 planes
+        long want = 4096;
+        long nch = (want + tiles - 1) / tiles;
+        if (nch < 1) nch = 1;
+        zc = (int)((a.nm + nch - 1) / nch);
+        if (zc < 16) zc = 16;
+    }
+    if (zc > a.nm) zc = a.nm;
+    a.zc = zc;
+    long ntz = (a.nm + zc - 1) / zc;
+    long nblk = tiles * ntz;
+    if (nblk > 0x7fffffffL) return fail(MGK_EINVAL, "stencil launch: too many blocks");
+    if (MODE == MODE_RESNORM && nblk > c->max_partials) {
+        // fewer, longer chunks so that the partial buffer suffices
+        ntz = c->max_partials / tiles;
+        if (ntz < 1) return fail(MGK_EINVAL, "stencil launch: partial buffer too small");
+        zc = (int)((a.nm + ntz - 1) / ntz);
+        a.zc = zc;
+        ntz = (a.nm + zc - 1) / zc;
+        nblk = tiles * ntz;
+    }
+    if (nblocks_out) *nblocks_out = (int)nblk;
+    hipLaunchKernelGGL((k_stencil<DIM, WX, WY, RY, MODE>), dim3((unsigned)nblk), dim3(64 * WX * WY), 0, s, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+template <int MODE>
+static int dispatch_st(mgk_ctx *c, const mgk_geom *g, StArgs &a, hipStream_t s, int *nblocks) {
+    a.nx = g->nx;
+    if (g->dim == 3) {
+        a.ny = g->ny; a.nm = g->nz; a.rs = g->pitch; a.ms = g->plane;
+        int v = g_variant;
+        if (v < 0) v = (g->nx >= 255) ? 2 : (g->nx >= 127 ? 1 : 0);
+        switch (v) {
+            case 0: return launch_st<3, 1, 2, 2, MODE>(c, a, g->ny, s, nblocks);   // 128 x 4, 128 thr
+            case 1: return launch_st<3, 1, 4, 2, MODE>(c, a, g->ny, s, nblocks);   // 128 x 8, 256 thr
+            case 2: return launch_st<3, 2, 2, 2, MODE>(c, a, g->ny, s, nblocks);   // 256 x 4, 256 thr
+            case 3: return launch_st<3, 2, 2, 4, MODE>(c, a, g->ny, s, nblocks);   // 256 x 8, 256 thr
+            case 4: return launch_st<3, 4, 1, 4, MODE>(c, a, g->ny, s, nblocks);   // 512 x 4, 256 thr
+            case 5: return launch_st<3, 2, 1, 4, MODE>(c, a, g->ny, s, nblocks);   // 256 x 4, 128 thr
+            case 6: return launch_st<3, 4, 2, 2, MODE>(c, a, g->ny, s, nblocks);   // 512 x 4, 512 thr
+            case 7: return launch_st<3, 2, 4, 2, MODE>(c, a, g->ny, s, nblocks);   // 256 x 8, 512 thr
+            default: return fail(MGK_EINVAL, "unknown 3-D stencil variant");
+        }
+    } else {
+        a.ny = 1; a.nm = g->ny; a.rs = 0; a.ms = g->pitch;
+        int v = g_variant;
+        if (v < 0) v = (g->nx >= 511) ? 2 : (g->nx >= 255 ? 1 : 0);
+        switch (v) {
+            case 0: return launch_st<2, 1, 1, 1, MODE>(c, a, 1, s, nblocks);
+            case 1: return launch_st<2, 2, 1, 1, MODE>(c, a, 1, s, nblocks);
+            case 2: return launch_st<2, 4, 1, 1, MODE>(c, a, 1, s, nblocks);
+            default: return fail(MGK_EINVAL, "unknown 2-D stencil variant");
+        }
+    }
+}
+
+static void set_coef(StArgs &a, const mgk_geom *g, const double *coef) {
+    if (g->dim == 3) {
+        a.a0 = coef[0]; a.a1 = coef[1]; a.a2 = coef[2]; a.a3 = coef[3]; a.a4 = coef[4]; a.a5 = coef[5]; a.a6 = coef[6];
+    } else {
+        a.a0 = coef[0]; a.a1 = 0.0; a.a2 = coef[1]; a.a3 = coef[2]; a.a4 = coef[3]; a.a5 = 0.0; a.a6 = coef[4];
+    }
+}
+
+extern "C" int mgk_jacobi_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
+                              const double *b, const double *u, double *unew, void *stream) {
+    if (!c || !g || !coef || !b || !u || !unew || u == unew) return fail(MGK_EINVAL, "mgk_jacobi_f64: bad arguments");
+    StArgs a; memset(&a, 0, sizeof(a));
+    a.u = u + g->org; a.b = b + g->org; a.out = unew + g->org;
+    set_coef(a, g, coef); a.dinv = dinv; a.scale = scale;
+    return dispatch_st<MODE_JACOBI>(c, g, a, S(c, stream), nullptr);
+}
+
+extern "C" int mgk_cheby_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv,
+                             double c_km1, double c_k, double c_z,
+                             const double *b, const double *pk, const double *pkm1, double *pkp1, void *stream) {
+    if (!c || !g || !coef || !b || !pk || !pkm1 || !pkp1 || pk == pkp1 || pkm1 == pkp1)
+        return fail(MGK_EINVAL, "mgk_cheby_f64: bad arguments");
+    StArgs a; memset(&a, 0, sizeof(a));
+    a.u = pk + g->org; a.b = b + g->org; a.aux = pkm1 + g->org; a.out = pkp1 + g->org;
+    set_coef(a, g, coef); a.dinv = dinv; a.ckm1 = c_km1; a.ck = c_k; a.cz = c_z;
+    return dispatch_st<MODE_CHEBY>(c, g, a, S(c, stream), nullptr);
+}
+
+extern "C" int mgk_residual_f64(mgk_ctx *c, const mgk_geom *g, const double *coef,
+                                const double *b, const double *u, double *r, void *stream) {
+    if (!c || !g || !coef || !b || !u || !r || u == r) return fail(MGK_EINVAL, "mgk_residual_f64: bad arguments");
+    StArgs a; memset(&a, 0, sizeof(a));
+    a.u = u + g->org; a.b = b + g->org; a.out = r + g->org;
+    set_coef(a, g, coef);
+    return dispatch_st<MODE_RESIDUAL>(c, g, a, S(c, stream), nullptr);
+}
+
+static int finish_to_host(mgk_ctx *c, int nparts, int nslots, hipStream_t s, double *host_out) {
+    for (int q = 0; q < nslots; q++)
+        hipLaunchKernelGGL(k_finish_sum, dim3(1), dim3(256), 0, s, c->partials + (long)q * c->max_partials, nparts, c->result_dev, q);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->result_host, c->result_dev, sizeof(double) * nslots, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int q = 0; q < nslots; q++) host_out[q] = c->result_host[q];
+    return 0;
+}
+
+extern "C" int mgk_residual_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const double *coef,
+                                      const double *b, const double *u, double *sumsq_host, void *stream) {
+    if (!c || !g || !coef || !b || !u || !sumsq_host) return fail(MGK_EINVAL, "mgk_residual_sumsq_f64: bad arguments");
+    StArgs a; memset(&a, 0, sizeof(a));
+    a.u = u + g->org; a.b = b + g->org; a.partials = c->partials;
+    set_coef(a, g, coef);
+    int nblk = 0;
+    int rc = dispatch_st<MODE_RESNORM>(c, g, a, S(c, stream), &nblk);
+    if (rc) return rc;
+    return finish_to_host(c, nblk, 1, S(c, stream), sumsq_host);
+}
+
+// ------------------------------------------------------------------------------------------
+// row-wise elementwise / reduction kernels: one lane per aligned x pair, blocks stride over rows
+// ------------------------------------------------------------------------------------------
+struct RowArgs {
+    int nx, ny, nz, npairs;
+    long pitch, plane;
+    long nrows;           // ny*nz
+};
+__device__ __forceinline__ long row_offset(const RowArgs &a, long row) {
+    const long k = row / a.ny, i = row - k * a.ny;
+    return k * a.plane + i * a.pitch;
+}
+
+__global__ void __launch_bounds__(256) k_jacobi_zero(RowArgs a, double dinv, double scale, const double *b, double *out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.npairs) return;
+    const int x0 = 2 * p;
+    for (long row = blockIdx.y; row < a.nrows; row += gridDim.y) {
+        const long o = row_offset(a, row) + x0;
+        double2 bv = *reinterpret_cast<const double2 *>(b + o), r;
+        double zx = bv.x * dinv, zy = bv.y * dinv;
+        r.x = scale * zx; r.y = scale * zy;
+        if (x0 + 1 == a.nx) r.y = 0.0;
+        *reinterpret_cast<double2 *>(out + o) = r;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sumsq(RowArgs a, const double *x, double *partials) {
+    __shared__ double red[16];
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x0 = 2 * p;
+    double acc = 0.0;
+    if (p < a.npairs)
+        for (long row = blockIdx.y; row < a.nrows; row += gridDim.y) {
+            double2 v = *reinterpret_cast<const double2 *>(x + row_offset(a, row) + x0);
+            if (x0 + 1 == a.nx) v.y = 0.0;
+            acc += v.x * v.x + v.y * v.y;
+        }
+    double s = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_fill_separable(RowArgs a, const double *cx, const double *sy, const double *sz, double *out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.npairs) return;
+    const int x0 = 2 * p;
+    const double c0 = cx[x0], c1 = (x0 + 1 < a.nx) ? cx[x0 + 1] : 0.0;
+    for (long row = blockIdx.y; row < a.nrows; row += gridDim.y) {
+        const long k = row / a.ny, i = row - k * a.ny;
+        double2 r;
+        r.x = c0 * sy[i]; r.y = c1 * sy[i];
+        if (sz) { r.x = r.x * sz[k]; r.y = r.y * sz[k]; }
+        if (x0 + 1 == a.nx) r.y = 0.0;
+        *reinterpret_cast<double2 *>(out + k * a.plane + i * a.pitch + x0) = r;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_error_sums(RowArgs a, const double *u, const double *sx, const double *sy,
+                                                    const double *sz, double *partials, int maxp) {
+    __shared__ double red[16];
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x0 = 2 * p;
+    double emax = 0.0, e1 = 0.0, e2 = 0.0;
+    if (p < a.npairs) {
+        const double s0 = sx[x0], s1 = (x0 + 1 < a.nx) ? sx[x0 + 1] : 0.0;
+        for (long row = blockIdx.y; row < a.nrows; row += gridDim.y) {
+            const long k = row / a.ny, i = row - k * a.ny;
+            double2 v = *reinterpret_cast<const double2 *>(u + k * a.plane + i * a.pitch + x0);
+            double sol0 = s0 * sy[i], sol1 = s1 * sy[i];
+            if (sz) { sol0 = sol0 * sz[k]; sol1 = sol1 * sz[k]; }
+            double d0 = fabs(v.x - sol0), d1 = (x0 + 1 < a.nx) ? fabs(v.y - sol1) : 0.0;
+            emax = fmax(emax, fmax(d0, d1));
+            e1 += d0 + d1;
+            e2 += d0 * d0 + d1 * d1;
+        }
+    }
+    const int slot = blockIdx.y * gridDim.x + blockIdx.x;
+    double m = block_max(emax, red);
+    if (threadIdx.x == 0) partials[slot] = m;
+    double s = block_sum(e1, red);
+    if (threadIdx.x == 0) partials[maxp + slot] = s;
+    s = block_sum(e2, red);
+    if (threadIdx.x == 0) partials[2 * maxp + slot] = s;
+}
+
+__global__ void __launch_bounds__(256) k_pack(RowArgs a, const double *compact, double *padded, int to_padded) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.nx) return;
+    for (long row = blockIdx.y; row < a.nrows; row += gridDim.y) {
+        const long o = row_offset(a, row) + j, cidx = row * a.nx + j;
+        if (to_padded) padded[o] = compact[cidx];
+        else ((double *)compact)[cidx] = padded[o];
+    }
+}
+
+static RowArgs row_args(const mgk_geom *g) {
+    RowArgs a;
+    a.nx = g->nx; a.ny = g->ny; a.nz = g->nz; a.npairs = (g->nx + 1) / 2;
+    a.pitch = g->pitch; a.plane = g->plane; a.nrows = (long)g->ny * g->nz;
+    return a;
+}
+static void row_grid(const RowArgs &a, int cols, dim3 &grid, dim3 &block, int max_blocks) {
+    block = dim3(256);
+    unsigned gx = (cols + 255) / 256;
+    long gy = a.nrows;
+    long cap = max_blocks / (long)gx;
+    if (cap < 1) cap = 1;
+    if (gy > cap) gy = cap;
+    grid = dim3(gx, (unsigned)gy);
+}
+
+extern "C" int mgk_jacobi_zero_f64(mgk_ctx *c, const mgk_geom *g, double dinv, double scale,
+                                   const double *b, double *unew, void *stream) {
+    if (!c || !g || !b || !unew) return fail(MGK_EINVAL, "mgk_jacobi_zero_f64: bad arguments");
+    RowArgs a = row_args(g);
+    dim3 grid, block;
+    row_grid(a, a.npairs, grid, block, 8192);
+    hipLaunchKernelGGL(k_jacobi_zero, grid, block, 0, S(c, stream), a, dinv, scale, b + g->org, unew + g->org);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mgk_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const double *x, double *sumsq_host, void *stream) {
+    if (!c || !g || !x || !sumsq_host) return fail(MGK_EINVAL, "mgk_sumsq_f64: bad arguments");
+    RowArgs a = row_args(g);
+    dim3 grid, block;
+    row_grid(a, a.npairs, grid, block, 4096);
+    hipLaunchKernelGGL(k_sumsq, grid, block, 0, S(c, stream), a, x + g->org, c->partials);
+    HIPCHK(hipGetLastError());
+    return finish_to_host(c, (int)(grid.x * grid.y), 1, S(c, stream), sumsq_host);
+}
+
+extern "C" int mgk_fill_separable_f64(mgk_ctx *c, const mgk_geom *g, const double *cx, const double *sy,
+                                      const double *sz, double *out, void *stream) {
+    if (!c || !g || !cx || !sy || !out || (g->dim == 3 && !sz)) return fail(MGK_EINVAL, "mgk_fill_separable_f64: bad arguments");
+    RowArgs a = row_args(g);
+    dim3 grid, block;
+    row_grid(a, a.npairs, grid, block, 8192);
+    hipLaunchKernelGGL(k_fill_separable, grid, block, 0, S(c, stream), a, cx, sy, g->dim == 3 ? sz : nullptr, out + g->org);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mgk_error_sums_f64(mgk_ctx *c, const mgk_geom *g, const double *u, const double *sx,
+                                  const double *sy, const double *sz, double *err3_host, void *stream) {
+    if (!c || !g || !u || !sx || !sy || !err3_host || (g->dim == 3 && !sz)) return fail(MGK_EINVAL, "mgk_error_sums_f64: bad arguments");
+    RowArgs a = row_args(g);
+    dim3 grid, block;
+    row_grid(a, a.npairs, grid, block, 4096);
+    hipStream_t s = S(c, stream);
+    hipLaunchKernelGGL(k_error_sums, grid, block, 0, s, a, u + g->org, sx, sy, g->dim == 3 ? sz : nullptr, c->partials, c->max_partials);
+    HIPCHK(hipGetLastError());
+    const int np = (int)(grid.x * grid.y);
+    hipLaunchKernelGGL(k_finish_max, dim3(1), dim3(256), 0, s, c->partials, np, c->result_dev, 0);
+    hipLaunchKernelGGL(k_finish_sum, dim3(1), dim3(256), 0, s, c->partials + c->max_partials, np, c->result_dev, 1);
+    hipLaunchKernelGGL(k_finish_sum, dim3(1), dim3(256), 0, s, c->partials + 2L * c->max_partials, np, c->result_dev, 2);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->result_host, c->result_dev, sizeof(double) * 3, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int q = 0; q < 3; q++) err3_host[q] = c->result_host[q];
+    return 0;
+}
+
+extern "C" int mgk_pack_f64(mgk_ctx *c, const mgk_geom *g, const double *compact_dev, double *padded_dev, void *stream) {
+    if (!c || !g || !compact_dev || !padded_dev) return fail(MGK_EINVAL, "mgk_pack_f64: bad arguments");
+    RowArgs a = row_args(g);
+    dim3 grid, block;
+    row_grid(a, a.nx, grid, block, 8192);
+    hipLaunchKernelGGL(k_pack, grid, block, 0, S(c, stream), a, compact_dev, padded_dev + g->org, 1);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int mgk_unpack_f64(mgk_ctx *c, const mgk_geom *g, const double *padded_dev, double *compact_dev, void *stream) {
+    if (!c || !g || !compact_dev || !padded_dev) return fail(MGK_EINVAL, "mgk_unpack_f64: bad arguments");
+    RowArgs a = row_args(g);
+    dim3 grid, block;
+    row_grid(a, a.nx, grid, block, 8192);
+    hipLaunchKernelGGL(k_pack, grid, block, 0, S(c, stream), a, compact_dev, (double *)padded_dev + g->org, 0);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// grid transfer
+// ------------------------------------------------------------------------------------------
+struct XferArgs {
+    int nxf, nyf, nzf, nxc, nyc, nzc;
+    long pf, plf, pc, plc;       // pitches / planes of fine and coarse
+};
+
+// full weighting: one lane per coarse point; fine values summed in ascending fine index
+// (dk, di, dj) exactly like the 9/27-entry row of res (src/solver.c:1081-1090).
+template <int DIM>
+__global__ void __launch_bounds__(256) k_restrict(XferArgs a, const double *rf, double *bc) {
+    const int jc = blockIdx.x * blockDim.x + threadIdx.x;
+    if (jc > a.nxc) return;             // jc == nxc: the right ghost, written as 0
+    const long nrows = (long)a.nyc * a.nzc;
+    // weights: src/matbuild.c:422-431 (0.125-0.0625|1-i| ...); 3-D extension multiplies by {1/4,1/2,1/4}
+    const double w2[3][3] = {{0.0625, 0.125, 0.0625}, {0.125, 0.25, 0.125}, {0.0625, 0.125, 0.0625}};
+    const double w1[3] = {0.25, 0.5, 0.25};
+    for (long row = blockIdx.y; row < nrows; row += gridDim.y) {
+        const long kc = row / a.nyc, ic = row - kc * a.nyc;
+        double sum = 0.0;
+        if (jc < a.nxc) {
+            const double *base = rf + (DIM == 3 ? (2 * kc) * a.plf : 0) + (2 * ic) * a.pf + 2 * jc;
+            if (DIM == 3) {
+#pragma unroll
+                for (int dk = 0; dk < 3; dk++)
+#pragma unroll
+                    for (int di = 0; di < 3; di++)
+#pragma unroll
+                        for (int dj = 0; dj < 3; dj++)
+                            sum += (w1[dk] * w2[di][dj]) * base[dk * a.plf + di * a.pf + dj];
+            } else {
+#pragma unroll
+                for (int di = 0; di < 3; di++)
+#pragma unroll
+                    for (int dj = 0; dj < 3; dj++) sum += w2[di][dj] * base[di * a.pf + dj];
+            }
+        }
+        bc[(DIM == 3 ? kc * a.plc : 0) + ic * a.pc + jc] = sum;
+    }
+}
+
+// bilinear / trilinear interpolation + correction: one lane per aligned fine pair.
+// Row of pro summed in ascending coarse index (kc, ic, jc) (src/solver.c:1140-1148), then u + rv.
+// Out-of-grid parents are read from the coarse ghosts (0 at a global boundary, halo data at a slab
+// boundary), which adds +0 where the assembled row has no entry.
+template <int DIM>
+__global__ void __launch_bounds__(256) k_prolong_add(XferArgs a, const double *uc, double *uf) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x0 = 2 * p;                 // even fine x; x0+1 odd
+    if (x0 >= a.nxf) return;
+    const long nrows = (long)a.nyf * a.nzf;
+    const int jc1 = x0 / 2, jc0 = jc1 - 1;      // parents of x0 (weights 1/2, 1/2); parent of x0+1 is jc1 (weight 1)
+    for (long row = blockIdx.y; row < nrows; row += gridDim.y) {
+        const long k = row / a.nyf, i = row - k * a.nyf;
+        const int iodd = (int)(i & 1), kodd = (int)(k & 1);
+        const long ic0 = iodd ? (i - 1) / 2 : i / 2 - 1, ic1 = iodd ? ic0 : i / 2;
+        const long kc0 = (DIM == 3) ? (kodd ? (k - 1) / 2 : k / 2 - 1) : 0, kc1 = (DIM == 3) ? (kodd ? kc0 : k / 2) : 0;
+        const double wi = iodd ? 1.0 : 0.5, wk = (DIM == 3) ? (kodd ? 1.0 : 0.5) : 1.0;
+        double s0 = 0.0, s1 = 0.0;
+        for (long kc = kc0; kc <= kc1; kc++)
+            for (long ic = ic0; ic <= ic1; ic++) {
+                const double *cr = uc + (DIM == 3 ? kc * a.plc : 0) + ic * a.pc;
+                const double c0 = cr[jc0], c1 = cr[jc1];
+                const double wh = (DIM == 3) ? wk * (wi * 0.5) : wi * 0.5;
+                const double w1_ = (DIM == 3) ? wk * (wi * 1.0) : wi * 1.0;
+                s0 += wh * c0;
+                s0 += wh * c1;
+                s1 += w1_ * c1;
+            }
+        double *fp = uf + (DIM == 3 ? k * a.plf : 0) + i * a.pf + x0;
+        double2 v = *reinterpret_cast<double2 *>(fp);
+        v.x = v.x + s0;
+        v.y = (x0 + 1 < a.nxf) ? v.y + s1 : 0.0;
+        *reinterpret_cast<double2 *>(fp) = v;
+    }
+}
+
+static int xfer_args(const mgk_geom *gf, const mgk_geom *gc, XferArgs &a) {
+    if (gf->dim != gc->dim) return fail(MGK_EINVAL, "grid transfer: dimension mismatch");
+    if (gf->nx != 2 * gc->nx + 1 || gf->ny != 2 * gc->ny + 1) return fail(MGK_EINVAL, "grid transfer: need nf = 2*nc+1 in x and y");
+    if (gf->dim == 3 && !(gf->nz == 2 * gc->nz + 1 || gf->nz == 2 * gc->nz))
+        return fail(MGK_EINVAL, "grid transfer: need nzf = 2*nzc (+1 on the last slab)");
+    a.nxf = gf->nx; a.nyf = gf->ny; a.nzf = gf->nz; a.nxc = gc->nx; a.nyc = gc->ny; a.nzc = gc->nz;
+    a.pf = gf->pitch; a.plf = gf->plane; a.pc = gc->pitch; a.plc = gc->plane;
+    return 0;
+}
+
+extern "C" int mgk_restrict_fw_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc,
+                                   const double *rf, double *bc, void *stream) {
+    if (!c || !gf || !gc || !rf || !bc) return fail(MGK_EINVAL, "mgk_restrict_fw_f64: bad arguments");
+    XferArgs a;
+    int rc = xfer_args(gf, gc, a);
+    if (rc) return rc;
+    dim3 block(256), grid((gc->nx + 1 + 255) / 256, 1);
+    long rows = (long)gc->ny * gc->nz, cap = 16384 / grid.x;
+    grid.y = (unsigned)(rows < cap ? rows : cap);
+    if (gf->dim == 3) hipLaunchKernelGGL(k_restrict<3>, grid, block, 0, S(c, stream), a, rf + gf->org, bc + gc->org);
+    else hipLaunchKernelGGL(k_restrict<2>, grid, block, 0, S(c, stream), a, rf + gf->org, bc + gc->org);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mgk_prolong_add_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc,
+                                   const double *uc, double *uf, void *stream) {
+    if (!c || !gf || !gc || !uc || !uf) return fail(MGK_EINVAL, "mgk_prolong_add_f64: bad arguments");
+    XferArgs a;
+    int rc = xfer_args(gf, gc, a);
+    if (rc) return rc;
+    const int npairs = (gf->nx + 1) / 2;
+    dim3 block(256), grid((npairs + 255) / 256, 1);
+    long rows = (long)gf->ny * gf->nz, cap = 16384 / grid.x;
+    grid.y = (unsigned)(rows < cap ? rows : cap);
+    if (gf->dim == 3) hipLaunchKernelGGL(k_prolong_add<3>, grid, block, 0, S(c, stream), a, uc + gc->org, uf + gf->org);
+    else hipLaunchKernelGGL(k_prolong_add<2>, grid, block, 0, S(c, stream), a, uc + gc->org, uf + gf->org);
+    HIPCHK(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,160 @@
+"""GPU parity: every HIP kernel (through the C ABI, include/mgk.h) against the CPU oracle on the same
+seeded inputs.  Field values must be BIT-IDENTICAL (the kernels implement the canonical arithmetic of
+oracle/mgo.c: ascending-column sums, no FMA); reductions (sums of squares) agree to 1e-13 relative
+(summation order is not part of the contract; north_star tolerance for fp64 residual norms is 1e-12)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+RED_RTOL = 1e-13
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return Oracle()
+
+
+def _rand(rng, n):
+    return rng.uniform(-1.0, 1.0, n)
+
+
+def _stencil(orc, dim, n):
+    # coefficients of the level whose grid has n unknowns per side: npts = n + 2, level 0
+    return orc.level_stencil(dim, n + 2, 0)[0]
+
+
+CASES_3D = [(3, n, v) for n in (1, 3, 7, 31) for v in (0, 2)] + \
+           [(3, 63, v) for v in range(8)] + [(3, 127, v) for v in (1, 2, 3, 4, 6, 7)]
+CASES_2D = [(2, n, v) for n in (1, 3, 15, 127) for v in (0, 1)] + [(2, 255, v) for v in (0, 1, 2)] + \
+           [(2, 1023, 2), (2, 2047, 2)]
+
+
+@pytest.mark.parametrize("dim,n,variant", CASES_3D + CASES_2D)
+def test_stencil_modes_bit_exact(mgk, orc, dim, n, variant):
+    rng = np.random.default_rng(1000 * dim + n + variant)
+    N = n ** dim
+    As = _stencil(orc, dim, n)
+    dinv = 1.0 / As[3 if dim == 3 else 2]
+    u, b, pm = _rand(rng, N), _rand(rng, N), _rand(rng, N)
+    g = mgk.geom(dim, n)
+    du, db, dpm, dout = mgk.to_field(g, u), mgk.to_field(g, b), mgk.to_field(g, pm), mgk.field(g)
+    coef = mgk.coef(As)
+    L = mgk.L
+    for zchunk in (-1, 5):
+        L.mgk_set_tuning(variant, zchunk)
+        # Jacobi sweep, two scales
+        for scale in (1.0, 0.8):
+            mgk._chk(L.mgk_jacobi_f64(mgk.ctx, C.byref(g), coef, dinv, scale, db, du, dout, None))
+            got = mgk.from_field(g, dout)
+            want = orc.jacobi(dim, n, As, scale, b, u)
+            assert np.array_equal(got, want), f"jacobi scale={scale} maxdiff={np.abs(got - want).max()}"
+        # residual
+        mgk._chk(L.mgk_residual_f64(mgk.ctx, C.byref(g), coef, db, du, dout, None))
+        got = mgk.from_field(g, dout)
+        want = orc.residual(dim, n, As, b, u)
+        assert np.array_equal(got, want)
+        # fused residual + sum of squares
+        ss = C.c_double()
+        mgk._chk(L.mgk_residual_sumsq_f64(mgk.ctx, C.byref(g), coef, db, du, C.byref(ss), None))
+        ref = orc.sumsq(want)
+        assert abs(ss.value - ref) <= RED_RTOL * ref
+        # Chebyshev recurrence step
+        ck1, ck, cz = -0.37, 1.37, 0.21
+        mgk._chk(L.mgk_cheby_f64(mgk.ctx, C.byref(g), coef, dinv, ck1, ck, cz, db, du, dpm, dout, None))
+        got = mgk.from_field(g, dout)
+        want = orc.cheby_step(dim, n, As, b, u, pm, ck1, ck, cz)
+        assert np.array_equal(got, want)
+    L.mgk_set_tuning(-1, -1)
+    # ghosts of the output stay zero (Dirichlet ring is never written)
+    raw = mgk.raw_field(g, dout)
+    inter = mgk.from_field(g, dout)
+    assert abs(np.abs(raw).sum() - np.abs(inter).sum()) <= 1e-9 * max(1.0, np.abs(inter).sum())
+    for p in (du, db, dpm, dout):
+        mgk.free(p)
+
+
+@pytest.mark.parametrize("dim,n", [(2, 1), (2, 7), (2, 255), (3, 1), (3, 7), (3, 63)])
+def test_zero_guess_sweep_and_sumsq(mgk, orc, dim, n):
+    rng = np.random.default_rng(7 + n)
+    N = n ** dim
+    As = _stencil(orc, dim, n)
+    dinv = 1.0 / As[3 if dim == 3 else 2]
+    b = _rand(rng, N)
+    g = mgk.geom(dim, n)
+    db, dout = mgk.to_field(g, b), mgk.field(g)
+    mgk._chk(mgk.L.mgk_jacobi_zero_f64(mgk.ctx, C.byref(g), dinv, 0.8, db, dout, None))
+    got = mgk.from_field(g, dout)
+    want = orc.jacobi(dim, n, As, 0.8, b, np.zeros(N), zero_guess=True)
+    assert np.array_equal(got, want)
+    # identical to a full sweep from u = 0
+    assert np.array_equal(want, orc.jacobi(dim, n, As, 0.8, b, np.zeros(N)))
+    ss = C.c_double()
+    mgk._chk(mgk.L.mgk_sumsq_f64(mgk.ctx, C.byref(g), db, C.byref(ss), None))
+    ref = orc.sumsq(b)
+    assert abs(ss.value - ref) <= RED_RTOL * ref
+    mgk.free(db)
+    mgk.free(dout)
+
+
+@pytest.mark.parametrize("dim,nf", [(2, 3), (2, 7), (2, 127), (2, 1023), (3, 3), (3, 7), (3, 31), (3, 127)])
+def test_transfer_bit_exact(mgk, orc, dim, nf):
+    rng = np.random.default_rng(99 + nf)
+    nc = (nf - 1) // 2
+    rf, uc, uf = _rand(rng, nf ** dim), _rand(rng, nc ** dim), _rand(rng, nf ** dim)
+    gf, gc = mgk.geom(dim, nf), mgk.geom(dim, nc)
+    drf, duc, duf, dbc = mgk.to_field(gf, rf), mgk.to_field(gc, uc), mgk.to_field(gf, uf), mgk.field(gc)
+    mgk._chk(mgk.L.mgk_restrict_fw_f64(mgk.ctx, C.byref(gf), C.byref(gc), drf, dbc, None))
+    got = mgk.from_field(gc, dbc)
+    want = orc.restrict(dim, nf, rf)
+    assert np.array_equal(got, want)
+    mgk._chk(mgk.L.mgk_prolong_add_f64(mgk.ctx, C.byref(gf), C.byref(gc), duc, duf, None))
+    got = mgk.from_field(gf, duf)
+    want = orc.prolong_add(dim, nf, uc, uf)
+    assert np.array_equal(got, want)
+    # ghosts untouched
+    raw = mgk.raw_field(gf, duf)
+    assert abs(np.abs(raw).sum() - np.abs(got).sum()) <= 1e-9 * np.abs(got).sum()
+    for p in (drf, duc, duf, dbc):
+        mgk.free(p)
+
+
+def test_transfer_matches_assembled_matrices(orc):
+    """matrix-free transfer == MatMult with the assembled res/pro (runs on the GPU box too, CPU only)"""
+    rng = np.random.default_rng(5)
+    for dim, npts in ((2, 17), (3, 9)):
+        nf, nc = npts - 2, (npts - 3) // 2
+        R, P = orc.build("R", dim, npts, 0), orc.build("P", dim, npts, 0)
+        rf, uc = _rand(rng, nf ** dim), _rand(rng, nc ** dim)
+        assert np.array_equal(orc.csr_mult(R, rf), orc.restrict(dim, nf, rf))
+        assert np.array_equal(orc.csr_mult(P, uc), orc.prolong_add(dim, nf, uc, np.zeros(nf ** dim)))
+
+
+@pytest.mark.parametrize("dim,npts", [(2, 33), (3, 17)])
+def test_rhs_fill_and_error_sums(mgk, orc, dim, npts):
+    n = npts - 2
+    c = orc.coords(npts)
+    PI = 3.14159265358979323846
+    s = np.sin(PI * c[1:-1])
+    cx = ((-2 * PI * PI) if dim == 2 else (-3 * PI * PI)) * s     # ((-d*PI)*PI)*sin(PI*x), left to right
+    g = mgk.geom(dim, n)
+    dcx, ds, db = mgk.upload(cx), mgk.upload(s), mgk.field(g)
+    mgk._chk(mgk.L.mgk_fill_separable_f64(mgk.ctx, C.byref(g), dcx, ds, ds, db, None))
+    got = mgk.from_field(g, db)
+    want = orc.rhs(dim, npts)
+    assert np.array_equal(got, want)
+    # error sums against the exact solution
+    rng = np.random.default_rng(3)
+    u = _rand(rng, n ** dim)
+    du = mgk.to_field(g, u)
+    e = np.zeros(3)
+    mgk._chk(mgk.L.mgk_error_sums_f64(mgk.ctx, C.byref(g), du, ds, ds, ds, e.ctypes.data_as(C.POINTER(C.c_double)), None))
+    ref = orc.error_norms(dim, npts, u)
+    assert e[0] == ref[0]
+    assert abs(e[1] - ref[1]) <= 1e-12 * ref[1]
+    assert abs(np.sqrt(e[2]) - ref[2]) <= 1e-12 * ref[2]
+    for p in (dcx, ds, db, du):
+        mgk.free(p)
