@@ -176,6 +176,29 @@ __device__ __forceinline__ double2 ld2(const double *p, bool ok) {
     return ok ? *reinterpret_cast<const double2 *>(p) : make_double2(0.0, 0.0);
 }
 __device__ __forceinline__ double ld1(const double *p, bool ok) { return ok ? *p : 0.0; }
+// streaming (read-once / write-once) accesses: non-temporal so that they do not displace the u planes
+// and halo lines that neighbouring tiles re-read from L2 / Infinity Cache
+#ifndef MGK_NT
+#define MGK_NT 3
+#endif
+typedef double d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ld2_stream(const double *p, bool ok) {
+#if MGK_NT & 1
+    if (!ok) return make_double2(0.0, 0.0);
+    d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p));
+    return make_double2(v.x, v.y);
+#else
+    return ld2(p, ok);
+#endif
+}
+__device__ __forceinline__ void st2_stream(double *p, double2 v) {
+#if MGK_NT & 2
+    d2v t; t.x = v.x; t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<d2v *>(p));
+#else
+    *reinterpret_cast<double2 *>(p) = v;
+#endif
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -295,8 +318,8 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs a) {
         um[r] = ld2(up_ + (long)(z0 - 1) * a.ms + ro, rok[r]);
         uc[r] = ld2(up_ + (long)z0 * a.ms + ro, rok[r]);
         up[r] = ld2(up_ + (long)(z0 + 1) * a.ms + ro, rok[r]);
-        bc[r] = ld2(bp_ + (long)z0 * a.ms + ro, rok[r]);
-        if (MODE == MODE_CHEBY) ac[r] = ld2(ap_ + (long)z0 * a.ms + ro, rok[r]);
+        bc[r] = ld2_stream(bp_ + (long)z0 * a.ms + ro, rok[r]);
+        if (MODE == MODE_CHEBY) ac[r] = ld2_stream(ap_ + (long)z0 * a.ms + ro, rok[r]);
         const bool hok = xhok && (DIM == 2 || yb + r < a.ny);
         double xc = ld1(hp_ + (long)z0 * a.ms + ro, hok);
         xp[r] = ld1(hp_ + (long)(z0 + 1) * a.ms + ro, hok);
@@ -319,8 +342,8 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs a) {
             for (int r = 0; r < RY; r++) {
                 const long ro = (long)r * a.rs;
                 uq[r] = ld2(up_ + (long)(z + 2) * a.ms + ro, rok[r]);
-                bn[r] = ld2(bp_ + (long)(z + 1) * a.ms + ro, rok[r]);
-                if (MODE == MODE_CHEBY) an[r] = ld2(ap_ + (long)(z + 1) * a.ms + ro, rok[r]);
+                bn[r] = ld2_stream(bp_ + (long)(z + 1) * a.ms + ro, rok[r]);
+                if (MODE == MODE_CHEBY) an[r] = ld2_stream(ap_ + (long)(z + 1) * a.ms + ro, rok[r]);
                 const bool hok = xhok && (DIM == 2 || yb + r < a.ny);
                 xq[r] = ld1(hp_ + (long)(z + 2) * a.ms + ro, hok);
             }
@@ -381,7 +404,7 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs a) {
             if (lastpair) o.y = 0.0;
             if (rok[r]) {
                 if (MODE == MODE_RESNORM) acc += o.x * o.x + o.y * o.y;
-                else *reinterpret_cast<double2 *>(a.out + rowoff + x0 + (long)z * a.ms + (long)r * a.rs) = o;
+                else st2_stream(a.out + rowoff + x0 + (long)z * a.ms + (long)r * a.rs, o);
             }
         }
 
@@ -469,7 +492,7 @@ static int dispatch_st(mgk_ctx *c, const mgk_geom *g, StArgs &a, hipStream_t s, 
     if (g->dim == 3) {
         a.ny = g->ny; a.nm = g->nz; a.rs = g->pitch; a.ms = g->plane;
         int v = g_variant;
-        if (v < 0) v = (g->nx >= 255) ? 2 : (g->nx >= 127 ? 1 : 0);
+        if (v < 0) v = (g->nx >= 255) ? 3 : (g->nx >= 127 ? 1 : 0);
         switch (v) {
             case 0: return launch_st<3, 1, 2, 2, MODE>(c, a, g->ny, s, nblocks);   // 128 x 4, 128 thr
             case 1: return launch_st<3, 1, 4, 2, MODE>(c, a, g->ny, s, nblocks);   // 128 x 8, 256 thr

@@ -18,6 +18,10 @@
 #include <omp.h>
 #endif
 
+/* loops shorter than this run serially: the GPU box exposes far more hardware threads than the
+ * CPU share a job gets, and a parallel region per tiny coarse-level loop would dominate */
+#define MGO_PAR_MIN 32768
+
 int mgo_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
@@ -266,7 +270,7 @@ void mgo_rhs(int dim, int npts, double *b) {
         for (int i = 0; i < n; i++)
             for (int j = 0; j < n; j++) b[(long)i * n + j] = mgo_ffunc(2, c[j + 1], c[i + 1], 0.0);
     } else {
-#pragma omp parallel for
+#pragma omp parallel for if (n > 32)
         for (int k = 0; k < n; k++)
             for (int i = 0; i < n; i++)
                 for (int j = 0; j < n; j++)
@@ -454,7 +458,7 @@ mgo_csr *mgo_build_P(int dim, int npts, int l) {
 
 /* MatMult on AIJ (assumed PETSc semantics, mgo.h) */
 void mgo_csr_mult(const mgo_csr *m, const double *x, double *y) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (m->nrows > MGO_PAR_MIN)
     for (long r = 0; r < m->nrows; r++) {
         double sum = 0.0;
         for (long q = m->rowptr[r]; q < m->rowptr[r + 1]; q++) sum += m->val[q] * x[m->col[q]];
@@ -463,7 +467,7 @@ void mgo_csr_mult(const mgo_csr *m, const double *x, double *y) {
 }
 
 void mgo_csr_diag_inv(const mgo_csr *m, double *dinv) {   /* PCJACOBI setup: 1/diag */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (m->nrows > MGO_PAR_MIN)
     for (long r = 0; r < m->nrows; r++) {
         double d = 0.0;
         for (long q = m->rowptr[r]; q < m->rowptr[r + 1]; q++) if (m->col[q] == r) d = m->val[q];
@@ -474,7 +478,7 @@ void mgo_csr_diag_inv(const mgo_csr *m, double *dinv) {   /* PCJACOBI setup: 1/d
 /* KSPBuildResidual default: t = A x ; r = b - t  (solver.c:1534,1545) */
 void mgo_residual_csr(const mgo_csr *A, const double *b, const double *x, double *r) {
     mgo_csr_mult(A, x, r);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (A->nrows > MGO_PAR_MIN)
     for (long q = 0; q < A->nrows; q++) r[q] = b[q] - r[q];
 }
 
@@ -490,7 +494,7 @@ void mgo_richardson_csr(const mgo_csr *A, const double *dinv, const double *b, d
         mgo_residual_csr(A, b, x, r);                 /* r = b - A x */
     }
     for (int it = 0; it < maxit; it++) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n > MGO_PAR_MIN)
         for (long q = 0; q < n; q++) {
             z[q] = r[q] * dinv[q];                    /* PCApply (Jacobi) */
             x[q] = x[q] + scale * z[q];               /* VecAXPY */
@@ -561,7 +565,7 @@ static inline double st_row(int dim, int n, int nz, const double *As, const doub
 void mgo_st_apply(int dim, int n, int nz, const double *As, const double *x,
                   const double *zlo, const double *zhi, double *y) {
     if (dim == 2) nz = 1;
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(2) schedule(static) if ((long)nz * n * n > MGO_PAR_MIN)
     for (int k = 0; k < nz; k++)
         for (int i = 0; i < n; i++)
             for (int j = 0; j < n; j++)
@@ -574,7 +578,7 @@ void mgo_st_jacobi(int dim, int n, int nz, const double *As, double scale, const
                    const double *u, const double *zlo, const double *zhi, double *unew, int zero_guess) {
     if (dim == 2) nz = 1;
     double dinv = 1.0 / As[dim == 3 ? 3 : 2];
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(2) schedule(static) if ((long)nz * n * n > MGO_PAR_MIN)
     for (int k = 0; k < nz; k++)
         for (int i = 0; i < n; i++)
             for (int j = 0; j < n; j++) {
@@ -593,7 +597,7 @@ void mgo_st_cheby_step(int dim, int n, int nz, const double *As, const double *b
                        double c_km1, double c_k, double c_z, double *pkp1) {
     if (dim == 2) nz = 1;
     double dinv = 1.0 / As[dim == 3 ? 3 : 2];
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(2) schedule(static) if ((long)nz * n * n > MGO_PAR_MIN)
     for (int k = 0; k < nz; k++)
         for (int i = 0; i < n; i++)
             for (int j = 0; j < n; j++) {
@@ -608,7 +612,7 @@ void mgo_st_cheby_step(int dim, int n, int nz, const double *As, const double *b
 void mgo_st_residual(int dim, int n, int nz, const double *As, const double *b, const double *u,
                      const double *zlo, const double *zhi, double *r) {
     if (dim == 2) nz = 1;
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(2) schedule(static) if ((long)nz * n * n > MGO_PAR_MIN)
     for (int k = 0; k < nz; k++)
         for (int i = 0; i < n; i++)
             for (int j = 0; j < n; j++) {
@@ -623,7 +627,7 @@ void mgo_st_restrict(int dim, int nf, int nzf, int nzc, const double *rf, const 
     double w[9];
     mgo_restriction_stencil(w);
     if (dim == 2) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if ((long)nc * nc > MGO_PAR_MIN)
         for (int i1 = 0; i1 < nc; i1++)
             for (int j1 = 0; j1 < nc; j1++) {
                 double sum = 0.0;
@@ -635,7 +639,7 @@ void mgo_st_restrict(int dim, int nf, int nzf, int nzc, const double *rf, const 
         return;
     }
     long nnf = (long)nf * nf;
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(2) schedule(static) if ((long)nzc * nc * nc > MGO_PAR_MIN)
     for (int k1 = 0; k1 < nzc; k1++)
         for (int i1 = 0; i1 < nc; i1++)
             for (int j1 = 0; j1 < nc; j1++) {
@@ -658,7 +662,7 @@ void mgo_st_prolong_add(int dim, int nf, int nzf, int nzc, const double *uc,
     int nc = (nf - 1) / 2;
     int nk = dim == 3 ? nzf : 1;
     long ncc = (long)nc * nc;
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(2) schedule(static) if ((long)nk * nf * nf > MGO_PAR_MIN)
     for (int k = 0; k < nk; k++)
         for (int i = 0; i < nf; i++)
             for (int j = 0; j < nf; j++) {
@@ -697,7 +701,7 @@ double mgo_sumsq(const double *x, long n) {
     const long B = 4096;
     long nb = (n + B - 1) / B;
     long double *part = (long double *)malloc(sizeof(long double) * (nb ? nb : 1));
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (nb > 8)
     for (long bidx = 0; bidx < nb; bidx++) {
         long a = bidx * B, e = a + B < n ? a + B : n;
         long double s = 0.0L;

@@ -4,6 +4,9 @@ import os
 
 import numpy as np
 
+# bound the oracle's OpenMP team: a GPU box shows every hardware thread of the host but a job only
+# gets a share of them (16 per GPU)
+os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(16, os.cpu_count() or 1))))
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _LIB = os.path.join(ROOT, "oracle", "libmgo.so")
 

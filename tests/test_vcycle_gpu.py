@@ -1,0 +1,99 @@
+"""GPU parity of the whole V-cycle driver (C host + HIP kernels) against the CPU oracle.
+
+Bar (BASELINE.json north_star): iteration count identical, fp64 residual norms within 1e-12 relative
+per entry, solution field identical (the kernels are bit-faithful; only the norm's summation order
+differs), plus the closed-form known answer  err_max = d*pi^2 / ((4d/h^2) sin^2(pi h/2)) - 1."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return Oracle()
+
+
+CASES = [
+    # dim npts levels scale       (poisson.in default: npts 17, 2 levels, v 3,3)
+    (2, 17, 2, 1.0), (2, 17, 2, 0.8), (2, 17, 4, 0.8), (2, 33, 5, 0.8), (2, 129, 7, 0.8), (2, 129, 6, 0.8),
+    (2, 129, 2, 0.8), (2, 513, 9, 0.8), (2, 9, 1, 0.8),
+    (3, 9, 3, 0.8), (3, 17, 4, 6.0 / 7.0), (3, 17, 2, 1.0), (3, 33, 5, 6.0 / 7.0), (3, 65, 6, 6.0 / 7.0),
+    (3, 129, 7, 6.0 / 7.0),
+]
+
+
+@pytest.mark.parametrize("dim,npts,levels,scale", CASES)
+def test_solve_matches_oracle(orc, dim, npts, levels, scale):
+    from multigrid_petsc_amd.solver import Solver
+    maxiter = 200
+    s = Solver(dim, npts, levels, v=(3, 3), maxiter=maxiter, scale=scale)
+    s.set_rhs_problem()
+    it = s.solve()
+    ref = orc.vcycle(dim, npts, levels, 3, 3, maxiter=maxiter, scale=scale, use_csr=0)
+    assert it == ref["iters"]
+    assert abs(s.bnorm - ref["bnorm"]) <= RTOL * ref["bnorm"]
+    rn = s.rnorm
+    assert rn.shape == ref["rnorm"].shape
+    rel = np.abs(rn - ref["rnorm"]) / ref["rnorm"]
+    assert rel.max() <= RTOL, f"residual history differs: max rel {rel.max()}"
+    u = s.solution()
+    assert np.array_equal(u, ref["u"]), f"solution not bit-identical, max diff {np.abs(u - ref['u']).max()}"
+    e = s.error_norms()
+    eref = orc.error_norms(dim, npts, ref["u"])
+    assert e[0] == eref[0]
+    assert abs(e[1] - eref[1]) <= RTOL * eref[1] and abs(e[2] - eref[2]) <= RTOL * eref[2]
+    if it < maxiter:
+        h = 1.0 / (npts - 1)
+        kat = dim * math.pi ** 2 / ((4 * dim / h ** 2) * math.sin(math.pi * h / 2) ** 2) - 1.0
+        assert abs(e[0] - kat) <= 5e-7     # iteration stops at ||r|| <= 1e-7 ||b||, |u| = O(1)
+    s.close()
+
+
+@pytest.mark.parametrize("dim,npts,levels", [(2, 65, 5), (3, 33, 4)])
+def test_chebyshev_smoother_matches_oracle(orc, dim, npts, levels):
+    from multigrid_petsc_amd.solver import Solver
+    # Jacobi-preconditioned operator has spectrum in (0, 2); smooth the upper part
+    emin, emax = 0.2, 2.0
+    s = Solver(dim, npts, levels, v=(3, 3), maxiter=60, ksp_type="chebyshev", eigenvalues=(emin, emax))
+    s.set_rhs_problem()
+    it = s.solve()
+    ref = orc.vcycle(dim, npts, levels, 3, 3, maxiter=60, ksp_type=1, emin=emin, emax=emax, use_csr=0)
+    assert it == ref["iters"]
+    rel = np.abs(s.rnorm - ref["rnorm"]) / ref["rnorm"]
+    assert rel.max() <= RTOL
+    assert np.array_equal(s.solution(), ref["u"])
+    s.close()
+
+
+def test_unfused_final_residual_same_history(orc):
+    from multigrid_petsc_amd.solver import Solver
+    a = Solver(3, 33, 4, scale=6.0 / 7.0, maxiter=50, fuse=1)
+    b = Solver(3, 33, 4, scale=6.0 / 7.0, maxiter=50, fuse=0)
+    for s in (a, b):
+        s.set_rhs_problem()
+        s.solve()
+    assert a.iterations == b.iterations
+    assert np.allclose(a.rnorm, b.rnorm, rtol=1e-13, atol=0)
+    assert np.array_equal(a.solution(), b.solution())
+    a.close()
+    b.close()
+
+
+def test_fixed_cycles_and_random_rhs(orc):
+    """bench path: mg_solver_cycles from an arbitrary RHS"""
+    from multigrid_petsc_amd.solver import Solver
+    rng = np.random.default_rng(11)
+    s = Solver(3, 17, 3, scale=0.8, maxiter=10)
+    b = rng.uniform(-1, 1, s.local_unknowns)
+    s.set_rhs(b)
+    s.cycles(4)
+    assert s.iterations == 4
+    r = s.rnorm
+    assert np.all(np.diff(r) < 0)          # contracts every cycle
+    s.close()
