@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X multigrid V-cycle.
+
+Metric (BASELINE.json): fp64 DOF-updates/sec per V-cycle at 1024^3; achieved HBM GB/s vs peak.
+Workload: 3-D 7-point Poisson, npts = 1025 (1023^3 unknowns, the reference's vertex-centred
+"1024^3"), 10 levels, V(3,3) with 3 coarsest sweeps (poisson.in:12), Richardson +
+Jacobi smoother with scale 6/7, RHS f = -3 pi^2 sin sin sin, u0 = 0.  A "step" is one V-cycle
+(src/solver.c:1531-1549), including its residual-norm reduction.
+
+  python bench.py --gpus N --steps K --warmup W
+  N > 1: launched by torch.distributed.run, one rank per GPU; the grid is z-slab decomposed
+  (strong scaling: the total problem is fixed), halos travel over RCCL (C side, include/mg_comm.h).
+
+Rank 0 prints ONE JSON line.  Extra objects: "roofline" (fine-level Jacobi sweep, HIP-event timed
+inside the timed region) and "cpu_baseline" (the CPU oracle's assembled-CSR V-cycle on a bounded
+sample, timed on this box's host cores).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+JACOBI_BYTES_PER_DOF = 24.0  # read u, read b, write u' 
+
+
+def cpu_baseline(args):
+    """The oracle's assembled (AIJ/CSR) V-cycle -- the PETSc-equivalent data path of the reference --
+    on a bounded sample of the same workload, OpenMP over this box's host cores."""
+    threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    from oracle import Oracle
+    orc = Oracle()
+    npts, levels, cycles = args.cpu_npts, args.cpu_levels, args.cpu_cycles
+    r = orc.vcycle(3, npts, levels, 3, 3, maxiter=cycles, scale=6.0 / 7.0, use_csr=1,
+                   fixed_cycles=cycles, want_u=False)
+    dof = 0.0
+    for l in range(levels):
+        n = (npts - 1) // (2 ** l) - 1
+        dof += (3 if l == levels - 1 else 6) * float(n) ** 3
+    return {"value": dof * cycles / r["seconds"], "unit": "DOF-updates/s", "cores": orc.L.mgo_num_threads(),
+            "kind": "port",
+            "sample": f"oracle assembled-CSR V(3,3) cycle, 3-D npts={npts} ({npts - 2}^3 unknowns), "
+                      f"{levels} levels, {cycles} cycles, solve loop only ({r['seconds']:.2f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--npts", type=int, default=1025)
+    ap.add_argument("--levels", type=int, default=0, help="0: down to one unknown")
+    ap.add_argument("--dim", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-npts", type=int, default=257)
+    ap.add_argument("--cpu-levels", type=int, default=8)
+    ap.add_argument("--cpu-cycles", type=int, default=5)
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    from multigrid_petsc_amd.solver import Solver
+    levels = args.levels
+    if levels <= 0:     # coarsen down to a single unknown: n_l = (npts-1)/2^l - 1 >= 1
+        levels = 0
+        while (args.npts - 1) % (2 ** levels) == 0 and (args.npts - 1) // (2 ** levels) - 1 >= 1:
+            levels += 1
+
+    dist = None
+    comm = None
+    if world > 1:
+        import torch.distributed as dist   # control plane only (id broadcast, barrier, max-reduce)
+        import torch
+        from multigrid_petsc_amd.comm import rccl_comm
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        comm = rccl_comm(rank, world, local_rank, dist)
+
+    scale = 6.0 / 7.0 if args.dim == 3 else 0.8
+    s = Solver(args.dim, args.npts, levels, v=(3, 3), maxiter=args.steps + args.warmup + 1, scale=scale,
+               device=local_rank, rank=rank, nranks=world, comm=comm.handle if comm else None)
+    s.set_rhs_problem()
+
+    def barrier():
+        s.sync()                           # device-wide synchronise through the C ABI (all streams)
+        if dist is not None:
+            dist.barrier()
+
+    s.cycles(args.warmup)                  # untimed warm-up steps
+    barrier()
+    s.profile(True)
+    t0 = time.perf_counter()
+    s.cycles(args.steps)                   # EXACTLY K timed steps
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof_ms, prof_n = s.profile_read()
+
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    dof_per_cycle = s.dof_updates_per_cycle
+    value = dof_per_cycle * args.steps / elapsed
+    n0 = args.npts - 2
+    local_unknowns = s.local_unknowns
+    rn = s.rnorm
+    out = None
+    if rank == 0:
+        sweep_ms = prof_ms / max(prof_n, 1)
+        achieved = JACOBI_BYTES_PER_DOF * local_unknowns / (sweep_ms * 1e-3) / 1e9 if prof_n else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and world == 1 and args.npts == 1025:
+            try:
+                traffic = json.load(open(tpath)).get("jacobi_sweep_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "fp64 DOF-updates/sec per V-cycle at 1024^3",
+            "value": value, "unit": "DOF-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.dim}-D {2 * args.dim + 1}-point Poisson, npts={args.npts} "
+                                   f"({n0}^{args.dim} unknowns), {levels} levels, V(3,3), Richardson+Jacobi "
+                                   f"scale {scale:.6g}, one step = one V-cycle incl. residual norm",
+                       "decomposition": f"z-slabs x{world}" if world > 1 else "single GPU",
+                       "fine_unknowns": float(n0) ** args.dim,
+                       "dof_updates_per_cycle": dof_per_cycle},
+            "cycle_unknowns_per_s": float(n0) ** args.dim * args.steps / elapsed,
+            "residual_reduction_per_cycle": float((rn[-1] / rn[-1 - args.steps]) ** (1.0 / args.steps)) if len(rn) > args.steps else None,
+            "roofline": {"bound": "hbm", "kernel": "k_stencil<3,..,MODE_JACOBI> fine-level sweep",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                         "launches": prof_n, "avg_launch_ms": sweep_ms if prof_n else None,
+                         "algorithmic_bytes_per_launch": JACOBI_BYTES_PER_DOF * local_unknowns,
+                         "traffic": traffic},
+        }
+    s.close()
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args)
+            except Exception as e:   # the baseline is reporting only; never fail the GPU line for it
+                out["cpu_baseline"] = {"value": None, "error": str(e)}
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -61,6 +61,8 @@ int  mg_solver_reset(mg_solver *s);
 int  mg_solver_solve(mg_solver *s);
 /* exactly `ncycles` more V-cycles from the current state (no stopping test); used by bench.py */
 int  mg_solver_cycles(mg_solver *s, int ncycles);
+/* block until every stream of this solver's device is idle */
+int  mg_solver_sync(mg_solver *s);
 
 int    mg_solver_iterations(const mg_solver *s);          /* solver->numIter (src/solver.c:1558) */
 double mg_solver_bnorm(const mg_solver *s);

@@ -550,6 +550,7 @@ int mg_solver_cycles(mg_solver *s, int ncycles) {
     return 0;
 }
 
+int mg_solver_sync(mg_solver *s) { CHK(mgk_sync(s->ctx, NULL)); return 0; }
 int mg_solver_iterations(const mg_solver *s) { return s->iter; }
 double mg_solver_bnorm(const mg_solver *s) { return s->bnorm; }
 const double *mg_solver_rnorm(const mg_solver *s) { return s->rnorm; }

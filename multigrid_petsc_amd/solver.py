@@ -35,7 +35,7 @@ def _lib():
     L.mg_solver_create.argtypes = [C.POINTER(vp), C.POINTER(MgConfig), vp]
     L.mg_solver_destroy.argtypes = [vp]
     L.mg_last_error.restype = C.c_char_p
-    for f in ("mg_solver_set_rhs_problem", "mg_solver_reset", "mg_solver_solve"):
+    for f in ("mg_solver_set_rhs_problem", "mg_solver_reset", "mg_solver_solve", "mg_solver_sync"):
         getattr(L, f).restype = i
         getattr(L, f).argtypes = [vp]
     L.mg_solver_set_rhs_host.restype = i
@@ -142,6 +142,9 @@ class Solver:
 
     def cycles(self, n):
         self._chk(self.L.mg_solver_cycles(self.h, n))
+
+    def sync(self):
+        self._chk(self.L.mg_solver_sync(self.h))
 
     @property
     def iterations(self):
