@@ -47,6 +47,10 @@ void     mg_comm_loopback_shared_destroy(void *shared);
 mg_comm *mg_comm_loopback_create(void *shared, int rank);
 
 const char *mg_comm_last_error(void);
+void mg_comm_destroy(mg_comm *c);       /* calls c->destroy */
+/* plain-call forms of the hooks (bindings, tests) */
+int  mg_comm_halo(mg_comm *c, mgk_ctx *ctx, double *field, const mgk_geom *g);
+int  mg_comm_allreduce_sum(mg_comm *c, mgk_ctx *ctx, double *vals, int n);
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,7 @@ int  mgk_geom_init(mgk_geom *g, int dim, int nx, int ny, int nz);
 
 /* ---- context, memory, streams (thin wrappers so that host code stays C) ---- */
 int  mgk_device_count(void);
+int  mgk_set_device(int device);                                  /* hipSetDevice for the calling thread */
 int  mgk_ctx_create(mgk_ctx **ctx, int device);
 void mgk_ctx_destroy(mgk_ctx *ctx);
 const char *mgk_last_error(void);

@@ -25,7 +25,7 @@
 #define MG_MAX_LEVELS 32
 #define MG_MAX_TIMERS 4096
 
-static _Thread_local char g_mgerr[512] = "ok";
+static __thread char g_mgerr[512] = "ok";
 const char *mg_last_error(void) { return g_mgerr; }
 static int mgfail(int code, const char *what) {
     snprintf(g_mgerr, sizeof(g_mgerr), "%s (code %d; kernel layer: %s)", what, code, mgk_last_error());

@@ -49,6 +49,8 @@ extern "C" int mgk_device_count(void) {
     return n;
 }
 
+extern "C" int mgk_set_device(int device) { HIPCHK(hipSetDevice(device)); return 0; }
+
 extern "C" int mgk_ctx_create(mgk_ctx **out, int device) {
     if (!out) return fail(MGK_EINVAL, "mgk_ctx_create: null out");
     int n = 0;

@@ -21,6 +21,7 @@ def _sigs(L):
     S = {
         "mgk_geom_init": (i, [G, i, i, i, i]),
         "mgk_device_count": (i, []),
+        "mgk_set_device": (i, [i]),
         "mgk_ctx_create": (i, [C.POINTER(vp), i]),
         "mgk_ctx_destroy": (None, [vp]),
         "mgk_last_error": (C.c_char_p, []),
