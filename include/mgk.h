@@ -124,6 +124,22 @@ int  mgk_fill_separable_f64(mgk_ctx *ctx, const mgk_geom *g, const double *cx, c
 int  mgk_error_sums_f64(mgk_ctx *ctx, const mgk_geom *g, const double *u, const double *sx,
                         const double *sy, const double *sz, double *err3_host, void *stream);
 
+/* y = A x (MatMult on a stencil operator; src/solver.c:1516) */
+int  mgk_apply_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, const double *x, double *y, void *stream);
+
+/* ---- flat BLAS-1 / AIJ kernels behind the PETSc-surface shim (include/petscksp.h) ----
+ * n counts doubles of a whole allocation (padded fields: ghosts are 0 and stay 0). */
+int  mgk_flat_axpy(mgk_ctx *ctx, long n, double a, const double *x, double *y, void *stream);       /* VecAXPY  y += a x (src/solver.c:1517,1541) */
+int  mgk_flat_aypx(mgk_ctx *ctx, long n, double a, const double *x, double *y, void *stream);       /* VecAYPX  y = x + a y */
+int  mgk_flat_axpbypcz(mgk_ctx *ctx, long n, double a, double b, double g, const double *x, const double *y, double *z, void *stream);
+int  mgk_flat_fill(mgk_ctx *ctx, long n, double a, double *z, void *stream);                        /* VecSet (src/solver.c:1514) */
+int  mgk_flat_scale(mgk_ctx *ctx, long n, double a, double *z, void *stream);
+int  mgk_flat_pointwise_mult(mgk_ctx *ctx, long n, const double *x, const double *y, double *z, void *stream);
+int  mgk_flat_dot(mgk_ctx *ctx, long n, const double *x, const double *y, double *dot_host, void *stream);   /* VecDot / VecNorm^2 */
+/* generic assembled AIJ: y = A x, or y = addto + alpha*(A x) when addto != NULL (rows: ascending columns) */
+int  mgk_csr_mult_f64(mgk_ctx *ctx, long nrows, const long *rowptr, const int *col, const double *val,
+                      const double *x, double *y, double alpha, const double *addto, void *stream);
+
 /* tuning knob for the marching stencil kernel (profiling only): <=0 keeps the built-in choice */
 void mgk_set_tuning(int variant, int zchunk);
 

@@ -257,7 +257,7 @@ struct StArgs {
     double dinv, scale, ckm1, ck, cz;
 };
 
-enum { MODE_JACOBI = 0, MODE_RESIDUAL = 1, MODE_CHEBY = 2, MODE_RESNORM = 3 };
+enum { MODE_JACOBI = 0, MODE_RESIDUAL = 1, MODE_CHEBY = 2, MODE_RESNORM = 3, MODE_APPLY = 4 };
 
 template <int DIM, int WX, int WY, int RY, int MODE>
 __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs a) {
@@ -400,6 +400,8 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs a) {
                 double zx = rx * a.dinv, zy = ry * a.dinv;
                 o.x = (a.ckm1 * ac[r].x + a.ck * uc[r].x) + a.cz * zx;
                 o.y = (a.ckm1 * ac[r].y + a.ck * uc[r].y) + a.cz * zy;
+            } else if (MODE == MODE_APPLY) {
+                o.x = tx_; o.y = ty_;
             } else {
                 o.x = rx; o.y = ry;
             }
@@ -554,6 +556,15 @@ extern "C" int mgk_residual_f64(mgk_ctx *c, const mgk_geom *g, const double *coe
     a.u = u + g->org; a.b = b + g->org; a.out = r + g->org;
     set_coef(a, g, coef);
     return dispatch_st<MODE_RESIDUAL>(c, g, a, S(c, stream), nullptr);
+}
+
+extern "C" int mgk_apply_f64(mgk_ctx *c, const mgk_geom *g, const double *coef,
+                             const double *x, double *y, void *stream) {
+    if (!c || !g || !coef || !x || !y || x == y) return fail(MGK_EINVAL, "mgk_apply_f64: bad arguments");
+    StArgs a; memset(&a, 0, sizeof(a));
+    a.u = x + g->org; a.b = x + g->org; a.out = y + g->org;      // b is loaded but unused in this mode
+    set_coef(a, g, coef);
+    return dispatch_st<MODE_APPLY>(c, g, a, S(c, stream), nullptr);
 }
 
 static int finish_to_host(mgk_ctx *c, int nparts, int nslots, hipStream_t s, double *host_out) {
@@ -875,6 +886,74 @@ extern "C" int mgk_prolong_add_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geo
     grid.y = (unsigned)(rows < cap ? rows : cap);
     if (gf->dim == 3) hipLaunchKernelGGL(k_prolong_add<3>, grid, block, 0, S(c, stream), a, uc + gc->org, uf + gf->org);
     else hipLaunchKernelGGL(k_prolong_add<2>, grid, block, 0, S(c, stream), a, uc + gc->org, uf + gf->org);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// flat vector kernels (PETSc Vec BLAS-1 surface of the shim) and a generic CSR SpMV.
+// They run over a whole allocation (padded fields included: ghosts are zero and stay zero under
+// every linear combination), one element per lane-iteration, grid-stride.
+// ------------------------------------------------------------------------------------------
+enum { F_AXPY = 0, F_AYPX = 1, F_AXPBYPCZ = 2, F_FILL = 3, F_SCALE = 4, F_PWMULT = 5, F_COPY = 6 };
+template <int OP>
+__global__ void __launch_bounds__(256) k_flat(long n, double a, double b, double c, const double *x, const double *y, double *z) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride) {
+        if (OP == F_AXPY) z[q] = z[q] + a * x[q];                     // VecAXPY(z, a, x)
+        else if (OP == F_AYPX) z[q] = x[q] + a * z[q];                // VecAYPX(z, a, x)
+        else if (OP == F_AXPBYPCZ) z[q] = (a * x[q] + b * y[q]) + c * z[q];   // VecAXPBYPCZ(z,a,b,c,x,y)
+        else if (OP == F_FILL) z[q] = a;                              // VecSet
+        else if (OP == F_SCALE) z[q] = a * z[q];                      // VecScale
+        else if (OP == F_PWMULT) z[q] = x[q] * y[q];                  // VecPointwiseMult
+        else z[q] = x[q];                                             // VecCopy
+    }
+}
+__global__ void __launch_bounds__(256) k_flat_dot(long n, const double *x, const double *y, double *partials) {
+    __shared__ double red[16];
+    const long stride = (long)gridDim.x * blockDim.x;
+    double acc = 0.0;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride) acc += x[q] * y[q];
+    double s = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+// MatMult on assembled AIJ: one lane per row, ascending columns, separate multiply and add
+__global__ void __launch_bounds__(256) k_csr_mult(long nrows, const long *rowptr, const int *col, const double *val,
+                                                  const double *x, double *y, double alpha, const double *addto) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += stride) {
+        double sum = 0.0;
+        for (long q = rowptr[r]; q < rowptr[r + 1]; q++) sum += val[q] * x[col[q]];
+        y[r] = addto ? addto[r] + alpha * sum : sum;
+    }
+}
+static unsigned flat_grid(long n) {
+    long b = (n + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+#define FLAT_LAUNCH(OP, n, a, b, c_, x, y, z)                                                   \
+    do { hipLaunchKernelGGL(k_flat<OP>, dim3(flat_grid(n)), dim3(256), 0, S(c, stream), n, a, b, c_, x, y, z); \
+         HIPCHK(hipGetLastError()); return 0; } while (0)
+extern "C" int mgk_flat_axpy(mgk_ctx *c, long n, double a, const double *x, double *y, void *stream) { FLAT_LAUNCH(F_AXPY, n, a, 0.0, 0.0, x, nullptr, y); }
+extern "C" int mgk_flat_aypx(mgk_ctx *c, long n, double a, const double *x, double *y, void *stream) { FLAT_LAUNCH(F_AYPX, n, a, 0.0, 0.0, x, nullptr, y); }
+extern "C" int mgk_flat_axpbypcz(mgk_ctx *c, long n, double a, double b, double g, const double *x, const double *y, double *z, void *stream) { FLAT_LAUNCH(F_AXPBYPCZ, n, a, b, g, x, y, z); }
+extern "C" int mgk_flat_fill(mgk_ctx *c, long n, double a, double *z, void *stream) { FLAT_LAUNCH(F_FILL, n, a, 0.0, 0.0, nullptr, nullptr, z); }
+extern "C" int mgk_flat_scale(mgk_ctx *c, long n, double a, double *z, void *stream) { FLAT_LAUNCH(F_SCALE, n, a, 0.0, 0.0, nullptr, nullptr, z); }
+extern "C" int mgk_flat_pointwise_mult(mgk_ctx *c, long n, const double *x, const double *y, double *z, void *stream) { FLAT_LAUNCH(F_PWMULT, n, 0.0, 0.0, 0.0, x, y, z); }
+extern "C" int mgk_flat_dot(mgk_ctx *c, long n, const double *x, const double *y, double *dot_host, void *stream) {
+    if (!c || !x || !y || !dot_host) return fail(MGK_EINVAL, "mgk_flat_dot: bad arguments");
+    unsigned g = flat_grid(n);
+    if ((int)g > c->max_partials) g = c->max_partials;
+    hipLaunchKernelGGL(k_flat_dot, dim3(g), dim3(256), 0, S(c, stream), n, x, y, c->partials);
+    HIPCHK(hipGetLastError());
+    return finish_to_host(c, (int)g, 1, S(c, stream), dot_host);
+}
+extern "C" int mgk_csr_mult_f64(mgk_ctx *c, long nrows, const long *rowptr, const int *col, const double *val,
+                                const double *x, double *y, double alpha, const double *addto, void *stream) {
+    if (!c || !rowptr || !col || !val || !x || !y) return fail(MGK_EINVAL, "mgk_csr_mult_f64: bad arguments");
+    hipLaunchKernelGGL(k_csr_mult, dim3(flat_grid(nrows)), dim3(256), 0, S(c, stream), nrows, rowptr, col, val, x, y, alpha, addto);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -1,0 +1,827 @@
+/*
+ * petsc_shim.c -- the PETSc Mat/Vec/KSP call surface of include/petscksp.h on the MI355X kernel ABI.
+ *
+ * What the reference does with PETSc on the `-cycle 0` path (paths relative to /root/reference):
+ *   assembles A[l], res[l], pro[l] with MatSetValue            src/solver.c:185-253,1035-1154
+ *   fills b[0] with VecSetValue                                src/solver.c:558-620
+ *   runs KSPSolve / KSPBuildResidual / MatMult / VecAXPY / VecNorm in the cycle loop   :1530-1550
+ *   reads the solution back with VecGetArray                   src/solver.c:1255
+ * Here MatAssemblyEnd RECOGNISES the three operator families (constant 5-point rows, 9-entry full
+ * weighting rows, <=4-entry bilinear rows) and replaces them by matrix-free stencil operators on the
+ * padded device layout; anything else stays an assembled AIJ matrix that is multiplied on the GPU by a
+ * generic CSR kernel.  There is no CPU execution path for Mat/Vec/KSP operations.
+ *
+ * C99, no HIP: every device operation is a call into include/mgk.h.
+ */
+#include "petscksp.h"
+#include "mgk.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+/* ------------------------------------------------------------------ */
+/* global state, errors                                                */
+/* ------------------------------------------------------------------ */
+static mgk_ctx *G = NULL;
+static int g_notice_pc = 0;
+
+static void die(const char *what) {
+    fprintf(stderr, "[mgpetsc] FATAL: %s (kernel layer: %s)\n", what, mgk_last_error());
+    exit(86);
+}
+#define DEV(call) do { if ((call) != 0) die(#call); } while (0)
+#define UNSUPPORTED(name) do { fprintf(stderr, "[mgpetsc] FATAL: %s is outside the V-cycle hot path and is not implemented " \
+    "by this drop-in (see INTEGRATION.md)\n", name); exit(87); } while (0)
+
+static void need_ctx(void) {
+    if (!G) { fprintf(stderr, "[mgpetsc] FATAL: PetscInitialize() has not been called\n"); exit(85); }
+}
+
+/* ------------------------------------------------------------------ */
+/* options database: src/poisson.c:29,51-59; poisson.in                */
+/* ------------------------------------------------------------------ */
+typedef struct { char *key, *val; } opt_t;
+static opt_t *g_opt = NULL;
+static int g_nopt = 0, g_capopt = 0;
+
+static void opt_set(const char *key, const char *val) {
+    for (int q = 0; q < g_nopt; q++)
+        if (!strcmp(g_opt[q].key, key)) { free(g_opt[q].val); g_opt[q].val = strdup(val ? val : ""); return; }
+    if (g_nopt == g_capopt) { g_capopt = g_capopt ? 2 * g_capopt : 32; g_opt = (opt_t *)realloc(g_opt, sizeof(opt_t) * (size_t)g_capopt); }
+    g_opt[g_nopt].key = strdup(key); g_opt[g_nopt].val = strdup(val ? val : ""); g_nopt++;
+}
+static const char *opt_get(const char *key) {
+    for (int q = 0; q < g_nopt; q++) if (!strcmp(g_opt[q].key, key)) return g_opt[q].val;
+    return NULL;
+}
+static int is_key(const char *t) {      /* "-name": a dash followed by a letter (so "-1" stays a value) */
+    return t && t[0] == '-' && ((t[1] >= 'a' && t[1] <= 'z') || (t[1] >= 'A' && t[1] <= 'Z') || t[1] == '_');
+}
+static void opt_tokens(char **tok, int n) {
+    for (int q = 0; q < n; q++) {
+        if (!is_key(tok[q])) continue;
+        if (q + 1 < n && !is_key(tok[q + 1])) { opt_set(tok[q], tok[q + 1]); q++; }
+        else opt_set(tok[q], "");
+    }
+}
+static void opt_file(const char *path) {
+    FILE *f = fopen(path, "r");
+    if (!f) return;                              /* PETSc also treats a missing options file as empty */
+    char line[1024];
+    char *tok[4096]; int n = 0;
+    while (fgets(line, sizeof(line), f)) {
+        char *hash = strchr(line, '#');
+        if (hash) *hash = 0;
+        for (char *t = strtok(line, " \t\r\n"); t && n < 4096; t = strtok(NULL, " \t\r\n")) tok[n++] = strdup(t);
+    }
+    fclose(f);
+    opt_tokens(tok, n);
+    for (int q = 0; q < n; q++) free(tok[q]);
+}
+
+PetscErrorCode PetscInitialize(int *argc, char ***argv, const char file[], const char help[]) {
+    (void)help;
+    if (file) opt_file(file);
+    if (argc && argv && *argc > 1) opt_tokens(*argv + 1, *argc - 1);      /* command line overrides the file */
+    if (!G) {
+        int dev = 0;
+        const char *e = getenv("MGPETSC_DEVICE");
+        if (e) dev = atoi(e);
+        if (mgk_ctx_create(&G, dev) != 0) {
+            fprintf(stderr, "[mgpetsc] FATAL: cannot create a HIP context on device %d: %s\n"
+                            "          this PETSc-surface drop-in has no CPU fallback.\n", dev, mgk_last_error());
+            exit(84);
+        }
+    }
+    return 0;
+}
+PetscErrorCode PetscFinalize(void) {
+    if (G) { mgk_ctx_destroy(G); G = NULL; }
+    for (int q = 0; q < g_nopt; q++) { free(g_opt[q].key); free(g_opt[q].val); }
+    free(g_opt); g_opt = NULL; g_nopt = g_capopt = 0;
+    return 0;
+}
+static const char *opt_lookup(const char pre[], const char name[]) {
+    if (pre && pre[0]) {
+        char k[256];
+        snprintf(k, sizeof(k), "-%s%s", pre, name + 1);
+        const char *v = opt_get(k);
+        if (v) return v;
+        return NULL;
+    }
+    return opt_get(name);
+}
+PetscErrorCode PetscOptionsGetInt(void *o, const char pre[], const char name[], PetscInt *iv, PetscBool *set) {
+    (void)o;
+    const char *v = opt_lookup(pre, name);
+    if (v && v[0]) { *iv = (PetscInt)strtol(v, NULL, 10); if (set) *set = PETSC_TRUE; }
+    else if (set) *set = PETSC_FALSE;            /* absent: the variable is left untouched (src/poisson.c:38-41) */
+    return 0;
+}
+PetscErrorCode PetscOptionsGetReal(void *o, const char pre[], const char name[], PetscReal *dv, PetscBool *set) {
+    (void)o;
+    const char *v = opt_lookup(pre, name);
+    if (v && v[0]) { *dv = strtod(v, NULL); if (set) *set = PETSC_TRUE; }
+    else if (set) *set = PETSC_FALSE;
+    return 0;
+}
+PetscErrorCode PetscOptionsGetIntArray(void *o, const char pre[], const char name[], PetscInt iv[], PetscInt *nmax, PetscBool *set) {
+    (void)o;
+    const char *v = opt_lookup(pre, name);
+    if (!v || !v[0]) { if (set) *set = PETSC_FALSE; *nmax = 0; return 0; }
+    int n = 0;
+    const char *p = v;
+    while (*p && n < *nmax) {
+        char *end;
+        long x = strtol(p, &end, 10);
+        if (end == p) break;
+        iv[n++] = (PetscInt)x;
+        p = end;
+        while (*p == ',' || *p == ' ') p++;
+    }
+    *nmax = n;
+    if (set) *set = PETSC_TRUE;
+    return 0;
+}
+PetscErrorCode PetscOptionsSetValue(void *o, const char name[], const char value[]) { (void)o; opt_set(name, value); return 0; }
+
+PetscErrorCode PetscPrintf(MPI_Comm comm, const char format[], ...) {
+    (void)comm;
+    va_list ap; va_start(ap, format); vfprintf(stdout, format, ap); va_end(ap);
+    return 0;
+}
+PetscErrorCode PetscSynchronizedPrintf(MPI_Comm comm, const char format[], ...) {
+    (void)comm;
+    va_list ap; va_start(ap, format); vfprintf(stdout, format, ap); va_end(ap);
+    return 0;
+}
+PetscErrorCode PetscSynchronizedFlush(MPI_Comm comm, FILE *fd) { (void)comm; fflush(fd ? fd : stdout); return 0; }
+PetscErrorCode PetscLogStageRegister(const char name[], PetscLogStage *stage) { (void)name; if (stage) *stage = 1; return 0; }
+PetscErrorCode PetscLogStagePush(PetscLogStage stage) { (void)stage; return 0; }
+PetscErrorCode PetscLogStagePop(void) { return 0; }
+
+struct _p_PetscViewer { int kind; };
+static struct _p_PetscViewer g_viewer_stdout = {0}, g_viewer_draw = {1};
+PetscViewer PETSC_VIEWER_STDOUT_(MPI_Comm comm) { (void)comm; return &g_viewer_stdout; }
+PetscViewer PETSC_VIEWER_DRAW_(MPI_Comm comm) { (void)comm; return &g_viewer_draw; }
+
+/* ---- MPI: one process, one GPU ---- */
+int MPI_Comm_size(MPI_Comm comm, int *size) { (void)comm; *size = 1; return 0; }
+int MPI_Comm_rank(MPI_Comm comm, int *rank) { (void)comm; *rank = 0; return 0; }
+double MPI_Wtime(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec + 1e-9 * t.tv_nsec;
+}
+int MPI_Send(const void *b, int c, MPI_Datatype t, int d, int tag, MPI_Comm comm) {
+    (void)b; (void)c; (void)t; (void)d; (void)tag; (void)comm;
+    UNSUPPORTED("MPI_Send (more than one rank)");
+    return 1;
+}
+int MPI_Recv(void *b, int c, MPI_Datatype t, int s, int tag, MPI_Comm comm, MPI_Status *st) {
+    (void)b; (void)c; (void)t; (void)s; (void)tag; (void)comm; (void)st;
+    UNSUPPORTED("MPI_Recv (more than one rank)");
+    return 1;
+}
+
+/* ------------------------------------------------------------------ */
+/* Vec                                                                 */
+/* ------------------------------------------------------------------ */
+struct _p_Vec {
+    PetscInt n;             /* logical length */
+    int padded;             /* 1: grid field in the padded layout `g`; 0: flat array of n doubles */
+    mgk_geom g;
+    long nalloc;            /* doubles on the device */
+    double *dev;
+    double *host;           /* compact lexicographic mirror (VecSetValue staging / VecGetArray) */
+    int host_dirty;         /* host holds newer values than the device */
+    PetscInt ranges[2];
+};
+
+static Vec vec_new(PetscInt n, const mgk_geom *g) {
+    need_ctx();
+    Vec v = (Vec)calloc(1, sizeof(*v));
+    v->n = n;
+    if (g) { v->padded = 1; v->g = *g; v->nalloc = g->total; }
+    else { v->padded = 0; v->nalloc = ((long)n + 15) / 16 * 16; if (v->nalloc < 16) v->nalloc = 16; }
+    void *p = NULL;
+    DEV(mgk_malloc(G, &p, sizeof(double) * (size_t)v->nalloc));
+    v->dev = (double *)p;
+    v->ranges[0] = 0; v->ranges[1] = n;
+    return v;
+}
+static void vec_upload(Vec v) {          /* host mirror -> device */
+    if (!v->host) return;
+    if (!v->padded) { DEV(mgk_h2d(G, v->dev, v->host, sizeof(double) * (size_t)v->n)); }
+    else {
+        void *tmp = NULL;
+        DEV(mgk_malloc(G, &tmp, sizeof(double) * (size_t)v->n));
+        DEV(mgk_h2d(G, tmp, v->host, sizeof(double) * (size_t)v->n));
+        DEV(mgk_pack_f64(G, &v->g, (const double *)tmp, v->dev, NULL));
+        DEV(mgk_sync(G, NULL));
+        mgk_free(G, tmp);
+    }
+    v->host_dirty = 0;
+}
+static void vec_download(Vec v) {        /* device -> host mirror */
+    if (!v->host) v->host = (double *)malloc(sizeof(double) * (size_t)(v->n > 0 ? v->n : 1));
+    if (!v->padded) { DEV(mgk_d2h(G, v->host, v->dev, sizeof(double) * (size_t)v->n)); }
+    else {
+        void *tmp = NULL;
+        DEV(mgk_malloc(G, &tmp, sizeof(double) * (size_t)v->n));
+        DEV(mgk_unpack_f64(G, &v->g, v->dev, (double *)tmp, NULL));
+        DEV(mgk_d2h(G, v->host, tmp, sizeof(double) * (size_t)v->n));
+        mgk_free(G, tmp);
+    }
+}
+static double *vdev(Vec v) { if (v->host_dirty) vec_upload(v); return v->dev; }
+static int same_layout(Vec a, Vec b) {
+    if (a->n != b->n || a->padded != b->padded) return 0;
+    if (a->padded) return a->g.dim == b->g.dim && a->g.nx == b->g.nx && a->g.ny == b->g.ny && a->g.nz == b->g.nz;
+    return 1;
+}
+static void need_same(Vec a, Vec b, const char *who) {
+    if (!same_layout(a, b)) { fprintf(stderr, "[mgpetsc] FATAL: %s: vectors of different size/layout\n", who); exit(88); }
+}
+
+PetscErrorCode VecCreateSeq(MPI_Comm comm, PetscInt n, Vec *v) { (void)comm; *v = vec_new(n, NULL); return 0; }
+PetscErrorCode VecDuplicate(Vec v, Vec *nv) { *nv = vec_new(v->n, v->padded ? &v->g : NULL); return 0; }
+PetscErrorCode VecDestroy(Vec *v) {
+    if (!v || !*v) return 0;
+    if (G) mgk_free(G, (*v)->dev);
+    free((*v)->host); free(*v); *v = NULL;
+    return 0;
+}
+PetscErrorCode VecGetSize(Vec v, PetscInt *n) { *n = v->n; return 0; }
+PetscErrorCode VecGetLocalSize(Vec v, PetscInt *n) { *n = v->n; return 0; }
+PetscErrorCode VecGetOwnershipRange(Vec v, PetscInt *lo, PetscInt *hi) { if (lo) *lo = 0; if (hi) *hi = v->n; return 0; }
+PetscErrorCode VecGetOwnershipRanges(Vec v, const PetscInt *ranges[]) { *ranges = v->ranges; return 0; }
+PetscErrorCode VecSetValue(Vec v, PetscInt row, PetscScalar value, InsertMode mode) {
+    if (row < 0) return 0;                                   /* PETSc ignores negative indices */
+    if (row >= v->n) { fprintf(stderr, "[mgpetsc] FATAL: VecSetValue: row %d out of range %d\n", row, v->n); exit(88); }
+    if (!v->host_dirty) { vec_download(v); v->host_dirty = 1; }      /* stage on the current values */
+    if (mode == ADD_VALUES) v->host[row] += value; else v->host[row] = value;
+    return 0;
+}
+PetscErrorCode VecAssemblyBegin(Vec v) { (void)v; return 0; }
+PetscErrorCode VecAssemblyEnd(Vec v) { if (v->host_dirty) vec_upload(v); return 0; }
+PetscErrorCode VecSet(Vec v, PetscScalar a) {
+    v->host_dirty = 0;
+    if (a == 0.0) { DEV(mgk_memset0(G, v->dev, sizeof(double) * (size_t)v->nalloc, NULL)); return 0; }
+    if (!v->padded) { DEV(mgk_flat_fill(G, v->n, a, v->dev, NULL)); return 0; }
+    /* padded: only the interior may be non-zero */
+    if (!v->host) v->host = (double *)malloc(sizeof(double) * (size_t)v->n);
+    for (PetscInt q = 0; q < v->n; q++) v->host[q] = a;
+    vec_upload(v);
+    return 0;
+}
+PetscErrorCode VecCopy(Vec x, Vec y) {
+    need_same(x, y, "VecCopy");
+    y->host_dirty = 0;
+    DEV(mgk_d2d(G, y->dev, vdev(x), sizeof(double) * (size_t)x->nalloc, NULL));
+    return 0;
+}
+PetscErrorCode VecScale(Vec v, PetscScalar a) { DEV(mgk_flat_scale(G, v->nalloc, a, vdev(v), NULL)); return 0; }
+PetscErrorCode VecAXPY(Vec y, PetscScalar a, Vec x) {       /* y = y + a x  (src/solver.c:1517,1541) */
+    need_same(x, y, "VecAXPY");
+    DEV(mgk_flat_axpy(G, y->nalloc, a, vdev(x), vdev(y), NULL));
+    return 0;
+}
+PetscErrorCode VecAYPX(Vec y, PetscScalar a, Vec x) {       /* y = x + a y */
+    need_same(x, y, "VecAYPX");
+    DEV(mgk_flat_aypx(G, y->nalloc, a, vdev(x), vdev(y), NULL));
+    return 0;
+}
+PetscErrorCode VecAXPBYPCZ(Vec z, PetscScalar a, PetscScalar b, PetscScalar c, Vec x, Vec y) {
+    need_same(x, z, "VecAXPBYPCZ"); need_same(y, z, "VecAXPBYPCZ");
+    DEV(mgk_flat_axpbypcz(G, z->nalloc, a, b, c, vdev(x), vdev(y), vdev(z), NULL));
+    return 0;
+}
+PetscErrorCode VecDot(Vec x, Vec y, PetscScalar *val) {
+    need_same(x, y, "VecDot");
+    DEV(mgk_flat_dot(G, x->nalloc, vdev(x), vdev(y), val, NULL));
+    return 0;
+}
+PetscErrorCode VecTDot(Vec x, Vec y, PetscScalar *val) { return VecDot(x, y, val); }
+PetscErrorCode VecNorm(Vec x, NormType type, PetscReal *val) {     /* src/solver.c:1512,1518,1546 */
+    if (type != NORM_2 && type != NORM_FROBENIUS) UNSUPPORTED("VecNorm with a norm other than NORM_2");
+    double ss;
+    DEV(mgk_flat_dot(G, x->nalloc, vdev(x), vdev(x), &ss, NULL));
+    *val = sqrt(ss);
+    return 0;
+}
+PetscErrorCode VecGetArray(Vec v, PetscScalar **a) {       /* src/solver.c:1255 */
+    if (!v->host_dirty) vec_download(v);
+    v->host_dirty = 1;                                      /* the caller may write through the pointer */
+    *a = v->host;
+    return 0;
+}
+PetscErrorCode VecRestoreArray(Vec v, PetscScalar **a) { if (a) *a = NULL; if (v->host_dirty) vec_upload(v); return 0; }
+PetscErrorCode VecView(Vec v, PetscViewer viewer) {
+    (void)viewer;
+    vec_download(v);
+    for (PetscInt q = 0; q < v->n; q++) printf("%g\n", v->host[q]);
+    return 0;
+}
+PetscErrorCode VecGetSubVector(Vec v, IS is, Vec *sub) { (void)v; (void)is; (void)sub; UNSUPPORTED("VecGetSubVector"); return 1; }
+PetscErrorCode VecRestoreSubVector(Vec v, IS is, Vec *sub) { (void)v; (void)is; (void)sub; UNSUPPORTED("VecRestoreSubVector"); return 1; }
+PetscErrorCode ISCreateGeneral(MPI_Comm c, PetscInt n, const PetscInt idx[], PetscCopyMode m, IS *is) {
+    (void)c; (void)n; (void)idx; (void)m; (void)is; UNSUPPORTED("ISCreateGeneral (delayed cycles)"); return 1;
+}
+PetscErrorCode ISDestroy(IS *is) { if (is) *is = NULL; return 0; }
+PetscErrorCode ISView(IS is, PetscViewer v) { (void)is; (void)v; return 0; }
+
+/* ------------------------------------------------------------------ */
+/* Mat                                                                 */
+/* ------------------------------------------------------------------ */
+enum { MAT_GENERIC = 0, MAT_STENCIL = 1, MAT_RESTRICT = 2, MAT_PROLONG = 3 };
+struct _p_Mat {
+    PetscInt m, n;
+    int *crow, *ccol; double *cval; long cnz, ccap;     /* MatSetValue stash (COO, insertion order) */
+    int assembled;
+    long *rowptr; int *col; double *val; long nz;        /* host CSR after assembly */
+    int kind;
+    mgk_geom gf, gc;                                     /* STENCIL: gf; RESTRICT/PROLONG: fine gf, coarse gc */
+    double coef[7];
+    long *d_rowptr; int *d_col; double *d_val; double *d_dinv;   /* device CSR (generic), lazily built */
+    int dev_stale;
+    Vec work;
+};
+
+PetscErrorCode MatCreateAIJ(MPI_Comm comm, PetscInt m, PetscInt n, PetscInt M, PetscInt N, PetscInt d_nz,
+                            const PetscInt d_nnz[], PetscInt o_nz, const PetscInt o_nnz[], Mat *A) {
+    (void)comm; (void)d_nnz; (void)o_nz; (void)o_nnz;
+    need_ctx();
+    Mat a = (Mat)calloc(1, sizeof(*a));
+    a->m = m >= 0 ? m : M; a->n = n >= 0 ? n : N;
+    a->ccap = (long)a->m * (d_nz > 0 ? d_nz : 8) + 16;
+    a->crow = (int *)malloc(sizeof(int) * (size_t)a->ccap);
+    a->ccol = (int *)malloc(sizeof(int) * (size_t)a->ccap);
+    a->cval = (double *)malloc(sizeof(double) * (size_t)a->ccap);
+    *A = a;
+    return 0;
+}
+PetscErrorCode MatSetValue(Mat A, PetscInt row, PetscInt col, PetscScalar value, InsertMode mode) {
+    (void)mode;                                          /* the reference only uses ADD_VALUES on fresh matrices */
+    if (row < 0 || col < 0) return 0;
+    if (A->assembled) UNSUPPORTED("MatSetValue after MatAssemblyEnd");
+    if (A->cnz == A->ccap) {
+        A->ccap = A->ccap * 2;
+        A->crow = (int *)realloc(A->crow, sizeof(int) * (size_t)A->ccap);
+        A->ccol = (int *)realloc(A->ccol, sizeof(int) * (size_t)A->ccap);
+        A->cval = (double *)realloc(A->cval, sizeof(double) * (size_t)A->ccap);
+    }
+    A->crow[A->cnz] = row; A->ccol[A->cnz] = col; A->cval[A->cnz] = value; A->cnz++;
+    return 0;
+}
+PetscErrorCode MatAssemblyBegin(Mat A, MatAssemblyType t) { (void)A; (void)t; return 0; }
+
+/* COO -> CSR: rows in ascending column order, duplicates accumulated in insertion order */
+static void mat_compress(Mat A) {
+    const long m = A->m, nz = A->cnz;
+    long *cnt = (long *)calloc((size_t)m + 1, sizeof(long));
+    for (long q = 0; q < nz; q++) cnt[A->crow[q] + 1]++;
+    for (long r = 0; r < m; r++) cnt[r + 1] += cnt[r];
+    long *pos = (long *)malloc(sizeof(long) * ((size_t)m + 1));
+    memcpy(pos, cnt, sizeof(long) * ((size_t)m + 1));
+    int *scol = (int *)malloc(sizeof(int) * (size_t)(nz ? nz : 1));
+    double *sval = (double *)malloc(sizeof(double) * (size_t)(nz ? nz : 1));
+    for (long q = 0; q < nz; q++) { long p = pos[A->crow[q]]++; scol[p] = A->ccol[q]; sval[p] = A->cval[q]; }
+    A->rowptr = (long *)malloc(sizeof(long) * ((size_t)m + 1));
+    A->col = (int *)malloc(sizeof(int) * (size_t)(nz ? nz : 1));
+    A->val = (double *)malloc(sizeof(double) * (size_t)(nz ? nz : 1));
+    long out = 0;
+    for (long r = 0; r < m; r++) {
+        A->rowptr[r] = out;
+        const long a = cnt[r], b = cnt[r + 1];
+        for (long q = a + 1; q < b; q++) {               /* stable insertion sort (rows are short) */
+            int c = scol[q]; double v = sval[q]; long p = q - 1;
+            while (p >= a && scol[p] > c) { scol[p + 1] = scol[p]; sval[p + 1] = sval[p]; p--; }
+            scol[p + 1] = c; sval[p + 1] = v;
+        }
+        for (long q = a; q < b; q++) {
+            if (out > A->rowptr[r] && A->col[out - 1] == scol[q]) A->val[out - 1] += sval[q];
+            else { A->col[out] = scol[q]; A->val[out] = sval[q]; out++; }
+        }
+    }
+    A->rowptr[m] = out; A->nz = out;
+    free(cnt); free(pos); free(scol); free(sval);
+    free(A->crow); free(A->ccol); free(A->cval); A->crow = A->ccol = NULL; A->cval = NULL; A->cnz = A->ccap = 0;
+}
+
+static int isqrt_exact(long v) { long r = (long)floor(sqrt((double)v) + 0.5); return (r * r == v) ? (int)r : -1; }
+
+/* constant 5-point rows in lexicographic numbering, out-of-grid neighbours absent (src/solver.c:239-251) */
+static int recognise_stencil(Mat A) {
+    if (A->m != A->n) return 0;
+    const int n = isqrt_exact(A->m);
+    if (n < 1 || (n & 1) == 0) return 0;
+    double c[5]; int have[5] = {0, 0, 0, 0, 0};
+    for (long r = 0; r < A->m; r++) {
+        const int i = (int)(r / n), j = (int)(r % n);
+        long q = A->rowptr[r];
+        const long e = A->rowptr[r + 1];
+        const long want[5] = {i > 0 ? r - n : -1, j > 0 ? r - 1 : -1, r, j < n - 1 ? r + 1 : -1, i < n - 1 ? r + n : -1};
+        for (int k = 0; k < 5; k++) {
+            if (want[k] < 0) continue;
+            if (q >= e || A->col[q] != want[k]) return 0;
+            if (!have[k]) { c[k] = A->val[q]; have[k] = 1; }
+            else if (A->val[q] != c[k]) return 0;
+            q++;
+        }
+        if (q != e) return 0;
+    }
+    if (!have[2] || c[2] == 0.0) return 0;
+    for (int k = 0; k < 5; k++) A->coef[k] = have[k] ? c[k] : 0.0;
+    if (mgk_geom_init(&A->gf, 2, n, n, 1)) return 0;
+    A->kind = MAT_STENCIL;
+    return 1;
+}
+/* full weighting rows [1 2 1;2 4 2;1 2 1]/16 centred on fine (2i+1,2j+1) (src/solver.c:1071-1092, matbuild.c:422-431) */
+static int recognise_restrict(Mat A) {
+    const int nc = isqrt_exact(A->m), nf = isqrt_exact(A->n);
+    if (nc < 1 || nf != 2 * nc + 1) return 0;
+    static const double w[3][3] = {{0.0625, 0.125, 0.0625}, {0.125, 0.25, 0.125}, {0.0625, 0.125, 0.0625}};
+    for (long r = 0; r < A->m; r++) {
+        const int i1 = (int)(r / nc), j1 = (int)(r % nc);
+        long q = A->rowptr[r];
+        if (A->rowptr[r + 1] - q != 9) return 0;
+        for (int di = 0; di < 3; di++)
+            for (int dj = 0; dj < 3; dj++, q++)
+                if (A->col[q] != (long)(2 * i1 + di) * nf + 2 * j1 + dj || A->val[q] != w[di][dj]) return 0;
+    }
+    if (mgk_geom_init(&A->gf, 2, nf, nf, 1) || mgk_geom_init(&A->gc, 2, nc, nc, 1)) return 0;
+    A->kind = MAT_RESTRICT;
+    return 1;
+}
+/* bilinear rows: weights 1, 1/2, 1/4 over the 1/2/4 parents (src/solver.c:1131-1152, matbuild.c:398-407) */
+static int recognise_prolong(Mat A) {
+    const int nf = isqrt_exact(A->m), nc = isqrt_exact(A->n);
+    if (nc < 1 || nf != 2 * nc + 1) return 0;
+    for (long r = 0; r < A->m; r++) {
+        const int i = (int)(r / nf), j = (int)(r % nf);
+        const int ic0 = (i & 1) ? (i - 1) / 2 : i / 2 - 1, ic1 = (i & 1) ? ic0 : i / 2;
+        const int jc0 = (j & 1) ? (j - 1) / 2 : j / 2 - 1, jc1 = (j & 1) ? jc0 : j / 2;
+        long q = A->rowptr[r];
+        const long e = A->rowptr[r + 1];
+        for (int ic = ic0; ic <= ic1; ic++) {
+            if (ic < 0 || ic >= nc) continue;
+            for (int jc = jc0; jc <= jc1; jc++) {
+                if (jc < 0 || jc >= nc) continue;
+                const double wt = ((i & 1) ? 1.0 : 0.5) * ((j & 1) ? 1.0 : 0.5);
+                if (q >= e || A->col[q] != (long)ic * nc + jc || A->val[q] != wt) return 0;
+                q++;
+            }
+        }
+        if (q != e) return 0;
+    }
+    if (mgk_geom_init(&A->gf, 2, nf, nf, 1) || mgk_geom_init(&A->gc, 2, nc, nc, 1)) return 0;
+    A->kind = MAT_PROLONG;
+    return 1;
+}
+
+PetscErrorCode MatAssemblyEnd(Mat A, MatAssemblyType t) {
+    if (t != MAT_FINAL_ASSEMBLY || A->assembled) return 0;
+    mat_compress(A);
+    A->assembled = 1;
+    A->kind = MAT_GENERIC;
+    if (!getenv("MGPETSC_NO_RECOGNITION"))
+        if (!recognise_stencil(A) && !recognise_restrict(A)) recognise_prolong(A);
+    A->dev_stale = 1;
+    return 0;
+}
+
+static void mat_device_csr(Mat A) {
+    if (!A->dev_stale && A->d_rowptr) return;
+    void *p;
+    if (!A->d_rowptr) {
+        DEV(mgk_malloc(G, &p, sizeof(long) * ((size_t)A->m + 1))); A->d_rowptr = (long *)p;
+        DEV(mgk_malloc(G, &p, sizeof(int) * (size_t)(A->nz ? A->nz : 1))); A->d_col = (int *)p;
+        DEV(mgk_malloc(G, &p, sizeof(double) * (size_t)(A->nz ? A->nz : 1))); A->d_val = (double *)p;
+        DEV(mgk_malloc(G, &p, sizeof(double) * (size_t)(A->m ? A->m : 1))); A->d_dinv = (double *)p;
+    }
+    DEV(mgk_h2d(G, A->d_rowptr, A->rowptr, sizeof(long) * ((size_t)A->m + 1)));
+    DEV(mgk_h2d(G, A->d_col, A->col, sizeof(int) * (size_t)A->nz));
+    DEV(mgk_h2d(G, A->d_val, A->val, sizeof(double) * (size_t)A->nz));
+    double *dinv = (double *)malloc(sizeof(double) * (size_t)(A->m ? A->m : 1));
+    for (long r = 0; r < A->m; r++) {
+        double d = 0.0;
+        for (long q = A->rowptr[r]; q < A->rowptr[r + 1]; q++) if (A->col[q] == r) d = A->val[q];
+        dinv[r] = 1.0 / d;                               /* PCJACOBI */
+    }
+    DEV(mgk_h2d(G, A->d_dinv, dinv, sizeof(double) * (size_t)A->m));
+    free(dinv);
+    A->dev_stale = 0;
+}
+
+PetscErrorCode MatCreateVecs(Mat A, Vec *right, Vec *left) {       /* src/solver.c:1172: (u, b) */
+    const mgk_geom *gr = NULL, *gl = NULL;
+    if (A->kind == MAT_STENCIL) gr = gl = &A->gf;
+    else if (A->kind == MAT_RESTRICT) { gr = &A->gf; gl = &A->gc; }
+    else if (A->kind == MAT_PROLONG) { gr = &A->gc; gl = &A->gf; }
+    if (right) *right = vec_new(A->n, gr);
+    if (left) *left = vec_new(A->m, gl);
+    return 0;
+}
+PetscErrorCode MatGetSize(Mat A, PetscInt *m, PetscInt *n) { if (m) *m = A->m; if (n) *n = A->n; return 0; }
+
+static int geom_eq(const mgk_geom *a, const mgk_geom *b) { return a->dim == b->dim && a->nx == b->nx && a->ny == b->ny && a->nz == b->nz; }
+static void need_vec(Vec v, int padded, const mgk_geom *g, PetscInt n, const char *who) {
+    int ok = (v->n == n) && (v->padded == padded) && (!padded || geom_eq(&v->g, g));
+    if (!ok) { fprintf(stderr, "[mgpetsc] FATAL: %s: vector does not match the operator's layout (create it with MatCreateVecs/VecDuplicate)\n", who); exit(88); }
+}
+
+PetscErrorCode MatMult(Mat A, Vec x, Vec y) {                       /* src/solver.c:1516,1535,1540 */
+    if (!A->assembled) UNSUPPORTED("MatMult on an unassembled matrix");
+    if (x == y) UNSUPPORTED("MatMult with x == y");
+    y->host_dirty = 0;
+    switch (A->kind) {
+    case MAT_STENCIL:
+        need_vec(x, 1, &A->gf, A->n, "MatMult"); need_vec(y, 1, &A->gf, A->m, "MatMult");
+        DEV(mgk_apply_f64(G, &A->gf, A->coef, vdev(x), y->dev, NULL));
+        break;
+    case MAT_RESTRICT:
+        need_vec(x, 1, &A->gf, A->n, "MatMult"); need_vec(y, 1, &A->gc, A->m, "MatMult");
+        DEV(mgk_restrict_fw_f64(G, &A->gf, &A->gc, vdev(x), y->dev, NULL));
+        break;
+    case MAT_PROLONG:
+        need_vec(x, 1, &A->gc, A->n, "MatMult"); need_vec(y, 1, &A->gf, A->m, "MatMult");
+        DEV(mgk_memset0(G, y->dev, sizeof(double) * (size_t)y->nalloc, NULL));      /* y = 0 + P x */
+        DEV(mgk_prolong_add_f64(G, &A->gf, &A->gc, vdev(x), y->dev, NULL));
+        break;
+    default:
+        need_vec(x, 0, NULL, A->n, "MatMult"); need_vec(y, 0, NULL, A->m, "MatMult");
+        mat_device_csr(A);
+        DEV(mgk_csr_mult_f64(G, A->m, A->d_rowptr, A->d_col, A->d_val, vdev(x), y->dev, 1.0, NULL, NULL));
+    }
+    return 0;
+}
+static Vec mat_work(Mat A, Vec like) { if (!A->work) VecDuplicate(like, &A->work); return A->work; }
+PetscErrorCode MatMultAdd(Mat A, Vec x, Vec y, Vec z) {            /* z = y + A x */
+    if (A->kind == MAT_GENERIC) {
+        need_vec(x, 0, NULL, A->n, "MatMultAdd");
+        mat_device_csr(A);
+        z->host_dirty = 0;
+        DEV(mgk_csr_mult_f64(G, A->m, A->d_rowptr, A->d_col, A->d_val, vdev(x), z->dev, 1.0, vdev(y), NULL));
+        return 0;
+    }
+    Vec t = mat_work(A, y);
+    MatMult(A, x, t);
+    if (z != y) VecCopy(y, z);
+    return VecAXPY(z, 1.0, t);
+}
+PetscErrorCode MatResidual(Mat A, Vec b, Vec x, Vec r) {           /* r = b - A x */
+    r->host_dirty = 0;
+    if (A->kind == MAT_STENCIL) {
+        need_vec(x, 1, &A->gf, A->n, "MatResidual");
+        DEV(mgk_residual_f64(G, &A->gf, A->coef, vdev(b), vdev(x), r->dev, NULL));
+        return 0;
+    }
+    if (A->kind == MAT_GENERIC) {
+        mat_device_csr(A);
+        DEV(mgk_csr_mult_f64(G, A->m, A->d_rowptr, A->d_col, A->d_val, vdev(x), r->dev, -1.0, vdev(b), NULL));
+        return 0;
+    }
+    MatMult(A, x, r);
+    return VecAYPX(r, -1.0, b);
+}
+PetscErrorCode MatScale(Mat A, PetscScalar a) {
+    for (long q = 0; q < A->nz; q++) A->val[q] *= a;
+    for (int k = 0; k < 7; k++) A->coef[k] *= a;
+    if (A->kind == MAT_RESTRICT || A->kind == MAT_PROLONG) A->kind = MAT_GENERIC;     /* weights no longer the canonical ones */
+    A->dev_stale = 1;
+    return 0;
+}
+PetscErrorCode MatMatMult(Mat A, Mat B, MatReuse s, PetscReal f, Mat *C) { (void)A; (void)B; (void)s; (void)f; (void)C; UNSUPPORTED("MatMatMult (additive cycles)"); return 1; }
+PetscErrorCode MatView(Mat A, PetscViewer v) {
+    (void)v;
+    static const char *kinds[] = {"assembled AIJ (generic CSR kernel)", "matrix-free 5-point stencil", "matrix-free full weighting", "matrix-free bilinear prolongation"};
+    printf("Mat Object: %d x %d, %ld nonzeros, device operator: %s\n", A->m, A->n, A->nz, kinds[A->kind]);
+    return 0;
+}
+PetscErrorCode MatDestroy(Mat *pA) {
+    if (!pA || !*pA) return 0;
+    Mat A = *pA;
+    free(A->crow); free(A->ccol); free(A->cval); free(A->rowptr); free(A->col); free(A->val);
+    if (G) {
+        if (A->d_rowptr) mgk_free(G, A->d_rowptr);
+        if (A->d_col) mgk_free(G, A->d_col);
+        if (A->d_val) mgk_free(G, A->d_val);
+        if (A->d_dinv) mgk_free(G, A->d_dinv);
+    }
+    if (A->work) VecDestroy(&A->work);
+    free(A); *pA = NULL;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* KSP / PC                                                            */
+/* ------------------------------------------------------------------ */
+enum { K_RICHARDSON = 0, K_CHEBYSHEV = 1, K_OTHER = 2 };
+enum { P_DEFAULT = 0, P_JACOBI = 1, P_NONE = 2 };
+struct _p_PC { KSP ksp; };
+struct _p_KSP {
+    Mat A;
+    int type, pc;
+    double scale, emin, emax;
+    PetscInt maxits;
+    int guess_nonzero;
+    KSPNormType normtype;
+    Vec work[3];
+    Vec b, x;                   /* vec_rhs / vec_sol of the last KSPSolve (KSPBuildResidual, src/solver.c:1534) */
+    PetscInt its;
+    char prefix[64];
+    struct _p_PC pcobj;
+};
+
+PetscErrorCode KSPCreate(MPI_Comm comm, KSP *out) {
+    (void)comm;
+    need_ctx();
+    KSP k = (KSP)calloc(1, sizeof(*k));
+    k->type = K_OTHER;          /* PETSc's default is GMRES: a type must be chosen */
+    k->pc = P_DEFAULT; k->scale = 1.0; k->maxits = 10000; k->normtype = KSP_NORM_DEFAULT;
+    k->pcobj.ksp = k;
+    *out = k;
+    return 0;
+}
+static int ksp_type_from(const char *t) {
+    if (!strcmp(t, KSPRICHARDSON)) return K_RICHARDSON;
+    if (!strcmp(t, KSPCHEBYSHEV)) return K_CHEBYSHEV;
+    return K_OTHER;
+}
+static int pc_type_from(const char *t) {
+    if (!strcmp(t, PCJACOBI)) return P_JACOBI;
+    if (!strcmp(t, PCNONE)) return P_NONE;
+    fprintf(stderr, "[mgpetsc] FATAL: -pc_type %s is not provided by this drop-in (available: jacobi, none)\n", t);
+    exit(87);
+}
+PetscErrorCode KSPSetType(KSP k, KSPType t) { k->type = ksp_type_from(t); return 0; }
+PetscErrorCode KSPSetOperators(KSP k, Mat A, Mat P) { (void)P; k->A = A; return 0; }
+PetscErrorCode KSPSetNormType(KSP k, KSPNormType n) { k->normtype = n; return 0; }
+PetscErrorCode KSPSetTolerances(KSP k, PetscReal rtol, PetscReal atol, PetscReal dtol, PetscInt maxits) {
+    (void)rtol; (void)atol; (void)dtol;          /* KSP_NORM_NONE: only max_it matters (src/solver.c:1473-1474) */
+    if (maxits != PETSC_DEFAULT) k->maxits = maxits;
+    return 0;
+}
+PetscErrorCode KSPRichardsonSetScale(KSP k, PetscReal s) { k->scale = s; return 0; }
+PetscErrorCode KSPChebyshevSetEigenvalues(KSP k, PetscReal emax, PetscReal emin) { k->emax = emax; k->emin = emin; return 0; }
+PetscErrorCode PetscObjectSetOptionsPrefix(void *obj, const char prefix[]) {
+    KSP k = (KSP)obj;           /* the reference only prefixes KSPs (src/solver.c:1624,1634,1643) */
+    snprintf(k->prefix, sizeof(k->prefix), "%s", prefix ? prefix : "");
+    return 0;
+}
+static const char *kopt(KSP k, const char *name) {
+    char key[128];
+    snprintf(key, sizeof(key), "-%s%s", k->prefix, name);
+    return opt_get(key);
+}
+PetscErrorCode KSPSetFromOptions(KSP k) {                         /* src/solver.c:1476,1492,1509 */
+    const char *v;
+    if ((v = kopt(k, "ksp_type")) && v[0]) k->type = ksp_type_from(v);
+    if ((v = kopt(k, "pc_type")) && v[0]) k->pc = pc_type_from(v);
+    if ((v = kopt(k, "ksp_richardson_scale")) && v[0]) k->scale = strtod(v, NULL);
+    if ((v = kopt(k, "ksp_max_it")) && v[0]) k->maxits = (PetscInt)strtol(v, NULL, 10);
+    if ((v = kopt(k, "ksp_chebyshev_eigenvalues")) && v[0]) {
+        char *end;
+        k->emin = strtod(v, &end);
+        while (*end == ',' || *end == ' ') end++;
+        k->emax = strtod(end, NULL);
+    }
+    return 0;
+}
+PetscErrorCode KSPSetInitialGuessNonzero(KSP k, PetscBool f) { k->guess_nonzero = (f == PETSC_TRUE); return 0; }
+PetscErrorCode KSPGetPC(KSP k, PC *pc) { *pc = &k->pcobj; return 0; }
+PetscErrorCode PCSetType(PC pc, PCType t) {
+    if (!strcmp(t, PCMG)) UNSUPPORTED("PCSetType(PCMG): PETSc's own multigrid is excluded (north star)");
+    pc->ksp->pc = pc_type_from(t);
+    return 0;
+}
+PetscErrorCode KSPGetIterationNumber(KSP k, PetscInt *its) { *its = k->its; return 0; }
+PetscErrorCode KSPSetResidualHistory(KSP k, PetscReal a[], PetscInt na, PetscBool r) { (void)k; (void)a; (void)na; (void)r; UNSUPPORTED("KSPSetResidualHistory"); return 1; }
+PetscErrorCode KSPMonitorSet(KSP k, PetscErrorCode (*m)(KSP, PetscInt, PetscReal, void *), void *c, PetscErrorCode (*d)(void **)) {
+    (void)k; (void)m; (void)c; (void)d; UNSUPPORTED("KSPMonitorSet (delayed cycles)"); return 1;
+}
+PetscErrorCode PCMGSetLevels(PC pc, PetscInt l, MPI_Comm *c) { (void)pc; (void)l; (void)c; UNSUPPORTED("PCMG"); return 1; }
+PetscErrorCode PCMGGetCoarseSolve(PC pc, KSP *k) { (void)pc; (void)k; UNSUPPORTED("PCMG"); return 1; }
+PetscErrorCode PCMGGetSmoother(PC pc, PetscInt l, KSP *k) { (void)pc; (void)l; (void)k; UNSUPPORTED("PCMG"); return 1; }
+PetscErrorCode PCMGSetInterpolation(PC pc, PetscInt l, Mat m) { (void)pc; (void)l; (void)m; UNSUPPORTED("PCMG"); return 1; }
+PetscErrorCode PCMGSetRestriction(PC pc, PetscInt l, Mat m) { (void)pc; (void)l; (void)m; UNSUPPORTED("PCMG"); return 1; }
+PetscErrorCode PCMGSetR(PC pc, PetscInt l, Vec c) { (void)pc; (void)l; (void)c; UNSUPPORTED("PCMG"); return 1; }
+PetscErrorCode PCMGSetRhs(PC pc, PetscInt l, Vec c) { (void)pc; (void)l; (void)c; UNSUPPORTED("PCMG"); return 1; }
+PetscErrorCode PCMGSetX(PC pc, PetscInt l, Vec c) { (void)pc; (void)l; (void)c; UNSUPPORTED("PCMG"); return 1; }
+
+static int ksp_pc(KSP k) {
+    if (k->pc == P_DEFAULT) {
+        if (!g_notice_pc) {
+            fprintf(stderr, "[mgpetsc] note: PETSc's default preconditioner (ILU(0)) is not provided; "
+                            "using -pc_type jacobi (pass it explicitly to silence this note)\n");
+            g_notice_pc = 1;
+        }
+        return P_JACOBI;
+    }
+    return k->pc;
+}
+static Vec ksp_work(KSP k, int q, Vec like) {
+    if (k->work[q] && !same_layout(k->work[q], like)) VecDestroy(&k->work[q]);
+    if (!k->work[q]) VecDuplicate(like, &k->work[q]);
+    return k->work[q];
+}
+static void swap_dev(Vec a, Vec b) { double *t = a->dev; a->dev = b->dev; b->dev = t; }
+
+/* KSPSolve, KSP_NORM_NONE: exactly max_it iterations (src/solver.c:1531,1536,1542) */
+PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
+    Mat A = k->A;
+    if (!A || !A->assembled) UNSUPPORTED("KSPSolve without assembled operators");
+    if (k->type == K_OTHER) UNSUPPORTED("KSPSolve with a Krylov type other than richardson/chebyshev");
+    need_same(b, x, "KSPSolve");
+    const int pc = ksp_pc(k);
+    const PetscInt maxit = k->maxits;
+    k->b = b; k->x = x; k->its = 0;
+    (void)vdev(b); (void)vdev(x);
+    /* KSPSolve zero-fills x when the guess flag is off; on the stencil path the first sweep overwrites the
+     * whole interior without reading x, so the fill is only issued when no sweep follows or on the AIJ path */
+    if (!k->guess_nonzero) {
+        x->host_dirty = 0;
+        if (maxit <= 0 || A->kind != MAT_STENCIL) DEV(mgk_memset0(G, x->dev, sizeof(double) * (size_t)x->nalloc, NULL));
+    }
+    if (maxit <= 0) return 0;
+
+    if (A->kind == MAT_STENCIL) {
+        need_vec(x, 1, &A->gf, A->n, "KSPSolve");
+        const double dinv = (pc == P_JACOBI) ? 1.0 / A->coef[2] : 1.0;
+        Vec w = ksp_work(k, 0, x);
+        if (k->type == K_RICHARDSON) {
+            for (PetscInt it = 0; it < maxit; it++) {
+                if (it == 0 && !k->guess_nonzero) DEV(mgk_jacobi_zero_f64(G, &A->gf, dinv, k->scale, b->dev, w->dev, NULL));
+                else DEV(mgk_jacobi_f64(G, &A->gf, A->coef, dinv, k->scale, b->dev, x->dev, w->dev, NULL));
+                swap_dev(x, w);
+            }
+            k->its = maxit;
+            return 0;
+        }
+        /* chebyshev, classic recurrence (see oracle/mgo.c) */
+        if (!(k->emax > k->emin && k->emin > 0.0)) UNSUPPORTED("chebyshev without -ksp_chebyshev_eigenvalues emin,emax (no eigenvalue estimation)");
+        Vec w2 = ksp_work(k, 1, x);
+        double scale = 2.0 / (k->emax + k->emin), alpha = 1.0 - scale * k->emin, Gamma = 1.0;
+        double mu = 1.0 / alpha, omegaprod = 2.0 / alpha, ckm1 = 1.0, ck = mu, ckp1;
+        double *pkm1 = x->dev, *pk = w->dev, *pkp1 = w2->dev, *t;
+        if (!k->guess_nonzero) DEV(mgk_jacobi_zero_f64(G, &A->gf, dinv, scale, b->dev, pk, NULL));
+        else DEV(mgk_jacobi_f64(G, &A->gf, A->coef, dinv, scale, b->dev, pkm1, pk, NULL));
+        for (PetscInt it = 1; it < maxit; it++) {
+            ckp1 = 2.0 * mu * ck - ckm1;
+            double omega = omegaprod * ck / ckp1;
+            DEV(mgk_cheby_f64(G, &A->gf, A->coef, dinv, 1.0 - omega, omega, omega * Gamma * scale, b->dev, pk, pkm1, pkp1, NULL));
+            t = pkm1; pkm1 = pk; pk = pkp1; pkp1 = t;
+            ckm1 = ck; ck = ckp1;
+        }
+        x->dev = pk; w->dev = pkm1; w2->dev = pkp1;
+        k->its = maxit;
+        return 0;
+    }
+
+    if (A->kind != MAT_GENERIC) UNSUPPORTED("KSPSolve on a transfer operator");
+    if (k->type != K_RICHARDSON) UNSUPPORTED("chebyshev on an unrecognised (assembled AIJ) operator");
+    need_vec(x, 0, NULL, A->n, "KSPSolve");
+    mat_device_csr(A);
+    Vec r = ksp_work(k, 0, x), z = ksp_work(k, 1, x);
+    if (!k->guess_nonzero) DEV(mgk_d2d(G, r->dev, b->dev, sizeof(double) * (size_t)b->nalloc, NULL));
+    else DEV(mgk_csr_mult_f64(G, A->m, A->d_rowptr, A->d_col, A->d_val, x->dev, r->dev, -1.0, b->dev, NULL));
+    for (PetscInt it = 0; it < maxit; it++) {
+        if (pc == P_JACOBI) DEV(mgk_flat_pointwise_mult(G, A->m, r->dev, A->d_dinv, z->dev, NULL));
+        else DEV(mgk_d2d(G, z->dev, r->dev, sizeof(double) * (size_t)r->nalloc, NULL));
+        DEV(mgk_flat_axpy(G, A->m, k->scale, z->dev, x->dev, NULL));
+        if (it + 1 < maxit) DEV(mgk_csr_mult_f64(G, A->m, A->d_rowptr, A->d_col, A->d_val, x->dev, r->dev, -1.0, b->dev, NULL));
+    }
+    k->its = maxit;
+    return 0;
+}
+
+/* KSPBuildResidual(ksp, NULL, v, &V): V = v = b - A x (src/solver.c:1534,1545) */
+PetscErrorCode KSPBuildResidual(KSP k, Vec t, Vec v, Vec *V) {
+    (void)t;
+    if (!k->b || !k->x) UNSUPPORTED("KSPBuildResidual before KSPSolve");
+    if (!v) UNSUPPORTED("KSPBuildResidual with v == NULL");
+    MatResidual(k->A, k->b, k->x, v);
+    if (V) *V = v;
+    return 0;
+}
+PetscErrorCode KSPView(KSP k, PetscViewer viewer) {               /* src/solver.c:1562 */
+    (void)viewer;
+    static const char *tn[] = {"richardson", "chebyshev", "(unsupported)"}, *pn[] = {"jacobi (default ILU(0) unavailable)", "jacobi", "none"};
+    printf("KSP Object: 1 MPI process\n  type: %s\n", tn[k->type]);
+    if (k->type == K_RICHARDSON) printf("    damping factor=%g\n", k->scale);
+    if (k->type == K_CHEBYSHEV) printf("    eigenvalue targets used: min %g, max %g\n", k->emin, k->emax);
+    printf("  maximum iterations=%d, %s initial guess\n  using NONE norm type for convergence test\n", k->maxits,
+           k->guess_nonzero ? "nonzero" : "zero");
+    printf("PC Object: 1 MPI process\n  type: %s\n", pn[k->pc]);
+    if (k->A) { printf("  linear system matrix = precond matrix:\n  "); MatView(k->A, viewer); }
+    printf("  backend: mgpetsc (MI355X / gfx950 HIP kernels, fp64, matrix-free where recognised)\n");
+    return 0;
+}
+PetscErrorCode KSPDestroy(KSP *pk) {
+    if (!pk || !*pk) return 0;
+    for (int q = 0; q < 3; q++) if ((*pk)->work[q]) VecDestroy(&(*pk)->work[q]);
+    free(*pk); *pk = NULL;
+    return 0;
+}

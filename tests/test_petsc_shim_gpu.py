@@ -1,0 +1,231 @@
+"""GPU parity of the PETSc-surface drop-in (include/petscksp.h, libmgpetsc.so).
+
+1. ctypes leg: the call sequence of Assemble + MultigridVcycle (src/solver.c:1156-1209,1414-1575) issued through
+   the shim's own entry points (MatCreateAIJ/MatSetValue/.../KSPSolve/KSPBuildResidual/MatMult/VecAXPY/VecNorm),
+   with stencil recognition on (matrix-free kernels) and off (generic AIJ kernel): both must reproduce the oracle.
+2. reference-driver leg: the reference's UNMODIFIED src/*.c, linked against the drop-in by __graft_entry__.build()
+   (build/refdriver/poisson), run on the GPU with an options file of ours; its outputs (rData.dat, uData.dat,
+   eData.dat, iteration count) are compared with the oracle."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFDRV = os.path.join(ROOT, "build", "refdriver", "poisson")
+ADD, INSERT, FINAL, NORM_2 = 2, 1, 0, 1
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return Oracle()
+
+
+def _shim():
+    from multigrid_petsc_amd._lib import load_mgpetsc
+    L = load_mgpetsc()
+    vp, i, d = C.c_void_p, C.c_int, C.c_double
+    L.PetscInitialize.argtypes = [vp, vp, C.c_char_p, C.c_char_p]
+    L.PetscOptionsSetValue.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.MatCreateAIJ.argtypes = [i, i, i, i, i, i, vp, i, vp, C.POINTER(vp)]
+    L.MatSetValue.argtypes = [vp, i, i, d, i]
+    L.MatAssemblyBegin.argtypes = [vp, i]
+    L.MatAssemblyEnd.argtypes = [vp, i]
+    L.MatCreateVecs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.MatMult.argtypes = [vp, vp, vp]
+    L.MatDestroy.argtypes = [C.POINTER(vp)]
+    L.VecSetValue.argtypes = [vp, i, d, i]
+    L.VecAssemblyBegin.argtypes = [vp]
+    L.VecAssemblyEnd.argtypes = [vp]
+    L.VecDuplicate.argtypes = [vp, C.POINTER(vp)]
+    L.VecSet.argtypes = [vp, d]
+    L.VecAXPY.argtypes = [vp, d, vp]
+    L.VecNorm.argtypes = [vp, i, C.POINTER(d)]
+    L.VecGetArray.argtypes = [vp, C.POINTER(C.POINTER(d))]
+    L.VecRestoreArray.argtypes = [vp, C.POINTER(C.POINTER(d))]
+    L.VecDestroy.argtypes = [C.POINTER(vp)]
+    L.KSPCreate.argtypes = [i, C.POINTER(vp)]
+    L.KSPSetType.argtypes = [vp, C.c_char_p]
+    L.KSPSetOperators.argtypes = [vp, vp, vp]
+    L.KSPSetNormType.argtypes = [vp, i]
+    L.KSPSetTolerances.argtypes = [vp, d, d, d, i]
+    L.KSPSetFromOptions.argtypes = [vp]
+    L.KSPSetInitialGuessNonzero.argtypes = [vp, i]
+    L.KSPSolve.argtypes = [vp, vp, vp]
+    L.KSPBuildResidual.argtypes = [vp, vp, vp, C.POINTER(vp)]
+    L.KSPDestroy.argtypes = [C.POINTER(vp)]
+    L.MatView.argtypes = [vp, vp]
+    return L
+
+
+def _vcycle_through_shim(L, orc, npts, levels, scale, maxiter):
+    """Assemble (2-D) and cycle exactly as the reference's -cycle 0 path does, through the drop-in's API."""
+    vp = C.c_void_p
+    n = [(npts - 1) // 2 ** l - 1 for l in range(levels)]
+    A, u, b, R, P = [], [], [], [], []
+    for l in range(levels):
+        As, _ = orc.level_stencil(2, npts, l)
+        m = vp()
+        N = n[l] * n[l]
+        L.MatCreateAIJ(1, N, N, -1, -1, 6, None, 6, None, C.byref(m))
+        for row in range(N):
+            i0, j0 = divmod(row, n[l])
+            if i0 - 1 >= 0:
+                L.MatSetValue(m, row, row - n[l], As[0], ADD)
+            if j0 - 1 >= 0:
+                L.MatSetValue(m, row, row - 1, As[1], ADD)
+            L.MatSetValue(m, row, row, As[2], ADD)
+            if j0 + 1 < n[l]:
+                L.MatSetValue(m, row, row + 1, As[3], ADD)
+            if i0 + 1 < n[l]:
+                L.MatSetValue(m, row, row + n[l], As[4], ADD)
+        L.MatAssemblyBegin(m, FINAL)
+        L.MatAssemblyEnd(m, FINAL)
+        uu, bb = vp(), vp()
+        L.MatCreateVecs(m, C.byref(uu), C.byref(bb))
+        A.append(m); u.append(uu); b.append(bb)
+    rhs = orc.rhs(2, npts)
+    for row, val in enumerate(rhs):
+        L.VecSetValue(b[0], row, val, INSERT)
+    L.VecAssemblyBegin(b[0]); L.VecAssemblyEnd(b[0])
+    wr, wp = np.zeros(9), np.zeros(9)
+    orc.L.mgo_restriction_stencil(wr.ctypes.data)
+    orc.L.mgo_prolongation_stencil(wp.ctypes.data)
+    for l in range(levels - 1):
+        nf, nc = n[l], n[l + 1]
+        r, p = vp(), vp()
+        L.MatCreateAIJ(1, nc * nc, nf * nf, -1, -1, 9, None, 9, None, C.byref(r))
+        L.MatCreateAIJ(1, nf * nf, nc * nc, -1, -1, 4, None, 4, None, C.byref(p))
+        for c in range(nc * nc):
+            i1, j1 = divmod(c, nc)
+            for di in range(3):
+                for dj in range(3):
+                    f = (2 * i1 + di) * nf + 2 * j1 + dj
+                    L.MatSetValue(r, c, f, wr[di * 3 + dj], ADD)
+                    L.MatSetValue(p, f, c, wp[di * 3 + dj], ADD)
+        for m in (r, p):
+            L.MatAssemblyBegin(m, FINAL); L.MatAssemblyEnd(m, FINAL)
+        R.append(r); P.append(p)
+    # MultigridVcycle
+    rv = []
+    for l in range(levels):
+        t = vp(); L.VecDuplicate(b[l], C.byref(t)); rv.append(t)
+    ksp = []
+    for l in range(levels):
+        k = vp(); L.KSPCreate(1, C.byref(k))
+        L.KSPSetType(k, b"richardson"); L.KSPSetOperators(k, A[l], A[l]); L.KSPSetNormType(k, 0)
+        L.KSPSetTolerances(k, 1e-7, -2.0, -2.0, 3)
+        L.KSPSetFromOptions(k)
+        ksp.append(k)
+    val = C.c_double()
+    L.VecNorm(b[0], NORM_2, C.byref(val)); bnorm = val.value
+    L.VecSet(u[0], 0.0)
+    L.MatMult(A[0], u[0], rv[0]); L.VecAXPY(rv[0], -1.0, b[0])
+    L.VecNorm(rv[0], NORM_2, C.byref(val)); rn = [val.value]
+    it = 0
+    V = vp()
+    while it < maxiter and 1e8 * bnorm > rn[-1] and rn[-1] > 1e-7 * bnorm:
+        L.KSPSolve(ksp[0], b[0], u[0])
+        if it == 0:
+            L.KSPSetInitialGuessNonzero(ksp[0], 1)
+        for l in range(1, levels):
+            L.KSPBuildResidual(ksp[l - 1], None, rv[l - 1], C.byref(V))
+            L.MatMult(R[l - 1], V, b[l])
+            L.KSPSolve(ksp[l], b[l], u[l])
+            if l != levels - 1:
+                L.KSPSetInitialGuessNonzero(ksp[l], 1)
+        for l in range(levels - 2, -1, -1):
+            L.MatMult(P[l], u[l + 1], rv[l]); L.VecAXPY(u[l], 1.0, rv[l])
+            L.KSPSolve(ksp[l], b[l], u[l])
+            if l != 0:
+                L.KSPSetInitialGuessNonzero(ksp[l], 0)
+        L.KSPBuildResidual(ksp[0], None, rv[0], C.byref(V))
+        L.VecNorm(V, NORM_2, C.byref(val)); rn.append(val.value)
+        it += 1
+    px = C.POINTER(C.c_double)()
+    L.VecGetArray(u[0], C.byref(px))
+    sol = np.array([px[q] for q in range(n[0] * n[0])])
+    L.VecRestoreArray(u[0], C.byref(px))
+    for lst in (ksp,):
+        for h in lst:
+            L.KSPDestroy(C.byref(h))
+    for h in rv + u + b:
+        L.VecDestroy(C.byref(h))
+    for h in A + R + P:
+        L.MatDestroy(C.byref(h))
+    return it, np.array(rn), sol, bnorm
+
+
+@pytest.mark.parametrize("recognise", [True, False])
+@pytest.mark.parametrize("npts,levels,scale", [(17, 2, 0.8), (17, 4, 0.8), (33, 3, 1.0)])
+def test_shim_call_sequence_matches_oracle(orc, recognise, npts, levels, scale):
+    L = _shim()
+    L.PetscInitialize(None, None, None, None)
+    L.PetscOptionsSetValue(None, b"-pc_type", b"jacobi")
+    L.PetscOptionsSetValue(None, b"-ksp_richardson_scale", repr(scale).encode())
+    if recognise:
+        os.environ.pop("MGPETSC_NO_RECOGNITION", None)
+    else:
+        os.environ["MGPETSC_NO_RECOGNITION"] = "1"
+    try:
+        it, rn, sol, bnorm = _vcycle_through_shim(L, orc, npts, levels, scale, 150)
+    finally:
+        os.environ.pop("MGPETSC_NO_RECOGNITION", None)
+    ref = orc.vcycle(2, npts, levels, 3, 3, maxiter=150, scale=scale, use_csr=1)
+    assert it == ref["iters"]
+    assert abs(bnorm - ref["bnorm"]) <= 1e-12 * ref["bnorm"]
+    assert np.max(np.abs(rn - ref["rnorm"]) / ref["rnorm"]) <= 1e-12
+    assert np.array_equal(sol, ref["u"])
+
+
+def _run_reference_driver(tmp_path, opts, extra_env=None):
+    (tmp_path / "poisson.in").write_text("# options of the reference driver (same keys as its poisson.in)\n" + opts)
+    env = dict(os.environ)
+    env.update(extra_env or {})
+    p = subprocess.run([REFDRV], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:]
+    out = p.stdout
+    it = int(re.search(r"Number of iterations:\s+(\d+)", out).group(1))
+    rdat = np.array((tmp_path / "rData.dat").read_text().split(), dtype=np.float64)
+    u = np.array((tmp_path / "uData.dat").read_text().split(), dtype=np.float64)
+    e = np.array((tmp_path / "eData.dat").read_text().split(), dtype=np.float64)
+    return it, rdat, u, e, out
+
+
+@pytest.mark.skipif(not os.path.exists(REFDRV), reason="build/refdriver/poisson absent: __graft_entry__.build() links it only "
+                    "where /root/reference exists (the build container); the binary then travels with the snapshot")
+@pytest.mark.parametrize("npts,levels,scale,env", [
+    (17, 2, 0.8, None), (17, 2, 1.0, None), (129, 7, 0.8, None), (129, 6, 0.8, None), (513, 9, 0.8, None),
+    (33, 4, 0.8, {"MGPETSC_NO_RECOGNITION": "1"}),
+])
+def test_unmodified_reference_driver_on_the_gpu(orc, tmp_path, npts, levels, scale, env):
+    opts = (f"-npts {npts}\n-mesh 0\n-iter 1000\n-grids {levels}\n-levels {levels}\n-cycle 0\n-map 2\n-v 3,3\n-moreNorm 0\n"
+            f"-pc_type jacobi\n-ksp_richardson_scale {scale!r}\n")
+    it, rdat, u, e, out = _run_reference_driver(tmp_path, opts, env)
+    ref = orc.vcycle(2, npts, levels, 3, 3, maxiter=1000, scale=scale, use_csr=0)
+    assert it == ref["iters"]
+    want = ref["rnorm"] / ref["rnorm"][0]                # solver.c:1554-1557 normalises by rnorm[0]
+    assert rdat.size == it + 1
+    assert np.max(np.abs(rdat - want) / want) <= 1e-12
+    assert np.array_equal(u, ref["u"])                   # %.16e round-trips a double
+    eref = orc.error_norms(2, npts, ref["u"])
+    assert np.allclose(e, eref, rtol=1e-12, atol=0)
+    assert "matrix-free 5-point stencil" in out or env  # KSPView reports the recognised operator
+
+
+@pytest.mark.skipif(not os.path.exists(REFDRV), reason="build/refdriver/poisson absent")
+def test_reference_driver_default_options_file(orc, tmp_path):
+    """the reference's default run (poisson.in: npts 17, 2 grids, 2 levels, V(3,3), no -pc_type): PETSc would use ILU(0);
+    the drop-in says so on stderr and smooths with Jacobi, scale 1 -> 99 cycles."""
+    opts = "-npts 17\n-mesh 0\n-iter 100000\n-grids 2\n-levels 2\n-cycle 0\n-map 2\n-v 3,3\n-moreNorm 0\n"
+    it, rdat, u, e, out = _run_reference_driver(tmp_path, opts)
+    ref = orc.vcycle(2, 17, 2, 3, 3, maxiter=100000, scale=1.0, use_csr=0)
+    assert it == ref["iters"] == 99
+    assert "default preconditioner (ILU(0)) is not provided" in out
+    assert np.array_equal(u, ref["u"])
