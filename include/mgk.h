@@ -87,6 +87,10 @@ int  mgk_unpack_f64(mgk_ctx *ctx, const mgk_geom *g, const double *padded_dev, d
  * unew = u + scale*((b - A u)*dinv);  u and unew must be different buffers. */
 int  mgk_jacobi_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale,
                     const double *b, const double *u, double *unew, void *stream);
+/* the same sweep restricted to the marching planes [zbeg, zend) (3-D: z planes, 2-D: rows): lets a slab rank
+ * update its two boundary planes first, ship them, and sweep the interior while the halo travels */
+int  mgk_jacobi_range_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale,
+                          const double *b, const double *u, double *unew, int zbeg, int zend, void *stream);
 /* first sweep after KSPSolve zero-filled the guess: unew = scale*(b*dinv), u is not read */
 int  mgk_jacobi_zero_f64(mgk_ctx *ctx, const mgk_geom *g, double dinv, double scale,
                          const double *b, double *unew, void *stream);

@@ -38,6 +38,7 @@ typedef struct mg_config {
     int rank, nranks;   /* z-slab decomposition over `nranks` GPUs (1: whole grid) */
     int dist_min_n;     /* levels with n >= dist_min_n stay distributed, coarser ones are replicated; <=0: default 127 */
     int fuse;           /* bit 0: final residual fused with its norm (no rv write); default on (-1) */
+    int overlap;        /* nranks > 1: halo of sweep k on the comm stream while sweep k's interior runs; default on (-1) */
 } mg_config;
 
 void mg_config_default(mg_config *cfg);     /* poisson.in defaults + -pc_type jacobi -ksp_richardson_scale 1 */

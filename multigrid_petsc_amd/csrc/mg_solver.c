@@ -41,6 +41,8 @@ typedef struct mg_level {
     double coef[7], dinv, h;
     double *u, *b, *rv, *tmp, *p2;
     int guess_nonzero;      /* KSPSetInitialGuessNonzero state of ksp[l] (src/solver.c:1532,1537,1543) */
+    int u_ghost_ok;         /* z ghost planes of `u` hold the neighbours' current boundary planes */
+    int u_ghost_pending;    /* ... but the exchange is still in flight on the comm stream */
 } mg_level;
 
 struct mg_solver {
@@ -159,6 +161,7 @@ void mg_config_default(mg_config *c) {
     c->device = 0; c->precision = MG_PREC_FP64;
     c->rank = 0; c->nranks = 1; c->dist_min_n = 127;
     c->fuse = -1;
+    c->overlap = -1;
 }
 
 static int alloc_field(mg_solver *s, const mgk_geom *g, double **p) {
@@ -191,6 +194,7 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
     if (s->cfg.rtol <= 0) s->cfg.rtol = 1.e-7;
     if (s->cfg.dist_min_n <= 0) s->cfg.dist_min_n = 127;
     if (s->cfg.fuse < 0) s->cfg.fuse = 1;
+    if (s->cfg.overlap < 0) s->cfg.overlap = 1;
     if (s->cfg.nranks < 1) s->cfg.nranks = 1;
     s->comm = comm;
     s->levels = cfg->levels;
@@ -352,9 +356,29 @@ int mg_solver_error_norms(mg_solver *s, double err[3]) {
 /* ------------------------------------------------------------------ */
 /* the cycle                                                           */
 /* ------------------------------------------------------------------ */
+/* Every RCCL operation of a solver is issued on ITS comm stream (one communicator, one stream: a
+ * single total order on every rank); cross-stream events tie it to the compute stream.
+ * Blocking form: the exchange sees everything queued on the compute stream so far, and everything
+ * queued on the compute stream afterwards sees the ghosts. */
 static int halo(mg_solver *s, mg_level *L, double *field) {
     if (!L->distributed) return 0;
-    return s->comm->halo(s->comm, s->ctx, field, &L->g, NULL);
+    void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
+    CHK(mgk_stream_wait(s->ctx, ms, cs));
+    CHK(s->comm->halo(s->comm, s->ctx, field, &L->g, ms));
+    CHK(mgk_stream_wait(s->ctx, cs, ms));
+    return 0;
+}
+
+/* make the ghost planes of L->u valid and visible to the compute stream */
+static int ensure_u_ghosts(mg_solver *s, mg_level *L) {
+    if (!L->distributed) return 0;
+    if (L->u_ghost_pending) {
+        CHK(mgk_stream_wait(s->ctx, mgk_stream_compute(s->ctx), mgk_stream_comm(s->ctx)));
+        L->u_ghost_pending = 0;
+        L->u_ghost_ok = 1;
+    }
+    if (!L->u_ghost_ok) { CHK(halo(s, L, L->u)); L->u_ghost_ok = 1; }
+    return 0;
 }
 
 static void *prof_begin(mg_solver *s, int level) {
@@ -385,17 +409,33 @@ static int smooth(mg_solver *s, int l, int maxit) {
     mg_level *L = &s->L[l];
     const size_t bytes = sizeof(double) * (size_t)L->g.total;
     if (s->cfg.ksp_type == MG_KSP_RICHARDSON) {
-        if (maxit == 0 && !L->guess_nonzero) CHK(mgk_memset0(s->ctx, L->u, bytes, NULL));   /* KSPSolve zero-fills */
+        if (maxit == 0 && !L->guess_nonzero) { CHK(mgk_memset0(s->ctx, L->u, bytes, NULL)); L->u_ghost_ok = 0; L->u_ghost_pending = 0; }   /* KSPSolve zero-fills */
         for (int it = 0; it < maxit; it++) {
             if (it == 0 && !L->guess_nonzero) {
                 /* r = b, x = 0 + scale*(B b): u is not read */
                 CHK(mgk_jacobi_zero_f64(s->ctx, &L->g, L->dinv, s->cfg.scale, L->b, L->tmp, NULL));
+            } else if (L->distributed && s->cfg.overlap && L->g.nz >= 3) {
+                /* boundary planes first, ship them on the comm stream, sweep the interior meanwhile */
+                void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
+                const int nz = L->g.nz;
+                CHK(ensure_u_ghosts(s, L));
+                CHK(mgk_jacobi_range_f64(s->ctx, &L->g, L->coef, L->dinv, s->cfg.scale, L->b, L->u, L->tmp, 0, 1, cs));
+                CHK(mgk_jacobi_range_f64(s->ctx, &L->g, L->coef, L->dinv, s->cfg.scale, L->b, L->u, L->tmp, nz - 1, nz, cs));
+                CHK(mgk_stream_wait(s->ctx, ms, cs));
+                void *t = prof_begin(s, l);
+                CHK(mgk_jacobi_range_f64(s->ctx, &L->g, L->coef, L->dinv, s->cfg.scale, L->b, L->u, L->tmp, 1, nz - 1, cs));
+                prof_end(s, t);
+                CHK(s->comm->halo(s->comm, s->ctx, L->tmp, &L->g, ms));
+                swap_ptr(&L->u, &L->tmp);
+                L->u_ghost_pending = 1; L->u_ghost_ok = 0;
+                continue;
             } else {
-                CHK(halo(s, L, L->u));
+                CHK(ensure_u_ghosts(s, L));
                 void *t = prof_begin(s, l);
                 CHK(mgk_jacobi_f64(s->ctx, &L->g, L->coef, L->dinv, s->cfg.scale, L->b, L->u, L->tmp, NULL));
                 prof_end(s, t);
             }
+            L->u_ghost_ok = 0; L->u_ghost_pending = 0;
             swap_ptr(&L->u, &L->tmp);
         }
         return 0;
@@ -406,9 +446,10 @@ static int smooth(mg_solver *s, int l, int maxit) {
     double *pkm1 = L->u, *pk = L->tmp, *pkp1 = L->p2;
     if (!L->guess_nonzero) {
         CHK(mgk_memset0(s->ctx, pkm1, bytes, NULL));
+        L->u_ghost_ok = 0; L->u_ghost_pending = 0;
         if (maxit > 0) CHK(mgk_jacobi_zero_f64(s->ctx, &L->g, L->dinv, scale, L->b, pk, NULL));
     } else if (maxit > 0) {
-        CHK(halo(s, L, pkm1));
+        CHK(ensure_u_ghosts(s, L));
         CHK(mgk_jacobi_f64(s->ctx, &L->g, L->coef, L->dinv, scale, L->b, pkm1, pk, NULL));
     }
     if (maxit == 0) return 0;
@@ -422,13 +463,14 @@ static int smooth(mg_solver *s, int l, int maxit) {
         ckm1 = ck; ck = ckp1;
     }
     L->u = pk; L->tmp = pkm1; L->p2 = pkp1;
+    L->u_ghost_ok = 0; L->u_ghost_pending = 0;
     return 0;
 }
 
 /* KSPBuildResidual(ksp[l],NULL,rv[l],&r) : rv = b - A u (src/solver.c:1534,1545) */
 static int residual(mg_solver *s, int l) {
     mg_level *L = &s->L[l];
-    CHK(halo(s, L, L->u));
+    CHK(ensure_u_ghosts(s, L));
     CHK(mgk_residual_f64(s->ctx, &L->g, L->coef, L->b, L->u, L->rv, NULL));
     return 0;
 }
@@ -449,7 +491,12 @@ static int restrict_to(mg_solver *s, int l) {
         int c0 = s->zstart[s->cfg.rank], c1 = s->zstart[s->cfg.rank + 1];
         gc.nz = c1 - c0;
         CHK(mgk_restrict_fw_f64(s->ctx, &F->g, &gc, F->rv, Cq->b + (long)c0 * Cq->g.plane, NULL));
-        CHK(s->comm->allgather_planes(s->comm, s->ctx, Cq->b, &Cq->g, s->zstart, NULL));
+        {
+            void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
+            CHK(mgk_stream_wait(s->ctx, ms, cs));
+            CHK(s->comm->allgather_planes(s->comm, s->ctx, Cq->b, &Cq->g, s->zstart, ms));
+            CHK(mgk_stream_wait(s->ctx, cs, ms));
+        }
         return 0;
     }
     CHK(mgk_restrict_fw_f64(s->ctx, &F->g, &Cq->g, F->rv, Cq->b, NULL));
@@ -463,11 +510,15 @@ static int prolong_from(mg_solver *s, int l) {
         mgk_geom gc = Cq->g;
         int c0 = s->zstart[s->cfg.rank], c1 = s->zstart[s->cfg.rank + 1];
         gc.nz = c1 - c0;
+        if (F->u_ghost_pending) CHK(ensure_u_ghosts(s, F));
         CHK(mgk_prolong_add_f64(s->ctx, &F->g, &gc, Cq->u + (long)c0 * Cq->g.plane, F->u, NULL));
+        F->u_ghost_ok = 0;
         return 0;
     }
-    CHK(halo(s, Cq, Cq->u));
+    CHK(ensure_u_ghosts(s, Cq));
+    if (F->u_ghost_pending) CHK(ensure_u_ghosts(s, F));
     CHK(mgk_prolong_add_f64(s->ctx, &F->g, &Cq->g, Cq->u, F->u, NULL));
+    F->u_ghost_ok = 0;
     return 0;
 }
 
@@ -490,7 +541,7 @@ static int vcycle_once(mg_solver *s) {
     /* :1545-1546  r0 = b0 - A0 u0 ; ||r0|| */
     mg_level *L = &s->L[0];
     double ss;
-    CHK(halo(s, L, L->u));
+    CHK(ensure_u_ghosts(s, L));
     if (s->cfg.fuse & 1) CHK(mgk_residual_sumsq_f64(s->ctx, &L->g, L->coef, L->b, L->u, &ss, NULL));
     else {
         CHK(mgk_residual_f64(s->ctx, &L->g, L->coef, L->b, L->u, L->rv, NULL));
@@ -508,7 +559,7 @@ static int start(mg_solver *s) {
     double ss;
     CHK(mgk_sumsq_f64(s->ctx, &L->g, L->b, &ss, NULL));                 /* VecNorm(b[0]) :1512 */
     CHK(norm_from_sumsq(s, ss, &s->bnorm));
-    for (int l = 0; l < s->levels; l++) s->L[l].guess_nonzero = 0;
+    for (int l = 0; l < s->levels; l++) { s->L[l].guess_nonzero = 0; s->L[l].u_ghost_ok = 0; s->L[l].u_ghost_pending = 0; }
     CHK(mgk_memset0(s->ctx, L->u, sizeof(double) * (size_t)L->g.total, NULL));   /* VecSet(u[0],0) :1514 */
     /* rv = A u - b with u = 0 (:1516-1517); ||A u - b|| = ||b - A u||, evaluated by the same residual kernel */
     CHK(mgk_residual_sumsq_f64(s->ctx, &L->g, L->coef, L->b, L->u, &ss, NULL));

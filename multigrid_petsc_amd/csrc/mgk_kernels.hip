@@ -253,6 +253,7 @@ struct StArgs {
     int nx, ny, nm;       // nm: number of marching planes (nz in 3-D, ny in 2-D)
     long rs, ms;          // row stride (3-D: pitch), marching stride (3-D: plane, 2-D: pitch)
     int zc, ntx, nty;
+    int zbeg, zend;       // marching range [zbeg, zend) of this launch (whole grid: 0, nm)
     double a0, a1, a2, a3, a4, a5, a6;   // (m-1), S, W, C, E, N, (m+1); 2-D: S and N unused
     double dinv, scale, ckm1, ck, cz;
 };
@@ -283,8 +284,8 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs a) {
     const int x0 = tx * TX + xl;                 // global x (even)
     const int yb = (DIM == 3) ? ty * TY + wy * RY : 0;
     const int lrow = (DIM == 3) ? wy * RY : 0;   // first own row inside the LDS tile
-    const int z0 = tz * a.zc;
-    const int z1 = min(z0 + a.zc, a.nm);
+    const int z0 = a.zbeg + tz * a.zc;
+    const int z1 = min(z0 + a.zc, a.zend);
     if (z0 >= z1) return;
 
     const bool xok = x0 < a.nx;                  // pair in bounds (x0+1 <= nx: right ghost at most)
@@ -461,27 +462,29 @@ static int launch_st(mgk_ctx *c, StArgs &a, int nrows, hipStream_t s, int *nbloc
     a.ntx = (a.nx + 1 + TX - 1) / TX;
     a.nty = (DIM == 3) ? (nrows + TY - 1) / TY : 1;
     long tiles = (long)a.ntx * a.nty;
+    if (a.zend <= a.zbeg) { a.zbeg = 0; a.zend = a.nm; }
+    const int nmr = a.zend - a.zbeg;      // planes marched by this launch
     int zc = g_zchunk;
     if (zc <= 0) {
         // Few, long streams: ~256-512 blocks, each marching a long run of planes over a full-row tile,
         // keep HBM pages open (measured at 1023^3: 256 blocks x 1023 planes 5.7 TB/s vs 4096 blocks 5.2).
         // The store-free residual-norm mode is latency bound instead and wants many short blocks.
         long nch = (MODE == MODE_RESNORM) ? (4096 + tiles - 1) / tiles : (tiles >= 256) ? 1 : (512 + tiles - 1) / tiles;
-        zc = (int)((a.nm + nch - 1) / nch);
+        zc = (int)((nmr + nch - 1) / nch);
         if (zc < ((MODE == MODE_RESNORM) ? 16 : 8)) zc = (MODE == MODE_RESNORM) ? 16 : 8;
     }
-    if (zc > a.nm) zc = a.nm;
+    if (zc > nmr) zc = nmr;
     a.zc = zc;
-    long ntz = (a.nm + zc - 1) / zc;
+    long ntz = (nmr + zc - 1) / zc;
     long nblk = tiles * ntz;
     if (nblk > 0x7fffffffL) return fail(MGK_EINVAL, "stencil launch: too many blocks");
     if (MODE == MODE_RESNORM && nblk > c->max_partials) {
         // fewer, longer chunks so that the partial buffer suffices
         ntz = c->max_partials / tiles;
         if (ntz < 1) return fail(MGK_EINVAL, "stencil launch: partial buffer too small");
-        zc = (int)((a.nm + ntz - 1) / ntz);
+        zc = (int)((nmr + ntz - 1) / ntz);
         a.zc = zc;
-        ntz = (a.nm + zc - 1) / zc;
+        ntz = (nmr + zc - 1) / zc;
         nblk = tiles * ntz;
     }
     if (nblocks_out) *nblocks_out = (int)nblk;
@@ -534,13 +537,21 @@ static void set_coef(StArgs &a, const mgk_geom *g, const double *coef) {
     }
 }
 
-extern "C" int mgk_jacobi_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
-                              const double *b, const double *u, double *unew, void *stream) {
+extern "C" int mgk_jacobi_range_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
+                                    const double *b, const double *u, double *unew, int zbeg, int zend, void *stream) {
     if (!c || !g || !coef || !b || !u || !unew || u == unew) return fail(MGK_EINVAL, "mgk_jacobi_f64: bad arguments");
+    const int nm = (g->dim == 3) ? g->nz : g->ny;
+    if (zbeg < 0 || zend > nm || zbeg >= zend) return fail(MGK_EINVAL, "mgk_jacobi_range_f64: empty or out-of-range plane range");
     StArgs a; memset(&a, 0, sizeof(a));
     a.u = u + g->org; a.b = b + g->org; a.out = unew + g->org;
     set_coef(a, g, coef); a.dinv = dinv; a.scale = scale;
+    a.zbeg = zbeg; a.zend = zend;
     return dispatch_st<MODE_JACOBI>(c, g, a, S(c, stream), nullptr);
+}
+extern "C" int mgk_jacobi_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
+                              const double *b, const double *u, double *unew, void *stream) {
+    if (!g) return fail(MGK_EINVAL, "mgk_jacobi_f64: bad arguments");
+    return mgk_jacobi_range_f64(c, g, coef, dinv, scale, b, u, unew, 0, (g->dim == 3) ? g->nz : g->ny, stream);
 }
 
 extern "C" int mgk_cheby_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv,

@@ -70,6 +70,15 @@ def test_slab_ranks_equal_single_rank(P, npts, levels, dist_min_n):
 
 
 @pytest.mark.timeout(300)
+def test_overlapped_and_blocking_halo_agree():
+    """overlap=1: boundary planes -> comm-stream exchange while the interior sweeps; overlap=0: exchange, then sweep"""
+    a = _solve_ranks(4, 65, 5, 6.0 / 7.0, 40, 15, overlap=1)
+    b = _solve_ranks(4, 65, 5, 6.0 / 7.0, 40, 15, overlap=0)
+    for ra, rb in zip(a, b):
+        assert ra[0] == rb[0] and np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2])
+
+
+@pytest.mark.timeout(300)
 def test_slab_ranks_chebyshev(mgk):
     it1, rn1, u1, _ = _solve_single(65, 5, 1.0, 40, ksp_type="chebyshev", eigenvalues=(0.2, 2.0))
     res = _solve_ranks(4, 65, 5, 1.0, 40, 15, ksp_type="chebyshev", eigenvalues=(0.2, 2.0))
