@@ -144,6 +144,27 @@ int  mgk_flat_dot(mgk_ctx *ctx, long n, const double *x, const double *y, double
 int  mgk_csr_mult_f64(mgk_ctx *ctx, long nrows, const long *rowptr, const int *col, const double *val,
                       const double *x, double *y, double alpha, const double *addto, void *stream);
 
+/* ---- fp32 fields and the fp64<->fp32 bridges of the mixed-precision cycle (BASELINE.json config 5:
+ * "fp32 smoother sweeps with fp64 residual/correction"; no reference counterpart).
+ * Same kernels with T = float (one lane owns 4 unknowns); same canonical arithmetic evaluated in fp32;
+ * coefficients are passed as doubles and rounded to float once.  3-D only. */
+int  mgk_geom_init_f32(mgk_geom *g, int dim, int nx, int ny, int nz);      /* geometry of a float field (element units) */
+int  mgk_jacobi_f32(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale,
+                    const float *b, const float *u, float *unew, void *stream);
+int  mgk_jacobi_range_f32(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale,
+                          const float *b, const float *u, float *unew, int zbeg, int zend, void *stream);
+int  mgk_jacobi_zero_f32(mgk_ctx *ctx, const mgk_geom *g, double dinv, double scale, const float *b, float *unew, void *stream);
+int  mgk_residual_f32(mgk_ctx *ctx, const mgk_geom *g, const double *coef, const float *b, const float *u, float *r, void *stream);
+int  mgk_restrict_fw_f32(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const float *rf, float *bc, void *stream);
+int  mgk_prolong_add_f32(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const float *uc, float *uf, void *stream);
+/* fp64 residual b - A u stored as fp32 + its fp64 sum of squares, one pass (reads 16 B, writes 4 B per unknown) */
+int  mgk_residual_f64_to_f32(mgk_ctx *ctx, const mgk_geom *g, const mgk_geom *g32, const double *coef,
+                             const double *b, const double *u, float *r32, double *sumsq_host, void *stream);
+/* u64 += (double) e32 */
+int  mgk_correct_f64_from_f32(mgk_ctx *ctx, const mgk_geom *g, const mgk_geom *g32, const float *e32, double *u, void *stream);
+int  mgk_pack_f32(mgk_ctx *ctx, const mgk_geom *g32, const double *compact_dev, float *padded_dev, void *stream);
+int  mgk_unpack_f32(mgk_ctx *ctx, const mgk_geom *g32, const float *padded_dev, double *compact_dev, void *stream);
+
 /* tuning knob for the marching stencil kernel (profiling only): <=0 keeps the built-in choice */
 void mgk_set_tuning(int variant, int zchunk);
 

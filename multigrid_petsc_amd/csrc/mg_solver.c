@@ -40,6 +40,8 @@ typedef struct mg_level {
     mgk_geom g;             /* local geometry */
     double coef[7], dinv, h;
     double *u, *b, *rv, *tmp, *p2;
+    mgk_geom g32;           /* mixed precision: geometry and fields of the fp32 correction cycle */
+    float *u32, *b32, *rv32, *tmp32;
     int guess_nonzero;      /* KSPSetInitialGuessNonzero state of ksp[l] (src/solver.c:1532,1537,1543) */
     int u_ghost_ok;         /* z ghost planes of `u` hold the neighbours' current boundary planes */
     int u_ghost_pending;    /* ... but the exchange is still in flight on the comm stream */
@@ -176,7 +178,8 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
     if (cfg->dim != 2 && cfg->dim != 3) return mgfail(MGK_EINVAL, "mg_solver_create: dim must be 2 or 3");
     if (cfg->levels < 1 || cfg->levels > MG_MAX_LEVELS) return mgfail(MGK_EINVAL, "mg_solver_create: bad level count");
     if (cfg->npts < 3) return mgfail(MGK_EINVAL, "mg_solver_create: npts < 3");
-    if (cfg->precision != MG_PREC_FP64) return mgfail(MGK_EINVAL, "mg_solver_create: mixed precision is not built yet");
+    if (cfg->precision == MG_PREC_MIXED && (cfg->dim != 3 || cfg->nranks > 1 || cfg->ksp_type != MG_KSP_RICHARDSON))
+        return mgfail(MGK_EINVAL, "mg_solver_create: mixed precision is built for 3-D, one GPU, Richardson+Jacobi");
     /* npts-1 must be divisible by 2^(levels-1) and the coarsest grid must keep >= 1 unknown */
     for (int l = 0; l < cfg->levels; l++) {
         int n = mg_grid_n(cfg->npts, l);
@@ -234,6 +237,18 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
         if (rc) { mg_solver_destroy(s); return mgfail(rc, "mg_solver_create: geometry"); }
         level_stencil(cfg->dim, L->n, L->coef, &L->h);
         L->dinv = 1.0 / L->coef[cfg->dim == 3 ? 3 : 2];      /* PCJACOBI: 1/diag(A) */
+        if (cfg->precision == MG_PREC_MIXED) {
+            /* fp64 only where the outer defect correction lives (level 0: u, b); fp32 everywhere else */
+            void *q = NULL;
+            if (l == 0 && ((rc = alloc_field(s, &L->g, &L->u)) || (rc = alloc_field(s, &L->g, &L->b)))) { mg_solver_destroy(s); return rc; }
+            if ((rc = mgk_geom_init_f32(&L->g32, 3, L->n, L->n, L->n))) { mg_solver_destroy(s); return mgfail(rc, "mg_solver_create: fp32 geometry"); }
+            float **f[4] = {&L->u32, &L->b32, &L->rv32, &L->tmp32};
+            for (int k = 0; k < 4; k++) {
+                if ((rc = mgk_malloc(s->ctx, &q, sizeof(float) * (size_t)L->g32.total))) { mg_solver_destroy(s); return mgfail(rc, "mg_solver_create: fp32 field"); }
+                *f[k] = (float *)q;
+            }
+            continue;
+        }
         if ((rc = alloc_field(s, &L->g, &L->u)) || (rc = alloc_field(s, &L->g, &L->b)) ||
             (rc = alloc_field(s, &L->g, &L->rv)) || (rc = alloc_field(s, &L->g, &L->tmp))) {
             mg_solver_destroy(s); return rc;
@@ -258,6 +273,10 @@ void mg_solver_destroy(mg_solver *s) {
             if (L->rv) mgk_free(s->ctx, L->rv);
             if (L->tmp) mgk_free(s->ctx, L->tmp);
             if (L->p2) mgk_free(s->ctx, L->p2);
+            if (L->u32) mgk_free(s->ctx, L->u32);
+            if (L->b32) mgk_free(s->ctx, L->b32);
+            if (L->rv32) mgk_free(s->ctx, L->rv32);
+            if (L->tmp32) mgk_free(s->ctx, L->tmp32);
         }
         mgk_ctx_destroy(s->ctx);
     }
@@ -522,8 +541,49 @@ static int prolong_from(mg_solver *s, int l) {
     return 0;
 }
 
+/* ---- mixed precision (BASELINE config 5): fp32 correction cycle inside an fp64 defect-correction loop ---- */
+static int smooth32(mg_solver *s, int l, int maxit, int guess_nonzero) {
+    mg_level *L = &s->L[l];
+    if (maxit == 0 && !guess_nonzero) CHK(mgk_memset0(s->ctx, L->u32, sizeof(float) * (size_t)L->g32.total, NULL));
+    for (int it = 0; it < maxit; it++) {
+        if (it == 0 && !guess_nonzero) CHK(mgk_jacobi_zero_f32(s->ctx, &L->g32, L->dinv, s->cfg.scale, L->b32, L->tmp32, NULL));
+        else {
+            void *t = prof_begin(s, l);
+            CHK(mgk_jacobi_f32(s->ctx, &L->g32, L->coef, L->dinv, s->cfg.scale, L->b32, L->u32, L->tmp32, NULL));
+            prof_end(s, t);
+        }
+        float *q = L->u32; L->u32 = L->tmp32; L->tmp32 = q;
+    }
+    return 0;
+}
+
+/* one outer iteration: e = Vcycle32((float) r) from e = 0;  u += (double) e;  r = b - A u (fp64), ||r|| */
+static int vcycle_once_mixed(mg_solver *s) {
+    const int levels = s->levels, *v = s->cfg.v;
+    CHK(smooth32(s, 0, v[0], 0));
+    for (int l = 1; l < levels; l++) {
+        mg_level *F = &s->L[l - 1], *Cq = &s->L[l];
+        CHK(mgk_residual_f32(s->ctx, &F->g32, F->coef, F->b32, F->u32, F->rv32, NULL));
+        CHK(mgk_restrict_fw_f32(s->ctx, &F->g32, &Cq->g32, F->rv32, Cq->b32, NULL));
+        CHK(smooth32(s, l, l == levels - 1 ? v[1] : v[0], 0));
+    }
+    for (int l = levels - 2; l >= 0; l--) {
+        CHK(mgk_prolong_add_f32(s->ctx, &s->L[l].g32, &s->L[l + 1].g32, s->L[l + 1].u32, s->L[l].u32, NULL));
+        CHK(smooth32(s, l, v[0], 1));
+    }
+    mg_level *L = &s->L[0];
+    double ss;
+    CHK(mgk_correct_f64_from_f32(s->ctx, &L->g, &L->g32, L->u32, L->u, NULL));
+    CHK(mgk_residual_f64_to_f32(s->ctx, &L->g, &L->g32, L->coef, L->b, L->u, L->b32, &ss, NULL));
+    s->rchk = sqrt(ss);
+    s->iter++;
+    if (s->iter < s->rnorm_cap) s->rnorm[s->iter] = s->rchk;
+    return 0;
+}
+
 /* body of the while loop, src/solver.c:1531-1549 */
 static int vcycle_once(mg_solver *s) {
+    if (s->cfg.precision == MG_PREC_MIXED) return vcycle_once_mixed(s);
     const int levels = s->levels, *v = s->cfg.v;
     CHK(smooth(s, 0, v[0]));                                            /* :1531 */
     if (s->iter == 0) s->L[0].guess_nonzero = 1;                        /* :1532 */
@@ -562,7 +622,8 @@ static int start(mg_solver *s) {
     for (int l = 0; l < s->levels; l++) { s->L[l].guess_nonzero = 0; s->L[l].u_ghost_ok = 0; s->L[l].u_ghost_pending = 0; }
     CHK(mgk_memset0(s->ctx, L->u, sizeof(double) * (size_t)L->g.total, NULL));   /* VecSet(u[0],0) :1514 */
     /* rv = A u - b with u = 0 (:1516-1517); ||A u - b|| = ||b - A u||, evaluated by the same residual kernel */
-    CHK(mgk_residual_sumsq_f64(s->ctx, &L->g, L->coef, L->b, L->u, &ss, NULL));
+    if (s->cfg.precision == MG_PREC_MIXED) CHK(mgk_residual_f64_to_f32(s->ctx, &L->g, &L->g32, L->coef, L->b, L->u, L->b32, &ss, NULL));
+    else CHK(mgk_residual_sumsq_f64(s->ctx, &L->g, L->coef, L->b, L->u, &ss, NULL));
     CHK(norm_from_sumsq(s, ss, &s->rchk));
     s->iter = 0;
     s->rnorm[0] = s->rchk;                                              /* :1520 */

@@ -246,27 +246,78 @@ __device__ __forceinline__ double block_max(double v, double *red) {
 // lane; x halos across tile borders are fetched by the two edge lanes of a row.
 // Each u plane is read from HBM once per tile column (+ halo lines that neighbouring tiles also
 // touch: L2 / Infinity-Cache hits), b once, the output written once: 24 B per unknown.
+// 16-byte lane vector: 2 doubles or 4 floats
+template <typename T> struct alignas(16) V16 { T v[16 / sizeof(T)]; };
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ V16<T> v16_zero() {
+    V16<T> r;
+#pragma unroll
+    for (int e = 0; e < (int)(16 / sizeof(T)); e++) r.v[e] = (T)0;
+    return r;
+}
+template <typename T> __device__ __forceinline__ V16<T> ldv(const T *p, bool ok) {
+    return ok ? *reinterpret_cast<const V16<T> *>(p) : v16_zero<T>();
+}
+__device__ __forceinline__ V16<double> ldv_stream(const double *p, bool ok) {
+    double2 t = ld2_stream(p, ok);
+    V16<double> r; r.v[0] = t.x; r.v[1] = t.y;
+    return r;
+}
+__device__ __forceinline__ V16<float> ldv_stream(const float *p, bool ok) {
+    V16<float> r = v16_zero<float>();
+    if (ok) {
+#if MGK_NT & 1
+        f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p));
+        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+#else
+        r = *reinterpret_cast<const V16<float> *>(p);
+#endif
+    }
+    return r;
+}
+__device__ __forceinline__ void stv_stream(double *p, const V16<double> &v) { st2_stream(p, make_double2(v.v[0], v.v[1])); }
+__device__ __forceinline__ void stv_stream(float *p, const V16<float> &v) {
+#if MGK_NT & 2
+    f4v t; t.x = v.v[0]; t.y = v.v[1]; t.z = v.v[2]; t.w = v.v[3];
+    __builtin_nontemporal_store(t, reinterpret_cast<f4v *>(p));
+#else
+    *reinterpret_cast<V16<float> *>(p) = v;
+#endif
+}
+
+// aligned pair of unknowns (row kernels): double2 / float2
+template <typename T> struct alignas(2 * sizeof(T)) P2 { T x, y; };
+__device__ __forceinline__ P2<double> ldp_stream(const double *p) { double2 t = ld2_stream(p, true); P2<double> r; r.x = t.x; r.y = t.y; return r; }
+__device__ __forceinline__ P2<float> ldp_stream(const float *p) { return *reinterpret_cast<const P2<float> *>(p); }
+__device__ __forceinline__ void stp_stream(double *p, P2<double> v) { st2_stream(p, make_double2(v.x, v.y)); }
+__device__ __forceinline__ void stp_stream(float *p, P2<float> v) { *reinterpret_cast<P2<float> *>(p) = v; }
+
+template <typename T>
 struct StArgs {
-    const double *u, *b, *aux;
-    double *out;
+    const T *u, *b, *aux;
+    T *out;
+    float *out32;          // MODE_RES32: float copy of the fp64 residual (own strides below)
     double *partials;
     int nx, ny, nm;       // nm: number of marching planes (nz in 3-D, ny in 2-D)
     long rs, ms;          // row stride (3-D: pitch), marching stride (3-D: plane, 2-D: pitch)
+    long ors, oms;        // strides of out32
     int zc, ntx, nty;
     int zbeg, zend;       // marching range [zbeg, zend) of this launch (whole grid: 0, nm)
-    double a0, a1, a2, a3, a4, a5, a6;   // (m-1), S, W, C, E, N, (m+1); 2-D: S and N unused
-    double dinv, scale, ckm1, ck, cz;
+    T a0, a1, a2, a3, a4, a5, a6;   // (m-1), S, W, C, E, N, (m+1); 2-D: S and N unused
+    T dinv, scale, ckm1, ck, cz;
 };
 
-enum { MODE_JACOBI = 0, MODE_RESIDUAL = 1, MODE_CHEBY = 2, MODE_RESNORM = 3, MODE_APPLY = 4 };
+enum { MODE_JACOBI = 0, MODE_RESIDUAL = 1, MODE_CHEBY = 2, MODE_RESNORM = 3, MODE_APPLY = 4, MODE_RES32 = 5 };
 
-template <int DIM, int WX, int WY, int RY, int MODE>
-__global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs a) {
-    constexpr int TX = 128 * WX;
+template <typename T, int DIM, int WX, int WY, int RY, int MODE>
+__global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
+    constexpr int VX = 16 / sizeof(T);           // unknowns per lane: one 16-byte access
+    constexpr int TX = 64 * VX * WX;
     constexpr int TY = (DIM == 3) ? WY * RY : 1;
-    constexpr int LW = TX + 4;
+    constexpr int LW = TX + 2 * VX;
     static_assert(DIM == 3 || (WY == 1 && RY == 1), "2-D marches along y: one row per tile");
-    __shared__ __attribute__((aligned(16))) double lds[2][TY][LW];
+    __shared__ __attribute__((aligned(16))) T lds[2][TY][LW];
+    using VT = V16<T>;
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wx = w % WX, wy = w / WX;
@@ -280,16 +331,16 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs a) {
     const int t2 = bid / a.ntx;
     const int ty = t2 % a.nty, tz = t2 / a.nty;
 
-    const int xl = wx * 128 + 2 * lane;          // local x of the own pair
-    const int x0 = tx * TX + xl;                 // global x (even)
+    const int xl = wx * 64 * VX + VX * lane;     // local x of the own vector
+    const int x0 = tx * TX + xl;                 // global x (multiple of VX)
     const int yb = (DIM == 3) ? ty * TY + wy * RY : 0;
     const int lrow = (DIM == 3) ? wy * RY : 0;   // first own row inside the LDS tile
     const int z0 = a.zbeg + tz * a.zc;
     const int z1 = min(z0 + a.zc, a.zend);
     if (z0 >= z1) return;
 
-    const bool xok = x0 < a.nx;                  // pair in bounds (x0+1 <= nx: right ghost at most)
-    const bool lastpair = (x0 + 1 == a.nx);      // .y is the right ghost: must stay 0
+    const bool xok = x0 < a.nx;                  // vector in bounds (x0+VX-1 <= nx: right ghost at most)
+    const bool lastvec = (x0 + VX > a.nx);       // elements at x >= nx are the right ghost / row padding: must stay 0
     bool rok[RY];
 #pragma unroll
     for (int r = 0; r < RY; r++) rok[r] = xok && (DIM == 2 || yb + r < a.ny);
@@ -297,44 +348,44 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs a) {
     const bool isW = (lane == 0 && wx == 0), isE = (lane == 63 && wx == WX - 1);
     const int xh = isW ? tx * TX - 1 : tx * TX + TX;
     const bool xhok = (isW || isE) && xh <= a.nx;
-    const int xhl = isW ? 1 : TX + 2;            // LDS column of the halo cell
+    const int xhl = isW ? VX - 1 : TX + VX;      // LDS column of the halo cell
 
     const long rowoff = (DIM == 3) ? (long)yb * a.rs : 0;
-    const double *up_ = a.u + rowoff + x0;       // own pair, row 0, plane 0
-    const double *bp_ = a.b + rowoff + x0;
-    const double *ap_ = (MODE == MODE_CHEBY) ? a.aux + rowoff + x0 : nullptr;
-    const double *hp_ = a.u + rowoff + xh;       // x-halo cell, row 0, plane 0
+    const T *up_ = a.u + rowoff + x0;            // own vector, row 0, plane 0
+    const T *bp_ = a.b + rowoff + x0;
+    const T *ap_ = (MODE == MODE_CHEBY) ? a.aux + rowoff + x0 : nullptr;
+    const T *hp_ = a.u + rowoff + xh;            // x-halo cell, row 0, plane 0
     // y halos across the tile border (3-D only)
     const bool needS = (DIM == 3) && (wy == 0);
     const bool needN = (DIM == 3) && (wy == WY - 1);
     const bool okS = needS && xok;                              // row yb-1 >= -1 always exists
     const bool okN = needN && xok && (yb + RY <= a.ny);         // ghost row ny is the last one
 
-    double2 um[RY], uc[RY], up[RY], uq[RY], bc[RY], bn[RY], ac[RY], an[RY];
-    double xp[RY], xq[RY];
-    double2 hS = make_double2(0, 0), hN = hS, hSn = hS, hNn = hS;
+    VT um[RY], uc[RY], up[RY], uq[RY], bc[RY], bn[RY], ac[RY], an[RY];
+    T xp[RY], xq[RY];
+    VT hS = v16_zero<T>(), hN = hS, hSn = hS, hNn = hS;
 
     // ---- prologue: planes z0-1, z0, z0+1; stage plane z0 in LDS ----
 #pragma unroll
     for (int r = 0; r < RY; r++) {
         const long ro = (long)r * a.rs;
-        um[r] = ld2(up_ + (long)(z0 - 1) * a.ms + ro, rok[r]);
-        uc[r] = ld2(up_ + (long)z0 * a.ms + ro, rok[r]);
-        up[r] = ld2(up_ + (long)(z0 + 1) * a.ms + ro, rok[r]);
-        bc[r] = ld2_stream(bp_ + (long)z0 * a.ms + ro, rok[r]);
-        if (MODE == MODE_CHEBY) ac[r] = ld2_stream(ap_ + (long)z0 * a.ms + ro, rok[r]);
+        um[r] = ldv(up_ + (long)(z0 - 1) * a.ms + ro, rok[r]);
+        uc[r] = ldv(up_ + (long)z0 * a.ms + ro, rok[r]);
+        up[r] = ldv(up_ + (long)(z0 + 1) * a.ms + ro, rok[r]);
+        bc[r] = ldv_stream(bp_ + (long)z0 * a.ms + ro, rok[r]);
+        if (MODE == MODE_CHEBY) ac[r] = ldv_stream(ap_ + (long)z0 * a.ms + ro, rok[r]);
         const bool hok = xhok && (DIM == 2 || yb + r < a.ny);
-        double xc = ld1(hp_ + (long)z0 * a.ms + ro, hok);
-        xp[r] = ld1(hp_ + (long)(z0 + 1) * a.ms + ro, hok);
-        *reinterpret_cast<double2 *>(&lds[0][lrow + r][xl + 2]) = uc[r];
+        T xc = hok ? hp_[(long)z0 * a.ms + ro] : (T)0;
+        xp[r] = hok ? hp_[(long)(z0 + 1) * a.ms + ro] : (T)0;
+        *reinterpret_cast<VT *>(&lds[0][lrow + r][xl + VX]) = uc[r];
         if (isW || isE) lds[0][lrow + r][xhl] = xc;
     }
     if (DIM == 3) {
-        hS = ld2(up_ + (long)z0 * a.ms - a.rs, okS);
-        hN = ld2(up_ + (long)z0 * a.ms + (long)RY * a.rs, okN);
+        hS = ldv(up_ + (long)z0 * a.ms - a.rs, okS);
+        hN = ldv(up_ + (long)z0 * a.ms + (long)RY * a.rs, okN);
     }
 
-    double acc = 0.0;   // MODE_RESNORM
+    double acc = 0.0;   // MODE_RESNORM / MODE_RES32
 
     for (int z = z0; z < z1; z++) {
         const int buf = (z - z0) & 1;
@@ -344,72 +395,77 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs a) {
 #pragma unroll
             for (int r = 0; r < RY; r++) {
                 const long ro = (long)r * a.rs;
-                uq[r] = ld2(up_ + (long)(z + 2) * a.ms + ro, rok[r]);
-                bn[r] = ld2_stream(bp_ + (long)(z + 1) * a.ms + ro, rok[r]);
-                if (MODE == MODE_CHEBY) an[r] = ld2_stream(ap_ + (long)(z + 1) * a.ms + ro, rok[r]);
+                uq[r] = ldv(up_ + (long)(z + 2) * a.ms + ro, rok[r]);
+                bn[r] = ldv_stream(bp_ + (long)(z + 1) * a.ms + ro, rok[r]);
+                if (MODE == MODE_CHEBY) an[r] = ldv_stream(ap_ + (long)(z + 1) * a.ms + ro, rok[r]);
                 const bool hok = xhok && (DIM == 2 || yb + r < a.ny);
-                xq[r] = ld1(hp_ + (long)(z + 2) * a.ms + ro, hok);
+                xq[r] = hok ? hp_[(long)(z + 2) * a.ms + ro] : (T)0;
             }
             if (DIM == 3) {
-                hSn = ld2(up_ + (long)(z + 1) * a.ms - a.rs, okS);
-                hNn = ld2(up_ + (long)(z + 1) * a.ms + (long)RY * a.rs, okN);
+                hSn = ldv(up_ + (long)(z + 1) * a.ms - a.rs, okS);
+                hNn = ldv(up_ + (long)(z + 1) * a.ms + (long)RY * a.rs, okN);
             }
         }
         __syncthreads();   // lds[buf] (plane z) complete
 
         // ---- neighbours of plane z ----
-        double Wn[RY], En[RY];
+        T Wn[RY], En[RY];
 #pragma unroll
         for (int r = 0; r < RY; r++) {
-            Wn[r] = lds[buf][lrow + r][xl + 1];
-            En[r] = lds[buf][lrow + r][xl + 4];
+            Wn[r] = lds[buf][lrow + r][xl + VX - 1];
+            En[r] = lds[buf][lrow + r][xl + 2 * VX];
         }
-        double2 Sn = hS, Nn = hN;
+        VT Sn = hS, Nn = hN;
         if (DIM == 3 && WY > 1) {
-            if (wy > 0) Sn = *reinterpret_cast<const double2 *>(&lds[buf][lrow - 1][xl + 2]);
-            if (wy < WY - 1) Nn = *reinterpret_cast<const double2 *>(&lds[buf][lrow + RY][xl + 2]);
+            if (wy > 0) Sn = *reinterpret_cast<const VT *>(&lds[buf][lrow - 1][xl + VX]);
+            if (wy < WY - 1) Nn = *reinterpret_cast<const VT *>(&lds[buf][lrow + RY][xl + VX]);
         }
 
         // ---- compute + store plane z ----
 #pragma unroll
         for (int r = 0; r < RY; r++) {
-            double2 s2 = (r == 0) ? Sn : uc[r > 0 ? r - 1 : 0];
-            double2 n2 = (r == RY - 1) ? Nn : uc[r < RY - 1 ? r + 1 : r];
-            double tx_, ty_;
-            if (DIM == 3) {
-                tx_ = a.a0 * um[r].x;           ty_ = a.a0 * um[r].y;
-                tx_ = tx_ + a.a1 * s2.x;        ty_ = ty_ + a.a1 * s2.y;
-                tx_ = tx_ + a.a2 * Wn[r];       ty_ = ty_ + a.a2 * uc[r].x;
-                tx_ = tx_ + a.a3 * uc[r].x;     ty_ = ty_ + a.a3 * uc[r].y;
-                tx_ = tx_ + a.a4 * uc[r].y;     ty_ = ty_ + a.a4 * En[r];
-                tx_ = tx_ + a.a5 * n2.x;        ty_ = ty_ + a.a5 * n2.y;
-                tx_ = tx_ + a.a6 * up[r].x;     ty_ = ty_ + a.a6 * up[r].y;
-            } else {
-                tx_ = a.a0 * um[r].x;           ty_ = a.a0 * um[r].y;
-                tx_ = tx_ + a.a2 * Wn[r];       ty_ = ty_ + a.a2 * uc[r].x;
-                tx_ = tx_ + a.a3 * uc[r].x;     ty_ = ty_ + a.a3 * uc[r].y;
-                tx_ = tx_ + a.a4 * uc[r].y;     ty_ = ty_ + a.a4 * En[r];
-                tx_ = tx_ + a.a6 * up[r].x;     ty_ = ty_ + a.a6 * up[r].y;
+            const VT s2 = (r == 0) ? Sn : uc[r > 0 ? r - 1 : 0];
+            const VT n2 = (r == RY - 1) ? Nn : uc[r < RY - 1 ? r + 1 : r];
+            VT o;
+#pragma unroll
+            for (int e = 0; e < VX; e++) {
+                const T wv = (e == 0) ? Wn[r] : uc[r].v[e > 0 ? e - 1 : 0];
+                const T ev = (e == VX - 1) ? En[r] : uc[r].v[e < VX - 1 ? e + 1 : e];
+                T t = a.a0 * um[r].v[e];
+                if (DIM == 3) t = t + a.a1 * s2.v[e];
+                t = t + a.a2 * wv;
+                t = t + a.a3 * uc[r].v[e];
+                t = t + a.a4 * ev;
+                if (DIM == 3) t = t + a.a5 * n2.v[e];
+                t = t + a.a6 * up[r].v[e];
+                const T res = bc[r].v[e] - t;
+                if (MODE == MODE_JACOBI) {
+                    const T zz = res * a.dinv;
+                    o.v[e] = uc[r].v[e] + a.scale * zz;
+                } else if (MODE == MODE_CHEBY) {
+                    const T zz = res * a.dinv;
+                    o.v[e] = (a.ckm1 * ac[r].v[e] + a.ck * uc[r].v[e]) + a.cz * zz;
+                } else if (MODE == MODE_APPLY) {
+                    o.v[e] = t;
+                } else {
+                    o.v[e] = res;
+                }
             }
-            double rx = bc[r].x - tx_, ry = bc[r].y - ty_;
-            double2 o;
-            if (MODE == MODE_JACOBI) {
-                double zx = rx * a.dinv, zy = ry * a.dinv;
-                o.x = uc[r].x + a.scale * zx;
-                o.y = uc[r].y + a.scale * zy;
-            } else if (MODE == MODE_CHEBY) {
-                double zx = rx * a.dinv, zy = ry * a.dinv;
-                o.x = (a.ckm1 * ac[r].x + a.ck * uc[r].x) + a.cz * zx;
-                o.y = (a.ckm1 * ac[r].y + a.ck * uc[r].y) + a.cz * zy;
-            } else if (MODE == MODE_APPLY) {
-                o.x = tx_; o.y = ty_;
-            } else {
-                o.x = rx; o.y = ry;
+            if (lastvec) {                       // the vector straddles the end of the row: ghost / padding stay 0
+#pragma unroll
+                for (int e = 0; e < VX; e++) if (x0 + e >= a.nx) o.v[e] = (T)0;
             }
-            if (lastpair) o.y = 0.0;
             if (rok[r]) {
-                if (MODE == MODE_RESNORM) acc += o.x * o.x + o.y * o.y;
-                else st2_stream(a.out + rowoff + x0 + (long)z * a.ms + (long)r * a.rs, o);
+                if (MODE == MODE_RESNORM || MODE == MODE_RES32) {
+#pragma unroll
+                    for (int e = 0; e < VX; e++) acc += (double)o.v[e] * (double)o.v[e];
+                }
+                if (MODE == MODE_RES32) {
+                    float2 f; f.x = (float)o.v[0]; f.y = (float)o.v[VX - 1];     // T == double here (VX == 2)
+                    *reinterpret_cast<float2 *>(a.out32 + (DIM == 3 ? (long)yb * a.ors : 0) + x0 + (long)z * a.oms + (long)r * a.ors) = f;
+                } else if (MODE != MODE_RESNORM) {
+                    stv_stream(a.out + rowoff + x0 + (long)z * a.ms + (long)r * a.rs, o);
+                }
             }
         }
 
@@ -417,7 +473,7 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs a) {
         if (more) {
 #pragma unroll
             for (int r = 0; r < RY; r++) {
-                *reinterpret_cast<double2 *>(&lds[buf ^ 1][lrow + r][xl + 2]) = up[r];
+                *reinterpret_cast<VT *>(&lds[buf ^ 1][lrow + r][xl + VX]) = up[r];
                 if (isW || isE) lds[buf ^ 1][lrow + r][xhl] = xp[r];
                 um[r] = uc[r]; uc[r] = up[r]; up[r] = uq[r];
                 bc[r] = bn[r]; xp[r] = xq[r];
@@ -427,7 +483,7 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs a) {
         }
     }
 
-    if (MODE == MODE_RESNORM) {
+    if (MODE == MODE_RESNORM || MODE == MODE_RES32) {
         __shared__ double red[16];
         double s = block_sum(acc, red);
         if (threadIdx.x == 0) a.partials[blockIdx.x] = s;
@@ -456,9 +512,11 @@ __global__ void __launch_bounds__(256) k_finish_max(const double *partials, int 
 static int g_variant = -1, g_zchunk = -1;
 extern "C" void mgk_set_tuning(int variant, int zchunk) { g_variant = variant; g_zchunk = zchunk; }
 
-template <int DIM, int WX, int WY, int RY, int MODE>
-static int launch_st(mgk_ctx *c, StArgs &a, int nrows, hipStream_t s, int *nblocks_out) {
-    constexpr int TX = 128 * WX, TY = (DIM == 3) ? WY * RY : 1;
+template <typename T, int DIM, int WX, int WY, int RY, int MODE>
+static int launch_st(mgk_ctx *c, StArgs<T> &a, int nrows, hipStream_t s, int *nblocks_out) {
+    constexpr int VX = 16 / sizeof(T);
+    constexpr int TX = 64 * VX * WX, TY = (DIM == 3) ? WY * RY : 1;
+    constexpr bool REDUCE = (MODE == MODE_RESNORM || MODE == MODE_RES32);
     a.ntx = (a.nx + 1 + TX - 1) / TX;
     a.nty = (DIM == 3) ? (nrows + TY - 1) / TY : 1;
     long tiles = (long)a.ntx * a.nty;
@@ -468,17 +526,21 @@ static int launch_st(mgk_ctx *c, StArgs &a, int nrows, hipStream_t s, int *nbloc
     if (zc <= 0) {
         // Few, long streams: ~256-512 blocks, each marching a long run of planes over a full-row tile,
         // keep HBM pages open (measured at 1023^3: 256 blocks x 1023 planes 5.7 TB/s vs 4096 blocks 5.2).
-        // The store-free residual-norm mode is latency bound instead and wants many short blocks.
-        long nch = (MODE == MODE_RESNORM) ? (4096 + tiles - 1) / tiles : (tiles >= 256) ? 1 : (512 + tiles - 1) / tiles;
+        // The store-free residual-norm mode is latency bound instead and wants many short blocks;
+        // so does the 2-D kernel (a tile is one row segment: little work per marching step).
+        long nch = (MODE == MODE_RESNORM) ? (4096 + tiles - 1) / tiles
+                 : (DIM == 2)             ? (1024 + tiles - 1) / tiles
+                 : (tiles >= 256)         ? 1 : (512 + tiles - 1) / tiles;
         zc = (int)((nmr + nch - 1) / nch);
-        if (zc < ((MODE == MODE_RESNORM) ? 16 : 8)) zc = (MODE == MODE_RESNORM) ? 16 : 8;
+        const int zmin = (MODE == MODE_RESNORM || DIM == 2) ? 16 : 8;
+        if (zc < zmin) zc = zmin;
     }
     if (zc > nmr) zc = nmr;
     a.zc = zc;
     long ntz = (nmr + zc - 1) / zc;
     long nblk = tiles * ntz;
     if (nblk > 0x7fffffffL) return fail(MGK_EINVAL, "stencil launch: too many blocks");
-    if (MODE == MODE_RESNORM && nblk > c->max_partials) {
+    if (REDUCE && nblk > c->max_partials) {
         // fewer, longer chunks so that the partial buffer suffices
         ntz = c->max_partials / tiles;
         if (ntz < 1) return fail(MGK_EINVAL, "stencil launch: partial buffer too small");
@@ -488,32 +550,27 @@ static int launch_st(mgk_ctx *c, StArgs &a, int nrows, hipStream_t s, int *nbloc
         nblk = tiles * ntz;
     }
     if (nblocks_out) *nblocks_out = (int)nblk;
-    hipLaunchKernelGGL((k_stencil<DIM, WX, WY, RY, MODE>), dim3((unsigned)nblk), dim3(64 * WX * WY), 0, s, a);
+    hipLaunchKernelGGL((k_stencil<T, DIM, WX, WY, RY, MODE>), dim3((unsigned)nblk), dim3(64 * WX * WY), 0, s, a);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
+// fp64 variants (tile = 128*WX x WY*RY)
 template <int MODE>
-static int dispatch_st(mgk_ctx *c, const mgk_geom *g, StArgs &a, hipStream_t s, int *nblocks) {
+static int dispatch_st(mgk_ctx *c, const mgk_geom *g, StArgs<double> &a, hipStream_t s, int *nblocks) {
     a.nx = g->nx;
     if (g->dim == 3) {
         a.ny = g->ny; a.nm = g->nz; a.rs = g->pitch; a.ms = g->plane;
         int v = g_variant;
         if (v < 0) v = (MODE == MODE_RESNORM && g->nx >= 255) ? 3 : (g->nx >= 1023) ? 12 : (g->nx >= 511) ? 6 : (g->nx >= 255) ? 2 : (g->nx >= 127 ? 1 : 0);
         switch (v) {
-            case 0: return launch_st<3, 1, 2, 2, MODE>(c, a, g->ny, s, nblocks);   // 128 x 4, 128 thr
-            case 1: return launch_st<3, 1, 4, 2, MODE>(c, a, g->ny, s, nblocks);   // 128 x 8, 256 thr
-            case 2: return launch_st<3, 2, 2, 2, MODE>(c, a, g->ny, s, nblocks);   // 256 x 4, 256 thr
-            case 3: return launch_st<3, 2, 2, 4, MODE>(c, a, g->ny, s, nblocks);   // 256 x 8, 256 thr
-            case 4: return launch_st<3, 4, 1, 4, MODE>(c, a, g->ny, s, nblocks);   // 512 x 4, 256 thr
-            case 5: return launch_st<3, 2, 1, 4, MODE>(c, a, g->ny, s, nblocks);   // 256 x 4, 128 thr
-            case 6: return launch_st<3, 4, 2, 2, MODE>(c, a, g->ny, s, nblocks);   // 512 x 4, 512 thr
-            case 7: return launch_st<3, 2, 4, 2, MODE>(c, a, g->ny, s, nblocks);   // 256 x 8, 512 thr
-            case 8: return launch_st<3, 8, 1, 2, MODE>(c, a, g->ny, s, nblocks);   // 1024 x 2, 512 thr
-            case 9: return launch_st<3, 8, 1, 4, MODE>(c, a, g->ny, s, nblocks);   // 1024 x 4, 512 thr
-            case 10: return launch_st<3, 4, 2, 4, MODE>(c, a, g->ny, s, nblocks);  // 512 x 8, 512 thr
-            case 11: return launch_st<3, 4, 1, 2, MODE>(c, a, g->ny, s, nblocks);  // 512 x 2, 256 thr
-            case 12: return launch_st<3, 8, 2, 2, MODE>(c, a, g->ny, s, nblocks);  // 1024 x 4, 1024 thr
+            case 0: return launch_st<double, 3, 1, 2, 2, MODE>(c, a, g->ny, s, nblocks);   // 128 x 4, 128 thr
+            case 1: return launch_st<double, 3, 1, 4, 2, MODE>(c, a, g->ny, s, nblocks);   // 128 x 8, 256 thr
+            case 2: return launch_st<double, 3, 2, 2, 2, MODE>(c, a, g->ny, s, nblocks);   // 256 x 4, 256 thr
+            case 3: return launch_st<double, 3, 2, 2, 4, MODE>(c, a, g->ny, s, nblocks);   // 256 x 8, 256 thr
+            case 6: return launch_st<double, 3, 4, 2, 2, MODE>(c, a, g->ny, s, nblocks);   // 512 x 4, 512 thr
+            case 9: return launch_st<double, 3, 8, 1, 4, MODE>(c, a, g->ny, s, nblocks);   // 1024 x 4, 512 thr
+            case 12: return launch_st<double, 3, 8, 2, 2, MODE>(c, a, g->ny, s, nblocks);  // 1024 x 4, 1024 thr
             default: return fail(MGK_EINVAL, "unknown 3-D stencil variant");
         }
     } else {
@@ -521,19 +578,36 @@ static int dispatch_st(mgk_ctx *c, const mgk_geom *g, StArgs &a, hipStream_t s, 
         int v = g_variant;
         if (v < 0) v = (g->nx >= 511) ? 2 : (g->nx >= 255 ? 1 : 0);
         switch (v) {
-            case 0: return launch_st<2, 1, 1, 1, MODE>(c, a, 1, s, nblocks);
-            case 1: return launch_st<2, 2, 1, 1, MODE>(c, a, 1, s, nblocks);
-            case 2: return launch_st<2, 4, 1, 1, MODE>(c, a, 1, s, nblocks);
+            case 0: return launch_st<double, 2, 1, 1, 1, MODE>(c, a, 1, s, nblocks);
+            case 1: return launch_st<double, 2, 2, 1, 1, MODE>(c, a, 1, s, nblocks);
+            case 2: return launch_st<double, 2, 4, 1, 1, MODE>(c, a, 1, s, nblocks);
             default: return fail(MGK_EINVAL, "unknown 2-D stencil variant");
         }
     }
 }
+// fp32 variants (tile = 256*WX x WY*RY; 3-D only: the mixed-precision inner cycle)
+template <int MODE>
+static int dispatch_st(mgk_ctx *c, const mgk_geom *g, StArgs<float> &a, hipStream_t s, int *nblocks) {
+    a.nx = g->nx;
+    if (g->dim != 3) return fail(MGK_EINVAL, "fp32 stencil kernels are built for 3-D only");
+    a.ny = g->ny; a.nm = g->nz; a.rs = g->pitch; a.ms = g->plane;
+    int v = g_variant;
+    if (v < 0) v = (g->nx >= 1023) ? 2 : (g->nx >= 511) ? 1 : 0;
+    switch (v) {
+        case 0: return launch_st<float, 3, 1, 2, 2, MODE>(c, a, g->ny, s, nblocks);   // 256 x 4, 128 thr
+        case 1: return launch_st<float, 3, 2, 2, 2, MODE>(c, a, g->ny, s, nblocks);   // 512 x 4, 256 thr
+        case 2: return launch_st<float, 3, 4, 2, 2, MODE>(c, a, g->ny, s, nblocks);   // 1024 x 4, 512 thr
+        case 3: return launch_st<float, 3, 4, 1, 4, MODE>(c, a, g->ny, s, nblocks);   // 1024 x 4, 256 thr
+        default: return fail(MGK_EINVAL, "unknown fp32 stencil variant");
+    }
+}
 
-static void set_coef(StArgs &a, const mgk_geom *g, const double *coef) {
+template <typename T>
+static void set_coef(StArgs<T> &a, const mgk_geom *g, const double *coef) {
     if (g->dim == 3) {
-        a.a0 = coef[0]; a.a1 = coef[1]; a.a2 = coef[2]; a.a3 = coef[3]; a.a4 = coef[4]; a.a5 = coef[5]; a.a6 = coef[6];
+        a.a0 = (T)coef[0]; a.a1 = (T)coef[1]; a.a2 = (T)coef[2]; a.a3 = (T)coef[3]; a.a4 = (T)coef[4]; a.a5 = (T)coef[5]; a.a6 = (T)coef[6];
     } else {
-        a.a0 = coef[0]; a.a1 = 0.0; a.a2 = coef[1]; a.a3 = coef[2]; a.a4 = coef[3]; a.a5 = 0.0; a.a6 = coef[4];
+        a.a0 = (T)coef[0]; a.a1 = (T)0; a.a2 = (T)coef[1]; a.a3 = (T)coef[2]; a.a4 = (T)coef[3]; a.a5 = (T)0; a.a6 = (T)coef[4];
     }
 }
 
@@ -542,7 +616,7 @@ extern "C" int mgk_jacobi_range_f64(mgk_ctx *c, const mgk_geom *g, const double 
     if (!c || !g || !coef || !b || !u || !unew || u == unew) return fail(MGK_EINVAL, "mgk_jacobi_f64: bad arguments");
     const int nm = (g->dim == 3) ? g->nz : g->ny;
     if (zbeg < 0 || zend > nm || zbeg >= zend) return fail(MGK_EINVAL, "mgk_jacobi_range_f64: empty or out-of-range plane range");
-    StArgs a; memset(&a, 0, sizeof(a));
+    StArgs<double> a; memset(&a, 0, sizeof(a));
     a.u = u + g->org; a.b = b + g->org; a.out = unew + g->org;
     set_coef(a, g, coef); a.dinv = dinv; a.scale = scale;
     a.zbeg = zbeg; a.zend = zend;
@@ -559,7 +633,7 @@ extern "C" int mgk_cheby_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, 
                              const double *b, const double *pk, const double *pkm1, double *pkp1, void *stream) {
     if (!c || !g || !coef || !b || !pk || !pkm1 || !pkp1 || pk == pkp1 || pkm1 == pkp1)
         return fail(MGK_EINVAL, "mgk_cheby_f64: bad arguments");
-    StArgs a; memset(&a, 0, sizeof(a));
+    StArgs<double> a; memset(&a, 0, sizeof(a));
     a.u = pk + g->org; a.b = b + g->org; a.aux = pkm1 + g->org; a.out = pkp1 + g->org;
     set_coef(a, g, coef); a.dinv = dinv; a.ckm1 = c_km1; a.ck = c_k; a.cz = c_z;
     return dispatch_st<MODE_CHEBY>(c, g, a, S(c, stream), nullptr);
@@ -568,7 +642,7 @@ extern "C" int mgk_cheby_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, 
 extern "C" int mgk_residual_f64(mgk_ctx *c, const mgk_geom *g, const double *coef,
                                 const double *b, const double *u, double *r, void *stream) {
     if (!c || !g || !coef || !b || !u || !r || u == r) return fail(MGK_EINVAL, "mgk_residual_f64: bad arguments");
-    StArgs a; memset(&a, 0, sizeof(a));
+    StArgs<double> a; memset(&a, 0, sizeof(a));
     a.u = u + g->org; a.b = b + g->org; a.out = r + g->org;
     set_coef(a, g, coef);
     return dispatch_st<MODE_RESIDUAL>(c, g, a, S(c, stream), nullptr);
@@ -577,7 +651,7 @@ extern "C" int mgk_residual_f64(mgk_ctx *c, const mgk_geom *g, const double *coe
 extern "C" int mgk_apply_f64(mgk_ctx *c, const mgk_geom *g, const double *coef,
                              const double *x, double *y, void *stream) {
     if (!c || !g || !coef || !x || !y || x == y) return fail(MGK_EINVAL, "mgk_apply_f64: bad arguments");
-    StArgs a; memset(&a, 0, sizeof(a));
+    StArgs<double> a; memset(&a, 0, sizeof(a));
     a.u = x + g->org; a.b = x + g->org; a.out = y + g->org;      // b is loaded but unused in this mode
     set_coef(a, g, coef);
     return dispatch_st<MODE_APPLY>(c, g, a, S(c, stream), nullptr);
@@ -596,7 +670,7 @@ static int finish_to_host(mgk_ctx *c, int nparts, int nslots, hipStream_t s, dou
 extern "C" int mgk_residual_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const double *coef,
                                       const double *b, const double *u, double *sumsq_host, void *stream) {
     if (!c || !g || !coef || !b || !u || !sumsq_host) return fail(MGK_EINVAL, "mgk_residual_sumsq_f64: bad arguments");
-    StArgs a; memset(&a, 0, sizeof(a));
+    StArgs<double> a; memset(&a, 0, sizeof(a));
     a.u = u + g->org; a.b = b + g->org; a.partials = c->partials;
     set_coef(a, g, coef);
     int nblk = 0;
@@ -625,17 +699,18 @@ __device__ __forceinline__ long row_offset(const RowArgs &a, long row) {
     return k * a.plane + i * a.pitch;
 }
 
-__global__ void __launch_bounds__(256) k_jacobi_zero(RowArgs a, double dinv, double scale, const double *b, double *out) {
+template <typename T>
+__global__ void __launch_bounds__(256) k_jacobi_zero(RowArgs a, T dinv, T scale, const T *b, T *out) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.npairs) return;
     const int x0 = 2 * p;
     ROW_RANGE(a.nrows) for (long row = row0_; row < row1_; row++) {
         const long o = row_offset(a, row) + x0;
-        double2 bv = ld2_stream(b + o, true), r;
-        double zx = bv.x * dinv, zy = bv.y * dinv;
+        P2<T> bv = ldp_stream(b + o), r;
+        T zx = bv.x * dinv, zy = bv.y * dinv;
         r.x = scale * zx; r.y = scale * zy;
-        if (x0 + 1 == a.nx) r.y = 0.0;
-        st2_stream(out + o, r);
+        if (x0 + 1 == a.nx) r.y = (T)0;
+        stp_stream(out + o, r);
     }
 }
 
@@ -730,7 +805,7 @@ extern "C" int mgk_jacobi_zero_f64(mgk_ctx *c, const mgk_geom *g, double dinv, d
     RowArgs a = row_args(g);
     dim3 grid, block;
     row_grid(a, a.npairs, grid, block, 1024);
-    hipLaunchKernelGGL(k_jacobi_zero, grid, block, 0, S(c, stream), a, dinv, scale, b + g->org, unew + g->org);
+    hipLaunchKernelGGL(k_jacobi_zero<double>, grid, block, 0, S(c, stream), a, dinv, scale, b + g->org, unew + g->org);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -805,20 +880,20 @@ struct XferArgs {
 
 // full weighting: one lane per coarse point; fine values summed in ascending fine index
 // (dk, di, dj) exactly like the 9/27-entry row of res (src/solver.c:1081-1090).
-template <int DIM>
-__global__ void __launch_bounds__(256) k_restrict(XferArgs a, const double *rf, double *bc) {
+template <typename T, int DIM>
+__global__ void __launch_bounds__(256) k_restrict(XferArgs a, const T *rf, T *bc) {
     const int jc = blockIdx.x * blockDim.x + threadIdx.x;
     if (jc > a.nxc) return;             // jc == nxc: the right ghost, written as 0
     const long nrows = (long)a.nyc * a.nzc;
     // weights: src/matbuild.c:422-431 (0.125-0.0625|1-i| ...); 3-D extension multiplies by {1/4,1/2,1/4}
-    const double w2[3][3] = {{0.0625, 0.125, 0.0625}, {0.125, 0.25, 0.125}, {0.0625, 0.125, 0.0625}};
-    const double w1[3] = {0.25, 0.5, 0.25};
+    const T w2[3][3] = {{(T)0.0625, (T)0.125, (T)0.0625}, {(T)0.125, (T)0.25, (T)0.125}, {(T)0.0625, (T)0.125, (T)0.0625}};
+    const T w1[3] = {(T)0.25, (T)0.5, (T)0.25};
     ROW_RANGE(nrows)
     int kc = (int)(row0_ / a.nyc), ic = (int)(row0_ - (long)kc * a.nyc);
     for (long row = row0_; row < row1_; row++) {
-        double sum = 0.0;
+        T sum = (T)0;
         if (jc < a.nxc) {
-            const double *base = rf + (DIM == 3 ? (long)(2 * kc) * a.plf : 0) + (long)(2 * ic) * a.pf + 2 * jc;
+            const T *base = rf + (DIM == 3 ? (long)(2 * kc) * a.plf : 0) + (long)(2 * ic) * a.pf + 2 * jc;
             if (DIM == 3) {
 #pragma unroll
                 for (int dk = 0; dk < 3; dk++)
@@ -843,8 +918,8 @@ __global__ void __launch_bounds__(256) k_restrict(XferArgs a, const double *rf, 
 // Row of pro summed in ascending coarse index (kc, ic, jc) (src/solver.c:1140-1148), then u + rv.
 // Out-of-grid parents are read from the coarse ghosts (0 at a global boundary, halo data at a slab
 // boundary), which adds +0 where the assembled row has no entry.
-template <int DIM>
-__global__ void __launch_bounds__(256) k_prolong_add(XferArgs a, const double *uc, double *uf) {
+template <typename T, int DIM>
+__global__ void __launch_bounds__(256) k_prolong_add(XferArgs a, const T *uc, T *uf) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const int x0 = 2 * p;                 // even fine x; x0+1 odd
     if (x0 >= a.nxf) return;
@@ -857,24 +932,24 @@ __global__ void __launch_bounds__(256) k_prolong_add(XferArgs a, const double *u
         const int iodd = i & 1, kodd = k & 1;
         const int ic0 = iodd ? (i - 1) / 2 : i / 2 - 1, nic = iodd ? 1 : 2;
         const int kc0 = (DIM == 3) ? (kodd ? (k - 1) / 2 : k / 2 - 1) : 0, nkc = (DIM == 3) ? (kodd ? 1 : 2) : 1;
-        const double wi = iodd ? 1.0 : 0.5, wk = (DIM == 3) ? (kodd ? 1.0 : 0.5) : 1.0;
-        const double wh = (DIM == 3) ? wk * (wi * 0.5) : wi * 0.5;
-        const double w1_ = (DIM == 3) ? wk * (wi * 1.0) : wi * 1.0;
-        double *fp = uf + (DIM == 3 ? (long)k * a.plf : 0) + (long)i * a.pf + x0;
-        double2 v = ld2_stream(fp, true);
-        const double *cr = uc + (DIM == 3 ? (long)kc0 * a.plc : 0) + (long)ic0 * a.pc;
-        double s0 = 0.0, s1 = 0.0;
+        const T wi = iodd ? (T)1 : (T)0.5, wk = (DIM == 3) ? (kodd ? (T)1 : (T)0.5) : (T)1;
+        const T wh = (DIM == 3) ? wk * (wi * (T)0.5) : wi * (T)0.5;
+        const T w1_ = (DIM == 3) ? wk * (wi * (T)1) : wi * (T)1;
+        T *fp = uf + (DIM == 3 ? (long)k * a.plf : 0) + (long)i * a.pf + x0;
+        P2<T> v = ldp_stream(fp);
+        const T *cr = uc + (DIM == 3 ? (long)kc0 * a.plc : 0) + (long)ic0 * a.pc;
+        T s0 = (T)0, s1 = (T)0;
         for (int qk = 0; qk < nkc; qk++)
             for (int qi = 0; qi < nic; qi++) {
-                const double *c = cr + (long)qk * a.plc + (long)qi * a.pc;
-                const double c0 = c[jc0], c1 = c[jc1];
+                const T *c = cr + (long)qk * a.plc + (long)qi * a.pc;
+                const T c0 = c[jc0], c1 = c[jc1];
                 s0 += wh * c0;
                 s0 += wh * c1;
                 s1 += w1_ * c1;
             }
         v.x = v.x + s0;
-        v.y = last ? 0.0 : v.y + s1;
-        st2_stream(fp, v);
+        v.y = last ? (T)0 : v.y + s1;
+        stp_stream(fp, v);
         if (++i == a.nyf) { i = 0; k++; }
     }
 }
@@ -898,8 +973,8 @@ extern "C" int mgk_restrict_fw_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geo
     dim3 block(256), grid((gc->nx + 1 + 255) / 256, 1);
     long rows = (long)gc->ny * gc->nz, cap = 1024 / grid.x; if (cap < 1) cap = 1;
     grid.y = (unsigned)(rows < cap ? rows : cap);
-    if (gf->dim == 3) hipLaunchKernelGGL(k_restrict<3>, grid, block, 0, S(c, stream), a, rf + gf->org, bc + gc->org);
-    else hipLaunchKernelGGL(k_restrict<2>, grid, block, 0, S(c, stream), a, rf + gf->org, bc + gc->org);
+    if (gf->dim == 3) hipLaunchKernelGGL((k_restrict<double, 3>), grid, block, 0, S(c, stream), a, rf + gf->org, bc + gc->org);
+    else hipLaunchKernelGGL((k_restrict<double, 2>), grid, block, 0, S(c, stream), a, rf + gf->org, bc + gc->org);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -914,8 +989,8 @@ extern "C" int mgk_prolong_add_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geo
     dim3 block(256), grid((npairs + 255) / 256, 1);
     long rows = (long)gf->ny * gf->nz, cap = 1024 / grid.x; if (cap < 1) cap = 1;
     grid.y = (unsigned)(rows < cap ? rows : cap);
-    if (gf->dim == 3) hipLaunchKernelGGL(k_prolong_add<3>, grid, block, 0, S(c, stream), a, uc + gc->org, uf + gf->org);
-    else hipLaunchKernelGGL(k_prolong_add<2>, grid, block, 0, S(c, stream), a, uc + gc->org, uf + gf->org);
+    if (gf->dim == 3) hipLaunchKernelGGL((k_prolong_add<double, 3>), grid, block, 0, S(c, stream), a, uc + gc->org, uf + gf->org);
+    else hipLaunchKernelGGL((k_prolong_add<double, 2>), grid, block, 0, S(c, stream), a, uc + gc->org, uf + gf->org);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -984,6 +1059,157 @@ extern "C" int mgk_csr_mult_f64(mgk_ctx *c, long nrows, const long *rowptr, cons
                                 const double *x, double *y, double alpha, const double *addto, void *stream) {
     if (!c || !rowptr || !col || !val || !x || !y) return fail(MGK_EINVAL, "mgk_csr_mult_f64: bad arguments");
     hipLaunchKernelGGL(k_csr_mult, dim3(flat_grid(nrows)), dim3(256), 0, S(c, stream), nrows, rowptr, col, val, x, y, alpha, addto);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// fp32 fields and the fp64<->fp32 bridges of the mixed-precision cycle (BASELINE config 5:
+// fp32 smoother sweeps, fp64 residual and correction).  Same kernels, T = float: one lane owns
+// four unknowns (16 bytes), a wave row is 256 unknowns; same canonical arithmetic, in fp32.
+// ------------------------------------------------------------------------------------------
+extern "C" int mgk_geom_init_f32(mgk_geom *g, int dim, int nx, int ny, int nz) {
+    if (!g || dim != 3 || nx < 1 || ny < 1 || nz < 1 || (nx & 1) == 0)
+        return fail(MGK_EINVAL, "mgk_geom_init_f32: need dim 3 and odd nx");
+    g->dim = dim; g->nx = nx; g->ny = ny; g->nz = nz;
+    g->pitch = ((32 + nx + 1 + 31) / 32) * 32;            // rows start on 128-byte lines, interior x=0 at column 32
+    g->plane = (long)g->pitch * (ny + 2);
+    g->org = g->plane + g->pitch + 32;
+    g->total = g->plane * (nz + 2) + g->pitch;
+    return 0;
+}
+
+extern "C" int mgk_jacobi_range_f32(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
+                                    const float *b, const float *u, float *unew, int zbeg, int zend, void *stream) {
+    if (!c || !g || !coef || !b || !u || !unew || u == unew) return fail(MGK_EINVAL, "mgk_jacobi_f32: bad arguments");
+    if (zbeg < 0 || zend > g->nz || zbeg >= zend) return fail(MGK_EINVAL, "mgk_jacobi_range_f32: empty or out-of-range plane range");
+    StArgs<float> a; memset(&a, 0, sizeof(a));
+    a.u = u + g->org; a.b = b + g->org; a.out = unew + g->org;
+    set_coef(a, g, coef); a.dinv = (float)dinv; a.scale = (float)scale;
+    a.zbeg = zbeg; a.zend = zend;
+    return dispatch_st<MODE_JACOBI>(c, g, a, S(c, stream), nullptr);
+}
+extern "C" int mgk_jacobi_f32(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
+                              const float *b, const float *u, float *unew, void *stream) {
+    if (!g) return fail(MGK_EINVAL, "mgk_jacobi_f32: bad arguments");
+    return mgk_jacobi_range_f32(c, g, coef, dinv, scale, b, u, unew, 0, g->nz, stream);
+}
+extern "C" int mgk_residual_f32(mgk_ctx *c, const mgk_geom *g, const double *coef,
+                                const float *b, const float *u, float *r, void *stream) {
+    if (!c || !g || !coef || !b || !u || !r || u == r) return fail(MGK_EINVAL, "mgk_residual_f32: bad arguments");
+    StArgs<float> a; memset(&a, 0, sizeof(a));
+    a.u = u + g->org; a.b = b + g->org; a.out = r + g->org;
+    set_coef(a, g, coef);
+    return dispatch_st<MODE_RESIDUAL>(c, g, a, S(c, stream), nullptr);
+}
+extern "C" int mgk_jacobi_zero_f32(mgk_ctx *c, const mgk_geom *g, double dinv, double scale,
+                                   const float *b, float *unew, void *stream) {
+    if (!c || !g || !b || !unew) return fail(MGK_EINVAL, "mgk_jacobi_zero_f32: bad arguments");
+    RowArgs a = row_args(g);
+    dim3 grid, block;
+    row_grid(a, a.npairs, grid, block, 1024);
+    hipLaunchKernelGGL(k_jacobi_zero<float>, grid, block, 0, S(c, stream), a, (float)dinv, (float)scale, b + g->org, unew + g->org);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int mgk_restrict_fw_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc,
+                                   const float *rf, float *bc, void *stream) {
+    if (!c || !gf || !gc || !rf || !bc || gf->dim != 3) return fail(MGK_EINVAL, "mgk_restrict_fw_f32: bad arguments");
+    XferArgs a;
+    int rc = xfer_args(gf, gc, a);
+    if (rc) return rc;
+    dim3 block(256), grid((gc->nx + 1 + 255) / 256, 1);
+    long rows = (long)gc->ny * gc->nz, cap = 1024 / grid.x; if (cap < 1) cap = 1;
+    grid.y = (unsigned)(rows < cap ? rows : cap);
+    hipLaunchKernelGGL((k_restrict<float, 3>), grid, block, 0, S(c, stream), a, rf + gf->org, bc + gc->org);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int mgk_prolong_add_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc,
+                                   const float *uc, float *uf, void *stream) {
+    if (!c || !gf || !gc || !uc || !uf || gf->dim != 3) return fail(MGK_EINVAL, "mgk_prolong_add_f32: bad arguments");
+    XferArgs a;
+    int rc = xfer_args(gf, gc, a);
+    if (rc) return rc;
+    const int npairs = (gf->nx + 1) / 2;
+    dim3 block(256), grid((npairs + 255) / 256, 1);
+    long rows = (long)gf->ny * gf->nz, cap = 1024 / grid.x; if (cap < 1) cap = 1;
+    grid.y = (unsigned)(rows < cap ? rows : cap);
+    hipLaunchKernelGGL((k_prolong_add<float, 3>), grid, block, 0, S(c, stream), a, uc + gc->org, uf + gf->org);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// fp64 residual r = b - A u, written as fp32 (the right-hand side of the fp32 correction cycle) and reduced
+// to sum r^2 in fp64 in the same pass: reads 16 B, writes 4 B per unknown
+extern "C" int mgk_residual_f64_to_f32(mgk_ctx *c, const mgk_geom *g, const mgk_geom *g32, const double *coef,
+                                       const double *b, const double *u, float *r32, double *sumsq_host, void *stream) {
+    if (!c || !g || !g32 || !coef || !b || !u || !r32 || !sumsq_host || g->dim != 3 ||
+        g->nx != g32->nx || g->ny != g32->ny || g->nz != g32->nz)
+        return fail(MGK_EINVAL, "mgk_residual_f64_to_f32: bad arguments");
+    StArgs<double> a; memset(&a, 0, sizeof(a));
+    a.u = u + g->org; a.b = b + g->org; a.out32 = r32 + g32->org; a.ors = g32->pitch; a.oms = g32->plane;
+    a.partials = c->partials;
+    set_coef(a, g, coef);
+    int nblk = 0;
+    int rc = dispatch_st<MODE_RES32>(c, g, a, S(c, stream), &nblk);
+    if (rc) return rc;
+    return finish_to_host(c, nblk, 1, S(c, stream), sumsq_host);
+}
+
+// u64 += (double) e32  (the fp64 correction step)
+__global__ void __launch_bounds__(256) k_correct(RowArgs a, long pitch32, long plane32, const float *e, double *u) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.npairs) return;
+    const int x0 = 2 * p;
+    ROW_RANGE(a.nrows)
+    int k = (int)(row0_ / a.ny), i = (int)(row0_ - (long)k * a.ny);
+    for (long row = row0_; row < row1_; row++) {
+        double *up = u + (long)k * a.plane + (long)i * a.pitch + x0;
+        const P2<float> ev = *reinterpret_cast<const P2<float> *>(e + (long)k * plane32 + (long)i * pitch32 + x0);
+        P2<double> v = ldp_stream(up);
+        v.x = v.x + (double)ev.x;
+        v.y = (x0 + 1 == a.nx) ? 0.0 : v.y + (double)ev.y;
+        stp_stream(up, v);
+        if (++i == a.ny) { i = 0; k++; }
+    }
+}
+extern "C" int mgk_correct_f64_from_f32(mgk_ctx *c, const mgk_geom *g, const mgk_geom *g32, const float *e32, double *u, void *stream) {
+    if (!c || !g || !g32 || !e32 || !u || g->nx != g32->nx || g->ny != g32->ny || g->nz != g32->nz)
+        return fail(MGK_EINVAL, "mgk_correct_f64_from_f32: bad arguments");
+    RowArgs a = row_args(g);
+    dim3 grid, block;
+    row_grid(a, a.npairs, grid, block, 1024);
+    hipLaunchKernelGGL(k_correct, grid, block, 0, S(c, stream), a, (long)g32->pitch, g32->plane, e32 + g32->org, u + g->org);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// compact fp64 host/device array <-> padded fp32 field (tests)
+__global__ void __launch_bounds__(256) k_pack32(RowArgs a, const double *compact, float *padded, int to_padded) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.nx) return;
+    ROW_RANGE(a.nrows) for (long row = row0_; row < row1_; row++) {
+        const long o = row_offset(a, row) + j, cidx = row * a.nx + j;
+        if (to_padded) padded[o] = (float)compact[cidx];
+        else ((double *)compact)[cidx] = (double)padded[o];
+    }
+}
+extern "C" int mgk_pack_f32(mgk_ctx *c, const mgk_geom *g32, const double *compact_dev, float *padded_dev, void *stream) {
+    if (!c || !g32 || !compact_dev || !padded_dev) return fail(MGK_EINVAL, "mgk_pack_f32: bad arguments");
+    RowArgs a = row_args(g32);
+    dim3 grid, block;
+    row_grid(a, a.nx, grid, block, 1024);
+    hipLaunchKernelGGL(k_pack32, grid, block, 0, S(c, stream), a, compact_dev, padded_dev + g32->org, 1);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int mgk_unpack_f32(mgk_ctx *c, const mgk_geom *g32, const float *padded_dev, double *compact_dev, void *stream) {
+    if (!c || !g32 || !compact_dev || !padded_dev) return fail(MGK_EINVAL, "mgk_unpack_f32: bad arguments");
+    RowArgs a = row_args(g32);
+    dim3 grid, block;
+    row_grid(a, a.nx, grid, block, 1024);
+    hipLaunchKernelGGL(k_pack32, grid, block, 0, S(c, stream), a, compact_dev, (float *)padded_dev + g32->org, 0);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -53,6 +53,17 @@ def _sigs(L):
         "mgk_fill_separable_f64": (i, [vp, G, vp, vp, vp, vp, vp]),
         "mgk_error_sums_f64": (i, [vp, G, vp, vp, vp, vp, c_dp, vp]),
         "mgk_set_tuning": (None, [i, i]),
+        "mgk_geom_init_f32": (i, [G, i, i, i, i]),
+        "mgk_jacobi_f32": (i, [vp, G, c_dp, d, d, vp, vp, vp, vp]),
+        "mgk_jacobi_zero_f32": (i, [vp, G, d, d, vp, vp, vp]),
+        "mgk_residual_f32": (i, [vp, G, c_dp, vp, vp, vp, vp]),
+        "mgk_restrict_fw_f32": (i, [vp, G, G, vp, vp, vp]),
+        "mgk_prolong_add_f32": (i, [vp, G, G, vp, vp, vp]),
+        "mgk_residual_f64_to_f32": (i, [vp, G, G, c_dp, vp, vp, vp, C.POINTER(d), vp]),
+        "mgk_correct_f64_from_f32": (i, [vp, G, G, vp, vp, vp]),
+        "mgk_pack_f32": (i, [vp, G, vp, vp, vp]),
+        "mgk_unpack_f32": (i, [vp, G, vp, vp, vp]),
+        "mgk_apply_f64": (i, [vp, G, c_dp, vp, vp, vp]),
     }
     for name, (res, args) in S.items():
         f = getattr(L, name)
@@ -128,6 +139,29 @@ class Mgk:
         out = self.download(tmp, n)
         self.free(tmp)
         return out
+
+    # -- fp32 fields (mixed-precision cycle) --
+    def geom32(self, n):
+        g = Geom()
+        self._chk(self.L.mgk_geom_init_f32(C.byref(g), 3, n, n, n))
+        return g
+
+    def to_field32(self, g32, compact):
+        tmp = self.upload(np.asarray(compact, dtype=np.float64).ravel())
+        f = self.alloc(4 * g32.total)
+        self._chk(self.L.mgk_pack_f32(self.ctx, C.byref(g32), tmp, f, None))
+        self.sync()
+        self.free(tmp)
+        return f
+
+    def from_field32(self, g32, f):
+        n = g32.nx * g32.ny * g32.nz
+        tmp = self.alloc(8 * n)
+        self._chk(self.L.mgk_unpack_f32(self.ctx, C.byref(g32), f, tmp, None))
+        self.sync()
+        out = self.download(tmp, n)
+        self.free(tmp)
+        return out.astype(np.float32)
 
     def raw_field(self, g, f):
         """whole padded allocation (ghosts included) as a flat numpy array"""

@@ -99,7 +99,7 @@ class Solver:
 
     def __init__(self, dim, npts, levels, v=(3, 3), maxiter=100000, ksp_type="richardson", scale=1.0,
                  eigenvalues=(0.0, 0.0), rtol=1.0e-7, device=0, rank=0, nranks=1, comm=None,
-                 dist_min_n=0, fuse=-1, overlap=-1):
+                 dist_min_n=0, fuse=-1, overlap=-1, precision="fp64"):
         self.L = _lib()
         cfg = MgConfig()
         self.L.mg_config_default(C.byref(cfg))
@@ -111,6 +111,7 @@ class Solver:
         cfg.emin, cfg.emax = eigenvalues
         cfg.rtol = rtol
         cfg.device, cfg.rank, cfg.nranks = device, rank, nranks
+        cfg.precision = {"fp64": 0, "mixed": 1}[precision]
         cfg.dist_min_n, cfg.fuse, cfg.overlap = dist_min_n, fuse, overlap
         self.cfg = cfg
         self.h = C.c_void_p()

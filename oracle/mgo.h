@@ -138,6 +138,13 @@ int mgo_vcycle(const mgo_vcycle_cfg *cfg, double *rnorm_raw, double *u_out, doub
                double *solve_seconds);
 int mgo_num_threads(void);
 
+/* ---------------- fp32 leg (mgo_f32.c): mixed-precision cycle of BASELINE config 5, 3-D only ---------------- */
+void mgo_st_jacobi_f32(int n, const float *As, float dinv, float scale, const float *b, const float *u, float *unew, int zero_guess);
+void mgo_st_residual_f32(int n, const float *As, const float *b, const float *u, float *r);
+void mgo_st_restrict_f32(int nf, const float *rf, float *bc);
+void mgo_st_prolong_add_f32(int nf, const float *uc, float *uf);
+int  mgo_vcycle_mixed(const mgo_vcycle_cfg *cfg, double *rnorm_raw, double *u_out, double *bnorm_out, double *solve_seconds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,12 @@ class Oracle:
         L.mgo_restriction_stencil.argtypes = [C.c_void_p]
         L.mgo_prolongation_stencil.argtypes = [C.c_void_p]
         L.mgo_num_threads.restype = C.c_int
+        L.mgo_st_jacobi_f32.argtypes = [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.mgo_st_residual_f32.argtypes = [C.c_int] + [C.c_void_p] * 4
+        L.mgo_st_restrict_f32.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.mgo_st_prolong_add_f32.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.mgo_vcycle_mixed.restype = C.c_int
+        L.mgo_vcycle_mixed.argtypes = [C.POINTER(VcycleCfg), C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
 
     # ---- conveniences ----
     def level_stencil(self, dim, npts, l):
@@ -152,6 +158,39 @@ class Oracle:
         u = np.zeros((npts - 2) ** dim) if want_u else None
         bn, sec = C.c_double(), C.c_double()
         it = self.L.mgo_vcycle(C.byref(cfg), _p(rn), _p(u), C.byref(bn), C.byref(sec))
+        return {"iters": it, "rnorm": rn[:it + 1].copy(), "u": u, "bnorm": bn.value, "seconds": sec.value}
+
+    # ---- fp32 leg ----
+    def jacobi32(self, n, As, scale, b, u, zero_guess=False):
+        As32 = np.asarray(As, dtype=np.float32)
+        dinv = np.float32(1.0 / As[3])
+        out = np.zeros(n ** 3, dtype=np.float32)
+        self.L.mgo_st_jacobi_f32(n, _p(As32), dinv, np.float32(scale), _p(b), _p(u), _p(out), int(zero_guess))
+        return out
+
+    def residual32(self, n, As, b, u):
+        As32 = np.asarray(As, dtype=np.float32)
+        out = np.zeros(n ** 3, dtype=np.float32)
+        self.L.mgo_st_residual_f32(n, _p(As32), _p(b), _p(u), _p(out))
+        return out
+
+    def restrict32(self, nf, rf):
+        nc = (nf - 1) // 2
+        out = np.zeros(nc ** 3, dtype=np.float32)
+        self.L.mgo_st_restrict_f32(nf, _p(rf), _p(out))
+        return out
+
+    def prolong_add32(self, nf, uc, uf):
+        out = np.array(uf, dtype=np.float32, copy=True)
+        self.L.mgo_st_prolong_add_f32(nf, _p(uc), _p(out))
+        return out
+
+    def vcycle_mixed(self, npts, levels, v0=3, v1=3, maxiter=100, scale=1.0, fixed_cycles=0):
+        cfg = VcycleCfg(3, npts, levels, v0, v1, maxiter, 0, scale, 0.0, 0.0, 0, fixed_cycles, 0.0)
+        rn = np.zeros(max(maxiter, fixed_cycles) + 1)
+        u = np.zeros((npts - 2) ** 3)
+        bn, sec = C.c_double(), C.c_double()
+        it = self.L.mgo_vcycle_mixed(C.byref(cfg), _p(rn), _p(u), C.byref(bn), C.byref(sec))
         return {"iters": it, "rnorm": rn[:it + 1].copy(), "u": u, "bnorm": bn.value, "seconds": sec.value}
 
     # CSR handles

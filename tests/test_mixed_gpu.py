@@ -1,0 +1,98 @@
+"""BASELINE config 5 -- mixed precision: fp32 smoother sweeps inside an fp64 defect-correction loop.
+No reference counterpart exists; the arithmetic is defined by oracle/mgo_f32.c (same canonical order,
+IEEE binary32, no FMA) and the HIP kernels (T = float, 4 unknowns per lane) must match it BIT FOR BIT;
+acceptance of the scheme itself: it converges to the same fp64 stopping criterion and the same
+known-answer error as the fp64 cycle."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return Oracle()
+
+
+@pytest.mark.parametrize("n", [1, 3, 7, 31, 63, 127, 255])
+def test_fp32_kernels_bit_exact(mgk, orc, n):
+    rng = np.random.default_rng(n)
+    N = n ** 3
+    As = orc.level_stencil(3, n + 2, 0)[0]
+    dinv = 1.0 / As[3]
+    u, b = rng.uniform(-1, 1, N).astype(np.float32), rng.uniform(-1, 1, N).astype(np.float32)
+    g = mgk.geom32(n)
+    du, db, dout = mgk.to_field32(g, u), mgk.to_field32(g, b), mgk.alloc(4 * g.total)
+    coef = mgk.coef(As)
+    L = mgk.L
+    variants = [-1] if n < 255 else [-1, 0, 1, 2, 3]
+    for v in variants:
+        for zc in (-1, 5):
+            L.mgk_set_tuning(v, zc)
+            mgk._chk(L.mgk_jacobi_f32(mgk.ctx, C.byref(g), coef, dinv, 6.0 / 7.0, db, du, dout, None))
+            assert np.array_equal(mgk.from_field32(g, dout), orc.jacobi32(n, As, 6.0 / 7.0, b, u))
+            mgk._chk(L.mgk_residual_f32(mgk.ctx, C.byref(g), coef, db, du, dout, None))
+            assert np.array_equal(mgk.from_field32(g, dout), orc.residual32(n, As, b, u))
+    L.mgk_set_tuning(-1, -1)
+    mgk._chk(L.mgk_jacobi_zero_f32(mgk.ctx, C.byref(g), dinv, 6.0 / 7.0, db, dout, None))
+    assert np.array_equal(mgk.from_field32(g, dout), orc.jacobi32(n, As, 6.0 / 7.0, b, np.zeros(N, np.float32), zero_guess=True))
+    if n >= 7:
+        nc = (n - 1) // 2
+        gc = mgk.geom32(nc)
+        uc = rng.uniform(-1, 1, nc ** 3).astype(np.float32)
+        duc, dbc = mgk.to_field32(gc, uc), mgk.alloc(4 * gc.total)
+        mgk._chk(L.mgk_restrict_fw_f32(mgk.ctx, C.byref(g), C.byref(gc), du, dbc, None))
+        assert np.array_equal(mgk.from_field32(gc, dbc), orc.restrict32(n, u))
+        mgk._chk(L.mgk_prolong_add_f32(mgk.ctx, C.byref(g), C.byref(gc), duc, du, None))
+        assert np.array_equal(mgk.from_field32(g, du), orc.prolong_add32(n, uc, u))
+        mgk.free(duc); mgk.free(dbc)
+    for p in (du, db, dout):
+        mgk.free(p)
+
+
+@pytest.mark.parametrize("n", [7, 63])
+def test_bridges_fp64_fp32(mgk, orc, n):
+    rng = np.random.default_rng(5 + n)
+    N = n ** 3
+    As = orc.level_stencil(3, n + 2, 0)[0]
+    u, b = rng.uniform(-1, 1, N), rng.uniform(-1, 1, N)
+    g, g32 = mgk.geom(3, n), mgk.geom32(n)
+    du, db, dr32 = mgk.to_field(g, u), mgk.to_field(g, b), mgk.alloc(4 * g32.total)
+    ss = C.c_double()
+    mgk._chk(mgk.L.mgk_residual_f64_to_f32(mgk.ctx, C.byref(g), C.byref(g32), mgk.coef(As), db, du, dr32, C.byref(ss), None))
+    r = orc.residual(3, n, As, b, u)
+    assert np.array_equal(mgk.from_field32(g32, dr32), r.astype(np.float32))
+    ref = orc.sumsq(r)
+    assert abs(ss.value - ref) <= 1e-13 * ref
+    e = rng.uniform(-1, 1, N).astype(np.float32)
+    de = mgk.to_field32(g32, e)
+    mgk._chk(mgk.L.mgk_correct_f64_from_f32(mgk.ctx, C.byref(g), C.byref(g32), de, du, None))
+    assert np.array_equal(mgk.from_field(g, du), u + e.astype(np.float64))
+    for p in (du, db, dr32, de):
+        mgk.free(p)
+
+
+@pytest.mark.parametrize("npts,levels", [(17, 3), (17, 4), (33, 4), (65, 6), (129, 7)])
+def test_mixed_solve_matches_oracle_and_fp64_answer(orc, npts, levels):
+    from multigrid_petsc_amd.solver import Solver
+    scale = 6.0 / 7.0
+    s = Solver(3, npts, levels, scale=scale, maxiter=60, precision="mixed")
+    s.set_rhs_problem()
+    it = s.solve()
+    ref = orc.vcycle_mixed(npts, levels, maxiter=60, scale=scale)
+    assert it == ref["iters"]
+    assert np.max(np.abs(s.rnorm - ref["rnorm"]) / ref["rnorm"]) <= 1e-12
+    assert np.array_equal(s.solution(), ref["u"])
+    # the scheme: same stopping criterion in fp64, same known-answer error as the all-fp64 cycle
+    assert s.rnorm[-1] <= 1e-7 * s.bnorm
+    f = orc.vcycle(3, npts, levels, 3, 3, maxiter=60, scale=scale)
+    assert abs(it - f["iters"]) <= 1
+    h = 1.0 / (npts - 1)
+    kat = 3 * math.pi ** 2 / ((12 / h ** 2) * math.sin(math.pi * h / 2) ** 2) - 1.0
+    assert abs(s.error_norms()[0] - kat) <= 5e-7
+    s.close()
