@@ -116,6 +116,13 @@ int  mgk_restrict_fw_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc,
 int  mgk_prolong_add_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc,
                          const double *uc, double *uf, void *stream);
 
+/* K4 fused into the first post-smoothing sweep (src/solver.c:1540-1542): unew = Jacobi(u + P uc); the corrected
+ * u is never written.  Needs valid z ghost planes of u AND of uc on a slab.  3-D only. */
+int  mgk_prolong_jacobi_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv,
+                            double scale, const double *b, const double *uc, const double *u, double *unew, void *stream);
+int  mgk_prolong_jacobi_f32(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv,
+                            double scale, const float *b, const float *uc, const float *u, float *unew, void *stream);
+
 /* ---- K6: VecNorm(NORM_2) (src/solver.c:1512,1518,1546): returns sum of squares of the interior ---- */
 int  mgk_sumsq_f64(mgk_ctx *ctx, const mgk_geom *g, const double *x, double *sumsq_host, void *stream);
 

@@ -196,7 +196,7 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
     s->cfg = *cfg;
     if (s->cfg.rtol <= 0) s->cfg.rtol = 1.e-7;
     if (s->cfg.dist_min_n <= 0) s->cfg.dist_min_n = 127;
-    if (s->cfg.fuse < 0) s->cfg.fuse = 1;
+    if (s->cfg.fuse < 0) s->cfg.fuse = 3;
     if (s->cfg.overlap < 0) s->cfg.overlap = 1;
     if (s->cfg.nranks < 1) s->cfg.nranks = 1;
     s->comm = comm;
@@ -541,6 +541,32 @@ static int prolong_from(mg_solver *s, int l) {
     return 0;
 }
 
+/* prolongation fused into the first post-smoothing sweep: u <- Jacobi(u + P u_c)  (src/solver.c:1540-1542) */
+static int prolong_smooth(mg_solver *s, int l) {
+    mg_level *F = &s->L[l], *Cq = &s->L[l + 1];
+    const int v0 = s->cfg.v[0];
+    if (!(s->cfg.fuse & 2) || s->cfg.dim != 3 || s->cfg.ksp_type != MG_KSP_RICHARDSON || v0 < 1) {
+        CHK(prolong_from(s, l));
+        return smooth(s, l, v0);
+    }
+    mgk_geom gc = Cq->g;
+    const double *ucoarse = Cq->u;
+    if (F->distributed && !Cq->distributed) {
+        int c0 = s->zstart[s->cfg.rank], c1 = s->zstart[s->cfg.rank + 1];
+        gc.nz = c1 - c0;
+        ucoarse = Cq->u + (long)c0 * Cq->g.plane;
+    } else {
+        CHK(ensure_u_ghosts(s, Cq));
+    }
+    CHK(ensure_u_ghosts(s, F));          /* the neighbours' boundary planes BEFORE the correction */
+    void *t = prof_begin(s, l);
+    CHK(mgk_prolong_jacobi_f64(s->ctx, &F->g, &gc, F->coef, F->dinv, s->cfg.scale, F->b, ucoarse, F->u, F->tmp, NULL));
+    prof_end(s, t);
+    swap_ptr(&F->u, &F->tmp);
+    F->u_ghost_ok = 0; F->u_ghost_pending = 0;
+    return smooth(s, l, v0 - 1);
+}
+
 /* ---- mixed precision (BASELINE config 5): fp32 correction cycle inside an fp64 defect-correction loop ---- */
 static int smooth32(mg_solver *s, int l, int maxit, int guess_nonzero) {
     mg_level *L = &s->L[l];
@@ -568,8 +594,17 @@ static int vcycle_once_mixed(mg_solver *s) {
         CHK(smooth32(s, l, l == levels - 1 ? v[1] : v[0], 0));
     }
     for (int l = levels - 2; l >= 0; l--) {
-        CHK(mgk_prolong_add_f32(s->ctx, &s->L[l].g32, &s->L[l + 1].g32, s->L[l + 1].u32, s->L[l].u32, NULL));
-        CHK(smooth32(s, l, v[0], 1));
+        mg_level *F = &s->L[l];
+        if ((s->cfg.fuse & 2) && v[0] >= 1) {
+            void *t = prof_begin(s, l);
+            CHK(mgk_prolong_jacobi_f32(s->ctx, &F->g32, &s->L[l + 1].g32, F->coef, F->dinv, s->cfg.scale, F->b32, s->L[l + 1].u32, F->u32, F->tmp32, NULL));
+            prof_end(s, t);
+            float *q = F->u32; F->u32 = F->tmp32; F->tmp32 = q;
+            CHK(smooth32(s, l, v[0] - 1, 1));
+        } else {
+            CHK(mgk_prolong_add_f32(s->ctx, &F->g32, &s->L[l + 1].g32, s->L[l + 1].u32, F->u32, NULL));
+            CHK(smooth32(s, l, v[0], 1));
+        }
     }
     mg_level *L = &s->L[0];
     double ss;
@@ -594,8 +629,7 @@ static int vcycle_once(mg_solver *s) {
         if (l != levels - 1) s->L[l].guess_nonzero = 1;                 /* :1537 */
     }
     for (int l = levels - 2; l >= 0; l--) {
-        CHK(prolong_from(s, l));                                        /* :1540-1541 */
-        CHK(smooth(s, l, v[0]));                                        /* :1542 */
+        CHK(prolong_smooth(s, l));                                      /* :1540-1542 */
         if (l != 0) s->L[l].guess_nonzero = 0;                          /* :1543 */
     }
     /* :1545-1546  r0 = b0 - A0 u0 ; ||r0|| */

@@ -295,6 +295,8 @@ __device__ __forceinline__ void stp_stream(float *p, P2<float> v) { *reinterpret
 template <typename T>
 struct StArgs {
     const T *u, *b, *aux;
+    const T *uc;           // MODE_PJACOBI: coarse correction field (interior origin) and its strides
+    long crs, cms;
     T *out;
     float *out32;          // MODE_RES32: float copy of the fp64 residual (own strides below)
     double *partials;
@@ -307,7 +309,59 @@ struct StArgs {
     T dinv, scale, ckm1, ck, cz;
 };
 
-enum { MODE_JACOBI = 0, MODE_RESIDUAL = 1, MODE_CHEBY = 2, MODE_RESNORM = 3, MODE_APPLY = 4, MODE_RES32 = 5 };
+enum { MODE_JACOBI = 0, MODE_RESIDUAL = 1, MODE_CHEBY = 2, MODE_RESNORM = 3, MODE_APPLY = 4, MODE_RES32 = 5, MODE_PJACOBI = 6 };
+
+// Interpolated coarse correction (row of pro, src/solver.c:1140-1148) at the VX fine points (k, i, x0..x0+VX-1),
+// x0 a multiple of VX: parents summed in ascending coarse index (kc, ic, jc) exactly like k_prolong_add.
+// Ghost rows/planes (i or k = -1, n) are "odd" points whose single parent is the coarse ghost.
+template <typename T>
+__device__ __forceinline__ V16<T> prolong_vec(const T *uc, long crs, long cms, int k, int i, int x0) {
+    constexpr int VX = 16 / sizeof(T);
+    const int iodd = i & 1, kodd = k & 1;
+    const int ic0 = iodd ? (i - 1) / 2 : i / 2 - 1, nic = iodd ? 1 : 2;
+    const int kc0 = kodd ? (k - 1) / 2 : k / 2 - 1, nkc = kodd ? 1 : 2;
+    const T wi = iodd ? (T)1 : (T)0.5, wk = kodd ? (T)1 : (T)0.5;
+    const T wh = wk * (wi * (T)0.5), w1 = wk * (wi * (T)1);
+    const T *cr = uc + (long)kc0 * cms + (long)ic0 * crs + (x0 / 2 - 1);
+    V16<T> s = v16_zero<T>();
+    for (int qk = 0; qk < nkc; qk++)
+        for (int qi = 0; qi < nic; qi++) {
+            const T *c = cr + (long)qk * cms + (long)qi * crs;
+            const T c0 = c[0], c1 = c[1];
+            s.v[0] += wh * c0;
+            s.v[0] += wh * c1;
+            s.v[1] += w1 * c1;
+            if (VX == 4) {
+                const T c2 = c[2];
+                s.v[VX - 2] += wh * c1;
+                s.v[VX - 2] += wh * c2;
+                s.v[VX - 1] += w1 * c2;
+            }
+        }
+    return s;
+}
+template <typename T>
+__device__ __forceinline__ T prolong_one(const T *uc, long crs, long cms, int k, int i, int x) {
+    const int iodd = i & 1, kodd = k & 1, xodd = x & 1;
+    const int ic0 = iodd ? (i - 1) / 2 : i / 2 - 1, nic = iodd ? 1 : 2;
+    const int kc0 = kodd ? (k - 1) / 2 : k / 2 - 1, nkc = kodd ? 1 : 2;
+    const int jc0 = xodd ? (x - 1) / 2 : x / 2 - 1, njc = xodd ? 1 : 2;
+    const T wi = iodd ? (T)1 : (T)0.5, wk = kodd ? (T)1 : (T)0.5, wj = xodd ? (T)1 : (T)0.5;
+    const T w = wk * (wi * wj);
+    const T *cr = uc + (long)kc0 * cms + (long)ic0 * crs + jc0;
+    T s = (T)0;
+    for (int qk = 0; qk < nkc; qk++)
+        for (int qi = 0; qi < nic; qi++)
+            for (int qj = 0; qj < njc; qj++) s += w * cr[(long)qk * cms + (long)qi * crs + qj];
+    return s;
+}
+template <typename T>
+__device__ __forceinline__ V16<T> vadd(const V16<T> &a, const V16<T> &b) {
+    V16<T> r;
+#pragma unroll
+    for (int e = 0; e < (int)(16 / sizeof(T)); e++) r.v[e] = a.v[e] + b.v[e];
+    return r;
+}
 
 template <typename T, int DIM, int WX, int WY, int RY, int MODE>
 __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
@@ -377,12 +431,27 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
         const bool hok = xhok && (DIM == 2 || yb + r < a.ny);
         T xc = hok ? hp_[(long)z0 * a.ms + ro] : (T)0;
         xp[r] = hok ? hp_[(long)(z0 + 1) * a.ms + ro] : (T)0;
+        if (MODE == MODE_PJACOBI) {          // u := u + P e on everything this block reads
+            if (rok[r]) {
+                um[r] = vadd(um[r], prolong_vec(a.uc, a.crs, a.cms, z0 - 1, yb + r, x0));
+                uc[r] = vadd(uc[r], prolong_vec(a.uc, a.crs, a.cms, z0, yb + r, x0));
+                up[r] = vadd(up[r], prolong_vec(a.uc, a.crs, a.cms, z0 + 1, yb + r, x0));
+            }
+            if (hok) {
+                xc = xc + prolong_one(a.uc, a.crs, a.cms, z0, yb + r, xh);
+                xp[r] = xp[r] + prolong_one(a.uc, a.crs, a.cms, z0 + 1, yb + r, xh);
+            }
+        }
         *reinterpret_cast<VT *>(&lds[0][lrow + r][xl + VX]) = uc[r];
         if (isW || isE) lds[0][lrow + r][xhl] = xc;
     }
     if (DIM == 3) {
         hS = ldv(up_ + (long)z0 * a.ms - a.rs, okS);
         hN = ldv(up_ + (long)z0 * a.ms + (long)RY * a.rs, okN);
+        if (MODE == MODE_PJACOBI) {
+            if (okS) hS = vadd(hS, prolong_vec(a.uc, a.crs, a.cms, z0, yb - 1, x0));
+            if (okN) hN = vadd(hN, prolong_vec(a.uc, a.crs, a.cms, z0, yb + RY, x0));
+        }
     }
 
     double acc = 0.0;   // MODE_RESNORM / MODE_RES32
@@ -439,7 +508,7 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
                 if (DIM == 3) t = t + a.a5 * n2.v[e];
                 t = t + a.a6 * up[r].v[e];
                 const T res = bc[r].v[e] - t;
-                if (MODE == MODE_JACOBI) {
+                if (MODE == MODE_JACOBI || MODE == MODE_PJACOBI) {
                     const T zz = res * a.dinv;
                     o.v[e] = uc[r].v[e] + a.scale * zz;
                 } else if (MODE == MODE_CHEBY) {
@@ -478,8 +547,16 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
                 um[r] = uc[r]; uc[r] = up[r]; up[r] = uq[r];
                 bc[r] = bn[r]; xp[r] = xq[r];
                 if (MODE == MODE_CHEBY) ac[r] = an[r];
+                if (MODE == MODE_PJACOBI) {
+                    if (rok[r]) up[r] = vadd(up[r], prolong_vec(a.uc, a.crs, a.cms, z + 2, yb + r, x0));
+                    if (xhok && (DIM == 2 || yb + r < a.ny)) xp[r] = xp[r] + prolong_one(a.uc, a.crs, a.cms, z + 2, yb + r, xh);
+                }
             }
             hS = hSn; hN = hNn;
+            if (MODE == MODE_PJACOBI) {
+                if (okS) hS = vadd(hS, prolong_vec(a.uc, a.crs, a.cms, z + 1, yb - 1, x0));
+                if (okN) hN = vadd(hN, prolong_vec(a.uc, a.crs, a.cms, z + 1, yb + RY, x0));
+            }
         }
     }
 
@@ -1213,3 +1290,28 @@ extern "C" int mgk_unpack_f32(mgk_ctx *c, const mgk_geom *g32, const float *padd
     HIPCHK(hipGetLastError());
     return 0;
 }
+
+// K4 fused into the first post-smoothing sweep: unew = J(u + P uc)  (src/solver.c:1540-1542)
+template <typename T>
+static int prolong_jacobi(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
+                          const T *b, const T *ucoarse, const T *u, T *unew, void *stream) {
+    if (!c || !gf || !gc || !coef || !b || !ucoarse || !u || !unew || u == unew || gf->dim != 3)
+        return fail(MGK_EINVAL, "mgk_prolong_jacobi: bad arguments (3-D only)");
+    XferArgs x;
+    int rc = xfer_args(gf, gc, x);
+    if (rc) return rc;
+    StArgs<T> a; memset(&a, 0, sizeof(a));
+    a.u = u + gf->org; a.b = b + gf->org; a.out = unew + gf->org;
+    a.uc = ucoarse + gc->org; a.crs = gc->pitch; a.cms = gc->plane;
+    set_coef(a, gf, coef); a.dinv = (T)dinv; a.scale = (T)scale;
+    return dispatch_st<MODE_PJACOBI>(c, gf, a, S(c, stream), nullptr);
+}
+extern "C" int mgk_prolong_jacobi_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv,
+                                      double scale, const double *b, const double *uc, const double *u, double *unew, void *stream) {
+    return prolong_jacobi<double>(c, gf, gc, coef, dinv, scale, b, uc, u, unew, stream);
+}
+extern "C" int mgk_prolong_jacobi_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv,
+                                      double scale, const float *b, const float *uc, const float *u, float *unew, void *stream) {
+    return prolong_jacobi<float>(c, gf, gc, coef, dinv, scale, b, uc, u, unew, stream);
+}
+

@@ -158,3 +158,25 @@ def test_rhs_fill_and_error_sums(mgk, orc, dim, npts):
     assert abs(np.sqrt(e[2]) - ref[2]) <= 1e-12 * ref[2]
     for p in (dcx, ds, db, du):
         mgk.free(p)
+
+
+@pytest.mark.parametrize("nf,variant", [(3, -1), (7, 0), (31, 1), (63, 2), (63, 6), (127, 3), (127, 12), (255, -1)])
+def test_fused_prolong_jacobi_bit_exact(mgk, orc, nf, variant):
+    """unew = Jacobi(u + P uc) in one pass == prolong_add followed by a sweep (src/solver.c:1540-1542)"""
+    rng = np.random.default_rng(400 + nf)
+    nc = (nf - 1) // 2
+    As = _stencil(orc, 3, nf)
+    dinv = 1.0 / As[3]
+    u, b, uc = _rand(rng, nf ** 3), _rand(rng, nf ** 3), _rand(rng, max(nc, 1) ** 3)
+    gf, gc = mgk.geom(3, nf), mgk.geom(3, nc)
+    du, db, duc, dout = mgk.to_field(gf, u), mgk.to_field(gf, b), mgk.to_field(gc, uc), mgk.field(gf)
+    want = orc.jacobi(3, nf, As, 0.8, b, orc.prolong_add(3, nf, uc, u))
+    for zc in (-1, 3):
+        mgk.L.mgk_set_tuning(variant, zc)
+        mgk._chk(mgk.L.mgk_prolong_jacobi_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), dinv, 0.8, db, duc, du, dout, None))
+        got = mgk.from_field(gf, dout)
+        assert np.array_equal(got, want), f"max diff {np.abs(got - want).max()}"
+    mgk.L.mgk_set_tuning(-1, -1)
+    assert np.array_equal(mgk.from_field(gf, du), u)          # the input is left untouched
+    for p in (du, db, duc, dout):
+        mgk.free(p)
