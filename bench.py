@@ -149,7 +149,7 @@ def main():
                        "dof_updates_per_cycle": dof_per_cycle},
             "cycle_unknowns_per_s": float(n0) ** args.dim * args.steps / elapsed,
             "residual_reduction_per_cycle": float((rn[-1] / rn[-1 - args.steps]) ** (1.0 / args.steps)) if len(rn) > args.steps else None,
-            "roofline": {"bound": "hbm", "kernel": "k_stencil<3,..,MODE_JACOBI> fine-level sweep",
+            "roofline": {"bound": "hbm", "kernel": f"k_stencil<{'double' if args.precision == 'fp64' else 'float'},{args.dim},..,MODE_JACOBI> fine-level Jacobi sweep",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "launches": prof_n, "avg_launch_ms": sweep_ms if prof_n else None,

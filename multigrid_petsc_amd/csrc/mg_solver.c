@@ -559,9 +559,8 @@ static int prolong_smooth(mg_solver *s, int l) {
         CHK(ensure_u_ghosts(s, Cq));
     }
     CHK(ensure_u_ghosts(s, F));          /* the neighbours' boundary planes BEFORE the correction */
-    void *t = prof_begin(s, l);
+    /* not counted by the profile: that one times the plain sweep kernel (bench.py roofline leg) */
     CHK(mgk_prolong_jacobi_f64(s->ctx, &F->g, &gc, F->coef, F->dinv, s->cfg.scale, F->b, ucoarse, F->u, F->tmp, NULL));
-    prof_end(s, t);
     swap_ptr(&F->u, &F->tmp);
     F->u_ghost_ok = 0; F->u_ghost_pending = 0;
     return smooth(s, l, v0 - 1);
@@ -596,9 +595,7 @@ static int vcycle_once_mixed(mg_solver *s) {
     for (int l = levels - 2; l >= 0; l--) {
         mg_level *F = &s->L[l];
         if ((s->cfg.fuse & 2) && v[0] >= 1) {
-            void *t = prof_begin(s, l);
             CHK(mgk_prolong_jacobi_f32(s->ctx, &F->g32, &s->L[l + 1].g32, F->coef, F->dinv, s->cfg.scale, F->b32, s->L[l + 1].u32, F->u32, F->tmp32, NULL));
-            prof_end(s, t);
             float *q = F->u32; F->u32 = F->tmp32; F->tmp32 = q;
             CHK(smooth32(s, l, v[0] - 1, 1));
         } else {
