@@ -70,6 +70,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MG_BENCH_DEVICE"):      # debugging aid: pin every rank to one device ordinal
+        local_rank = int(os.environ["MG_BENCH_DEVICE"])
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")

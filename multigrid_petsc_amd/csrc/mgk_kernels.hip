@@ -39,6 +39,8 @@ struct mgk_ctx {
     double *result_dev;    // 8 doubles (device)
     double *result_host;   // 8 doubles (pinned host)
     int max_partials;
+    hipEvent_t ev[32];     // ring of dependency events for mgk_stream_wait (no create/destroy on the hot path)
+    int ev_next;
 };
 
 extern "C" const char *mgk_last_error(void) { return g_err; }
@@ -67,6 +69,8 @@ extern "C" int mgk_ctx_create(mgk_ctx **out, int device) {
     HIPCHK(hipMalloc(&c->partials, sizeof(double) * 3 * c->max_partials));
     HIPCHK(hipMalloc(&c->result_dev, sizeof(double) * 8));
     HIPCHK(hipHostMalloc(&c->result_host, sizeof(double) * 8, hipHostMallocDefault));
+    for (int q = 0; q < 32; q++) HIPCHK(hipEventCreateWithFlags(&c->ev[q], hipEventDisableTiming));
+    c->ev_next = 0;
     *out = c;
     return 0;
 }
@@ -78,6 +82,7 @@ extern "C" void mgk_ctx_destroy(mgk_ctx *c) {
     (void)hipFree(c->partials);
     (void)hipFree(c->result_dev);
     (void)hipHostFree(c->result_host);
+    for (int q = 0; q < 32; q++) (void)hipEventDestroy(c->ev[q]);
     (void)hipStreamDestroy(c->compute);
     (void)hipStreamDestroy(c->comm);
     delete c;
@@ -148,11 +153,12 @@ extern "C" void mgk_timer_destroy(mgk_ctx *c, void *t) {
     delete x;
 }
 extern "C" int mgk_stream_wait(mgk_ctx *c, void *waiter, void *signaller) {
-    hipEvent_t ev;
-    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    // A wait captures the state of the event at the time of the call, so an event of the ring can be
+    // re-recorded later without disturbing earlier waits.
+    hipEvent_t ev = c->ev[c->ev_next];
+    c->ev_next = (c->ev_next + 1) & 31;
     HIPCHK(hipEventRecord(ev, S(c, signaller)));
     HIPCHK(hipStreamWaitEvent(S(c, waiter), ev, 0));
-    HIPCHK(hipEventDestroy(ev));
     return 0;
 }
 
