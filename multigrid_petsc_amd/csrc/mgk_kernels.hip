@@ -977,19 +977,29 @@ __global__ void __launch_bounds__(256) k_restrict(XferArgs a, const T *rf, T *bc
         T sum = (T)0;
         if (jc < a.nxc) {
             const T *base = rf + (DIM == 3 ? (long)(2 * kc) * a.plf : 0) + (long)(2 * ic) * a.pf + 2 * jc;
+            // per fine row: the aligned pair (2jc, 2jc+1) as one vector load, then 2jc+2 (same lines as the next lane's pair)
             if (DIM == 3) {
 #pragma unroll
                 for (int dk = 0; dk < 3; dk++)
 #pragma unroll
-                    for (int di = 0; di < 3; di++)
-#pragma unroll
-                        for (int dj = 0; dj < 3; dj++)
-                            sum += (w1[dk] * w2[di][dj]) * base[dk * a.plf + di * a.pf + dj];
+                    for (int di = 0; di < 3; di++) {
+                        const T *rowp = base + dk * a.plf + di * a.pf;
+                        const P2<T> pr = *reinterpret_cast<const P2<T> *>(rowp);
+                        const T third = rowp[2];
+                        sum += (w1[dk] * w2[di][0]) * pr.x;
+                        sum += (w1[dk] * w2[di][1]) * pr.y;
+                        sum += (w1[dk] * w2[di][2]) * third;
+                    }
             } else {
 #pragma unroll
-                for (int di = 0; di < 3; di++)
-#pragma unroll
-                    for (int dj = 0; dj < 3; dj++) sum += w2[di][dj] * base[di * a.pf + dj];
+                for (int di = 0; di < 3; di++) {
+                    const T *rowp = base + di * a.pf;
+                    const P2<T> pr = *reinterpret_cast<const P2<T> *>(rowp);
+                    const T third = rowp[2];
+                    sum += w2[di][0] * pr.x;
+                    sum += w2[di][1] * pr.y;
+                    sum += w2[di][2] * third;
+                }
             }
         }
         bc[(DIM == 3 ? (long)kc * a.plc : 0) + (long)ic * a.pc + jc] = sum;
