@@ -147,9 +147,12 @@ int  mgk_flat_fill(mgk_ctx *ctx, long n, double a, double *z, void *stream);    
 int  mgk_flat_scale(mgk_ctx *ctx, long n, double a, double *z, void *stream);
 int  mgk_flat_pointwise_mult(mgk_ctx *ctx, long n, const double *x, const double *y, double *z, void *stream);
 int  mgk_flat_dot(mgk_ctx *ctx, long n, const double *x, const double *y, double *dot_host, void *stream);   /* VecDot / VecNorm^2 */
-/* generic assembled AIJ: y = A x, or y = addto + alpha*(A x) when addto != NULL (rows: ascending columns) */
+/* generic assembled AIJ: y = A x, or y = addto + alpha*(A x) when addto != NULL (rows: ascending columns).
+ * `col` holds element offsets into x (translated by the caller when x is a padded field); when y/addto are padded
+ * 2-D grid fields pass row_n > 0: row r lands at row_org + (r / row_n)*row_pitch + r % row_n. */
 int  mgk_csr_mult_f64(mgk_ctx *ctx, long nrows, const long *rowptr, const int *col, const double *val,
-                      const double *x, double *y, double alpha, const double *addto, void *stream);
+                      const double *x, double *y, double alpha, const double *addto,
+                      int row_n, long row_pitch, long row_org, void *stream);
 
 /* ---- fp32 fields and the fp64<->fp32 bridges of the mixed-precision cycle (BASELINE.json config 5:
  * "fp32 smoother sweeps with fp64 residual/correction"; no reference counterpart).

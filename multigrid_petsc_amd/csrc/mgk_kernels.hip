@@ -1115,14 +1115,18 @@ __global__ void __launch_bounds__(256) k_flat_dot(long n, const double *x, const
     double s = block_sum(acc, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
-// MatMult on assembled AIJ: one lane per row, ascending columns, separate multiply and add
+// MatMult on assembled AIJ: one lane per row, ascending columns, separate multiply and add.
+// Column indices are element offsets into x (already translated when x is a padded grid field);
+// rows map to y / addto through (row_n, row_pitch, row_org) when y is a padded 2-D grid field (row_n > 0).
 __global__ void __launch_bounds__(256) k_csr_mult(long nrows, const long *rowptr, const int *col, const double *val,
-                                                  const double *x, double *y, double alpha, const double *addto) {
+                                                  const double *x, double *y, double alpha, const double *addto,
+                                                  int row_n, long row_pitch, long row_org) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += stride) {
         double sum = 0.0;
         for (long q = rowptr[r]; q < rowptr[r + 1]; q++) sum += val[q] * x[col[q]];
-        y[r] = addto ? addto[r] + alpha * sum : sum;
+        const long o = row_n > 0 ? row_org + (r / row_n) * row_pitch + (r % row_n) : r;
+        y[o] = addto ? addto[o] + alpha * sum : sum;
     }
 }
 static unsigned flat_grid(long n) {
@@ -1149,9 +1153,11 @@ extern "C" int mgk_flat_dot(mgk_ctx *c, long n, const double *x, const double *y
     return finish_to_host(c, (int)g, 1, S(c, stream), dot_host);
 }
 extern "C" int mgk_csr_mult_f64(mgk_ctx *c, long nrows, const long *rowptr, const int *col, const double *val,
-                                const double *x, double *y, double alpha, const double *addto, void *stream) {
+                                const double *x, double *y, double alpha, const double *addto,
+                                int row_n, long row_pitch, long row_org, void *stream) {
     if (!c || !rowptr || !col || !val || !x || !y) return fail(MGK_EINVAL, "mgk_csr_mult_f64: bad arguments");
-    hipLaunchKernelGGL(k_csr_mult, dim3(flat_grid(nrows)), dim3(256), 0, S(c, stream), nrows, rowptr, col, val, x, y, alpha, addto);
+    hipLaunchKernelGGL(k_csr_mult, dim3(flat_grid(nrows)), dim3(256), 0, S(c, stream), nrows, rowptr, col, val, x, y, alpha, addto,
+                       row_n, row_pitch, row_org);
     HIPCHK(hipGetLastError());
     return 0;
 }

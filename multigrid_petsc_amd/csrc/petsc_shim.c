@@ -343,8 +343,10 @@ struct _p_Mat {
     long *rowptr; int *col; double *val; long nz;        /* host CSR after assembly */
     int kind;
     mgk_geom gf, gc;                                     /* STENCIL: gf; RESTRICT/PROLONG: fine gf, coarse gc */
+    int grow_ok, gcol_ok; mgk_geom grow, gcol;           /* GENERIC on n^2 index spaces (n odd): row / column vectors stay padded grid fields */
     double coef[7];
     long *d_rowptr; int *d_col; double *d_val; double *d_dinv;   /* device CSR (generic), lazily built */
+    long d_dinv_len;
     int dev_stale;
     Vec work;
 };
@@ -488,6 +490,14 @@ PetscErrorCode MatAssemblyEnd(Mat A, MatAssemblyType t) {
     A->kind = MAT_GENERIC;
     if (!getenv("MGPETSC_NO_RECOGNITION"))
         if (!recognise_stencil(A) && !recognise_restrict(A)) recognise_prolong(A);
+    if (A->kind == MAT_GENERIC) {
+        /* a matrix between n^2-sized index spaces keeps the padded grid layout for its vectors, so that it can
+         * be mixed with recognised operators on the same grids (e.g. variable-coefficient A with the transfer
+         * operators of the stretched-mesh runs, -mesh 1/2) */
+        int nr = isqrt_exact(A->m), ncq = isqrt_exact(A->n);
+        A->grow_ok = (nr >= 1 && (nr & 1)) && mgk_geom_init(&A->grow, 2, nr, nr, 1) == 0;
+        A->gcol_ok = (ncq >= 1 && (ncq & 1)) && mgk_geom_init(&A->gcol, 2, ncq, ncq, 1) == 0;
+    }
     A->dev_stale = 1;
     return 0;
 }
@@ -502,15 +512,27 @@ static void mat_device_csr(Mat A) {
         DEV(mgk_malloc(G, &p, sizeof(double) * (size_t)(A->m ? A->m : 1))); A->d_dinv = (double *)p;
     }
     DEV(mgk_h2d(G, A->d_rowptr, A->rowptr, sizeof(long) * ((size_t)A->m + 1)));
-    DEV(mgk_h2d(G, A->d_col, A->col, sizeof(int) * (size_t)A->nz));
+    if (A->gcol_ok) {                                    /* columns -> offsets into the padded x field */
+        int *pc = (int *)malloc(sizeof(int) * (size_t)(A->nz ? A->nz : 1));
+        const int n = A->gcol.nx;
+        for (long q = 0; q < A->nz; q++) pc[q] = (int)(A->gcol.org + (long)(A->col[q] / n) * A->gcol.pitch + A->col[q] % n);
+        DEV(mgk_h2d(G, A->d_col, pc, sizeof(int) * (size_t)A->nz));
+        free(pc);
+    } else {
+        DEV(mgk_h2d(G, A->d_col, A->col, sizeof(int) * (size_t)A->nz));
+    }
     DEV(mgk_h2d(G, A->d_val, A->val, sizeof(double) * (size_t)A->nz));
-    double *dinv = (double *)malloc(sizeof(double) * (size_t)(A->m ? A->m : 1));
+    /* PCJACOBI: 1/diag in the layout of the row vectors */
+    const long dlen = A->grow_ok ? A->grow.total : A->m;
+    if (!A->d_dinv_len) { void *pp; DEV(mgk_malloc(G, &pp, sizeof(double) * (size_t)(dlen ? dlen : 1))); mgk_free(G, A->d_dinv); A->d_dinv = (double *)pp; A->d_dinv_len = dlen; }
+    double *dinv = (double *)calloc((size_t)(dlen ? dlen : 1), sizeof(double));
     for (long r = 0; r < A->m; r++) {
         double d = 0.0;
         for (long q = A->rowptr[r]; q < A->rowptr[r + 1]; q++) if (A->col[q] == r) d = A->val[q];
-        dinv[r] = 1.0 / d;                               /* PCJACOBI */
+        const long o = A->grow_ok ? A->grow.org + (r / A->grow.nx) * A->grow.pitch + r % A->grow.nx : r;
+        dinv[o] = 1.0 / d;
     }
-    DEV(mgk_h2d(G, A->d_dinv, dinv, sizeof(double) * (size_t)A->m));
+    DEV(mgk_h2d(G, A->d_dinv, dinv, sizeof(double) * (size_t)dlen));
     free(dinv);
     A->dev_stale = 0;
 }
@@ -520,6 +542,7 @@ PetscErrorCode MatCreateVecs(Mat A, Vec *right, Vec *left) {       /* src/solver
     if (A->kind == MAT_STENCIL) gr = gl = &A->gf;
     else if (A->kind == MAT_RESTRICT) { gr = &A->gf; gl = &A->gc; }
     else if (A->kind == MAT_PROLONG) { gr = &A->gc; gl = &A->gf; }
+    else { if (A->gcol_ok) gr = &A->gcol; if (A->grow_ok) gl = &A->grow; }
     if (right) *right = vec_new(A->n, gr);
     if (left) *left = vec_new(A->m, gl);
     return 0;
@@ -530,6 +553,17 @@ static int geom_eq(const mgk_geom *a, const mgk_geom *b) { return a->dim == b->d
 static void need_vec(Vec v, int padded, const mgk_geom *g, PetscInt n, const char *who) {
     int ok = (v->n == n) && (v->padded == padded) && (!padded || geom_eq(&v->g, g));
     if (!ok) { fprintf(stderr, "[mgpetsc] FATAL: %s: vector does not match the operator's layout (create it with MatCreateVecs/VecDuplicate)\n", who); exit(88); }
+}
+
+/* y = A x (addto == NULL) or y = addto + alpha*(A x) on the assembled AIJ operator; vectors in the operator's layouts */
+static void csr_apply(Mat A, Vec x, Vec y, double alpha, Vec addto, const char *who) {
+    need_vec(x, A->gcol_ok, &A->gcol, A->n, who);
+    need_vec(y, A->grow_ok, &A->grow, A->m, who);
+    if (addto) need_vec(addto, A->grow_ok, &A->grow, A->m, who);
+    mat_device_csr(A);
+    y->host_dirty = 0;
+    DEV(mgk_csr_mult_f64(G, A->m, A->d_rowptr, A->d_col, A->d_val, vdev(x), y->dev, alpha, addto ? vdev(addto) : NULL,
+                         A->grow_ok ? A->grow.nx : 0, A->grow_ok ? A->grow.pitch : 0, A->grow_ok ? A->grow.org : 0, NULL));
 }
 
 PetscErrorCode MatMult(Mat A, Vec x, Vec y) {                       /* src/solver.c:1516,1535,1540 */
@@ -551,21 +585,13 @@ PetscErrorCode MatMult(Mat A, Vec x, Vec y) {                       /* src/solve
         DEV(mgk_prolong_add_f64(G, &A->gf, &A->gc, vdev(x), y->dev, NULL));
         break;
     default:
-        need_vec(x, 0, NULL, A->n, "MatMult"); need_vec(y, 0, NULL, A->m, "MatMult");
-        mat_device_csr(A);
-        DEV(mgk_csr_mult_f64(G, A->m, A->d_rowptr, A->d_col, A->d_val, vdev(x), y->dev, 1.0, NULL, NULL));
+        csr_apply(A, x, y, 1.0, NULL, "MatMult");
     }
     return 0;
 }
 static Vec mat_work(Mat A, Vec like) { if (!A->work) VecDuplicate(like, &A->work); return A->work; }
 PetscErrorCode MatMultAdd(Mat A, Vec x, Vec y, Vec z) {            /* z = y + A x */
-    if (A->kind == MAT_GENERIC) {
-        need_vec(x, 0, NULL, A->n, "MatMultAdd");
-        mat_device_csr(A);
-        z->host_dirty = 0;
-        DEV(mgk_csr_mult_f64(G, A->m, A->d_rowptr, A->d_col, A->d_val, vdev(x), z->dev, 1.0, vdev(y), NULL));
-        return 0;
-    }
+    if (A->kind == MAT_GENERIC) { csr_apply(A, x, z, 1.0, y, "MatMultAdd"); return 0; }
     Vec t = mat_work(A, y);
     MatMult(A, x, t);
     if (z != y) VecCopy(y, z);
@@ -578,11 +604,7 @@ PetscErrorCode MatResidual(Mat A, Vec b, Vec x, Vec r) {           /* r = b - A 
         DEV(mgk_residual_f64(G, &A->gf, A->coef, vdev(b), vdev(x), r->dev, NULL));
         return 0;
     }
-    if (A->kind == MAT_GENERIC) {
-        mat_device_csr(A);
-        DEV(mgk_csr_mult_f64(G, A->m, A->d_rowptr, A->d_col, A->d_val, vdev(x), r->dev, -1.0, vdev(b), NULL));
-        return 0;
-    }
+    if (A->kind == MAT_GENERIC) { csr_apply(A, x, r, -1.0, b, "MatResidual"); return 0; }
     MatMult(A, x, r);
     return VecAYPX(r, -1.0, b);
 }
@@ -782,16 +804,16 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
 
     if (A->kind != MAT_GENERIC) UNSUPPORTED("KSPSolve on a transfer operator");
     if (k->type != K_RICHARDSON) UNSUPPORTED("chebyshev on an unrecognised (assembled AIJ) operator");
-    need_vec(x, 0, NULL, A->n, "KSPSolve");
+    if (A->m != A->n) UNSUPPORTED("KSPSolve on a rectangular operator");
     mat_device_csr(A);
     Vec r = ksp_work(k, 0, x), z = ksp_work(k, 1, x);
-    if (!k->guess_nonzero) DEV(mgk_d2d(G, r->dev, b->dev, sizeof(double) * (size_t)b->nalloc, NULL));
-    else DEV(mgk_csr_mult_f64(G, A->m, A->d_rowptr, A->d_col, A->d_val, x->dev, r->dev, -1.0, b->dev, NULL));
+    if (!k->guess_nonzero) DEV(mgk_d2d(G, r->dev, b->dev, sizeof(double) * (size_t)b->nalloc, NULL));     /* r = b */
+    else csr_apply(A, x, r, -1.0, b, "KSPSolve");                                                          /* r = b - A x */
     for (PetscInt it = 0; it < maxit; it++) {
-        if (pc == P_JACOBI) DEV(mgk_flat_pointwise_mult(G, A->m, r->dev, A->d_dinv, z->dev, NULL));
+        if (pc == P_JACOBI) DEV(mgk_flat_pointwise_mult(G, x->nalloc, r->dev, A->d_dinv, z->dev, NULL));   /* z = B r */
         else DEV(mgk_d2d(G, z->dev, r->dev, sizeof(double) * (size_t)r->nalloc, NULL));
-        DEV(mgk_flat_axpy(G, A->m, k->scale, z->dev, x->dev, NULL));
-        if (it + 1 < maxit) DEV(mgk_csr_mult_f64(G, A->m, A->d_rowptr, A->d_col, A->d_val, x->dev, r->dev, -1.0, b->dev, NULL));
+        DEV(mgk_flat_axpy(G, x->nalloc, k->scale, z->dev, x->dev, NULL));                                  /* x += s z */
+        if (it + 1 < maxit) csr_apply(A, x, r, -1.0, b, "KSPSolve");
     }
     k->its = maxit;
     return 0;

@@ -299,6 +299,63 @@ void mgo_error_norms(int dim, int npts, const double *u, double err[3]) {
     free(c);
 }
 
+/* ---- stretched meshes (2-D only, -mesh 1 / 2): src/mesh.c:45-107 (metrics), :154-176 (coords) ---- */
+/* y coordinates: NONUNIFORM1 y_j = hi - L*cos(pi/2 * j/(n-1)), NONUNIFORM2 y_j = lo + L*(exp(2 eta)-1)/(exp(2)-1);
+ * x stays uniform (src/mesh.c:140-152). */
+void mgo_coords_mesh(int npts, int axis, int mesh, double *c) {
+    if (axis == 0 || mesh == 0) { mgo_coords_uniform(npts, axis, c); return; }
+    c[0] = 0.0; c[npts - 1] = 1.0;
+    double length = c[npts - 1] - c[0];
+    for (int j = 1; j < npts - 1; j++) {
+        if (mesh == 1) c[j] = 1.0 - length * (cos(MGO_PI * 0.5 * (j / (double)(npts - 1))));
+        else { double eta = (j / (double)(npts - 1)); c[j] = 0.0 + length * ((exp(2 * eta) - 1) / (exp(2) - 1)); }
+    }
+}
+/* metrics at (x,y) for bounds [0,1]^2: src/mesh.c:29-43 (uniform), :45-75 (NONUNIFORM1), :77-107 (NONUNIFORM2) */
+void mgo_metrics(int mesh, double x, double y, double *m) {
+    (void)x;
+    const double b0 = 0.0, b1 = 1.0, b2 = 0.0, b3 = 1.0;
+    if (mesh == 0) { m[0] = 1.0; m[1] = 1.0; m[2] = 0.0; m[3] = 0.0; m[4] = 0.0; return; }
+    if (mesh == 1) {
+        double temp = ((b3 - b2) * (b3 - b2) - (b3 - y) * (b3 - y));
+        m[0] = 1.0;
+        m[1] = 4.0 / (MGO_PI * MGO_PI * temp);
+        m[2] = 0.0;
+        m[3] = (-2.0 * (b3 - y)) / (MGO_PI * sqrt(temp * temp * temp));
+        m[4] = 0.0;
+        return;
+    }
+    double temp = ((exp(2) - 1) * (exp(2) - 1)) / (((y - b2) * (exp(2) - 1) + (b3 - b2)) * ((y - b2) * (exp(2) - 1) + (b3 - b2)));
+    m[0] = 1.0 / ((b1 - b0) * (b1 - b0));
+    m[1] = 0.25 * temp;
+    m[2] = 0.0;
+    m[3] = (-0.5) * temp;
+    m[4] = 0.0;
+}
+/* b0 and the error norms on a stretched mesh (src/solver.c:586-594, :1211-1237 with mesh->coord) */
+void mgo_rhs_mesh(int npts, int mesh, double *b) {
+    int n = npts - 2;
+    double *cx = (double *)malloc(sizeof(double) * npts), *cy = (double *)malloc(sizeof(double) * npts);
+    mgo_coords_mesh(npts, 0, mesh, cx); mgo_coords_mesh(npts, 1, mesh, cy);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) b[(long)i * n + j] = mgo_ffunc(2, cx[j + 1], cy[i + 1], 0.0);
+    free(cx); free(cy);
+}
+void mgo_error_norms_mesh(int npts, int mesh, const double *u, double err[3]) {
+    int n = npts - 2;
+    double *cx = (double *)malloc(sizeof(double) * npts), *cy = (double *)malloc(sizeof(double) * npts);
+    mgo_coords_mesh(npts, 0, mesh, cx); mgo_coords_mesh(npts, 1, mesh, cy);
+    err[0] = err[1] = err[2] = 0.0;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            double sol = mgo_solfunc(2, cx[j + 1], cy[i + 1], 0.0);
+            double diff = fabs(u[(long)i * n + j] - sol);
+            err[0] = fmax(diff, err[0]); err[1] = err[1] + diff; err[2] = err[2] + diff * diff;
+        }
+    err[2] = sqrt(err[2]);
+    free(cx); free(cy);
+}
+
 /* ------------------------------------------------------------------ */
 /* assembled (AIJ) path                                                */
 /* ------------------------------------------------------------------ */
@@ -360,6 +417,31 @@ void mgo_csr_row(const mgo_csr *m, long row, int *ncols, int *cols, double *vals
 /* src/solver.c:185-253 (fillJacobians) + 489-510 (levelMatrixA), one grid per level.
  * The grid->global map of a one-grid level is the lexicographic identity (all three styles,
  * checked in tests/test_oracle.py), so b[(i)*bj+j] is written as the formula. */
+/* variable-coefficient rows for -mesh 1/2 (2-D): metrics at the fine-grid point of (i0,j0), OpA with the level's h */
+mgo_csr *mgo_build_A_mesh(int npts, int l, int mesh) {
+    int n = mgo_grid_n(npts, l);
+    double h[2] = {1.0 / (n + 1), 1.0 / (n + 1)};
+    double *cx = (double *)malloc(sizeof(double) * npts), *cy = (double *)malloc(sizeof(double) * npts);
+    mgo_coords_mesh(npts, 0, mesh, cx); mgo_coords_mesh(npts, 1, mesh, cy);
+    coo_list L = {0};
+    long N = (long)n * n;
+    int f = mgo_ipow(2, l);
+    for (long row = 0; row < N; row++) {
+        int i0 = (int)(row / n), j0 = (int)(row % n);
+        int ifine = f * (i0 + 1) - 1, jfine = f * (j0 + 1) - 1;       /* solver.c:227-228 */
+        double metrics[5], As[5];
+        mgo_metrics(mesh, cx[jfine + 1], cy[ifine + 1], metrics);     /* :231 */
+        mgo_opA(metrics, h, As);                                      /* :232 */
+        if (i0 - 1 >= 0) coo_push(&L, row, (long)(i0 - 1) * n + j0, As[0]);
+        if (j0 - 1 >= 0) coo_push(&L, row, (long)i0 * n + j0 - 1, As[1]);
+        coo_push(&L, row, row, As[2]);
+        if (j0 + 1 < n) coo_push(&L, row, (long)i0 * n + j0 + 1, As[3]);
+        if (i0 + 1 < n) coo_push(&L, row, (long)(i0 + 1) * n + j0, As[4]);
+    }
+    free(cx); free(cy);
+    return coo_to_csr(&L, N, N);
+}
+
 mgo_csr *mgo_build_A(int dim, int npts, int l) {
     int n = mgo_grid_n(npts, l);
     double As[7];
@@ -787,13 +869,14 @@ int mgo_vcycle(const mgo_vcycle_cfg *c, double *rnorm, double *u_out, double *bn
         L[l].rv = (double *)calloc(L[l].N, sizeof(double));
         L[l].work = (double *)calloc(4 * L[l].N, sizeof(double));
         if (c->use_csr) {
-            L[l].A = mgo_build_A(dim, c->npts, l);
+            L[l].A = (c->mesh != 0 && dim == 2) ? mgo_build_A_mesh(c->npts, l, c->mesh) : mgo_build_A(dim, c->npts, l);
             L[l].dinv = (double *)malloc(sizeof(double) * L[l].N);
             mgo_csr_diag_inv(L[l].A, L[l].dinv);
             if (l < levels - 1) { L[l].R = mgo_build_R(dim, c->npts, l); L[l].P = mgo_build_P(dim, c->npts, l); }
         }
     }
-    mgo_rhs(dim, c->npts, L[0].b);                                  /* levelvecb */
+    if (c->mesh != 0 && dim == 2 && c->use_csr) mgo_rhs_mesh(c->npts, c->mesh, L[0].b);
+    else mgo_rhs(dim, c->npts, L[0].b);                             /* levelvecb */
     double bnorm = mgo_norm2(L[0].b, L[0].N);                       /* solver.c:1512 */
     memset(L[0].u, 0, sizeof(double) * L[0].N);                     /* :1514 */
     if (c->use_csr) mgo_csr_mult(L[0].A, L[0].u, L[0].rv);          /* :1516 */

@@ -74,6 +74,11 @@ double mgo_ffunc(int dim, double x, double y, double z);           /* problem.c:
 double mgo_solfunc(int dim, double x, double y, double z);         /* problem.c:30-34 */
 void   mgo_rhs(int dim, int npts, double *b);                      /* solver.c:558-620 (g0==g1 branch) */
 void   mgo_error_norms(int dim, int npts, const double *u, double err[3]); /* solver.c:1211-1237 */
+/* stretched meshes, 2-D (-mesh 1/2): src/mesh.c:45-107,154-176 */
+void   mgo_coords_mesh(int npts, int axis, int mesh, double *c);
+void   mgo_metrics(int mesh, double x, double y, double *m);
+void   mgo_rhs_mesh(int npts, int mesh, double *b);
+void   mgo_error_norms_mesh(int npts, int mesh, const double *u, double err[3]);
 
 /* ---------------- assembled (AIJ) path: src/solver.c ---------------- */
 typedef struct mgo_csr {
@@ -81,6 +86,7 @@ typedef struct mgo_csr {
     long *rowptr; int *col; double *val;
 } mgo_csr;
 void     mgo_csr_free(mgo_csr *m);
+mgo_csr *mgo_build_A_mesh(int npts, int l, int mesh);  /* variable-coefficient rows, -mesh 1/2 */
 mgo_csr *mgo_build_A(int dim, int npts, int l);      /* solver.c:185-253,489-510 via MatSetValue(ADD_VALUES) semantics */
 mgo_csr *mgo_build_R(int dim, int npts, int l);      /* solver.c:1035-1094: level l -> l+1 */
 mgo_csr *mgo_build_P(int dim, int npts, int l);      /* solver.c:1096-1154: level l+1 -> l */
@@ -131,6 +137,7 @@ typedef struct mgo_vcycle_cfg {
     int use_csr;           /* 1: assembled AIJ path, 0: matrix-free path */
     int fixed_cycles;      /* >0: run exactly this many cycles, ignore the stopping test */
     double rtol;           /* stopping factor, reference uses 1.e-7 (solver.c:1530) */
+    int mesh;              /* -mesh 0 uniform, 1 / 2 stretched in y (2-D, assembled leg only; src/mesh.c:45-107) */
 } mgo_vcycle_cfg;
 /* rnorm_raw: maxiter+1 doubles, absolute ||r|| per cycle (solver.c:1520,1549); u_out: N0 doubles or NULL.
  * returns number of cycles done (solver->numIter, solver.c:1558); bnorm_out = ||b0||. */

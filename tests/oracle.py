@@ -14,7 +14,7 @@ _LIB = os.path.join(ROOT, "oracle", "libmgo.so")
 class VcycleCfg(C.Structure):
     _fields_ = [("dim", C.c_int), ("npts", C.c_int), ("levels", C.c_int), ("v0", C.c_int), ("v1", C.c_int),
                 ("maxiter", C.c_int), ("ksp_type", C.c_int), ("scale", C.c_double), ("emin", C.c_double),
-                ("emax", C.c_double), ("use_csr", C.c_int), ("fixed_cycles", C.c_int), ("rtol", C.c_double)]
+                ("emax", C.c_double), ("use_csr", C.c_int), ("fixed_cycles", C.c_int), ("rtol", C.c_double), ("mesh", C.c_int)]
 
 
 def _p(a):
@@ -73,6 +73,7 @@ class Oracle:
         L.mgo_restriction_stencil.argtypes = [C.c_void_p]
         L.mgo_prolongation_stencil.argtypes = [C.c_void_p]
         L.mgo_num_threads.restype = C.c_int
+        L.mgo_error_norms_mesh.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.mgo_st_jacobi_f32.argtypes = [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.mgo_st_residual_f32.argtypes = [C.c_int] + [C.c_void_p] * 4
         L.mgo_st_restrict_f32.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
@@ -96,6 +97,12 @@ class Oracle:
         c = np.zeros(npts)
         self.L.mgo_coords_uniform(npts, 0, _p(c))
         return c
+
+    def error_norms_mesh(self, npts, mesh, u):
+        e = np.zeros(3)
+        u = np.ascontiguousarray(u)
+        self.L.mgo_error_norms_mesh(npts, mesh, _p(u), _p(e))
+        return e
 
     def error_norms(self, dim, npts, u):
         e = np.zeros(3)
@@ -152,8 +159,8 @@ class Oracle:
         return self.L.mgo_sumsq(_p(x), x.size)
 
     def vcycle(self, dim, npts, levels, v0=3, v1=3, maxiter=1000, ksp_type=0, scale=1.0, emin=0.0, emax=0.0,
-               use_csr=0, fixed_cycles=0, rtol=0.0, want_u=True):
-        cfg = VcycleCfg(dim, npts, levels, v0, v1, maxiter, ksp_type, scale, emin, emax, use_csr, fixed_cycles, rtol)
+               use_csr=0, fixed_cycles=0, rtol=0.0, want_u=True, mesh=0):
+        cfg = VcycleCfg(dim, npts, levels, v0, v1, maxiter, ksp_type, scale, emin, emax, use_csr, fixed_cycles, rtol, mesh)
         rn = np.zeros(max(maxiter, fixed_cycles) + 1)
         u = np.zeros((npts - 2) ** dim) if want_u else None
         bn, sec = C.c_double(), C.c_double()
@@ -186,7 +193,7 @@ class Oracle:
         return out
 
     def vcycle_mixed(self, npts, levels, v0=3, v1=3, maxiter=100, scale=1.0, fixed_cycles=0):
-        cfg = VcycleCfg(3, npts, levels, v0, v1, maxiter, 0, scale, 0.0, 0.0, 0, fixed_cycles, 0.0)
+        cfg = VcycleCfg(3, npts, levels, v0, v1, maxiter, 0, scale, 0.0, 0.0, 0, fixed_cycles, 0.0, 0)
         rn = np.zeros(max(maxiter, fixed_cycles) + 1)
         u = np.zeros((npts - 2) ** 3)
         bn, sec = C.c_double(), C.c_double()
