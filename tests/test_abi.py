@@ -99,3 +99,31 @@ def test_slab_split_is_nested_and_covers(npts, ldist, nranks):
                 assert a == 2 * ca and b == (n if r == nranks - 1 else 2 * cb)
             prev_end = b
         assert prev_end == n
+
+
+@pytest.mark.parametrize("npts,levels", [(9, 2), (17, 3), (33, 4)])
+@pytest.mark.parametrize("style", [0, 1, 2])
+def test_implicit_maps_equal_the_reference_maps_bit_exactly(npts, levels, style):
+    """a9: the product keeps no index arrays; its formula maps must reproduce, entry for entry, the grid->global and
+    global->(i,j,g) arrays the reference builds (src/matbuild.c:146-323, restated in the oracle) for every -map style
+    when each level holds one grid, and its ranges for any number of ranks."""
+    import ctypes as C
+    from multigrid_petsc_amd import solver as S
+    from oracle import Oracle
+    orc = Oracle()
+    L = S._lib()
+    for l in range(levels):
+        n = L.mg_grid_n(npts, l)
+        tot = n * n
+        for procs in (1, 3, 8):
+            glob = np.zeros(3 * tot, dtype=np.int32)
+            grid = np.zeros(tot, dtype=np.int32)
+            ranges = np.zeros(procs + 1, dtype=np.int32)
+            assert orc.L.mgo_mapping_2d(npts, levels, levels, style, procs, l, glob.ctypes.data, grid.ctypes.data, ranges.ctypes.data) == 0
+            mine = np.array([L.mg_grid_to_global(2, n, 0, i, j) for i in range(n) for j in range(n)], dtype=np.int64)
+            assert np.array_equal(mine, grid)
+            k, i, j = C.c_int(), C.c_int(), C.c_int()
+            for idx in range(tot):
+                L.mg_global_to_grid(2, n, idx, C.byref(k), C.byref(i), C.byref(j))
+                assert (i.value, j.value, l) == tuple(glob[3 * idx:3 * idx + 3])
+            assert np.array_equal(S.get_ranges(tot, procs), ranges)
