@@ -106,6 +106,11 @@ int  mgk_residual_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef,
 int  mgk_residual_sumsq_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef,
                             const double *b, const double *u, double *sumsq_host, void *stream);
 
+/* K2+K3 fused: b_coarse = R (b - A u), the fine residual is never written (src/solver.c:1534-1535).
+ * Whole grids only (gf->nz == 2*gc->nz + 1); a slab uses mgk_residual_f64 + halo + mgk_restrict_fw_f64.  3-D. */
+int  mgk_residual_restrict_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
+                               const double *b, const double *u, double *bc, void *stream);
+
 /* ---- K3: MatMult(res[l], r, b[l+1]) full weighting (src/solver.c:1535, matrix :1071-1092) ----
  * coarse (kc,ic,jc) gathers fine (2kc+dk, 2ic+di, 2jc+dj), d in {0,1,2}.  gc->nz coarse planes are
  * produced from fine planes 0..2*gc->nz (plane gf->nz is the fine ghost plane in the slab case). */

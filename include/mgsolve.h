@@ -38,7 +38,8 @@ typedef struct mg_config {
     int rank, nranks;   /* z-slab decomposition over `nranks` GPUs (1: whole grid) */
     int dist_min_n;     /* levels with n >= dist_min_n stay distributed, coarser ones are replicated; <=0: default 127 */
     int fuse;           /* bit 0: final residual fused with its norm (no rv write); bit 1: prolongation fused into the
-                         * first post-smoothing sweep; default (-1): all on */
+                         * first post-smoothing sweep; bit 2: pre-restriction residual fused with the restriction (whole grids);
+                         * default (-1): all on */
     int overlap;        /* nranks > 1: halo of sweep k on the comm stream while sweep k's interior runs; default on (-1) */
 } mg_config;
 

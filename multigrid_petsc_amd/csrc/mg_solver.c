@@ -196,7 +196,7 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
     s->cfg = *cfg;
     if (s->cfg.rtol <= 0) s->cfg.rtol = 1.e-7;
     if (s->cfg.dist_min_n <= 0) s->cfg.dist_min_n = 127;
-    if (s->cfg.fuse < 0) s->cfg.fuse = 3;
+    if (s->cfg.fuse < 0) s->cfg.fuse = 7;
     if (s->cfg.overlap < 0) s->cfg.overlap = 1;
     if (s->cfg.nranks < 1) s->cfg.nranks = 1;
     s->comm = comm;
@@ -620,8 +620,14 @@ static int vcycle_once(mg_solver *s) {
     CHK(smooth(s, 0, v[0]));                                            /* :1531 */
     if (s->iter == 0) s->L[0].guess_nonzero = 1;                        /* :1532 */
     for (int l = 1; l < levels; l++) {
-        CHK(residual(s, l - 1));                                        /* :1534 */
-        CHK(restrict_to(s, l));                                         /* :1535 */
+        mg_level *F = &s->L[l - 1];
+        if ((s->cfg.fuse & 4) && s->cfg.dim == 3 && !F->distributed && F->n + 1 <= 1024) {
+            /* :1534-1535 in one pass: b_l = R (b - A u), the fine residual is never written */
+            CHK(mgk_residual_restrict_f64(s->ctx, &F->g, &s->L[l].g, F->coef, F->b, F->u, s->L[l].b, NULL));
+        } else {
+            CHK(residual(s, l - 1));                                    /* :1534 */
+            CHK(restrict_to(s, l));                                     /* :1535 */
+        }
         CHK(smooth(s, l, l == levels - 1 ? v[1] : v[0]));               /* :1536 */
         if (l != levels - 1) s->L[l].guess_nonzero = 1;                 /* :1537 */
     }

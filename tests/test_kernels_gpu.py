@@ -180,3 +180,26 @@ def test_fused_prolong_jacobi_bit_exact(mgk, orc, nf, variant):
     assert np.array_equal(mgk.from_field(gf, du), u)          # the input is left untouched
     for p in (du, db, duc, dout):
         mgk.free(p)
+
+
+@pytest.mark.parametrize("nf", [3, 7, 15, 63, 127, 255])
+def test_fused_residual_restrict_bit_exact(mgk, orc, nf):
+    """b_c = R (b - A u) in one pass == residual followed by full weighting (src/solver.c:1534-1535)"""
+    rng = np.random.default_rng(700 + nf)
+    nc = (nf - 1) // 2
+    As = _stencil(orc, 3, nf)
+    u, b = _rand(rng, nf ** 3), _rand(rng, nf ** 3)
+    gf, gc = mgk.geom(3, nf), mgk.geom(3, nc)
+    du, db, dbc = mgk.to_field(gf, u), mgk.to_field(gf, b), mgk.field(gc)
+    want = orc.restrict(3, nf, orc.residual(3, nf, As, b, u))
+    for zc in (-1, 5):
+        mgk.L.mgk_set_tuning(-1, zc)
+        mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dbc, 8 * gc.total, None))
+        mgk._chk(mgk.L.mgk_residual_restrict_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), db, du, dbc, None))
+        got = mgk.from_field(gc, dbc)
+        assert np.array_equal(got, want), f"zc={zc} max diff {np.abs(got - want).max()}"
+        raw = mgk.raw_field(gc, dbc)
+        assert abs(np.abs(raw).sum() - np.abs(got).sum()) <= 1e-9 * np.abs(got).sum()
+    mgk.L.mgk_set_tuning(-1, -1)
+    for p in (du, db, dbc):
+        mgk.free(p)

@@ -73,7 +73,7 @@ def test_chebyshev_smoother_matches_oracle(orc, dim, npts, levels):
 
 def test_unfused_final_residual_same_history(orc):
     from multigrid_petsc_amd.solver import Solver
-    a = Solver(3, 33, 4, scale=6.0 / 7.0, maxiter=50, fuse=3)
+    a = Solver(3, 33, 4, scale=6.0 / 7.0, maxiter=50, fuse=7)
     b = Solver(3, 33, 4, scale=6.0 / 7.0, maxiter=50, fuse=0)
     for s in (a, b):
         s.set_rhs_problem()
