@@ -97,3 +97,42 @@ def test_fixed_cycles_and_random_rhs(orc):
     r = s.rnorm
     assert np.all(np.diff(r) < 0)          # contracts every cycle
     s.close()
+
+
+@pytest.mark.parametrize("dim,npts,levels,v,scale", [
+    (2, 17, 1, (3, 3), 0.8),        # one level: the cycle is just v0 sweeps per iteration (loops :1533-1544 are empty)
+    (3, 9, 1, (2, 5), 0.8),
+    (2, 5, 2, (3, 3), 0.8),         # 3x3 fine grid, one coarse unknown
+    (3, 5, 2, (1, 1), 0.8),
+    (2, 33, 3, (1, 2), 0.8),        # asymmetric -v
+    (3, 17, 3, (2, 4), 6.0 / 7.0),
+    (3, 17, 4, (4, 1), 6.0 / 7.0),
+    (2, 65, 6, (2, 0), 0.8),        # no coarsest sweeps: KSPSolve with max_it 0 zero-fills the coarsest correction
+    (3, 33, 5, (1, 0), 6.0 / 7.0),
+])
+def test_edge_configurations_match_oracle(orc, dim, npts, levels, v, scale):
+    from multigrid_petsc_amd.solver import Solver
+    maxiter = 40
+    s = Solver(dim, npts, levels, v=v, maxiter=maxiter, scale=scale)
+    s.set_rhs_problem()
+    it = s.solve()
+    ref = orc.vcycle(dim, npts, levels, v[0], v[1], maxiter=maxiter, scale=scale, use_csr=0)
+    assert it == ref["iters"]
+    rel = np.abs(s.rnorm - ref["rnorm"]) / ref["rnorm"]
+    assert rel.max() <= RTOL
+    assert np.array_equal(s.solution(), ref["u"])
+    s.close()
+
+
+def test_bad_arguments_fail_loudly():
+    from multigrid_petsc_amd.solver import Solver, MgError
+    with pytest.raises(MgError):
+        Solver(3, 1000, 3)              # npts-1 not divisible by 2^(levels-1)
+    with pytest.raises(MgError):
+        Solver(4, 17, 2)                # dimension
+    with pytest.raises(MgError):
+        Solver(2, 17, 5)                # too many levels: the coarsest grid would be empty
+    with pytest.raises(MgError):
+        Solver(2, 17, 2, ksp_type="chebyshev")      # no eigenvalue bounds
+    with pytest.raises(MgError):
+        Solver(3, 17, 2, rank=0, nranks=2)          # ranks without a communicator
