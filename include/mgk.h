@@ -77,6 +77,13 @@ void mgk_timer_destroy(mgk_ctx *ctx, void *timer);
 /* cross-stream dependency: work queued later on `waiter` starts after everything queued so far on `signaller` */
 int  mgk_stream_wait(mgk_ctx *ctx, void *waiter, void *signaller);
 
+/* HIP-graph capture of everything queued on the compute stream between begin and end (kernels, async memsets;
+ * no synchronous call may happen in between); the executable graph replays on the compute stream */
+int  mgk_capture_begin(mgk_ctx *ctx);
+int  mgk_capture_end(mgk_ctx *ctx, void **graph_exec);
+int  mgk_graph_launch(mgk_ctx *ctx, void *graph_exec);
+void mgk_graph_destroy(mgk_ctx *ctx, void *graph_exec);
+
 /* compact lexicographic (k*ny+i)*nx+j  <->  padded layout (VecGetArray/VecSetValue side, src/solver.c:588-617,1255) */
 int  mgk_pack_f64(mgk_ctx *ctx, const mgk_geom *g, const double *compact_dev, double *padded_dev, void *stream);
 int  mgk_unpack_f64(mgk_ctx *ctx, const mgk_geom *g, const double *padded_dev, double *compact_dev, void *stream);

@@ -41,6 +41,7 @@ typedef struct mg_config {
                          * first post-smoothing sweep; bit 2: pre-restriction residual fused with the restriction (whole grids);
                          * default (-1): all on */
     int overlap;        /* nranks > 1: halo of sweep k on the comm stream while sweep k's interior runs; default on (-1) */
+    int graph;          /* replay the launch-bound coarse levels as one captured HIP graph; default on (-1) */
 } mg_config;
 
 void mg_config_default(mg_config *cfg);     /* poisson.in defaults + -pc_type jacobi -ksp_richardson_scale 1 */

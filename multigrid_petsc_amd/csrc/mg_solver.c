@@ -61,6 +61,8 @@ struct mg_solver {
     int started;
     double solve_seconds;
     /* profiling */
+    int lgraph;             /* levels >= lgraph form the launch-bound coarse part replayed as one HIP graph (0: off) */
+    void *coarse_graph;
     int prof_on, prof_n;
     void *timers[MG_MAX_TIMERS];
     int ntimers_created;
@@ -164,6 +166,7 @@ void mg_config_default(mg_config *c) {
     c->rank = 0; c->nranks = 1; c->dist_min_n = 127;
     c->fuse = -1;
     c->overlap = -1;
+    c->graph = -1;
 }
 
 static int alloc_field(mg_solver *s, const mgk_geom *g, double **p) {
@@ -198,6 +201,7 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
     if (s->cfg.dist_min_n <= 0) s->cfg.dist_min_n = 127;
     if (s->cfg.fuse < 0) s->cfg.fuse = 7;
     if (s->cfg.overlap < 0) s->cfg.overlap = 1;
+    if (s->cfg.graph < 0) s->cfg.graph = 1;
     if (s->cfg.nranks < 1) s->cfg.nranks = 1;
     s->comm = comm;
     s->levels = cfg->levels;
@@ -255,6 +259,16 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
         }
         if (cfg->ksp_type == MG_KSP_CHEBYSHEV && (rc = alloc_field(s, &L->g, &L->p2))) { mg_solver_destroy(s); return rc; }
     }
+    /* coarse part for the HIP graph: the first level that is neither distributed nor fed by a distributed one and
+     * has at most 2^21 unknowns (3-D n <= 127, 2-D n <= 1023): below that a kernel is shorter than its launch */
+    s->lgraph = 0;
+    if (s->cfg.graph && s->cfg.ksp_type == MG_KSP_RICHARDSON && s->cfg.precision == MG_PREC_FP64) {
+        for (int l = (s->ldist > 0 ? s->ldist + 1 : 1); l < s->levels; l++) {
+            double N = pow((double)s->L[l].n, (double)cfg->dim);
+            if (N <= 2097152.0) { s->lgraph = l; break; }
+        }
+        if (s->lgraph && s->levels - s->lgraph < 2) s->lgraph = 0;      /* not worth a graph */
+    }
     s->rnorm_cap = (cfg->maxiter > 0 ? cfg->maxiter : 0) + 1;
     s->rnorm = (double *)calloc((size_t)s->rnorm_cap, sizeof(double));
     *out = s;
@@ -266,6 +280,7 @@ void mg_solver_destroy(mg_solver *s) {
     if (s->ctx) {
         mgk_sync(s->ctx, NULL);
         for (int q = 0; q < s->ntimers_created; q++) mgk_timer_destroy(s->ctx, s->timers[q]);
+        if (s->coarse_graph) mgk_graph_destroy(s->ctx, s->coarse_graph);
         for (int l = 0; l < s->levels; l++) {
             mg_level *L = &s->L[l];
             if (L->u) mgk_free(s->ctx, L->u);
@@ -613,25 +628,60 @@ static int vcycle_once_mixed(mg_solver *s) {
     return 0;
 }
 
+/* one step of the descent: b_l = R(b_{l-1} - A u_{l-1}); smooth level l from a zero guess (src/solver.c:1534-1537) */
+static int descend(mg_solver *s, int l) {
+    const int levels = s->levels, *v = s->cfg.v;
+    mg_level *F = &s->L[l - 1];
+    if ((s->cfg.fuse & 4) && s->cfg.dim == 3 && !F->distributed && F->n + 1 <= 1024) {
+        /* :1534-1535 in one pass: b_l = R (b - A u), the fine residual is never written */
+        CHK(mgk_residual_restrict_f64(s->ctx, &F->g, &s->L[l].g, F->coef, F->b, F->u, s->L[l].b, NULL));
+    } else {
+        CHK(residual(s, l - 1));                                        /* :1534 */
+        CHK(restrict_to(s, l));                                         /* :1535 */
+    }
+    CHK(smooth(s, l, l == levels - 1 ? v[1] : v[0]));                   /* :1536 */
+    if (l != levels - 1) s->L[l].guess_nonzero = 1;                     /* :1537 */
+    return 0;
+}
+
+/* levels lg..L-1: down from lg-1 and back up to lg.  Every buffer pointer is the same at entry of every cycle
+ * (each level swaps u/tmp an even number of times per cycle; the coarsest is copied back when v1 is odd), so the
+ * recorded kernels stay valid. */
+static int coarse_part(mg_solver *s, int lg) {
+    const int levels = s->levels;
+    for (int l = lg; l < levels; l++) CHK(descend(s, l));
+    if (s->cfg.v[1] & 1) {                                              /* restore the coarsest level's buffer identity */
+        mg_level *Cz = &s->L[levels - 1];
+        CHK(mgk_d2d(s->ctx, Cz->tmp, Cz->u, sizeof(double) * (size_t)Cz->g.total, NULL));
+        swap_ptr(&Cz->u, &Cz->tmp);
+    }
+    for (int l = levels - 2; l >= lg; l--) {
+        CHK(prolong_smooth(s, l));                                      /* :1540-1542 */
+        s->L[l].guess_nonzero = 0;                                      /* :1543 (l != 0 here) */
+    }
+    return 0;
+}
+
 /* body of the while loop, src/solver.c:1531-1549 */
 static int vcycle_once(mg_solver *s) {
     if (s->cfg.precision == MG_PREC_MIXED) return vcycle_once_mixed(s);
     const int levels = s->levels, *v = s->cfg.v;
+    const int lg = s->lgraph ? s->lgraph : levels;                      /* levels >= lg run as one HIP graph */
     CHK(smooth(s, 0, v[0]));                                            /* :1531 */
     if (s->iter == 0) s->L[0].guess_nonzero = 1;                        /* :1532 */
-    for (int l = 1; l < levels; l++) {
-        mg_level *F = &s->L[l - 1];
-        if ((s->cfg.fuse & 4) && s->cfg.dim == 3 && !F->distributed && F->n + 1 <= 1024) {
-            /* :1534-1535 in one pass: b_l = R (b - A u), the fine residual is never written */
-            CHK(mgk_residual_restrict_f64(s->ctx, &F->g, &s->L[l].g, F->coef, F->b, F->u, s->L[l].b, NULL));
-        } else {
-            CHK(residual(s, l - 1));                                    /* :1534 */
-            CHK(restrict_to(s, l));                                     /* :1535 */
+    for (int l = 1; l < lg; l++) CHK(descend(s, l));
+    if (lg < levels) {
+        if (!s->coarse_graph) {                                         /* record once ... */
+            CHK(mgk_capture_begin(s->ctx));
+            int rc = coarse_part(s, lg);
+            void *ge = NULL;
+            int rc2 = mgk_capture_end(s->ctx, &ge);
+            if (rc || rc2) return mgfail(rc ? rc : rc2, "HIP graph capture of the coarse levels");
+            s->coarse_graph = ge;
         }
-        CHK(smooth(s, l, l == levels - 1 ? v[1] : v[0]));               /* :1536 */
-        if (l != levels - 1) s->L[l].guess_nonzero = 1;                 /* :1537 */
+        CHK(mgk_graph_launch(s->ctx, s->coarse_graph));                 /* ... replay every cycle */
     }
-    for (int l = levels - 2; l >= 0; l--) {
+    for (int l = (lg < levels ? lg - 1 : levels - 2); l >= 0; l--) {
         CHK(prolong_smooth(s, l));                                      /* :1540-1542 */
         if (l != 0) s->L[l].guess_nonzero = 0;                          /* :1543 */
     }

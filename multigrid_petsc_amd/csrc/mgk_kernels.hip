@@ -162,6 +162,30 @@ extern "C" int mgk_stream_wait(mgk_ctx *c, void *waiter, void *signaller) {
     return 0;
 }
 
+// ---- HIP graphs: the launch-bound coarse part of a V-cycle is captured once and replayed ----
+extern "C" int mgk_capture_begin(mgk_ctx *c) {
+    HIPCHK(hipStreamBeginCapture(c->compute, hipStreamCaptureModeThreadLocal));
+    return 0;
+}
+extern "C" int mgk_capture_end(mgk_ctx *c, void **graph_exec) {
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamEndCapture(c->compute, &g));
+    hipGraphExec_t e = nullptr;
+    hipError_t rc = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (rc != hipSuccess) return fail((int)rc, "hipGraphInstantiate");
+    *graph_exec = (void *)e;
+    return 0;
+}
+extern "C" int mgk_graph_launch(mgk_ctx *c, void *graph_exec) {
+    HIPCHK(hipGraphLaunch((hipGraphExec_t)graph_exec, c->compute));
+    return 0;
+}
+extern "C" void mgk_graph_destroy(mgk_ctx *c, void *graph_exec) {
+    (void)c;
+    if (graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+}
+
 // ------------------------------------------------------------------------------------------
 // geometry
 // ------------------------------------------------------------------------------------------

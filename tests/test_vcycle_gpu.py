@@ -85,6 +85,28 @@ def test_unfused_final_residual_same_history(orc):
     b.close()
 
 
+@pytest.mark.parametrize("dim,npts,levels,v", [(3, 129, 7, (3, 3)), (3, 257, 8, (3, 2)), (2, 2049, 11, (3, 3)), (2, 129, 7, (2, 1))])
+def test_hip_graph_replay_of_coarse_levels_is_bit_identical(orc, dim, npts, levels, v):
+    from multigrid_petsc_amd.solver import Solver
+    scale = 6.0 / 7.0 if dim == 3 else 0.8
+    res = []
+    for graph in (1, 0):
+        s = Solver(dim, npts, levels, v=v, scale=scale, maxiter=40, graph=graph)
+        s.set_rhs_problem()
+        it = s.solve()
+        first = (it, s.rnorm.copy(), s.solution())
+        s.set_rhs_problem()                 # second solve on the same object: the recorded graph is replayed again
+        it2 = s.solve()
+        assert it2 == it and np.array_equal(s.rnorm, first[1]) and np.array_equal(s.solution(), first[2])
+        res.append(first)
+        s.close()
+    assert res[0][0] == res[1][0]
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    if npts <= 129:
+        ref = orc.vcycle(dim, npts, levels, v[0], v[1], maxiter=40, scale=scale)
+        assert res[0][0] == ref["iters"] and np.array_equal(res[0][2], ref["u"])
+
+
 def test_fixed_cycles_and_random_rhs(orc):
     """bench path: mg_solver_cycles from an arbitrary RHS"""
     from multigrid_petsc_amd.solver import Solver
