@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-npts", type=int, default=257)
     ap.add_argument("--cpu-levels", type=int, default=8)
-    ap.add_argument("--cpu-cycles", type=int, default=5)
+    ap.add_argument("--cpu-cycles", type=int, default=40)
     ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
 
