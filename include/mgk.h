@@ -150,6 +150,15 @@ int  mgk_error_sums_f64(mgk_ctx *ctx, const mgk_geom *g, const double *u, const 
 /* y = A x (MatMult on a stencil operator; src/solver.c:1516) */
 int  mgk_apply_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, const double *x, double *y, void *stream);
 
+/* 2-D operators whose coefficients depend on the grid row only: the reference's stretched meshes (-mesh 1/2; metrics are
+ * functions of y, src/mesh.c:45-107, OpA src/problem.c:3-22, row fill src/solver.c:231-251).  ctab: ny x 5 device doubles
+ * {(i-1),(j-1),C,(j+1),(i+1)} per grid row; dtab: ny device doubles 1/diag.  mode 0: unew = u + scale*((b-Au)*dtab[i]);
+ * mode 1: out = b - A u; mode 4: out = A u. */
+int  mgk_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *g, int mode, const double *ctab, const double *dtab, double scale,
+                     const double *b, const double *u, double *out, void *stream);
+int  mgk_jacobi_zero_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *g, const double *dtab, double scale,
+                                 const double *b, double *unew, void *stream);
+
 /* ---- flat BLAS-1 / AIJ kernels behind the PETSc-surface shim (include/petscksp.h) ----
  * n counts doubles of a whole allocation (padded fields: ghosts are 0 and stay 0). */
 int  mgk_flat_axpy(mgk_ctx *ctx, long n, double a, const double *x, double *y, void *stream);       /* VecAXPY  y += a x (src/solver.c:1517,1541) */

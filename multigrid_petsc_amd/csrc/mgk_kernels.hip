@@ -336,6 +336,8 @@ struct StArgs {
     int zc, ntx, nty;
     int zbeg, zend;       // marching range [zbeg, zend) of this launch (whole grid: 0, nm)
     T a0, a1, a2, a3, a4, a5, a6;   // (m-1), S, W, C, E, N, (m+1); 2-D: S and N unused
+    const T *ctab;        // 2-D only, optional: coefficients that vary with the marching index (stretched meshes):
+    const T *dtab;        //   ctab[5*i .. 5*i+4] = {(i-1), W, C, E, (i+1)} of grid row i, dtab[i] = 1/diag
     T dinv, scale, ckm1, ck, cz;
 };
 
@@ -506,6 +508,13 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
             }
         }
         __syncthreads();   // lds[buf] (plane z) complete
+        // coefficients of this marching step: launch constants, or (2-D stretched meshes) the table row of grid row z
+        T c0 = a.a0, c2 = a.a2, c3 = a.a3, c4 = a.a4, c6 = a.a6, dv = a.dinv;
+        if (DIM == 2 && a.ctab) {
+            const T *cr_ = a.ctab + 5 * (long)z;
+            c0 = cr_[0]; c2 = cr_[1]; c3 = cr_[2]; c4 = cr_[3]; c6 = cr_[4];
+            if (a.dtab) dv = a.dtab[z];
+        }
 
         // ---- neighbours of plane z ----
         T Wn[RY], En[RY];
@@ -530,19 +539,19 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
             for (int e = 0; e < VX; e++) {
                 const T wv = (e == 0) ? Wn[r] : uc[r].v[e > 0 ? e - 1 : 0];
                 const T ev = (e == VX - 1) ? En[r] : uc[r].v[e < VX - 1 ? e + 1 : e];
-                T t = a.a0 * um[r].v[e];
+                T t = c0 * um[r].v[e];
                 if (DIM == 3) t = t + a.a1 * s2.v[e];
-                t = t + a.a2 * wv;
-                t = t + a.a3 * uc[r].v[e];
-                t = t + a.a4 * ev;
+                t = t + c2 * wv;
+                t = t + c3 * uc[r].v[e];
+                t = t + c4 * ev;
                 if (DIM == 3) t = t + a.a5 * n2.v[e];
-                t = t + a.a6 * up[r].v[e];
+                t = t + c6 * up[r].v[e];
                 const T res = bc[r].v[e] - t;
                 if (MODE == MODE_JACOBI || MODE == MODE_PJACOBI) {
-                    const T zz = res * a.dinv;
+                    const T zz = res * dv;
                     o.v[e] = uc[r].v[e] + a.scale * zz;
                 } else if (MODE == MODE_CHEBY) {
-                    const T zz = res * a.dinv;
+                    const T zz = res * dv;
                     o.v[e] = (a.ckm1 * ac[r].v[e] + a.ck * uc[r].v[e]) + a.cz * zz;
                 } else if (MODE == MODE_APPLY) {
                     o.v[e] = t;
@@ -807,13 +816,14 @@ __device__ __forceinline__ long row_offset(const RowArgs &a, long row) {
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_jacobi_zero(RowArgs a, T dinv, T scale, const T *b, T *out) {
+__global__ void __launch_bounds__(256) k_jacobi_zero(RowArgs a, T dinv, T scale, const T *b, T *out, const T *dtab) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.npairs) return;
     const int x0 = 2 * p;
     ROW_RANGE(a.nrows) for (long row = row0_; row < row1_; row++) {
         const long o = row_offset(a, row) + x0;
         P2<T> bv = ldp_stream(b + o), r;
+        if (dtab) dinv = dtab[row % a.ny];          // 2-D stretched meshes: 1/diag of grid row i
         T zx = bv.x * dinv, zy = bv.y * dinv;
         r.x = scale * zx; r.y = scale * zy;
         if (x0 + 1 == a.nx) r.y = (T)0;
@@ -912,7 +922,7 @@ extern "C" int mgk_jacobi_zero_f64(mgk_ctx *c, const mgk_geom *g, double dinv, d
     RowArgs a = row_args(g);
     dim3 grid, block;
     row_grid(a, a.npairs, grid, block, 1024);
-    hipLaunchKernelGGL(k_jacobi_zero<double>, grid, block, 0, S(c, stream), a, dinv, scale, b + g->org, unew + g->org);
+    hipLaunchKernelGGL(k_jacobi_zero<double>, grid, block, 0, S(c, stream), a, dinv, scale, b + g->org, unew + g->org, (const double *)nullptr);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1231,7 +1241,7 @@ extern "C" int mgk_jacobi_zero_f32(mgk_ctx *c, const mgk_geom *g, double dinv, d
     RowArgs a = row_args(g);
     dim3 grid, block;
     row_grid(a, a.npairs, grid, block, 1024);
-    hipLaunchKernelGGL(k_jacobi_zero<float>, grid, block, 0, S(c, stream), a, (float)dinv, (float)scale, b + g->org, unew + g->org);
+    hipLaunchKernelGGL(k_jacobi_zero<float>, grid, block, 0, S(c, stream), a, (float)dinv, (float)scale, b + g->org, unew + g->org, (const float *)nullptr);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1529,6 +1539,37 @@ extern "C" int mgk_residual_restrict_f64(mgk_ctx *c, const mgk_geom *gf, const m
     else if (w <= 2) hipLaunchKernelGGL(k_resrestrict<2>, dim3(nblk), dim3(128), 0, s, a);
     else if (w <= 4) hipLaunchKernelGGL(k_resrestrict<4>, dim3(nblk), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_resrestrict<8>, dim3(nblk), dim3(512), 0, s, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// 2-D operators whose five coefficients depend on the grid row only (the reference's stretched meshes,
+// -mesh 1/2: metrics are functions of y, src/mesh.c:45-107, src/problem.c:3-22).  Same marching kernel; the
+// coefficients of a marching step come from a device table instead of launch constants.
+//   ctab: ny x 5 doubles {(i-1), (j-1), C, (j+1), (i+1)} per grid row;  dtab: ny doubles 1/diag (PCJACOBI)
+// mode: 0 Jacobi sweep, 1 residual, 4 apply
+// ------------------------------------------------------------------------------------------
+extern "C" int mgk_rowcoef_f64(mgk_ctx *c, const mgk_geom *g, int mode, const double *ctab, const double *dtab, double scale,
+                               const double *b, const double *u, double *out, void *stream) {
+    if (!c || !g || g->dim != 2 || !ctab || !u || !out || u == out || (mode != MODE_APPLY && !b) || (mode == MODE_JACOBI && !dtab))
+        return fail(MGK_EINVAL, "mgk_rowcoef_f64: bad arguments (2-D only)");
+    StArgs<double> a; memset(&a, 0, sizeof(a));
+    a.u = u + g->org; a.b = (b ? b : u) + g->org; a.out = out + g->org;
+    a.ctab = ctab; a.dtab = dtab; a.scale = scale; a.dinv = 1.0;
+    hipStream_t s = S(c, stream);
+    if (mode == MODE_JACOBI) return dispatch_st<MODE_JACOBI>(c, g, a, s, nullptr);
+    if (mode == MODE_RESIDUAL) return dispatch_st<MODE_RESIDUAL>(c, g, a, s, nullptr);
+    if (mode == MODE_APPLY) return dispatch_st<MODE_APPLY>(c, g, a, s, nullptr);
+    return fail(MGK_EINVAL, "mgk_rowcoef_f64: unknown mode");
+}
+extern "C" int mgk_jacobi_zero_rowcoef_f64(mgk_ctx *c, const mgk_geom *g, const double *dtab, double scale,
+                                           const double *b, double *unew, void *stream) {
+    if (!c || !g || g->dim != 2 || !dtab || !b || !unew) return fail(MGK_EINVAL, "mgk_jacobi_zero_rowcoef_f64: bad arguments");
+    RowArgs a = row_args(g);
+    dim3 grid, block;
+    row_grid(a, a.npairs, grid, block, 1024);
+    hipLaunchKernelGGL(k_jacobi_zero<double>, grid, block, 0, S(c, stream), a, 1.0, scale, b + g->org, unew + g->org, dtab);
     HIPCHK(hipGetLastError());
     return 0;
 }

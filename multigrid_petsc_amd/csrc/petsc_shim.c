@@ -335,7 +335,7 @@ PetscErrorCode ISView(IS is, PetscViewer v) { (void)is; (void)v; return 0; }
 /* ------------------------------------------------------------------ */
 /* Mat                                                                 */
 /* ------------------------------------------------------------------ */
-enum { MAT_GENERIC = 0, MAT_STENCIL = 1, MAT_RESTRICT = 2, MAT_PROLONG = 3 };
+enum { MAT_GENERIC = 0, MAT_STENCIL = 1, MAT_RESTRICT = 2, MAT_PROLONG = 3, MAT_STENCIL_ROW = 4 };
 struct _p_Mat {
     PetscInt m, n;
     int *crow, *ccol; double *cval; long cnz, ccap;     /* MatSetValue stash (COO, insertion order) */
@@ -347,6 +347,8 @@ struct _p_Mat {
     double coef[7];
     long *d_rowptr; int *d_col; double *d_val; double *d_dinv;   /* device CSR (generic), lazily built */
     long d_dinv_len;
+    double *h_ctab, *h_dtab;                             /* STENCIL_ROW: per-grid-row coefficients (n x 5) and 1/diag (n) */
+    double *d_ctab, *d_dtab, *d_ones;
     int dev_stale;
     Vec work;
 };
@@ -440,6 +442,54 @@ static int recognise_stencil(Mat A) {
     A->kind = MAT_STENCIL;
     return 1;
 }
+/* 5-point rows whose coefficients depend on the grid row i only: the stretched meshes (-mesh 1/2), where the
+ * metrics are functions of y (src/mesh.c:45-107) and every row of a grid line gets the same OpA (src/solver.c:231-251) */
+static int recognise_stencil_rowvar(Mat A) {
+    if (A->m != A->n) return 0;
+    const int n = isqrt_exact(A->m);
+    if (n < 1 || (n & 1) == 0) return 0;
+    double *ct = (double *)calloc((size_t)n * 5, sizeof(double)), *dt = (double *)calloc((size_t)n, sizeof(double));
+    char *have = (char *)calloc((size_t)n * 5, 1);
+    int ok = 1;
+    for (long r = 0; r < A->m && ok; r++) {
+        const int i = (int)(r / n), j = (int)(r % n);
+        long q = A->rowptr[r];
+        const long e = A->rowptr[r + 1];
+        const long want[5] = {i > 0 ? r - n : -1, j > 0 ? r - 1 : -1, r, j < n - 1 ? r + 1 : -1, i < n - 1 ? r + n : -1};
+        for (int k = 0; k < 5; k++) {
+            if (want[k] < 0) continue;
+            if (q >= e || A->col[q] != want[k]) { ok = 0; break; }
+            if (!have[i * 5 + k]) { ct[i * 5 + k] = A->val[q]; have[i * 5 + k] = 1; }
+            else if (A->val[q] != ct[i * 5 + k]) { ok = 0; break; }
+            q++;
+        }
+        if (ok && q != e) ok = 0;
+    }
+    for (int i = 0; i < n && ok; i++) { if (!have[i * 5 + 2] || ct[i * 5 + 2] == 0.0) ok = 0; else dt[i] = 1.0 / ct[i * 5 + 2]; }
+    free(have);
+    if (!ok || mgk_geom_init(&A->gf, 2, n, n, 1)) { free(ct); free(dt); return 0; }
+    A->h_ctab = ct; A->h_dtab = dt;
+    A->kind = MAT_STENCIL_ROW;
+    return 1;
+}
+static void mat_device_rowtabs(Mat A) {
+    if (A->d_ctab && !A->dev_stale) return;
+    const int n = A->gf.nx;
+    void *p;
+    if (!A->d_ctab) {
+        DEV(mgk_malloc(G, &p, sizeof(double) * (size_t)n * 5)); A->d_ctab = (double *)p;
+        DEV(mgk_malloc(G, &p, sizeof(double) * (size_t)n)); A->d_dtab = (double *)p;
+        DEV(mgk_malloc(G, &p, sizeof(double) * (size_t)n)); A->d_ones = (double *)p;
+        double *ones = (double *)malloc(sizeof(double) * (size_t)n);
+        for (int i = 0; i < n; i++) ones[i] = 1.0;
+        DEV(mgk_h2d(G, A->d_ones, ones, sizeof(double) * (size_t)n));
+        free(ones);
+    }
+    DEV(mgk_h2d(G, A->d_ctab, A->h_ctab, sizeof(double) * (size_t)n * 5));
+    DEV(mgk_h2d(G, A->d_dtab, A->h_dtab, sizeof(double) * (size_t)n));
+    A->dev_stale = 0;
+}
+
 /* full weighting rows [1 2 1;2 4 2;1 2 1]/16 centred on fine (2i+1,2j+1) (src/solver.c:1071-1092, matbuild.c:422-431) */
 static int recognise_restrict(Mat A) {
     const int nc = isqrt_exact(A->m), nf = isqrt_exact(A->n);
@@ -489,7 +539,7 @@ PetscErrorCode MatAssemblyEnd(Mat A, MatAssemblyType t) {
     A->assembled = 1;
     A->kind = MAT_GENERIC;
     if (!getenv("MGPETSC_NO_RECOGNITION"))
-        if (!recognise_stencil(A) && !recognise_restrict(A)) recognise_prolong(A);
+        if (!recognise_stencil(A) && !recognise_restrict(A) && !recognise_prolong(A)) recognise_stencil_rowvar(A);
     if (A->kind == MAT_GENERIC) {
         /* a matrix between n^2-sized index spaces keeps the padded grid layout for its vectors, so that it can
          * be mixed with recognised operators on the same grids (e.g. variable-coefficient A with the transfer
@@ -539,7 +589,7 @@ static void mat_device_csr(Mat A) {
 
 PetscErrorCode MatCreateVecs(Mat A, Vec *right, Vec *left) {       /* src/solver.c:1172: (u, b) */
     const mgk_geom *gr = NULL, *gl = NULL;
-    if (A->kind == MAT_STENCIL) gr = gl = &A->gf;
+    if (A->kind == MAT_STENCIL || A->kind == MAT_STENCIL_ROW) gr = gl = &A->gf;
     else if (A->kind == MAT_RESTRICT) { gr = &A->gf; gl = &A->gc; }
     else if (A->kind == MAT_PROLONG) { gr = &A->gc; gl = &A->gf; }
     else { if (A->gcol_ok) gr = &A->gcol; if (A->grow_ok) gl = &A->grow; }
@@ -575,6 +625,11 @@ PetscErrorCode MatMult(Mat A, Vec x, Vec y) {                       /* src/solve
         need_vec(x, 1, &A->gf, A->n, "MatMult"); need_vec(y, 1, &A->gf, A->m, "MatMult");
         DEV(mgk_apply_f64(G, &A->gf, A->coef, vdev(x), y->dev, NULL));
         break;
+    case MAT_STENCIL_ROW:
+        need_vec(x, 1, &A->gf, A->n, "MatMult"); need_vec(y, 1, &A->gf, A->m, "MatMult");
+        mat_device_rowtabs(A);
+        DEV(mgk_rowcoef_f64(G, &A->gf, 4, A->d_ctab, A->d_dtab, 1.0, NULL, vdev(x), y->dev, NULL));
+        break;
     case MAT_RESTRICT:
         need_vec(x, 1, &A->gf, A->n, "MatMult"); need_vec(y, 1, &A->gc, A->m, "MatMult");
         DEV(mgk_restrict_fw_f64(G, &A->gf, &A->gc, vdev(x), y->dev, NULL));
@@ -604,6 +659,12 @@ PetscErrorCode MatResidual(Mat A, Vec b, Vec x, Vec r) {           /* r = b - A 
         DEV(mgk_residual_f64(G, &A->gf, A->coef, vdev(b), vdev(x), r->dev, NULL));
         return 0;
     }
+    if (A->kind == MAT_STENCIL_ROW) {
+        need_vec(x, 1, &A->gf, A->n, "MatResidual");
+        mat_device_rowtabs(A);
+        DEV(mgk_rowcoef_f64(G, &A->gf, 1, A->d_ctab, A->d_dtab, 1.0, vdev(b), vdev(x), r->dev, NULL));
+        return 0;
+    }
     if (A->kind == MAT_GENERIC) { csr_apply(A, x, r, -1.0, b, "MatResidual"); return 0; }
     MatMult(A, x, r);
     return VecAYPX(r, -1.0, b);
@@ -612,13 +673,19 @@ PetscErrorCode MatScale(Mat A, PetscScalar a) {
     for (long q = 0; q < A->nz; q++) A->val[q] *= a;
     for (int k = 0; k < 7; k++) A->coef[k] *= a;
     if (A->kind == MAT_RESTRICT || A->kind == MAT_PROLONG) A->kind = MAT_GENERIC;     /* weights no longer the canonical ones */
+    if (A->kind == MAT_STENCIL_ROW) {
+        const int n = A->gf.nx;
+        for (int i = 0; i < n * 5; i++) A->h_ctab[i] *= a;
+        for (int i = 0; i < n; i++) A->h_dtab[i] = 1.0 / A->h_ctab[i * 5 + 2];
+    }
     A->dev_stale = 1;
     return 0;
 }
 PetscErrorCode MatMatMult(Mat A, Mat B, MatReuse s, PetscReal f, Mat *C) { (void)A; (void)B; (void)s; (void)f; (void)C; UNSUPPORTED("MatMatMult (additive cycles)"); return 1; }
 PetscErrorCode MatView(Mat A, PetscViewer v) {
     (void)v;
-    static const char *kinds[] = {"assembled AIJ (generic CSR kernel)", "matrix-free 5-point stencil", "matrix-free full weighting", "matrix-free bilinear prolongation"};
+    static const char *kinds[] = {"assembled AIJ (generic CSR kernel)", "matrix-free 5-point stencil", "matrix-free full weighting", "matrix-free bilinear prolongation",
+                                  "matrix-free 5-point stencil with row-dependent coefficients"};
     printf("Mat Object: %d x %d, %ld nonzeros, device operator: %s\n", A->m, A->n, A->nz, kinds[A->kind]);
     return 0;
 }
@@ -631,8 +698,12 @@ PetscErrorCode MatDestroy(Mat *pA) {
         if (A->d_col) mgk_free(G, A->d_col);
         if (A->d_val) mgk_free(G, A->d_val);
         if (A->d_dinv) mgk_free(G, A->d_dinv);
+        if (A->d_ctab) mgk_free(G, A->d_ctab);
+        if (A->d_dtab) mgk_free(G, A->d_dtab);
+        if (A->d_ones) mgk_free(G, A->d_ones);
     }
     if (A->work) VecDestroy(&A->work);
+    free(A->h_ctab); free(A->h_dtab);
     free(A); *pA = NULL;
     return 0;
 }
@@ -765,7 +836,7 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
      * whole interior without reading x, so the fill is only issued when no sweep follows or on the AIJ path */
     if (!k->guess_nonzero) {
         x->host_dirty = 0;
-        if (maxit <= 0 || A->kind != MAT_STENCIL) DEV(mgk_memset0(G, x->dev, sizeof(double) * (size_t)x->nalloc, NULL));
+        if (maxit <= 0 || (A->kind != MAT_STENCIL && A->kind != MAT_STENCIL_ROW)) DEV(mgk_memset0(G, x->dev, sizeof(double) * (size_t)x->nalloc, NULL));
     }
     if (maxit <= 0) return 0;
 
@@ -802,6 +873,20 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
         return 0;
     }
 
+    if (A->kind == MAT_STENCIL_ROW) {
+        if (k->type != K_RICHARDSON) UNSUPPORTED("chebyshev on a stretched-mesh operator");
+        need_vec(x, 1, &A->gf, A->n, "KSPSolve");
+        mat_device_rowtabs(A);
+        const double *dt = (pc == P_JACOBI) ? A->d_dtab : A->d_ones;
+        Vec w = ksp_work(k, 0, x);
+        for (PetscInt it = 0; it < maxit; it++) {
+            if (it == 0 && !k->guess_nonzero) DEV(mgk_jacobi_zero_rowcoef_f64(G, &A->gf, dt, k->scale, b->dev, w->dev, NULL));
+            else DEV(mgk_rowcoef_f64(G, &A->gf, 0, A->d_ctab, dt, k->scale, b->dev, x->dev, w->dev, NULL));
+            swap_dev(x, w);
+        }
+        k->its = maxit;
+        return 0;
+    }
     if (A->kind != MAT_GENERIC) UNSUPPORTED("KSPSolve on a transfer operator");
     if (k->type != K_RICHARDSON) UNSUPPORTED("chebyshev on an unrecognised (assembled AIJ) operator");
     if (A->m != A->n) UNSUPPORTED("KSPSolve on a rectangular operator");

@@ -232,19 +232,21 @@ def test_reference_driver_default_options_file(orc, tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(REFDRV), reason="build/refdriver/poisson absent")
-@pytest.mark.parametrize("mesh,npts,levels", [(1, 33, 4), (2, 33, 4), (1, 129, 6), (2, 65, 5)])
-def test_reference_driver_stretched_meshes(orc, tmp_path, mesh, npts, levels):
-    """-mesh 1/2 make the 5 coefficients depend on y (src/mesh.c:45-107, src/problem.c:17-21).  The
-    rows are no longer a constant stencil, so MatAssemblyEnd keeps A as an assembled AIJ matrix and the GPU runs the
-    generic CSR kernels (flat vectors); the transfer matrices are still recognised.  Same parity bar as -mesh 0."""
+@pytest.mark.parametrize("mesh,npts,levels,env", [(1, 33, 4, None), (2, 33, 4, None), (1, 129, 6, None), (2, 65, 5, None), (1, 513, 8, None),
+                                                  (1, 65, 5, {"MGPETSC_NO_RECOGNITION": "1"})])
+def test_reference_driver_stretched_meshes(orc, tmp_path, mesh, npts, levels, env):
+    """-mesh 1/2 make the 5 coefficients depend on y (src/mesh.c:45-107, src/problem.c:17-21).
+    MatAssemblyEnd recognises "5-point rows, coefficients constant along a grid row" and runs the same marching kernel
+    with a per-row coefficient table; with recognition switched off the assembled AIJ kernels run instead.  Same parity
+    bar as -mesh 0 either way."""
     scale = 0.8
     opts = (f"-npts {npts}\n-mesh {mesh}\n-iter 1000\n-grids {levels}\n-levels {levels}\n-cycle 0\n-map 0\n-v 3,3\n-moreNorm 0\n"
             f"-pc_type jacobi\n-ksp_richardson_scale {scale!r}\n")
-    it, rdat, u, e, out = _run_reference_driver(tmp_path, opts)
+    it, rdat, u, e, out = _run_reference_driver(tmp_path, opts, env)
     ref = orc.vcycle(2, npts, levels, 3, 3, maxiter=1000, scale=scale, use_csr=1, mesh=mesh)
     assert it == ref["iters"]
     want = ref["rnorm"] / ref["rnorm"][0]
     assert np.max(np.abs(rdat - want) / want) <= 1e-12
     assert np.array_equal(u, ref["u"])
     assert np.allclose(e, orc.error_norms_mesh(npts, mesh, ref["u"]), rtol=1e-12, atol=0)
-    assert "assembled AIJ (generic CSR kernel)" in out
+    assert ("assembled AIJ (generic CSR kernel)" if env else "row-dependent coefficients") in out
