@@ -325,8 +325,9 @@ __device__ __forceinline__ void stp_stream(float *p, P2<float> v) { *reinterpret
 template <typename T>
 struct StArgs {
     const T *u, *b, *aux;
-    const T *uc;           // MODE_PJACOBI: coarse correction field (interior origin) and its strides
+    const T *uc;           // MODE_PJACOBI: coarse correction field (interior origin), its strides and extents
     long crs, cms;
+    int nxc, nyc, nzc;
     T *out;
     float *out32;          // MODE_RES32: float copy of the fp64 residual (own strides below)
     double *partials;
@@ -387,6 +388,34 @@ __device__ __forceinline__ T prolong_one(const T *uc, long crs, long cms, int k,
             for (int qj = 0; qj < njc; qj++) s += w * cr[(long)qk * cms + (long)qi * crs + qj];
     return s;
 }
+// The same sum with the parents taken from the block's LDS ring of coarse plane tiles (MODE_PJACOBI marching loop):
+// cl[slot][row][col], slot = (kc+3)%3, row = ic - ic_base, col = jc - jc_base; `xh2` = (local x of the vector)/2.
+template <typename T, int TYC, int CWP>
+__device__ __forceinline__ V16<T> prolong_vec_lds(const T (&cl)[3][TYC][CWP], int ic_base, int k, int i, int xh2) {
+    constexpr int VX = 16 / sizeof(T);
+    const int iodd = i & 1, kodd = k & 1;
+    const int ic0 = iodd ? (i - 1) / 2 : i / 2 - 1, nic = iodd ? 1 : 2;
+    const int kc0 = kodd ? (k - 1) / 2 : k / 2 - 1, nkc = kodd ? 1 : 2;
+    const T wi = iodd ? (T)1 : (T)0.5, wk = kodd ? (T)1 : (T)0.5;
+    const T wh = wk * (wi * (T)0.5), w1 = wk * (wi * (T)1);
+    V16<T> s = v16_zero<T>();
+    int slot = (kc0 + 3) % 3;
+    for (int qk = 0; qk < nkc; qk++, slot = (slot == 2 ? 0 : slot + 1))
+        for (int qi = 0; qi < nic; qi++) {
+            const T *c = &cl[slot][ic0 + qi - ic_base][xh2];
+            const T c0 = c[0], c1 = c[1];
+            s.v[0] += wh * c0;
+            s.v[0] += wh * c1;
+            s.v[1] += w1 * c1;
+            if (VX == 4) {
+                const T c2 = c[2];
+                s.v[VX - 2] += wh * c1;
+                s.v[VX - 2] += wh * c2;
+                s.v[VX - 1] += w1 * c2;
+            }
+        }
+    return s;
+}
 template <typename T>
 __device__ __forceinline__ V16<T> vadd(const V16<T> &a, const V16<T> &b) {
     V16<T> r;
@@ -404,6 +433,14 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
     static_assert(DIM == 3 || (WY == 1 && RY == 1), "2-D marches along y: one row per tile");
     __shared__ __attribute__((aligned(16))) T lds[2][TY][LW];
     using VT = V16<T>;
+    // MODE_PJACOBI: ring of three coarse plane tiles (rows ic_base..ic_base+TYC-1, columns jc_base..) feeding the
+    // interpolation of the planes the loop brings in; loaded cooperatively one step ahead of its first use
+    // (only for blocks of <= 512 threads: a 1024-thread block is capped at 128 VGPRs and would spill)
+    constexpr bool PJ = (MODE == MODE_PJACOBI) && (DIM == 3) && (64 * WX * WY <= 512);
+    constexpr int TYC = PJ ? (TY / 2 + 2) : 1, CW = PJ ? (TX / 2 + 2) : 1, CWP = PJ ? (CW + 2) : 1;
+    constexpr int NTHR = 64 * WX * WY, NLC = PJ ? ((CW + NTHR - 1) / NTHR) : 1, NL = TYC * NLC;   // thread t loads column t (+k*NTHR) of every tile row
+    static_assert(!PJ || (TY % 2 == 0), "fused prolongation needs an even tile height");
+    __shared__ T cl[3][TYC][CWP];
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wx = w % WX, wy = w / WX;
@@ -487,6 +524,25 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
     }
 
     double acc = 0.0;   // MODE_RESNORM / MODE_RES32
+    const int ic_base = PJ ? (ty * TY) / 2 - 1 : 0, jc_base = PJ ? (tx * TX) / 2 - 1 : 0;
+    T cnew[NL];
+    int kc_new = -2;                             // coarse plane held in cnew (none)
+    if (PJ) {                                    // planes floor(z0/2), +1 are needed by the first step
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {
+            const int kc = z0 / 2 + pl;
+#pragma unroll
+            for (int qc = 0; qc < NLC; qc++) {
+                const int jcl = threadIdx.x + qc * NTHR, jc = jc_base + jcl;
+#pragma unroll
+                for (int icl = 0; icl < TYC; icl++) {
+                    const int ic = ic_base + icl;
+                    const bool ok = (jcl < CW) && (kc <= a.nzc) && (ic <= a.nyc) && (jc <= a.nxc);
+                    if (jcl < CW) cl[(kc + 3) % 3][icl][jcl] = ok ? a.uc[(long)kc * a.cms + (long)ic * a.crs + jc] : (T)0;
+                }
+            }
+        }
+    }
 
     for (int z = z0; z < z1; z++) {
         const int buf = (z - z0) & 1;
@@ -505,6 +561,19 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
             if (DIM == 3) {
                 hSn = ldv(up_ + (long)(z + 1) * a.ms - a.rs, okS);
                 hNn = ldv(up_ + (long)(z + 1) * a.ms + (long)RY * a.rs, okN);
+            }
+            if (PJ && (z & 1)) {                 // coarse plane (z+1)/2+1: first needed at step z+1
+                kc_new = (z + 1) / 2 + 1;
+#pragma unroll
+                for (int qc = 0; qc < NLC; qc++) {
+                    const int jcl = threadIdx.x + qc * NTHR, jc = jc_base + jcl;
+#pragma unroll
+                    for (int icl = 0; icl < TYC; icl++) {
+                        const int ic = ic_base + icl;
+                        const bool ok = (jcl < CW) && (kc_new <= a.nzc) && (ic <= a.nyc) && (jc <= a.nxc);
+                        cnew[qc * TYC + icl] = ok ? a.uc[(long)kc_new * a.cms + (long)ic * a.crs + jc] : (T)0;
+                    }
+                }
             }
         }
         __syncthreads();   // lds[buf] (plane z) complete
@@ -587,14 +656,25 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
                 bc[r] = bn[r]; xp[r] = xq[r];
                 if (MODE == MODE_CHEBY) ac[r] = an[r];
                 if (MODE == MODE_PJACOBI) {
-                    if (rok[r]) up[r] = vadd(up[r], prolong_vec(a.uc, a.crs, a.cms, z + 2, yb + r, x0));
+                    if (rok[r]) up[r] = vadd(up[r], PJ ? prolong_vec_lds(cl, ic_base, z + 2, yb + r, xl / 2)
+                                                        : prolong_vec(a.uc, a.crs, a.cms, z + 2, yb + r, x0));
                     if (xhok && (DIM == 2 || yb + r < a.ny)) xp[r] = xp[r] + prolong_one(a.uc, a.crs, a.cms, z + 2, yb + r, xh);
                 }
             }
             hS = hSn; hN = hNn;
             if (MODE == MODE_PJACOBI) {
-                if (okS) hS = vadd(hS, prolong_vec(a.uc, a.crs, a.cms, z + 1, yb - 1, x0));
-                if (okN) hN = vadd(hN, prolong_vec(a.uc, a.crs, a.cms, z + 1, yb + RY, x0));
+                if (okS) hS = vadd(hS, PJ ? prolong_vec_lds(cl, ic_base, z + 1, yb - 1, xl / 2) : prolong_vec(a.uc, a.crs, a.cms, z + 1, yb - 1, x0));
+                if (okN) hN = vadd(hN, PJ ? prolong_vec_lds(cl, ic_base, z + 1, yb + RY, xl / 2) : prolong_vec(a.uc, a.crs, a.cms, z + 1, yb + RY, x0));
+                if (PJ && kc_new >= -1) {        // publish the coarse plane fetched at the top of this step
+                    const int slot = (kc_new + 3) % 3;
+#pragma unroll
+                    for (int qc = 0; qc < NLC; qc++) {
+                        const int jcl = threadIdx.x + qc * NTHR;
+#pragma unroll
+                        for (int icl = 0; icl < TYC; icl++) if (jcl < CW) cl[slot][icl][jcl] = cnew[qc * TYC + icl];
+                    }
+                    kc_new = -2;
+                }
             }
         }
     }
@@ -678,7 +758,9 @@ static int dispatch_st(mgk_ctx *c, const mgk_geom *g, StArgs<double> &a, hipStre
     if (g->dim == 3) {
         a.ny = g->ny; a.nm = g->nz; a.rs = g->pitch; a.ms = g->plane;
         int v = g_variant;
-        if (v < 0) v = (MODE == MODE_RESNORM && g->nx >= 255) ? 3 : (g->nx >= 1023) ? 12 : (g->nx >= 511) ? 6 : (g->nx >= 255) ? 2 : (g->nx >= 127 ? 1 : 0);
+        if (v < 0) v = (MODE == MODE_RESNORM && g->nx >= 255) ? 3
+                     : (g->nx >= 1023) ? (MODE == MODE_PJACOBI ? 9 : 12)      // fused prolongation: 512-thread blocks (LDS-staged parents)
+                     : (g->nx >= 511) ? 6 : (g->nx >= 255) ? 2 : (g->nx >= 127 ? 1 : 0);
         switch (v) {
             case 0: return launch_st<double, 3, 1, 2, 2, MODE>(c, a, g->ny, s, nblocks);   // 128 x 4, 128 thr
             case 1: return launch_st<double, 3, 1, 4, 2, MODE>(c, a, g->ny, s, nblocks);   // 128 x 8, 256 thr
@@ -1359,6 +1441,7 @@ static int prolong_jacobi(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, co
     StArgs<T> a; memset(&a, 0, sizeof(a));
     a.u = u + gf->org; a.b = b + gf->org; a.out = unew + gf->org;
     a.uc = ucoarse + gc->org; a.crs = gc->pitch; a.cms = gc->plane;
+    a.nxc = gc->nx; a.nyc = gc->ny; a.nzc = gc->nz;
     set_coef(a, gf, coef); a.dinv = (T)dinv; a.scale = (T)scale;
     return dispatch_st<MODE_PJACOBI>(c, gf, a, S(c, stream), nullptr);
 }
