@@ -25,11 +25,11 @@ typedef struct mg_comm {
     /* fill the z ghost planes of `field` from the neighbouring slabs: my first interior plane ->
      * hi ghost of rank-1, my last interior plane -> lo ghost of rank+1.  Ordered after all work
      * already queued on `stream`; work queued on `stream` afterwards sees the ghosts. */
-    int (*halo)(struct mg_comm *c, mgk_ctx *ctx, double *field, const mgk_geom *g, void *stream);
+    int (*halo)(struct mg_comm *c, mgk_ctx *ctx, void *field, const mgk_geom *g, int esz, void *stream);   /* esz: 8 (fp64) or 4 (fp32) */
     /* `field` has the geometry of the WHOLE level (gfull); rank r produced planes
      * [zstart[r], zstart[r+1]); afterwards every rank holds all planes. */
-    int (*allgather_planes)(struct mg_comm *c, mgk_ctx *ctx, double *field, const mgk_geom *gfull,
-                            const int *zstart, void *stream);
+    int (*allgather_planes)(struct mg_comm *c, mgk_ctx *ctx, void *field, const mgk_geom *gfull,
+                            const int *zstart, int esz, void *stream);
     /* in-place sum over ranks of n host doubles (blocking) */
     int (*allreduce_sum)(struct mg_comm *c, mgk_ctx *ctx, double *vals, int n, void *stream);
     int (*barrier)(struct mg_comm *c, mgk_ctx *ctx);

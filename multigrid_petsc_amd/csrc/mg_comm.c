@@ -26,7 +26,7 @@ static int cfail(int code, const char *what, const char *detail) {
 
 void mg_comm_destroy(mg_comm *c) { if (c && c->destroy) c->destroy(c); }
 
-int mg_comm_halo(mg_comm *c, mgk_ctx *ctx, double *field, const mgk_geom *g) { return c->halo(c, ctx, field, g, NULL); }
+int mg_comm_halo(mg_comm *c, mgk_ctx *ctx, double *field, const mgk_geom *g) { return c->halo(c, ctx, field, g, 8, NULL); }
 int mg_comm_allreduce_sum(mg_comm *c, mgk_ctx *ctx, double *vals, int n) { return c->allreduce_sum(c, ctx, vals, n, NULL); }
 
 static void *stream_of(mgk_ctx *ctx, void *stream) { return stream ? stream : mgk_stream_compute(ctx); }
@@ -36,7 +36,7 @@ static void *stream_of(mgk_ctx *ctx, void *stream) { return stream ? stream : mg
 /* ================================================================== */
 typedef struct { char internal[MG_RCCL_ID_BYTES]; } nccl_uid;      /* ncclUniqueId */
 typedef void *nccl_comm_t;
-enum { NCCL_SUM = 0, NCCL_FLOAT64 = 8 };                            /* ncclSum, ncclDouble */
+enum { NCCL_SUM = 0, NCCL_FLOAT32 = 7, NCCL_FLOAT64 = 8 };          /* ncclSum, ncclFloat, ncclDouble */
 
 typedef struct rccl_api {
     void *dl;
@@ -94,37 +94,42 @@ int mg_comm_rccl_unique_id(void *id_out) {
     return 0;
 }
 
-static int rccl_halo(mg_comm *c, mgk_ctx *ctx, double *field, const mgk_geom *g, void *stream) {
+static int rccl_halo(mg_comm *c, mgk_ctx *ctx, void *field, const mgk_geom *g, int esz, void *stream) {
     rccl_impl *im = (rccl_impl *)c->impl;
     if (c->nranks == 1) return 0;
     void *s = stream_of(ctx, stream);
-    const size_t cnt = (size_t)g->plane;
+    const size_t cnt = (size_t)g->plane, pb = (size_t)esz * (size_t)g->plane;      /* elements / bytes per padded plane */
+    const int dt = (esz == 8) ? NCCL_FLOAT64 : NCCL_FLOAT32;
+    char *f = (char *)field;
     NCK(g_rccl.GroupStart());
     if (c->rank > 0) {
-        NCK(g_rccl.Send(field + g->plane, cnt, NCCL_FLOAT64, c->rank - 1, im->comm, s));              /* first interior plane */
-        NCK(g_rccl.Recv(field, cnt, NCCL_FLOAT64, c->rank - 1, im->comm, s));                         /* lo ghost */
+        NCK(g_rccl.Send(f + pb, cnt, dt, c->rank - 1, im->comm, s));                       /* first interior plane */
+        NCK(g_rccl.Recv(f, cnt, dt, c->rank - 1, im->comm, s));                            /* lo ghost */
     }
     if (c->rank < c->nranks - 1) {
-        NCK(g_rccl.Send(field + (long)g->nz * g->plane, cnt, NCCL_FLOAT64, c->rank + 1, im->comm, s));     /* last interior plane */
-        NCK(g_rccl.Recv(field + (long)(g->nz + 1) * g->plane, cnt, NCCL_FLOAT64, c->rank + 1, im->comm, s)); /* hi ghost */
+        NCK(g_rccl.Send(f + (size_t)g->nz * pb, cnt, dt, c->rank + 1, im->comm, s));       /* last interior plane */
+        NCK(g_rccl.Recv(f + (size_t)(g->nz + 1) * pb, cnt, dt, c->rank + 1, im->comm, s)); /* hi ghost */
     }
     NCK(g_rccl.GroupEnd());
     return 0;
 }
 
-static int rccl_allgather_planes(mg_comm *c, mgk_ctx *ctx, double *field, const mgk_geom *gf, const int *zstart, void *stream) {
+static int rccl_allgather_planes(mg_comm *c, mgk_ctx *ctx, void *field, const mgk_geom *gf, const int *zstart, int esz, void *stream) {
     rccl_impl *im = (rccl_impl *)c->impl;
     if (c->nranks == 1) return 0;
     void *s = stream_of(ctx, stream);
     const int me = c->rank;
-    double *mine = field + (long)(zstart[me] + 1) * gf->plane;
+    const size_t pb = (size_t)esz * (size_t)gf->plane;
+    const int dt = (esz == 8) ? NCCL_FLOAT64 : NCCL_FLOAT32;
+    char *f = (char *)field;
+    char *mine = f + (size_t)(zstart[me] + 1) * pb;
     const size_t mycnt = (size_t)(zstart[me + 1] - zstart[me]) * (size_t)gf->plane;
     NCK(g_rccl.GroupStart());
     for (int r = 0; r < c->nranks; r++) {
         if (r == me) continue;
         const size_t cnt = (size_t)(zstart[r + 1] - zstart[r]) * (size_t)gf->plane;
-        if (mycnt) NCK(g_rccl.Send(mine, mycnt, NCCL_FLOAT64, r, im->comm, s));
-        if (cnt) NCK(g_rccl.Recv(field + (long)(zstart[r] + 1) * gf->plane, cnt, NCCL_FLOAT64, r, im->comm, s));
+        if (mycnt) NCK(g_rccl.Send(mine, mycnt, dt, r, im->comm, s));
+        if (cnt) NCK(g_rccl.Recv(f + (size_t)(zstart[r] + 1) * pb, cnt, dt, r, im->comm, s));
     }
     NCK(g_rccl.GroupEnd());
     return 0;
@@ -178,7 +183,7 @@ mg_comm *mg_comm_rccl_create(int rank, int nranks, const void *id, int device) {
 typedef struct loop_shared {
     int nranks;
     pthread_barrier_t bar;
-    double **field;           /* posted field pointer per rank */
+    void **field;             /* posted field pointer per rank */
     int *nz;                  /* posted local plane count per rank */
     double *red;              /* nranks x 64 */
 } loop_shared;
@@ -189,7 +194,7 @@ void *mg_comm_loopback_shared_create(int nranks) {
     loop_shared *sh = (loop_shared *)calloc(1, sizeof(loop_shared));
     sh->nranks = nranks;
     pthread_barrier_init(&sh->bar, NULL, (unsigned)nranks);
-    sh->field = (double **)calloc((size_t)nranks, sizeof(double *));
+    sh->field = (void **)calloc((size_t)nranks, sizeof(void *));
     sh->nz = (int *)calloc((size_t)nranks, sizeof(int));
     sh->red = (double *)calloc((size_t)nranks * 64, sizeof(double));
     return sh;
@@ -201,33 +206,35 @@ void mg_comm_loopback_shared_destroy(void *p) {
     free(sh->field); free(sh->nz); free(sh->red); free(sh);
 }
 
-static int loop_halo(mg_comm *c, mgk_ctx *ctx, double *field, const mgk_geom *g, void *stream) {
+static int loop_halo(mg_comm *c, mgk_ctx *ctx, void *field, const mgk_geom *g, int esz, void *stream) {
     loop_shared *sh = ((loop_impl *)c->impl)->sh;
     void *s = stream_of(ctx, stream);
     CK(mgk_sync(ctx, s));                         /* my planes are final */
     sh->field[c->rank] = field; sh->nz[c->rank] = g->nz;
     pthread_barrier_wait(&sh->bar);
-    const size_t bytes = sizeof(double) * (size_t)g->plane;
+    const size_t pb = (size_t)esz * (size_t)g->plane;
+    char *f = (char *)field;
     if (c->rank > 0)
-        CK(mgk_d2d(ctx, field, sh->field[c->rank - 1] + (long)sh->nz[c->rank - 1] * g->plane, bytes, s));
+        CK(mgk_d2d(ctx, f, (char *)sh->field[c->rank - 1] + (size_t)sh->nz[c->rank - 1] * pb, pb, s));
     if (c->rank < c->nranks - 1)
-        CK(mgk_d2d(ctx, field + (long)(g->nz + 1) * g->plane, sh->field[c->rank + 1] + g->plane, bytes, s));
+        CK(mgk_d2d(ctx, f + (size_t)(g->nz + 1) * pb, (char *)sh->field[c->rank + 1] + pb, pb, s));
     CK(mgk_sync(ctx, s));
     pthread_barrier_wait(&sh->bar);               /* nobody overwrites a plane a neighbour still reads */
     return 0;
 }
 
-static int loop_allgather_planes(mg_comm *c, mgk_ctx *ctx, double *field, const mgk_geom *gf, const int *zstart, void *stream) {
+static int loop_allgather_planes(mg_comm *c, mgk_ctx *ctx, void *field, const mgk_geom *gf, const int *zstart, int esz, void *stream) {
     loop_shared *sh = ((loop_impl *)c->impl)->sh;
     void *s = stream_of(ctx, stream);
     CK(mgk_sync(ctx, s));
     sh->field[c->rank] = field;
     pthread_barrier_wait(&sh->bar);
+    const size_t pb = (size_t)esz * (size_t)gf->plane;
     for (int r = 0; r < c->nranks; r++) {
         if (r == c->rank) continue;
-        const long off = (long)(zstart[r] + 1) * gf->plane;
-        const size_t bytes = sizeof(double) * (size_t)(zstart[r + 1] - zstart[r]) * (size_t)gf->plane;
-        if (bytes) CK(mgk_d2d(ctx, field + off, sh->field[r] + off, bytes, s));
+        const size_t off = (size_t)(zstart[r] + 1) * pb;
+        const size_t bytes = (size_t)(zstart[r + 1] - zstart[r]) * pb;
+        if (bytes) CK(mgk_d2d(ctx, (char *)field + off, (char *)sh->field[r] + off, bytes, s));
     }
     CK(mgk_sync(ctx, s));
     pthread_barrier_wait(&sh->bar);

@@ -33,19 +33,55 @@ static int mgfail(int code, const char *what) {
 }
 #define CHK(call) do { int rc_ = (call); if (rc_) return mgfail(rc_, #call); } while (0)
 
+/* the fields of one level in one precision (index 0: fp64, 1: fp32) */
+typedef struct mg_fset {
+    mgk_geom g;             /* local geometry in elements of that precision */
+    void *u, *b, *rv, *tmp;
+    int guess_nonzero;      /* KSPSetInitialGuessNonzero state of ksp[l] (src/solver.c:1532,1537,1543) */
+    int u_ghost_ok;         /* z ghost planes of `u` hold the neighbours' current boundary planes */
+    int u_ghost_pending;    /* ... but the exchange is still in flight on the comm stream */
+} mg_fset;
+
 typedef struct mg_level {
     int n;                  /* unknowns per side of the whole grid */
     int z0, nzl;            /* owned planes [z0, z0+nzl) (3-D); whole grid when replicated / 2-D */
     int distributed;
-    mgk_geom g;             /* local geometry */
     double coef[7], dinv, h;
-    double *u, *b, *rv, *tmp, *p2;
-    mgk_geom g32;           /* mixed precision: geometry and fields of the fp32 correction cycle */
-    float *u32, *b32, *rv32, *tmp32;
-    int guess_nonzero;      /* KSPSetInitialGuessNonzero state of ksp[l] (src/solver.c:1532,1537,1543) */
-    int u_ghost_ok;         /* z ghost planes of `u` hold the neighbours' current boundary planes */
-    int u_ghost_pending;    /* ... but the exchange is still in flight on the comm stream */
+    mg_fset f[2];
+    double *p2;             /* Chebyshev: third recurrence vector (fp64) */
 } mg_level;
+
+/* the kernel ABI of one precision behind untyped pointers: the cycle code below is written once */
+typedef struct mg_ops {
+    int esz;
+    int (*jacobi_range)(mgk_ctx *, const mgk_geom *, const double *, double, double, const void *, const void *, void *, int, int, void *);
+    int (*jacobi_zero)(mgk_ctx *, const mgk_geom *, double, double, const void *, void *, void *);
+    int (*residual)(mgk_ctx *, const mgk_geom *, const double *, const void *, const void *, void *, void *);
+    int (*restrict_fw)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const void *, void *, void *);
+    int (*prolong_add)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const void *, void *, void *);
+    int (*prolong_jacobi)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const double *, double, double, const void *, const void *, const void *, void *, void *);
+    int (*residual_restrict)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const double *, const void *, const void *, void *, void *);   /* NULL: not built */
+} mg_ops;
+
+#define W64(name) static int name##_64
+#define W32(name) static int name##_32
+W64(jr)(mgk_ctx *c, const mgk_geom *g, const double *k, double d, double sc, const void *b, const void *u, void *o, int z0, int z1, void *st) { return mgk_jacobi_range_f64(c, g, k, d, sc, (const double *)b, (const double *)u, (double *)o, z0, z1, st); }
+W32(jr)(mgk_ctx *c, const mgk_geom *g, const double *k, double d, double sc, const void *b, const void *u, void *o, int z0, int z1, void *st) { return mgk_jacobi_range_f32(c, g, k, d, sc, (const float *)b, (const float *)u, (float *)o, z0, z1, st); }
+W64(jz)(mgk_ctx *c, const mgk_geom *g, double d, double sc, const void *b, void *o, void *st) { return mgk_jacobi_zero_f64(c, g, d, sc, (const double *)b, (double *)o, st); }
+W32(jz)(mgk_ctx *c, const mgk_geom *g, double d, double sc, const void *b, void *o, void *st) { return mgk_jacobi_zero_f32(c, g, d, sc, (const float *)b, (float *)o, st); }
+W64(rs)(mgk_ctx *c, const mgk_geom *g, const double *k, const void *b, const void *u, void *r, void *st) { return mgk_residual_f64(c, g, k, (const double *)b, (const double *)u, (double *)r, st); }
+W32(rs)(mgk_ctx *c, const mgk_geom *g, const double *k, const void *b, const void *u, void *r, void *st) { return mgk_residual_f32(c, g, k, (const float *)b, (const float *)u, (float *)r, st); }
+W64(rf)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const void *r, void *b, void *st) { return mgk_restrict_fw_f64(c, gf, gc, (const double *)r, (double *)b, st); }
+W32(rf)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const void *r, void *b, void *st) { return mgk_restrict_fw_f32(c, gf, gc, (const float *)r, (float *)b, st); }
+W64(pa)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const void *uc, void *uf, void *st) { return mgk_prolong_add_f64(c, gf, gc, (const double *)uc, (double *)uf, st); }
+W32(pa)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const void *uc, void *uf, void *st) { return mgk_prolong_add_f32(c, gf, gc, (const float *)uc, (float *)uf, st); }
+W64(pj)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, double d, double sc, const void *b, const void *uc, const void *u, void *o, void *st) { return mgk_prolong_jacobi_f64(c, gf, gc, k, d, sc, (const double *)b, (const double *)uc, (const double *)u, (double *)o, st); }
+W32(pj)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, double d, double sc, const void *b, const void *uc, const void *u, void *o, void *st) { return mgk_prolong_jacobi_f32(c, gf, gc, k, d, sc, (const float *)b, (const float *)uc, (const float *)u, (float *)o, st); }
+W64(rr)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, const void *b, const void *u, void *bc, void *st) { return mgk_residual_restrict_f64(c, gf, gc, k, (const double *)b, (const double *)u, (double *)bc, st); }
+static const mg_ops OPS[2] = {
+    {8, jr_64, jz_64, rs_64, rf_64, pa_64, pj_64, rr_64},
+    {4, jr_32, jz_32, rs_32, rf_32, pa_32, pj_32, NULL},
+};
 
 struct mg_solver {
     mg_config cfg;
@@ -60,9 +96,9 @@ struct mg_solver {
     double bnorm, rchk;
     int started;
     double solve_seconds;
-    /* profiling */
     int lgraph;             /* levels >= lgraph form the launch-bound coarse part replayed as one HIP graph (0: off) */
-    void *coarse_graph;
+    void *coarse_graph[2];  /* one recording per precision */
+    /* profiling */
     int prof_on, prof_n;
     void *timers[MG_MAX_TIMERS];
     int ntimers_created;
@@ -169,10 +205,13 @@ void mg_config_default(mg_config *c) {
     c->graph = -1;
 }
 
-static int alloc_field(mg_solver *s, const mgk_geom *g, double **p) {
-    void *q = NULL;
-    CHK(mgk_malloc(s->ctx, &q, sizeof(double) * (size_t)g->total));
-    *p = (double *)q;
+static int alloc_fset(mg_solver *s, mg_fset *F, int esz, int all4) {
+    void **f[4] = {&F->u, &F->b, &F->rv, &F->tmp};
+    for (int k = 0; k < (all4 ? 4 : 2); k++) {
+        void *q = NULL;
+        CHK(mgk_malloc(s->ctx, &q, (size_t)esz * (size_t)F->g.total));
+        *f[k] = q;
+    }
     return 0;
 }
 
@@ -181,8 +220,8 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
     if (cfg->dim != 2 && cfg->dim != 3) return mgfail(MGK_EINVAL, "mg_solver_create: dim must be 2 or 3");
     if (cfg->levels < 1 || cfg->levels > MG_MAX_LEVELS) return mgfail(MGK_EINVAL, "mg_solver_create: bad level count");
     if (cfg->npts < 3) return mgfail(MGK_EINVAL, "mg_solver_create: npts < 3");
-    if (cfg->precision == MG_PREC_MIXED && (cfg->dim != 3 || cfg->nranks > 1 || cfg->ksp_type != MG_KSP_RICHARDSON))
-        return mgfail(MGK_EINVAL, "mg_solver_create: mixed precision is built for 3-D, one GPU, Richardson+Jacobi");
+    if (cfg->precision == MG_PREC_MIXED && (cfg->dim != 3 || cfg->ksp_type != MG_KSP_RICHARDSON))
+        return mgfail(MGK_EINVAL, "mg_solver_create: mixed precision is built for 3-D, Richardson+Jacobi");
     /* npts-1 must be divisible by 2^(levels-1) and the coarsest grid must keep >= 1 unknown */
     for (int l = 0; l < cfg->levels; l++) {
         int n = mg_grid_n(cfg->npts, l);
@@ -227,6 +266,7 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
         }
     }
 
+    const int mixed = (cfg->precision == MG_PREC_MIXED);
     for (int l = 0; l < s->levels; l++) {
         mg_level *L = &s->L[l];
         L->n = mg_grid_n(cfg->npts, l);
@@ -237,32 +277,28 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
             mg_slab_range(cfg->npts, s->ldist, l, s->cfg.rank, s->cfg.nranks, &a, &b);
             L->z0 = a; L->nzl = b - a;
         }
-        rc = mgk_geom_init(&L->g, cfg->dim, L->n, L->n, L->nzl);
+        rc = mgk_geom_init(&L->f[0].g, cfg->dim, L->n, L->n, L->nzl);
         if (rc) { mg_solver_destroy(s); return mgfail(rc, "mg_solver_create: geometry"); }
         level_stencil(cfg->dim, L->n, L->coef, &L->h);
         L->dinv = 1.0 / L->coef[cfg->dim == 3 ? 3 : 2];      /* PCJACOBI: 1/diag(A) */
-        if (cfg->precision == MG_PREC_MIXED) {
-            /* fp64 only where the outer defect correction lives (level 0: u, b); fp32 everywhere else */
-            void *q = NULL;
-            if (l == 0 && ((rc = alloc_field(s, &L->g, &L->u)) || (rc = alloc_field(s, &L->g, &L->b)))) { mg_solver_destroy(s); return rc; }
-            if ((rc = mgk_geom_init_f32(&L->g32, 3, L->n, L->n, L->n))) { mg_solver_destroy(s); return mgfail(rc, "mg_solver_create: fp32 geometry"); }
-            float **f[4] = {&L->u32, &L->b32, &L->rv32, &L->tmp32};
-            for (int k = 0; k < 4; k++) {
-                if ((rc = mgk_malloc(s->ctx, &q, sizeof(float) * (size_t)L->g32.total))) { mg_solver_destroy(s); return mgfail(rc, "mg_solver_create: fp32 field"); }
-                *f[k] = (float *)q;
-            }
+        if (mixed) {
+            /* fp64 only where the outer defect correction lives (level 0: u, b); fp32 on every level */
+            if (l == 0 && (rc = alloc_fset(s, &L->f[0], 8, 0))) { mg_solver_destroy(s); return rc; }
+            if ((rc = mgk_geom_init_f32(&L->f[1].g, 3, L->n, L->n, L->nzl))) { mg_solver_destroy(s); return mgfail(rc, "mg_solver_create: fp32 geometry"); }
+            if ((rc = alloc_fset(s, &L->f[1], 4, 1))) { mg_solver_destroy(s); return rc; }
             continue;
         }
-        if ((rc = alloc_field(s, &L->g, &L->u)) || (rc = alloc_field(s, &L->g, &L->b)) ||
-            (rc = alloc_field(s, &L->g, &L->rv)) || (rc = alloc_field(s, &L->g, &L->tmp))) {
-            mg_solver_destroy(s); return rc;
+        if ((rc = alloc_fset(s, &L->f[0], 8, 1))) { mg_solver_destroy(s); return rc; }
+        if (cfg->ksp_type == MG_KSP_CHEBYSHEV) {
+            void *q = NULL;
+            if ((rc = mgk_malloc(s->ctx, &q, sizeof(double) * (size_t)L->f[0].g.total))) { mg_solver_destroy(s); return mgfail(rc, "mg_solver_create: field"); }
+            L->p2 = (double *)q;
         }
-        if (cfg->ksp_type == MG_KSP_CHEBYSHEV && (rc = alloc_field(s, &L->g, &L->p2))) { mg_solver_destroy(s); return rc; }
     }
     /* coarse part for the HIP graph: the first level that is neither distributed nor fed by a distributed one and
      * has at most 2^21 unknowns (3-D n <= 127, 2-D n <= 1023): below that a kernel is shorter than its launch */
     s->lgraph = 0;
-    if (s->cfg.graph && s->cfg.ksp_type == MG_KSP_RICHARDSON && s->cfg.precision == MG_PREC_FP64) {
+    if (s->cfg.graph && s->cfg.ksp_type == MG_KSP_RICHARDSON) {
         for (int l = (s->ldist > 0 ? s->ldist + 1 : 1); l < s->levels; l++) {
             double N = pow((double)s->L[l].n, (double)cfg->dim);
             if (N <= 2097152.0) { s->lgraph = l; break; }
@@ -280,18 +316,14 @@ void mg_solver_destroy(mg_solver *s) {
     if (s->ctx) {
         mgk_sync(s->ctx, NULL);
         for (int q = 0; q < s->ntimers_created; q++) mgk_timer_destroy(s->ctx, s->timers[q]);
-        if (s->coarse_graph) mgk_graph_destroy(s->ctx, s->coarse_graph);
+        for (int p = 0; p < 2; p++) if (s->coarse_graph[p]) mgk_graph_destroy(s->ctx, s->coarse_graph[p]);
         for (int l = 0; l < s->levels; l++) {
             mg_level *L = &s->L[l];
-            if (L->u) mgk_free(s->ctx, L->u);
-            if (L->b) mgk_free(s->ctx, L->b);
-            if (L->rv) mgk_free(s->ctx, L->rv);
-            if (L->tmp) mgk_free(s->ctx, L->tmp);
+            for (int p = 0; p < 2; p++) {
+                void *f[4] = {L->f[p].u, L->f[p].b, L->f[p].rv, L->f[p].tmp};
+                for (int k = 0; k < 4; k++) if (f[k]) mgk_free(s->ctx, f[k]);
+            }
             if (L->p2) mgk_free(s->ctx, L->p2);
-            if (L->u32) mgk_free(s->ctx, L->u32);
-            if (L->b32) mgk_free(s->ctx, L->b32);
-            if (L->rv32) mgk_free(s->ctx, L->rv32);
-            if (L->tmp32) mgk_free(s->ctx, L->tmp32);
         }
         mgk_ctx_destroy(s->ctx);
     }
@@ -335,30 +367,31 @@ static int sin_tables(mg_solver *s, double **cx, double **sx, double **sy, doubl
 
 int mg_solver_set_rhs_problem(mg_solver *s) {
     double *cx = NULL, *sy = NULL, *sz = NULL;
+    mg_fset *F = &s->L[0].f[0];
     CHK(sin_tables(s, &cx, NULL, &sy, &sz));
-    CHK(mgk_fill_separable_f64(s->ctx, &s->L[0].g, cx, sy, sz, s->L[0].b, NULL));
+    CHK(mgk_fill_separable_f64(s->ctx, &F->g, cx, sy, sz, (double *)F->b, NULL));
     CHK(mgk_sync(s->ctx, NULL));
     mgk_free(s->ctx, cx); mgk_free(s->ctx, sy); if (sz) mgk_free(s->ctx, sz);
     return mg_solver_reset(s);
 }
 
 int mg_solver_set_rhs_host(mg_solver *s, const double *b_compact) {
-    const mg_level *L = &s->L[0];
-    size_t n = (size_t)L->g.nx * L->g.ny * L->g.nz;
+    mg_fset *F = &s->L[0].f[0];
+    size_t n = (size_t)F->g.nx * F->g.ny * F->g.nz;
     double *d = NULL;
     CHK(upload(s, b_compact, n, &d));
-    CHK(mgk_pack_f64(s->ctx, &L->g, d, L->b, NULL));
+    CHK(mgk_pack_f64(s->ctx, &F->g, d, (double *)F->b, NULL));
     CHK(mgk_sync(s->ctx, NULL));
     mgk_free(s->ctx, d);
     return mg_solver_reset(s);
 }
 
 int mg_solver_get_solution(mg_solver *s, double *u_compact) {
-    const mg_level *L = &s->L[0];
-    size_t n = (size_t)L->g.nx * L->g.ny * L->g.nz;
+    mg_fset *F = &s->L[0].f[0];
+    size_t n = (size_t)F->g.nx * F->g.ny * F->g.nz;
     void *d = NULL;
     CHK(mgk_malloc(s->ctx, &d, sizeof(double) * n));
-    CHK(mgk_unpack_f64(s->ctx, &L->g, L->u, (double *)d, NULL));
+    CHK(mgk_unpack_f64(s->ctx, &F->g, (const double *)F->u, (double *)d, NULL));
     CHK(mgk_d2h(s->ctx, u_compact, d, sizeof(double) * n));
     mgk_free(s->ctx, d);
     return 0;
@@ -366,13 +399,13 @@ int mg_solver_get_solution(mg_solver *s, double *u_compact) {
 
 int mg_solver_error_norms(mg_solver *s, double err[3]) {
     double *sx = NULL, *sy = NULL, *sz = NULL;
+    mg_fset *F = &s->L[0].f[0];
     CHK(sin_tables(s, NULL, &sx, &sy, &sz));
     double e[3];
-    CHK(mgk_error_sums_f64(s->ctx, &s->L[0].g, s->L[0].u, sx, sy, sz, e, NULL));
+    CHK(mgk_error_sums_f64(s->ctx, &F->g, (const double *)F->u, sx, sy, sz, e, NULL));
     mgk_free(s->ctx, sx); mgk_free(s->ctx, sy); if (sz) mgk_free(s->ctx, sz);
     if (s->cfg.nranks > 1) {
-        /* max over ranks via sums of one-hot is not available: exchange through allreduce of
-         * [sum|e|, sum e^2] and a separate max emulated by gathering (ranks are few) */
+        /* sums through the all-reduce; the max by all-reducing a one-hot vector (ranks are few) */
         double v[2] = {e[1], e[2]};
         CHK(s->comm->allreduce_sum(s->comm, s->ctx, v, 2, NULL));
         e[1] = v[0]; e[2] = v[1];
@@ -388,30 +421,31 @@ int mg_solver_error_norms(mg_solver *s, double err[3]) {
 }
 
 /* ------------------------------------------------------------------ */
-/* the cycle                                                           */
+/* the cycle (written once for both precisions: P = 0 fp64, 1 fp32)    */
 /* ------------------------------------------------------------------ */
 /* Every RCCL operation of a solver is issued on ITS comm stream (one communicator, one stream: a
  * single total order on every rank); cross-stream events tie it to the compute stream.
  * Blocking form: the exchange sees everything queued on the compute stream so far, and everything
  * queued on the compute stream afterwards sees the ghosts. */
-static int halo(mg_solver *s, mg_level *L, double *field) {
+static int halo(mg_solver *s, int P, mg_level *L, void *field) {
     if (!L->distributed) return 0;
     void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
     CHK(mgk_stream_wait(s->ctx, ms, cs));
-    CHK(s->comm->halo(s->comm, s->ctx, field, &L->g, ms));
+    CHK(s->comm->halo(s->comm, s->ctx, field, &L->f[P].g, OPS[P].esz, ms));
     CHK(mgk_stream_wait(s->ctx, cs, ms));
     return 0;
 }
 
-/* make the ghost planes of L->u valid and visible to the compute stream */
-static int ensure_u_ghosts(mg_solver *s, mg_level *L) {
+/* make the ghost planes of u valid and visible to the compute stream */
+static int ensure_u_ghosts(mg_solver *s, int P, mg_level *L) {
+    mg_fset *F = &L->f[P];
     if (!L->distributed) return 0;
-    if (L->u_ghost_pending) {
+    if (F->u_ghost_pending) {
         CHK(mgk_stream_wait(s->ctx, mgk_stream_compute(s->ctx), mgk_stream_comm(s->ctx)));
-        L->u_ghost_pending = 0;
-        L->u_ghost_ok = 1;
+        F->u_ghost_pending = 0;
+        F->u_ghost_ok = 1;
     }
-    if (!L->u_ghost_ok) { CHK(halo(s, L, L->u)); L->u_ghost_ok = 1; }
+    if (!F->u_ghost_ok) { CHK(halo(s, P, L, F->u)); F->u_ghost_ok = 1; }
     return 0;
 }
 
@@ -436,76 +470,87 @@ int mg_solver_profile_read(mg_solver *s, double *total_ms, int *launches) {
     return 0;
 }
 
-static void swap_ptr(double **a, double **b) { double *t = *a; *a = *b; *b = t; }
+static void swap_ptr(void **a, void **b) { void *t = *a; *a = *b; *b = t; }
 
-/* KSPSolve(ksp[l], b[l], u[l]) with KSP_NORM_NONE and max_it = maxit (src/solver.c:1465-1509) */
-static int smooth(mg_solver *s, int l, int maxit) {
+/* KSPSolve(ksp[l], b[l], u[l]) with KSPCHEBYSHEV (fp64 only), classic three-term recurrence (oracle/mgo.c) */
+static int smooth_chebyshev(mg_solver *s, int l, int maxit) {
     mg_level *L = &s->L[l];
-    const size_t bytes = sizeof(double) * (size_t)L->g.total;
-    if (s->cfg.ksp_type == MG_KSP_RICHARDSON) {
-        if (maxit == 0 && !L->guess_nonzero) { CHK(mgk_memset0(s->ctx, L->u, bytes, NULL)); L->u_ghost_ok = 0; L->u_ghost_pending = 0; }   /* KSPSolve zero-fills */
-        for (int it = 0; it < maxit; it++) {
-            if (it == 0 && !L->guess_nonzero) {
-                /* r = b, x = 0 + scale*(B b): u is not read */
-                CHK(mgk_jacobi_zero_f64(s->ctx, &L->g, L->dinv, s->cfg.scale, L->b, L->tmp, NULL));
-            } else if (L->distributed && s->cfg.overlap && L->g.nz >= 3) {
-                /* boundary planes first, ship them on the comm stream, sweep the interior meanwhile */
-                void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
-                const int nz = L->g.nz;
-                CHK(ensure_u_ghosts(s, L));
-                CHK(mgk_jacobi_range_f64(s->ctx, &L->g, L->coef, L->dinv, s->cfg.scale, L->b, L->u, L->tmp, 0, 1, cs));
-                CHK(mgk_jacobi_range_f64(s->ctx, &L->g, L->coef, L->dinv, s->cfg.scale, L->b, L->u, L->tmp, nz - 1, nz, cs));
-                CHK(mgk_stream_wait(s->ctx, ms, cs));
-                void *t = prof_begin(s, l);
-                CHK(mgk_jacobi_range_f64(s->ctx, &L->g, L->coef, L->dinv, s->cfg.scale, L->b, L->u, L->tmp, 1, nz - 1, cs));
-                prof_end(s, t);
-                CHK(s->comm->halo(s->comm, s->ctx, L->tmp, &L->g, ms));
-                swap_ptr(&L->u, &L->tmp);
-                L->u_ghost_pending = 1; L->u_ghost_ok = 0;
-                continue;
-            } else {
-                CHK(ensure_u_ghosts(s, L));
-                void *t = prof_begin(s, l);
-                CHK(mgk_jacobi_f64(s->ctx, &L->g, L->coef, L->dinv, s->cfg.scale, L->b, L->u, L->tmp, NULL));
-                prof_end(s, t);
-            }
-            L->u_ghost_ok = 0; L->u_ghost_pending = 0;
-            swap_ptr(&L->u, &L->tmp);
-        }
-        return 0;
-    }
-    /* KSPCHEBYSHEV, classic three-term recurrence (see oracle/mgo.c mgo_chebyshev_csr) */
+    mg_fset *F = &L->f[0];
+    const size_t bytes = sizeof(double) * (size_t)F->g.total;
     double scale = 2.0 / (s->cfg.emax + s->cfg.emin), alpha = 1.0 - scale * s->cfg.emin, Gamma = 1.0;
     double mu = 1.0 / alpha, omegaprod = 2.0 / alpha, ckm1 = 1.0, ck = mu, ckp1;
-    double *pkm1 = L->u, *pk = L->tmp, *pkp1 = L->p2;
-    if (!L->guess_nonzero) {
+    double *pkm1 = (double *)F->u, *pk = (double *)F->tmp, *pkp1 = L->p2;
+    if (!F->guess_nonzero) {
         CHK(mgk_memset0(s->ctx, pkm1, bytes, NULL));
-        L->u_ghost_ok = 0; L->u_ghost_pending = 0;
-        if (maxit > 0) CHK(mgk_jacobi_zero_f64(s->ctx, &L->g, L->dinv, scale, L->b, pk, NULL));
+        F->u_ghost_ok = 0; F->u_ghost_pending = 0;
+        if (maxit > 0) CHK(mgk_jacobi_zero_f64(s->ctx, &F->g, L->dinv, scale, (const double *)F->b, pk, NULL));
     } else if (maxit > 0) {
-        CHK(ensure_u_ghosts(s, L));
-        CHK(mgk_jacobi_f64(s->ctx, &L->g, L->coef, L->dinv, scale, L->b, pkm1, pk, NULL));
+        CHK(ensure_u_ghosts(s, 0, L));
+        CHK(mgk_jacobi_f64(s->ctx, &F->g, L->coef, L->dinv, scale, (const double *)F->b, pkm1, pk, NULL));
     }
     if (maxit == 0) return 0;
     for (int it = 1; it < maxit; it++) {
         ckp1 = 2.0 * mu * ck - ckm1;
         double omega = omegaprod * ck / ckp1;
-        CHK(halo(s, L, pk));
-        CHK(mgk_cheby_f64(s->ctx, &L->g, L->coef, L->dinv, 1.0 - omega, omega, omega * Gamma * scale,
-                          L->b, pk, pkm1, pkp1, NULL));
+        CHK(halo(s, 0, L, pk));
+        CHK(mgk_cheby_f64(s->ctx, &F->g, L->coef, L->dinv, 1.0 - omega, omega, omega * Gamma * scale,
+                          (const double *)F->b, pk, pkm1, pkp1, NULL));
         double *t = pkm1; pkm1 = pk; pk = pkp1; pkp1 = t;
         ckm1 = ck; ck = ckp1;
     }
-    L->u = pk; L->tmp = pkm1; L->p2 = pkp1;
-    L->u_ghost_ok = 0; L->u_ghost_pending = 0;
+    F->u = pk; F->tmp = pkm1; L->p2 = pkp1;
+    F->u_ghost_ok = 0; F->u_ghost_pending = 0;
+    return 0;
+}
+
+/* KSPSolve(ksp[l], b[l], u[l]) with KSP_NORM_NONE and max_it = maxit (src/solver.c:1465-1509) */
+static int smooth(mg_solver *s, int P, int l, int maxit) {
+    if (s->cfg.ksp_type == MG_KSP_CHEBYSHEV) return smooth_chebyshev(s, l, maxit);
+    mg_level *L = &s->L[l];
+    mg_fset *F = &L->f[P];
+    const mg_ops *O = &OPS[P];
+    if (maxit == 0 && !F->guess_nonzero) {                          /* KSPSolve zero-fills */
+        CHK(mgk_memset0(s->ctx, F->u, (size_t)O->esz * (size_t)F->g.total, NULL));
+        F->u_ghost_ok = 0; F->u_ghost_pending = 0;
+    }
+    for (int it = 0; it < maxit; it++) {
+        if (it == 0 && !F->guess_nonzero) {
+            /* r = b, x = 0 + scale*(B b): u is not read */
+            CHK(O->jacobi_zero(s->ctx, &F->g, L->dinv, s->cfg.scale, F->b, F->tmp, NULL));
+        } else if (L->distributed && s->cfg.overlap && F->g.nz >= 3) {
+            /* boundary planes first, ship them on the comm stream, sweep the interior meanwhile */
+            void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
+            const int nz = F->g.nz;
+            CHK(ensure_u_ghosts(s, P, L));
+            CHK(O->jacobi_range(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, F->b, F->u, F->tmp, 0, 1, cs));
+            CHK(O->jacobi_range(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, F->b, F->u, F->tmp, nz - 1, nz, cs));
+            CHK(mgk_stream_wait(s->ctx, ms, cs));
+            void *t = prof_begin(s, l);
+            CHK(O->jacobi_range(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, F->b, F->u, F->tmp, 1, nz - 1, cs));
+            prof_end(s, t);
+            CHK(s->comm->halo(s->comm, s->ctx, F->tmp, &F->g, O->esz, ms));
+            swap_ptr(&F->u, &F->tmp);
+            F->u_ghost_pending = 1; F->u_ghost_ok = 0;
+            continue;
+        } else {
+            CHK(ensure_u_ghosts(s, P, L));
+            void *t = prof_begin(s, l);
+            CHK(O->jacobi_range(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, F->b, F->u, F->tmp, 0,
+                                F->g.dim == 3 ? F->g.nz : F->g.ny, NULL));
+            prof_end(s, t);
+        }
+        F->u_ghost_ok = 0; F->u_ghost_pending = 0;
+        swap_ptr(&F->u, &F->tmp);
+    }
     return 0;
 }
 
 /* KSPBuildResidual(ksp[l],NULL,rv[l],&r) : rv = b - A u (src/solver.c:1534,1545) */
-static int residual(mg_solver *s, int l) {
+static int residual(mg_solver *s, int P, int l) {
     mg_level *L = &s->L[l];
-    CHK(ensure_u_ghosts(s, L));
-    CHK(mgk_residual_f64(s->ctx, &L->g, L->coef, L->b, L->u, L->rv, NULL));
+    mg_fset *F = &L->f[P];
+    CHK(ensure_u_ghosts(s, P, L));
+    CHK(OPS[P].residual(s->ctx, &F->g, L->coef, F->b, F->u, F->rv, NULL));
     return 0;
 }
 
@@ -516,183 +561,157 @@ static int norm_from_sumsq(mg_solver *s, double ss, double *out) {
 }
 
 /* MatMult(res[l-1], r[l-1], b[l]) (src/solver.c:1535) */
-static int restrict_to(mg_solver *s, int l) {
-    mg_level *F = &s->L[l - 1], *Cq = &s->L[l];
-    CHK(halo(s, F, F->rv));
-    if (F->distributed && !Cq->distributed) {
+static int restrict_to(mg_solver *s, int P, int l) {
+    mg_level *Lf = &s->L[l - 1], *Lc = &s->L[l];
+    mg_fset *F = &Lf->f[P], *Cq = &Lc->f[P];
+    const mg_ops *O = &OPS[P];
+    CHK(halo(s, P, Lf, F->rv));
+    if (Lf->distributed && !Lc->distributed) {
         /* slab -> replicated: produce my coarse planes in place, then all-gather them */
         mgk_geom gc = Cq->g;
         int c0 = s->zstart[s->cfg.rank], c1 = s->zstart[s->cfg.rank + 1];
         gc.nz = c1 - c0;
-        CHK(mgk_restrict_fw_f64(s->ctx, &F->g, &gc, F->rv, Cq->b + (long)c0 * Cq->g.plane, NULL));
-        {
-            void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
-            CHK(mgk_stream_wait(s->ctx, ms, cs));
-            CHK(s->comm->allgather_planes(s->comm, s->ctx, Cq->b, &Cq->g, s->zstart, ms));
-            CHK(mgk_stream_wait(s->ctx, cs, ms));
-        }
+        CHK(O->restrict_fw(s->ctx, &F->g, &gc, F->rv, (char *)Cq->b + (size_t)O->esz * (size_t)c0 * (size_t)Cq->g.plane, NULL));
+        void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
+        CHK(mgk_stream_wait(s->ctx, ms, cs));
+        CHK(s->comm->allgather_planes(s->comm, s->ctx, Cq->b, &Cq->g, s->zstart, O->esz, ms));
+        CHK(mgk_stream_wait(s->ctx, cs, ms));
         return 0;
     }
-    CHK(mgk_restrict_fw_f64(s->ctx, &F->g, &Cq->g, F->rv, Cq->b, NULL));
+    CHK(O->restrict_fw(s->ctx, &F->g, &Cq->g, F->rv, Cq->b, NULL));
     return 0;
 }
 
 /* MatMult(pro[l],u[l+1],rv[l]); VecAXPY(u[l],1.0,rv[l]) (src/solver.c:1540-1541) */
-static int prolong_from(mg_solver *s, int l) {
-    mg_level *F = &s->L[l], *Cq = &s->L[l + 1];
-    if (F->distributed && !Cq->distributed) {
+static int prolong_from(mg_solver *s, int P, int l) {
+    mg_level *Lf = &s->L[l], *Lc = &s->L[l + 1];
+    mg_fset *F = &Lf->f[P], *Cq = &Lc->f[P];
+    const mg_ops *O = &OPS[P];
+    if (F->u_ghost_pending) CHK(ensure_u_ghosts(s, P, Lf));
+    if (Lf->distributed && !Lc->distributed) {
         mgk_geom gc = Cq->g;
         int c0 = s->zstart[s->cfg.rank], c1 = s->zstart[s->cfg.rank + 1];
         gc.nz = c1 - c0;
-        if (F->u_ghost_pending) CHK(ensure_u_ghosts(s, F));
-        CHK(mgk_prolong_add_f64(s->ctx, &F->g, &gc, Cq->u + (long)c0 * Cq->g.plane, F->u, NULL));
-        F->u_ghost_ok = 0;
-        return 0;
+        CHK(O->prolong_add(s->ctx, &F->g, &gc, (char *)Cq->u + (size_t)O->esz * (size_t)c0 * (size_t)Cq->g.plane, F->u, NULL));
+    } else {
+        CHK(ensure_u_ghosts(s, P, Lc));
+        CHK(O->prolong_add(s->ctx, &F->g, &Cq->g, Cq->u, F->u, NULL));
     }
-    CHK(ensure_u_ghosts(s, Cq));
-    if (F->u_ghost_pending) CHK(ensure_u_ghosts(s, F));
-    CHK(mgk_prolong_add_f64(s->ctx, &F->g, &Cq->g, Cq->u, F->u, NULL));
     F->u_ghost_ok = 0;
     return 0;
 }
 
 /* prolongation fused into the first post-smoothing sweep: u <- Jacobi(u + P u_c)  (src/solver.c:1540-1542) */
-static int prolong_smooth(mg_solver *s, int l) {
-    mg_level *F = &s->L[l], *Cq = &s->L[l + 1];
+static int prolong_smooth(mg_solver *s, int P, int l) {
+    mg_level *Lf = &s->L[l], *Lc = &s->L[l + 1];
+    mg_fset *F = &Lf->f[P], *Cq = &Lc->f[P];
+    const mg_ops *O = &OPS[P];
     const int v0 = s->cfg.v[0];
     if (!(s->cfg.fuse & 2) || s->cfg.dim != 3 || s->cfg.ksp_type != MG_KSP_RICHARDSON || v0 < 1) {
-        CHK(prolong_from(s, l));
-        return smooth(s, l, v0);
+        CHK(prolong_from(s, P, l));
+        return smooth(s, P, l, v0);
     }
     mgk_geom gc = Cq->g;
-    const double *ucoarse = Cq->u;
-    if (F->distributed && !Cq->distributed) {
+    const void *ucoarse = Cq->u;
+    if (Lf->distributed && !Lc->distributed) {
         int c0 = s->zstart[s->cfg.rank], c1 = s->zstart[s->cfg.rank + 1];
         gc.nz = c1 - c0;
-        ucoarse = Cq->u + (long)c0 * Cq->g.plane;
+        ucoarse = (const char *)Cq->u + (size_t)O->esz * (size_t)c0 * (size_t)Cq->g.plane;
     } else {
-        CHK(ensure_u_ghosts(s, Cq));
+        CHK(ensure_u_ghosts(s, P, Lc));
     }
-    CHK(ensure_u_ghosts(s, F));          /* the neighbours' boundary planes BEFORE the correction */
+    CHK(ensure_u_ghosts(s, P, Lf));          /* the neighbours' boundary planes BEFORE the correction */
     /* not counted by the profile: that one times the plain sweep kernel (bench.py roofline leg) */
-    CHK(mgk_prolong_jacobi_f64(s->ctx, &F->g, &gc, F->coef, F->dinv, s->cfg.scale, F->b, ucoarse, F->u, F->tmp, NULL));
+    CHK(O->prolong_jacobi(s->ctx, &F->g, &gc, Lf->coef, Lf->dinv, s->cfg.scale, F->b, ucoarse, F->u, F->tmp, NULL));
     swap_ptr(&F->u, &F->tmp);
     F->u_ghost_ok = 0; F->u_ghost_pending = 0;
-    return smooth(s, l, v0 - 1);
-}
-
-/* ---- mixed precision (BASELINE config 5): fp32 correction cycle inside an fp64 defect-correction loop ---- */
-static int smooth32(mg_solver *s, int l, int maxit, int guess_nonzero) {
-    mg_level *L = &s->L[l];
-    if (maxit == 0 && !guess_nonzero) CHK(mgk_memset0(s->ctx, L->u32, sizeof(float) * (size_t)L->g32.total, NULL));
-    for (int it = 0; it < maxit; it++) {
-        if (it == 0 && !guess_nonzero) CHK(mgk_jacobi_zero_f32(s->ctx, &L->g32, L->dinv, s->cfg.scale, L->b32, L->tmp32, NULL));
-        else {
-            void *t = prof_begin(s, l);
-            CHK(mgk_jacobi_f32(s->ctx, &L->g32, L->coef, L->dinv, s->cfg.scale, L->b32, L->u32, L->tmp32, NULL));
-            prof_end(s, t);
-        }
-        float *q = L->u32; L->u32 = L->tmp32; L->tmp32 = q;
-    }
-    return 0;
-}
-
-/* one outer iteration: e = Vcycle32((float) r) from e = 0;  u += (double) e;  r = b - A u (fp64), ||r|| */
-static int vcycle_once_mixed(mg_solver *s) {
-    const int levels = s->levels, *v = s->cfg.v;
-    CHK(smooth32(s, 0, v[0], 0));
-    for (int l = 1; l < levels; l++) {
-        mg_level *F = &s->L[l - 1], *Cq = &s->L[l];
-        CHK(mgk_residual_f32(s->ctx, &F->g32, F->coef, F->b32, F->u32, F->rv32, NULL));
-        CHK(mgk_restrict_fw_f32(s->ctx, &F->g32, &Cq->g32, F->rv32, Cq->b32, NULL));
-        CHK(smooth32(s, l, l == levels - 1 ? v[1] : v[0], 0));
-    }
-    for (int l = levels - 2; l >= 0; l--) {
-        mg_level *F = &s->L[l];
-        if ((s->cfg.fuse & 2) && v[0] >= 1) {
-            CHK(mgk_prolong_jacobi_f32(s->ctx, &F->g32, &s->L[l + 1].g32, F->coef, F->dinv, s->cfg.scale, F->b32, s->L[l + 1].u32, F->u32, F->tmp32, NULL));
-            float *q = F->u32; F->u32 = F->tmp32; F->tmp32 = q;
-            CHK(smooth32(s, l, v[0] - 1, 1));
-        } else {
-            CHK(mgk_prolong_add_f32(s->ctx, &F->g32, &s->L[l + 1].g32, s->L[l + 1].u32, F->u32, NULL));
-            CHK(smooth32(s, l, v[0], 1));
-        }
-    }
-    mg_level *L = &s->L[0];
-    double ss;
-    CHK(mgk_correct_f64_from_f32(s->ctx, &L->g, &L->g32, L->u32, L->u, NULL));
-    CHK(mgk_residual_f64_to_f32(s->ctx, &L->g, &L->g32, L->coef, L->b, L->u, L->b32, &ss, NULL));
-    s->rchk = sqrt(ss);
-    s->iter++;
-    if (s->iter < s->rnorm_cap) s->rnorm[s->iter] = s->rchk;
-    return 0;
+    return smooth(s, P, l, v0 - 1);
 }
 
 /* one step of the descent: b_l = R(b_{l-1} - A u_{l-1}); smooth level l from a zero guess (src/solver.c:1534-1537) */
-static int descend(mg_solver *s, int l) {
+static int descend(mg_solver *s, int P, int l) {
     const int levels = s->levels, *v = s->cfg.v;
-    mg_level *F = &s->L[l - 1];
-    if ((s->cfg.fuse & 4) && s->cfg.dim == 3 && !F->distributed && F->n + 1 <= 1024) {
+    mg_level *Lf = &s->L[l - 1];
+    const mg_ops *O = &OPS[P];
+    if ((s->cfg.fuse & 4) && O->residual_restrict && s->cfg.dim == 3 && !Lf->distributed && Lf->n + 1 <= 1024) {
         /* :1534-1535 in one pass: b_l = R (b - A u), the fine residual is never written */
-        CHK(mgk_residual_restrict_f64(s->ctx, &F->g, &s->L[l].g, F->coef, F->b, F->u, s->L[l].b, NULL));
+        CHK(O->residual_restrict(s->ctx, &Lf->f[P].g, &s->L[l].f[P].g, Lf->coef, Lf->f[P].b, Lf->f[P].u, s->L[l].f[P].b, NULL));
     } else {
-        CHK(residual(s, l - 1));                                        /* :1534 */
-        CHK(restrict_to(s, l));                                         /* :1535 */
+        CHK(residual(s, P, l - 1));                                     /* :1534 */
+        CHK(restrict_to(s, P, l));                                      /* :1535 */
     }
-    CHK(smooth(s, l, l == levels - 1 ? v[1] : v[0]));                   /* :1536 */
-    if (l != levels - 1) s->L[l].guess_nonzero = 1;                     /* :1537 */
+    CHK(smooth(s, P, l, l == levels - 1 ? v[1] : v[0]));                /* :1536 */
+    if (l != levels - 1) s->L[l].f[P].guess_nonzero = 1;                /* :1537 */
     return 0;
 }
 
 /* levels lg..L-1: down from lg-1 and back up to lg.  Every buffer pointer is the same at entry of every cycle
  * (each level swaps u/tmp an even number of times per cycle; the coarsest is copied back when v1 is odd), so the
  * recorded kernels stay valid. */
-static int coarse_part(mg_solver *s, int lg) {
+static int coarse_part(mg_solver *s, int P, int lg) {
     const int levels = s->levels;
-    for (int l = lg; l < levels; l++) CHK(descend(s, l));
+    for (int l = lg; l < levels; l++) CHK(descend(s, P, l));
     if (s->cfg.v[1] & 1) {                                              /* restore the coarsest level's buffer identity */
-        mg_level *Cz = &s->L[levels - 1];
-        CHK(mgk_d2d(s->ctx, Cz->tmp, Cz->u, sizeof(double) * (size_t)Cz->g.total, NULL));
+        mg_fset *Cz = &s->L[levels - 1].f[P];
+        CHK(mgk_d2d(s->ctx, Cz->tmp, Cz->u, (size_t)OPS[P].esz * (size_t)Cz->g.total, NULL));
         swap_ptr(&Cz->u, &Cz->tmp);
     }
     for (int l = levels - 2; l >= lg; l--) {
-        CHK(prolong_smooth(s, l));                                      /* :1540-1542 */
-        s->L[l].guess_nonzero = 0;                                      /* :1543 (l != 0 here) */
+        CHK(prolong_smooth(s, P, l));                                   /* :1540-1542 */
+        s->L[l].f[P].guess_nonzero = 0;                                 /* :1543 (l != 0 here) */
+    }
+    return 0;
+}
+
+/* the multigrid part of one iteration of the while loop (src/solver.c:1531-1544) in precision P.
+ * first: the level-0 KSP has not been switched to a non-zero initial guess yet (:1532) */
+static int cycle_body(mg_solver *s, int P, int first) {
+    const int levels = s->levels, *v = s->cfg.v;
+    const int lg = s->lgraph ? s->lgraph : levels;                      /* levels >= lg run as one HIP graph */
+    CHK(smooth(s, P, 0, v[0]));                                         /* :1531 */
+    if (first) s->L[0].f[P].guess_nonzero = 1;                          /* :1532 */
+    for (int l = 1; l < lg; l++) CHK(descend(s, P, l));
+    if (lg < levels) {
+        if (!s->coarse_graph[P]) {                                      /* record once ... */
+            CHK(mgk_capture_begin(s->ctx));
+            int rc = coarse_part(s, P, lg);
+            void *ge = NULL;
+            int rc2 = mgk_capture_end(s->ctx, &ge);
+            if (rc || rc2) return mgfail(rc ? rc : rc2, "HIP graph capture of the coarse levels");
+            s->coarse_graph[P] = ge;
+        }
+        CHK(mgk_graph_launch(s->ctx, s->coarse_graph[P]));              /* ... replay every cycle */
+    }
+    for (int l = (lg < levels ? lg - 1 : levels - 2); l >= 0; l--) {
+        CHK(prolong_smooth(s, P, l));                                   /* :1540-1542 */
+        if (l != 0) s->L[l].f[P].guess_nonzero = 0;                     /* :1543 */
     }
     return 0;
 }
 
 /* body of the while loop, src/solver.c:1531-1549 */
 static int vcycle_once(mg_solver *s) {
-    if (s->cfg.precision == MG_PREC_MIXED) return vcycle_once_mixed(s);
-    const int levels = s->levels, *v = s->cfg.v;
-    const int lg = s->lgraph ? s->lgraph : levels;                      /* levels >= lg run as one HIP graph */
-    CHK(smooth(s, 0, v[0]));                                            /* :1531 */
-    if (s->iter == 0) s->L[0].guess_nonzero = 1;                        /* :1532 */
-    for (int l = 1; l < lg; l++) CHK(descend(s, l));
-    if (lg < levels) {
-        if (!s->coarse_graph) {                                         /* record once ... */
-            CHK(mgk_capture_begin(s->ctx));
-            int rc = coarse_part(s, lg);
-            void *ge = NULL;
-            int rc2 = mgk_capture_end(s->ctx, &ge);
-            if (rc || rc2) return mgfail(rc ? rc : rc2, "HIP graph capture of the coarse levels");
-            s->coarse_graph = ge;
-        }
-        CHK(mgk_graph_launch(s->ctx, s->coarse_graph));                 /* ... replay every cycle */
-    }
-    for (int l = (lg < levels ? lg - 1 : levels - 2); l >= 0; l--) {
-        CHK(prolong_smooth(s, l));                                      /* :1540-1542 */
-        if (l != 0) s->L[l].guess_nonzero = 0;                          /* :1543 */
-    }
-    /* :1545-1546  r0 = b0 - A0 u0 ; ||r0|| */
     mg_level *L = &s->L[0];
+    mg_fset *F = &L->f[0];
     double ss;
-    CHK(ensure_u_ghosts(s, L));
-    if (s->cfg.fuse & 1) CHK(mgk_residual_sumsq_f64(s->ctx, &L->g, L->coef, L->b, L->u, &ss, NULL));
-    else {
-        CHK(mgk_residual_f64(s->ctx, &L->g, L->coef, L->b, L->u, L->rv, NULL));
-        CHK(mgk_sumsq_f64(s->ctx, &L->g, L->rv, &ss, NULL));
+    if (s->cfg.precision == MG_PREC_MIXED) {
+        /* BASELINE config 5: e = Vcycle32((float) r) from e = 0;  u += (double) e;  r = b - A u in fp64, ||r|| */
+        mg_fset *E = &L->f[1];
+        E->guess_nonzero = 0;
+        CHK(cycle_body(s, 1, 1));
+        CHK(mgk_correct_f64_from_f32(s->ctx, &F->g, &E->g, (const float *)E->u, (double *)F->u, NULL));
+        F->u_ghost_ok = 0; F->u_ghost_pending = 0;
+        CHK(ensure_u_ghosts(s, 0, L));
+        CHK(mgk_residual_f64_to_f32(s->ctx, &F->g, &E->g, L->coef, (const double *)F->b, (const double *)F->u, (float *)E->b, &ss, NULL));
+    } else {
+        CHK(cycle_body(s, 0, s->iter == 0));
+        /* :1545-1546  r0 = b0 - A0 u0 ; ||r0|| */
+        CHK(ensure_u_ghosts(s, 0, L));
+        if (s->cfg.fuse & 1) CHK(mgk_residual_sumsq_f64(s->ctx, &F->g, L->coef, (const double *)F->b, (const double *)F->u, &ss, NULL));
+        else {
+            CHK(mgk_residual_f64(s->ctx, &F->g, L->coef, (const double *)F->b, (const double *)F->u, (double *)F->rv, NULL));
+            CHK(mgk_sumsq_f64(s->ctx, &F->g, (const double *)F->rv, &ss, NULL));
+        }
     }
     CHK(norm_from_sumsq(s, ss, &s->rchk));
     s->iter++;
@@ -703,14 +722,17 @@ static int vcycle_once(mg_solver *s) {
 /* src/solver.c:1512-1523 */
 static int start(mg_solver *s) {
     mg_level *L = &s->L[0];
+    mg_fset *F = &L->f[0];
     double ss;
-    CHK(mgk_sumsq_f64(s->ctx, &L->g, L->b, &ss, NULL));                 /* VecNorm(b[0]) :1512 */
+    CHK(mgk_sumsq_f64(s->ctx, &F->g, (const double *)F->b, &ss, NULL)); /* VecNorm(b[0]) :1512 */
     CHK(norm_from_sumsq(s, ss, &s->bnorm));
-    for (int l = 0; l < s->levels; l++) { s->L[l].guess_nonzero = 0; s->L[l].u_ghost_ok = 0; s->L[l].u_ghost_pending = 0; }
-    CHK(mgk_memset0(s->ctx, L->u, sizeof(double) * (size_t)L->g.total, NULL));   /* VecSet(u[0],0) :1514 */
+    for (int l = 0; l < s->levels; l++)
+        for (int p = 0; p < 2; p++) { s->L[l].f[p].guess_nonzero = 0; s->L[l].f[p].u_ghost_ok = 0; s->L[l].f[p].u_ghost_pending = 0; }
+    CHK(mgk_memset0(s->ctx, F->u, sizeof(double) * (size_t)F->g.total, NULL));   /* VecSet(u[0],0) :1514 */
     /* rv = A u - b with u = 0 (:1516-1517); ||A u - b|| = ||b - A u||, evaluated by the same residual kernel */
-    if (s->cfg.precision == MG_PREC_MIXED) CHK(mgk_residual_f64_to_f32(s->ctx, &L->g, &L->g32, L->coef, L->b, L->u, L->b32, &ss, NULL));
-    else CHK(mgk_residual_sumsq_f64(s->ctx, &L->g, L->coef, L->b, L->u, &ss, NULL));
+    if (s->cfg.precision == MG_PREC_MIXED)
+        CHK(mgk_residual_f64_to_f32(s->ctx, &F->g, &L->f[1].g, L->coef, (const double *)F->b, (const double *)F->u, (float *)L->f[1].b, &ss, NULL));
+    else CHK(mgk_residual_sumsq_f64(s->ctx, &F->g, L->coef, (const double *)F->b, (const double *)F->u, &ss, NULL));
     CHK(norm_from_sumsq(s, ss, &s->rchk));
     s->iter = 0;
     s->rnorm[0] = s->rchk;                                              /* :1520 */
@@ -762,8 +784,8 @@ int mg_solver_level_local_planes(const mg_solver *s, int l, int *z0) {
     return s->L[l].nzl;
 }
 long mg_solver_local_unknowns(const mg_solver *s) {
-    const mg_level *L = &s->L[0];
-    return (long)L->g.nx * L->g.ny * L->g.nz;
+    const mgk_geom *g = &s->L[0].f[0].g;
+    return (long)g->nx * g->ny * g->nz;
 }
 double mg_solver_dof_updates_per_cycle(const mg_solver *s) {
     double tot = 0.0;

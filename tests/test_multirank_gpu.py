@@ -79,6 +79,18 @@ def test_overlapped_and_blocking_halo_agree():
 
 
 @pytest.mark.timeout(300)
+@pytest.mark.parametrize("P,npts,levels,dist_min_n", [(2, 33, 5, 15), (4, 65, 6, 15), (3, 65, 4, 31)])
+def test_slab_ranks_mixed_precision(P, npts, levels, dist_min_n):
+    """BASELINE config 5 on slabs: fp32 halos (4-byte planes) inside, fp64 residual/correction outside"""
+    it1, rn1, u1, e1 = _solve_single(npts, levels, 6.0 / 7.0, 60, precision="mixed")
+    res = _solve_ranks(P, npts, levels, 6.0 / 7.0, 60, dist_min_n, precision="mixed")
+    for r in res:
+        assert r[0] == it1
+        assert np.allclose(r[1], rn1, rtol=1e-13, atol=0)
+    assert np.array_equal(np.concatenate([r[2] for r in res]), u1)
+
+
+@pytest.mark.timeout(300)
 def test_slab_ranks_chebyshev(mgk):
     it1, rn1, u1, _ = _solve_single(65, 5, 1.0, 40, ksp_type="chebyshev", eigenvalues=(0.2, 2.0))
     res = _solve_ranks(4, 65, 5, 1.0, 40, 15, ksp_type="chebyshev", eigenvalues=(0.2, 2.0))
