@@ -1,0 +1,104 @@
+/*
+ * mgpoisson.c -- the product's own command-line driver (C99), counterpart of the reference's
+ * src/poisson.c:27-138 for sizes its O(N) host maps cannot reach (3-D, >= 4097^2) and for N GPUs.
+ *
+ *   mgpoisson [-dim 2|3] [-npts N] [-levels L] [-iter M] [-v v0,v1] [-ksp_type richardson|chebyshev]
+ *             [-ksp_richardson_scale s] [-ksp_chebyshev_eigenvalues emin,emax] [-precision fp64|mixed]
+ *             [-device d] [-options_file poisson.in]
+ *
+ * Same option spelling as the reference where it has one (-npts -levels -iter -v; poisson.in syntax: '#'
+ * comments, "-key value" lines); -grids is implied (= -levels: one grid per level), -cycle is 0, -mesh 0.
+ * Output mirrors what the reference prints: the PrintInfo block (src/poisson.c:165-214), error[0..2]
+ * (src/solver.c:1333), "Relative residual" (:1354), "Solver walltime" (:1572), and rData.dat (:1350-1353).
+ */
+#include "mgsolve.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct { char key[64], val[128]; } kv;
+static kv g_kv[128];
+static int g_nkv = 0;
+
+static void put(const char *k, const char *v) {
+    for (int q = 0; q < g_nkv; q++) if (!strcmp(g_kv[q].key, k)) { snprintf(g_kv[q].val, sizeof(g_kv[q].val), "%s", v); return; }
+    if (g_nkv < 128) { snprintf(g_kv[g_nkv].key, 64, "%s", k); snprintf(g_kv[g_nkv].val, 128, "%s", v); g_nkv++; }
+}
+static const char *get(const char *k) {
+    for (int q = 0; q < g_nkv; q++) if (!strcmp(g_kv[q].key, k)) return g_kv[q].val;
+    return NULL;
+}
+static int is_key(const char *t) { return t[0] == '-' && ((t[1] >= 'a' && t[1] <= 'z') || (t[1] >= 'A' && t[1] <= 'Z')); }
+static void tokens(char **t, int n) {
+    for (int q = 0; q < n; q++) {
+        if (!is_key(t[q])) continue;
+        if (q + 1 < n && !is_key(t[q + 1])) { put(t[q], t[q + 1]); q++; } else put(t[q], "");
+    }
+}
+static void read_file(const char *path) {
+    FILE *f = fopen(path, "r");
+    if (!f) return;
+    char line[512];
+    static char store[256][128];
+    char *tok[256];
+    int n = 0;
+    while (fgets(line, sizeof(line), f)) {
+        char *h = strchr(line, '#');
+        if (h) *h = 0;
+        for (char *t = strtok(line, " \t\r\n"); t && n < 256; t = strtok(NULL, " \t\r\n")) { snprintf(store[n], 128, "%s", t); tok[n] = store[n]; n++; }
+    }
+    fclose(f);
+    tokens(tok, n);
+}
+
+int main(int argc, char **argv) {
+    read_file("poisson.in");                          /* default options file of the reference (src/poisson.c:29) */
+    for (int q = 1; q + 1 < argc; q++) if (!strcmp(argv[q], "-options_file")) read_file(argv[q + 1]);
+    tokens(argv + 1, argc - 1);                       /* the command line overrides the files */
+
+    mg_config c;
+    mg_config_default(&c);
+    const char *v;
+    if ((v = get("-dim"))) c.dim = atoi(v);
+    if ((v = get("-npts"))) c.npts = atoi(v);
+    if ((v = get("-levels"))) c.levels = atoi(v);
+    if ((v = get("-iter"))) c.maxiter = atoi(v);
+    if ((v = get("-v"))) { int a = c.v[0], b = c.v[1]; if (sscanf(v, "%d,%d", &a, &b) >= 1) { c.v[0] = a; c.v[1] = b; } }
+    if ((v = get("-ksp_type"))) c.ksp_type = !strcmp(v, "chebyshev") ? MG_KSP_CHEBYSHEV : MG_KSP_RICHARDSON;
+    if ((v = get("-ksp_richardson_scale"))) c.scale = atof(v);
+    if ((v = get("-ksp_chebyshev_eigenvalues"))) sscanf(v, "%lf,%lf", &c.emin, &c.emax);
+    if ((v = get("-precision"))) c.precision = !strcmp(v, "mixed") ? MG_PREC_MIXED : MG_PREC_FP64;
+    if ((v = get("-device"))) c.device = atoi(v);
+    if ((v = get("-pc_type")) && strcmp(v, "jacobi")) { fprintf(stderr, "mgpoisson: only -pc_type jacobi is built\n"); return 2; }
+    if ((v = get("-cycle")) && atoi(v) != 0) { fprintf(stderr, "mgpoisson: only -cycle 0 (V-cycle) is built\n"); return 2; }
+    if ((v = get("-mesh")) && atoi(v) != 0) { fprintf(stderr, "mgpoisson: only -mesh 0 (uniform) is built in this driver\n"); return 2; }
+
+    mg_solver *s = NULL;
+    if (mg_solver_create(&s, &c, NULL)) { fprintf(stderr, "mgpoisson: %s\n", mg_last_error()); return 1; }
+    if (mg_solver_set_rhs_problem(s) || mg_solver_solve(s)) { fprintf(stderr, "mgpoisson: %s\n", mg_last_error()); return 1; }
+    const int it = mg_solver_iterations(s);
+    const double *rn = mg_solver_rnorm(s);
+    double err[3];
+    if (mg_solver_error_norms(s, err)) { fprintf(stderr, "mgpoisson: %s\n", mg_last_error()); return 1; }
+
+    printf("rank = [0]; Solver walltime:               %lf\n", mg_solver_solve_seconds(s));
+    for (int q = 0; q < 3; q++) printf("\nerror[%d] = %.16e\n", q, err[q]);
+    printf("Relative residual = %.16e ", rn[it] / rn[0]);
+    FILE *f = fopen("rData.dat", "w");
+    if (f) { for (int q = 0; q <= it; q++) fprintf(f, "%.16e ", rn[q] / rn[0]); fprintf(f, "\n"); fclose(f); }
+    printf("=============================================================\n");
+    if (c.dim == 2) printf("Size:\t\t\t\t%d x %d\n", c.npts, c.npts); else printf("Size:\t\t\t\t%d x %d x %d\n", c.npts, c.npts, c.npts);
+    printf("Mesh Type:\t\t\tUniform\n");
+    printf("Number of grids:\t\t%d\n", c.levels);
+    printf("Number of levels:\t\t%d\n", c.levels);
+    printf("Number of unknowns per level:\t");
+    for (int l = 0; l < c.levels; l++) { double n = mg_solver_level_n(s, l); printf("%.0f\t", c.dim == 3 ? n * n * n : n * n); }
+    printf("\nCycle :\t\t\t\tV-Cycle\n");
+    printf("Number of smoothing steps :\t%d(fine) %d(coarsest)\n", c.v[0], c.v[1]);
+    printf("Number of processes:\t\t1\n");
+    printf("Number of iterations:\t\t%d\n", it);
+    printf("DOF-updates per second:\t\t%.6e\n", mg_solver_dof_updates_per_cycle(s) * it / mg_solver_solve_seconds(s));
+    printf("=============================================================\n");
+    mg_solver_destroy(s);
+    return 0;
+}

@@ -158,3 +158,23 @@ def test_bad_arguments_fail_loudly():
         Solver(2, 17, 2, ksp_type="chebyshev")      # no eigenvalue bounds
     with pytest.raises(MgError):
         Solver(3, 17, 2, rank=0, nranks=2)          # ranks without a communicator
+
+
+def test_own_c_driver_prints_reference_style_summary(orc, tmp_path):
+    """multigrid_petsc_amd/mgpoisson: the product's C main (counterpart of src/poisson.c) with the reference's option spelling"""
+    import os
+    import re
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multigrid_petsc_amd", "mgpoisson")
+    (tmp_path / "poisson.in").write_text("# same syntax as the reference's options file\n-npts 65\n-levels 6\n-iter 100\n-v 3,3\n")
+    p = subprocess.run([exe, "-dim", "3", "-ksp_richardson_scale", repr(6.0 / 7.0)], cwd=tmp_path, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout
+    ref = orc.vcycle(3, 65, 6, 3, 3, maxiter=100, scale=6.0 / 7.0)
+    assert int(re.search(r"Number of iterations:\s+(\d+)", p.stdout).group(1)) == ref["iters"]
+    rel = float(re.search(r"Relative residual = (\S+)", p.stdout).group(1))
+    assert abs(rel - ref["rnorm"][-1] / ref["rnorm"][0]) <= 1e-12 * rel
+    e0 = float(re.search(r"error\[0\] = (\S+)", p.stdout).group(1))
+    assert e0 == orc.error_norms(3, 65, ref["u"])[0]
+    rdat = np.array((tmp_path / "rData.dat").read_text().split(), dtype=np.float64)
+    assert np.max(np.abs(rdat - ref["rnorm"] / ref["rnorm"][0]) / rdat) <= 1e-12
