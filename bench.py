@@ -86,12 +86,28 @@ def main():
 
     dist = None
     comm = None
+    transport = "none"
     if world > 1:
         import torch.distributed as dist   # control plane only (id broadcast, barrier, max-reduce)
         import torch
-        from multigrid_petsc_amd.comm import rccl_comm
+        from multigrid_petsc_amd.comm import rccl_comm, HostStagedComm
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        comm = rccl_comm(rank, world, local_rank, dist)
+        transport = os.environ.get("MG_BENCH_TRANSPORT", "rccl")       # rccl (default) | host
+        if transport == "rccl":
+            ok = 1
+            try:
+                comm = rccl_comm(rank, world, local_rank, dist)
+            except Exception as e:          # every rank must take the same decision
+                print(f"[bench rank {rank}] RCCL communicator failed ({e}); falling back to the host-staged transport", flush=True)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag[0]) == 0:
+                if comm is not None:
+                    comm.close()
+                transport = "host"
+        if transport == "host":
+            comm = HostStagedComm(rank, world, dist)
 
     scale = 6.0 / 7.0 if args.dim == 3 else 0.8
     s = Solver(args.dim, args.npts, levels, v=(3, 3), maxiter=args.steps + args.warmup + 1, scale=scale,
@@ -146,7 +162,7 @@ def main():
             "config": {"workload": f"{args.dim}-D {2 * args.dim + 1}-point Poisson, npts={args.npts} "
                                    f"({n0}^{args.dim} unknowns), {levels} levels, V(3,3), Richardson+Jacobi "
                                    f"scale {scale:.6g}, one step = one V-cycle incl. residual norm",
-                       "decomposition": f"z-slabs x{world}" if world > 1 else "single GPU",
+                       "decomposition": f"z-slabs x{world}, halo transport {transport}" if world > 1 else "single GPU",
                        "fine_unknowns": float(n0) ** args.dim,
                        "dof_updates_per_cycle": dof_per_cycle},
             "cycle_unknowns_per_s": float(n0) ** args.dim * args.steps / elapsed,

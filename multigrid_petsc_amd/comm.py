@@ -99,3 +99,120 @@ class LoopbackWorld:
         if self.shared:
             _lib().mg_comm_loopback_shared_destroy(self.shared)
             self.shared = None
+
+
+# ---------------------------------------------------------------------------------------------
+# host-staged transport: the same mg_comm hooks implemented with device<->host copies and the
+# caller's torch.distributed group (gloo).  A slow but dependency-free fallback for the case that
+# RCCL cannot build its communicator (it is also what lets two ranks share ONE GPU in the tests).
+# ---------------------------------------------------------------------------------------------
+class _Geom(C.Structure):
+    _fields_ = [("dim", C.c_int), ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
+                ("pitch", C.c_int), ("plane", C.c_long), ("org", C.c_long), ("total", C.c_long)]
+
+
+_HALO = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_Geom), C.c_int, C.c_void_p)
+_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_Geom), C.POINTER(C.c_int), C.c_int, C.c_void_p)
+_REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_void_p)
+_BARRIER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+_DESTROY = C.CFUNCTYPE(None, C.c_void_p)
+
+
+class _MgComm(C.Structure):
+    _fields_ = [("rank", C.c_int), ("nranks", C.c_int), ("impl", C.c_void_p), ("halo", _HALO),
+                ("allgather_planes", _GATHER), ("allreduce_sum", _REDUCE), ("barrier", _BARRIER), ("destroy", _DESTROY)]
+
+
+class HostStagedComm:
+    """mg_comm whose hooks run in Python: planes are copied to the host, exchanged with torch.distributed
+    (any CPU-capable backend), and copied back.  Blocking; correctness fallback, not a performance path."""
+
+    def __init__(self, rank, world, dist):
+        import numpy as np
+        import torch
+        from ._lib import load_mgk
+        self.np, self.torch, self.dist = np, torch, dist
+        self.rank, self.world = rank, world
+        self.K = load_mgk()
+        self.K.mgk_sync.argtypes = [C.c_void_p, C.c_void_p]
+        self.K.mgk_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        self.K.mgk_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        self._cb = (_HALO(self._halo), _GATHER(self._gather), _REDUCE(self._reduce), _BARRIER(self._barrier), _DESTROY(self._destroy))
+        self.struct = _MgComm(rank, world, None, *self._cb)
+        self.handle = C.c_void_p(C.addressof(self.struct))
+
+    # device plane <-> host tensor
+    def _get(self, ctx, addr, nbytes):
+        t = self.torch.empty(nbytes, dtype=self.torch.uint8)
+        if self.K.mgk_d2h(ctx, C.c_void_p(t.data_ptr()), C.c_void_p(addr), nbytes):
+            raise RuntimeError("mgk_d2h failed")
+        return t
+
+    def _put(self, ctx, addr, t):
+        if self.K.mgk_h2d(ctx, C.c_void_p(addr), C.c_void_p(t.data_ptr()), t.numel()):
+            raise RuntimeError("mgk_h2d failed")
+
+    def _halo(self, c, ctx, field, gptr, esz, stream):
+        try:
+            g = gptr.contents
+            pb = esz * g.plane
+            self.K.mgk_sync(ctx, stream)
+            ops, recv = [], []
+            if self.rank > 0:
+                ops.append(self.dist.P2POp(self.dist.isend, self._get(ctx, field + pb, pb), self.rank - 1))
+                lo = self.torch.empty(pb, dtype=self.torch.uint8)
+                ops.append(self.dist.P2POp(self.dist.irecv, lo, self.rank - 1))
+                recv.append((field, lo))
+            if self.rank < self.world - 1:
+                ops.append(self.dist.P2POp(self.dist.isend, self._get(ctx, field + g.nz * pb, pb), self.rank + 1))
+                hi = self.torch.empty(pb, dtype=self.torch.uint8)
+                ops.append(self.dist.P2POp(self.dist.irecv, hi, self.rank + 1))
+                recv.append((field + (g.nz + 1) * pb, hi))
+            for w in (self.dist.batch_isend_irecv(ops) if ops else []):
+                w.wait()
+            for addr, t in recv:
+                self._put(ctx, addr, t)
+            return 0
+        except Exception as e:      # noqa: BLE001 - reported through the C return code
+            print("[HostStagedComm.halo]", e, flush=True)
+            return 10003
+
+    def _gather(self, c, ctx, field, gptr, zstart, esz, stream):
+        try:
+            g = gptr.contents
+            pb = esz * g.plane
+            self.K.mgk_sync(ctx, stream)
+            for src in range(self.world):
+                n = (zstart[src + 1] - zstart[src]) * pb
+                if n == 0:
+                    continue
+                addr = field + (zstart[src] + 1) * pb
+                t = self._get(ctx, addr, n) if src == self.rank else self.torch.empty(n, dtype=self.torch.uint8)
+                self.dist.broadcast(t, src)
+                if src != self.rank:
+                    self._put(ctx, addr, t)
+            return 0
+        except Exception as e:      # noqa: BLE001
+            print("[HostStagedComm.allgather]", e, flush=True)
+            return 10003
+
+    def _reduce(self, c, ctx, vals, n, stream):
+        try:
+            t = self.torch.tensor([vals[q] for q in range(n)], dtype=self.torch.float64)
+            self.dist.all_reduce(t)
+            for q in range(n):
+                vals[q] = float(t[q])
+            return 0
+        except Exception as e:      # noqa: BLE001
+            print("[HostStagedComm.allreduce]", e, flush=True)
+            return 10003
+
+    def _barrier(self, c, ctx):
+        self.dist.barrier()
+        return 0
+
+    def _destroy(self, c):
+        return None
+
+    def close(self):
+        self.handle = None

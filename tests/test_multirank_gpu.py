@@ -139,3 +139,29 @@ def test_rccl_two_ranks_on_one_gpu_if_allowed():
         pytest.skip("RCCL does not run two ranks on one GPU here: " + " | ".join(o.strip().splitlines()[-1] for o in outs if o.strip()))
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and "PAIR_OK" in o, o
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_processes_host_staged_transport(tmp_path):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), here with both
+    ranks pinned to GPU 0 and the host-staged halo transport (RCCL refuses two ranks on one device): exercises the
+    whole multi-process path -- rendezvous, slab solver per process, halos through the mg_comm hooks, max-over-ranks
+    timing, rank-0 JSON -- and must reproduce the single-process numerics."""
+    import json
+    env = dict(os.environ, MG_BENCH_DEVICE="0", MG_BENCH_TRANSPORT="host", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    bench = os.path.join(ROOT, "bench.py")
+    common = ["--steps", "4", "--warmup", "1", "--npts", "129", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, bench, "--gpus", "1"] + common, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    j1 = json.loads(one.stdout.strip().splitlines()[-1])
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", bench, "--gpus", "2"] + common, env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=800)
+    assert two.returncode == 0, (two.stdout[-1500:], two.stderr[-3000:])
+    lines = [l for l in two.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # rank 0 only
+    j2 = json.loads(lines[0])
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "strong" and "host" in j2["config"]["decomposition"]
+    assert j2["config"]["dof_updates_per_cycle"] == j1["config"]["dof_updates_per_cycle"]
+    assert abs(j2["residual_reduction_per_cycle"] - j1["residual_reduction_per_cycle"]) <= 1e-12
