@@ -188,6 +188,8 @@ int  mgk_jacobi_zero_f32(mgk_ctx *ctx, const mgk_geom *g, double dinv, double sc
 int  mgk_residual_f32(mgk_ctx *ctx, const mgk_geom *g, const double *coef, const float *b, const float *u, float *r, void *stream);
 int  mgk_restrict_fw_f32(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const float *rf, float *bc, void *stream);
 int  mgk_prolong_add_f32(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const float *uc, float *uf, void *stream);
+int  mgk_residual_restrict_f32(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
+                               const float *b, const float *u, float *bc, void *stream);
 /* fp64 residual b - A u stored as fp32 + its fp64 sum of squares, one pass (reads 16 B, writes 4 B per unknown) */
 int  mgk_residual_f64_to_f32(mgk_ctx *ctx, const mgk_geom *g, const mgk_geom *g32, const double *coef,
                              const double *b, const double *u, float *r32, double *sumsq_host, void *stream);

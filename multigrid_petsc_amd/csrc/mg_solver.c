@@ -78,9 +78,10 @@ W32(pa)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const void *uc, void
 W64(pj)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, double d, double sc, const void *b, const void *uc, const void *u, void *o, void *st) { return mgk_prolong_jacobi_f64(c, gf, gc, k, d, sc, (const double *)b, (const double *)uc, (const double *)u, (double *)o, st); }
 W32(pj)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, double d, double sc, const void *b, const void *uc, const void *u, void *o, void *st) { return mgk_prolong_jacobi_f32(c, gf, gc, k, d, sc, (const float *)b, (const float *)uc, (const float *)u, (float *)o, st); }
 W64(rr)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, const void *b, const void *u, void *bc, void *st) { return mgk_residual_restrict_f64(c, gf, gc, k, (const double *)b, (const double *)u, (double *)bc, st); }
+W32(rr)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, const void *b, const void *u, void *bc, void *st) { return mgk_residual_restrict_f32(c, gf, gc, k, (const float *)b, (const float *)u, (float *)bc, st); }
 static const mg_ops OPS[2] = {
     {8, jr_64, jz_64, rs_64, rf_64, pa_64, pj_64, rr_64},
-    {4, jr_32, jz_32, rs_32, rf_32, pa_32, pj_32, NULL},
+    {4, jr_32, jz_32, rs_32, rf_32, pa_32, pj_32, rr_32},
 };
 
 struct mg_solver {

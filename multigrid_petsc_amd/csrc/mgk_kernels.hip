@@ -1465,63 +1465,72 @@ extern "C" int mgk_prolong_jacobi_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_
 // coarse plane z/2-1 and dk = 0 of z/2 (equal weights: the products are computed once).
 // Traffic: 16 B per fine unknown read (+ the recomputed row from L2) and 1 B written.  3-D, fp64.
 // ------------------------------------------------------------------------------------------
+template <typename T>
 struct RRArgs {
-    const double *u, *b;
-    double *bc;
+    const T *u, *b;
+    T *bc;
     int nx, ny, nz;          // fine
     int nxc, nyc, nzc;       // coarse
     long rs, ms, crs, cms;   // fine / coarse row and plane strides
     int kcc, nty;            // coarse planes per chunk, tiles in y
-    double a0, a1, a2, a3, a4, a5, a6;
+    T a0, a1, a2, a3, a4, a5, a6;
 };
 
-template <int WX>
-__global__ void __launch_bounds__(64 * WX) k_resrestrict(const RRArgs a) {
-    constexpr int RR = 5, TX = 128 * WX, LW = TX + 4;
-    __shared__ __attribute__((aligned(16))) double lds[2][RR][LW];
-    __shared__ __attribute__((aligned(16))) double rt[RR][LW];
+template <typename T, int WX>
+__global__ void __launch_bounds__(64 * WX) k_resrestrict(const RRArgs<T> a) {
+    constexpr int VX = 16 / sizeof(T);           // fine columns per lane
+    constexpr int NCJ = VX / 2;                  // coarse columns per lane
+    constexpr int RR = 5, TX = 64 * VX * WX, LW = TX + 2 * VX;
+    __shared__ __attribute__((aligned(16))) T lds[2][RR][LW];
+    __shared__ __attribute__((aligned(16))) T rt[RR][LW];
+    using VT = V16<T>;
     const int tid = threadIdx.x;
     int bid = blockIdx.x;
     const int nblk = gridDim.x;
     if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
     const int ty = bid % a.nty, tz = bid / a.nty;
-    const int xl = 2 * tid, x0 = xl;             // full-row tile: tx = 0
+    const int xl = VX * tid, x0 = xl;            // full-row tile: tx = 0
     const int yb = 4 * ty;
     const int kc0 = tz * a.kcc, kc1 = min(kc0 + a.kcc, a.nzc);
     if (kc0 >= kc1) return;
     const int z0 = 2 * kc0, z1 = 2 * kc1 + 1;    // fine planes z0 .. z1-1 (= 2*kc1, shared with the next chunk)
     const bool xok = x0 < a.nx;
-    const bool lastvec = (x0 + 2 > a.nx);
+    const bool lastvec = (x0 + VX > a.nx);
     bool rok[RR];
 #pragma unroll
     for (int r = 0; r < RR; r++) rok[r] = xok && (yb + r < a.ny);
     const long rowoff = (long)yb * a.rs;
-    const double *up_ = a.u + rowoff + x0, *bp_ = a.b + rowoff + x0;
+    const T *up_ = a.u + rowoff + x0, *bp_ = a.b + rowoff + x0;
     const bool okS = xok, okN = xok && (yb + RR <= a.ny);
-    // coarse ownership: lane `tid` -> coarse column jc = tid, coarse rows 2*ty + {0,1}
-    const int jc = tid;
-    const bool cok0 = (jc < a.nxc) && (2 * ty < a.nyc), cok1 = (jc < a.nxc) && (2 * ty + 1 < a.nyc);
-    const double w2[3][3] = {{0.0625, 0.125, 0.0625}, {0.125, 0.25, 0.125}, {0.0625, 0.125, 0.0625}};
+    // coarse ownership: lane `tid` -> coarse columns NCJ*tid .. NCJ*tid+NCJ-1, coarse rows 2*ty + {0,1}
+    const int jc0 = NCJ * tid;
+    const bool crow0 = (2 * ty < a.nyc), crow1 = (2 * ty + 1 < a.nyc);
+    const T w2[3][3] = {{(T)0.0625, (T)0.125, (T)0.0625}, {(T)0.125, (T)0.25, (T)0.125}, {(T)0.0625, (T)0.125, (T)0.0625}};
 
-    double2 um[RR], uc[RR], up[RR], uq[RR], bcur[RR], bn[RR];
-    double2 hS, hN, hSn = make_double2(0, 0), hNn = hSn;
+    VT um[RR], uc[RR], up[RR], uq[RR], bcur[RR], bn[RR];
+    VT hS, hN, hSn = v16_zero<T>(), hNn = hSn;
 #pragma unroll
     for (int r = 0; r < RR; r++) {
         const long ro = (long)r * a.rs;
-        um[r] = ld2(up_ + (long)(z0 - 1) * a.ms + ro, rok[r]);
-        uc[r] = ld2(up_ + (long)z0 * a.ms + ro, rok[r]);
-        up[r] = ld2(up_ + (long)(z0 + 1) * a.ms + ro, rok[r]);
-        bcur[r] = ld2_stream(bp_ + (long)z0 * a.ms + ro, rok[r]);
-        *reinterpret_cast<double2 *>(&lds[0][r][xl + 2]) = uc[r];
+        um[r] = ldv(up_ + (long)(z0 - 1) * a.ms + ro, rok[r]);
+        uc[r] = ldv(up_ + (long)z0 * a.ms + ro, rok[r]);
+        up[r] = ldv(up_ + (long)(z0 + 1) * a.ms + ro, rok[r]);
+        bcur[r] = ldv_stream(bp_ + (long)z0 * a.ms + ro, rok[r]);
+        *reinterpret_cast<VT *>(&lds[0][r][xl + VX]) = uc[r];
     }
     if (tid == 0) {
 #pragma unroll
-        for (int r = 0; r < RR; r++) { lds[0][r][1] = 0.0; lds[1][r][1] = 0.0; lds[0][r][TX + 2] = 0.0; lds[1][r][TX + 2] = 0.0; }
+        for (int r = 0; r < RR; r++) { lds[0][r][VX - 1] = (T)0; lds[1][r][VX - 1] = (T)0; lds[0][r][TX + VX] = (T)0; lds[1][r][TX + VX] = (T)0; }
     }
-    hS = ld2(up_ + (long)z0 * a.ms - a.rs, okS);
-    hN = ld2(up_ + (long)z0 * a.ms + (long)RR * a.rs, okN);
+    hS = ldv(up_ + (long)z0 * a.ms - a.rs, okS);
+    hN = ldv(up_ + (long)z0 * a.ms + (long)RR * a.rs, okN);
 
-    double acc[2] = {0.0, 0.0}, accn[2] = {0.0, 0.0};
+    T acc[2][NCJ], accn[2][NCJ];
+#pragma unroll
+    for (int cl = 0; cl < 2; cl++)
+#pragma unroll
+        for (int q = 0; q < NCJ; q++) { acc[cl][q] = (T)0; accn[cl][q] = (T)0; }
+
     for (int z = z0; z < z1; z++) {
         const int buf = (z - z0) & 1;
         const bool more = (z + 1 < z1);
@@ -1529,62 +1538,73 @@ __global__ void __launch_bounds__(64 * WX) k_resrestrict(const RRArgs a) {
 #pragma unroll
             for (int r = 0; r < RR; r++) {
                 const long ro = (long)r * a.rs;
-                uq[r] = ld2(up_ + (long)(z + 2) * a.ms + ro, rok[r]);
-                bn[r] = ld2_stream(bp_ + (long)(z + 1) * a.ms + ro, rok[r]);
+                uq[r] = ldv(up_ + (long)(z + 2) * a.ms + ro, rok[r]);
+                bn[r] = ldv_stream(bp_ + (long)(z + 1) * a.ms + ro, rok[r]);
             }
-            hSn = ld2(up_ + (long)(z + 1) * a.ms - a.rs, okS);
-            hNn = ld2(up_ + (long)(z + 1) * a.ms + (long)RR * a.rs, okN);
+            hSn = ldv(up_ + (long)(z + 1) * a.ms - a.rs, okS);
+            hNn = ldv(up_ + (long)(z + 1) * a.ms + (long)RR * a.rs, okN);
         }
         __syncthreads();                          // u tile of plane z complete; rt of plane z-1 consumed
 #pragma unroll
         for (int r = 0; r < RR; r++) {
-            const double Wv = lds[buf][r][xl + 1], Ev = lds[buf][r][xl + 4];
-            const double2 s2 = (r == 0) ? hS : uc[r > 0 ? r - 1 : 0];
-            const double2 n2 = (r == RR - 1) ? hN : uc[r < RR - 1 ? r + 1 : r];
-            double tx_ = a.a0 * um[r].x, ty_ = a.a0 * um[r].y;
-            tx_ = tx_ + a.a1 * s2.x;     ty_ = ty_ + a.a1 * s2.y;
-            tx_ = tx_ + a.a2 * Wv;       ty_ = ty_ + a.a2 * uc[r].x;
-            tx_ = tx_ + a.a3 * uc[r].x;  ty_ = ty_ + a.a3 * uc[r].y;
-            tx_ = tx_ + a.a4 * uc[r].y;  ty_ = ty_ + a.a4 * Ev;
-            tx_ = tx_ + a.a5 * n2.x;     ty_ = ty_ + a.a5 * n2.y;
-            tx_ = tx_ + a.a6 * up[r].x;  ty_ = ty_ + a.a6 * up[r].y;
-            double2 res;
-            res.x = bcur[r].x - tx_; res.y = bcur[r].y - ty_;
-            if (lastvec) res.y = 0.0;
-            if (!rok[r]) { res.x = 0.0; res.y = 0.0; }
-            *reinterpret_cast<double2 *>(&rt[r][xl + 2]) = res;
+            const T Wv = lds[buf][r][xl + VX - 1], Ev = lds[buf][r][xl + 2 * VX];
+            const VT s2 = (r == 0) ? hS : uc[r > 0 ? r - 1 : 0];
+            const VT n2 = (r == RR - 1) ? hN : uc[r < RR - 1 ? r + 1 : r];
+            VT res;
+#pragma unroll
+            for (int e = 0; e < VX; e++) {
+                const T wv = (e == 0) ? Wv : uc[r].v[e > 0 ? e - 1 : 0];
+                const T ev = (e == VX - 1) ? Ev : uc[r].v[e < VX - 1 ? e + 1 : e];
+                T t = a.a0 * um[r].v[e];
+                t = t + a.a1 * s2.v[e];
+                t = t + a.a2 * wv;
+                t = t + a.a3 * uc[r].v[e];
+                t = t + a.a4 * ev;
+                t = t + a.a5 * n2.v[e];
+                t = t + a.a6 * up[r].v[e];
+                res.v[e] = bcur[r].v[e] - t;
+                if ((lastvec && x0 + e >= a.nx) || !rok[r]) res.v[e] = (T)0;
+            }
+            *reinterpret_cast<VT *>(&rt[r][xl + VX]) = res;
         }
         __syncthreads();                          // residual plane z visible
         {
             const bool even = ((z & 1) == 0);
-            const double wk = even ? 0.25 : 0.5;
+            const T wk = even ? (T)0.25 : (T)0.5;
 #pragma unroll
             for (int cl = 0; cl < 2; cl++) {
-                if (!(cl == 0 ? cok0 : cok1)) continue;
+                if (!(cl == 0 ? crow0 : crow1)) continue;
 #pragma unroll
-                for (int di = 0; di < 3; di++) {
-                    const double *row = &rt[2 * cl + di][2 * jc + 2];
+                for (int q = 0; q < NCJ; q++) {
+                    if (jc0 + q >= a.nxc) continue;
 #pragma unroll
-                    for (int dj = 0; dj < 3; dj++) {
-                        const double p = (wk * w2[di][dj]) * row[dj];
-                        acc[cl] += p;
-                        if (even) accn[cl] += p;
+                    for (int di = 0; di < 3; di++) {
+                        const T *row = &rt[2 * cl + di][2 * (jc0 + q) + VX];
+#pragma unroll
+                        for (int dj = 0; dj < 3; dj++) {
+                            const T p = (wk * w2[di][dj]) * row[dj];
+                            acc[cl][q] += p;
+                            if (even) accn[cl][q] += p;
+                        }
                     }
                 }
             }
             if (even) {
                 const int kc = z / 2 - 1;         // completed coarse plane
-                if (kc >= kc0) {
-                    if (cok0) a.bc[(long)kc * a.cms + (long)(2 * ty) * a.crs + jc] = acc[0];
-                    if (cok1) a.bc[(long)kc * a.cms + (long)(2 * ty + 1) * a.crs + jc] = acc[1];
-                }
-                acc[0] = accn[0]; acc[1] = accn[1]; accn[0] = 0.0; accn[1] = 0.0;
+#pragma unroll
+                for (int cl = 0; cl < 2; cl++)
+#pragma unroll
+                    for (int q = 0; q < NCJ; q++) {
+                        if (kc >= kc0 && (cl == 0 ? crow0 : crow1) && jc0 + q < a.nxc)
+                            a.bc[(long)kc * a.cms + (long)(2 * ty + cl) * a.crs + jc0 + q] = acc[cl][q];
+                        acc[cl][q] = accn[cl][q]; accn[cl][q] = (T)0;
+                    }
             }
         }
         if (more) {
 #pragma unroll
             for (int r = 0; r < RR; r++) {
-                *reinterpret_cast<double2 *>(&lds[buf ^ 1][r][xl + 2]) = up[r];
+                *reinterpret_cast<VT *>(&lds[buf ^ 1][r][xl + VX]) = up[r];
                 um[r] = uc[r]; uc[r] = up[r]; up[r] = uq[r]; bcur[r] = bn[r];
             }
             hS = hSn; hN = hNn;
@@ -1592,20 +1612,22 @@ __global__ void __launch_bounds__(64 * WX) k_resrestrict(const RRArgs a) {
     }
 }
 
-extern "C" int mgk_residual_restrict_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
-                                         const double *b, const double *u, double *bc, void *stream) {
+template <typename T>
+static int residual_restrict(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
+                             const T *b, const T *u, T *bc, void *stream) {
+    constexpr int VX = 16 / sizeof(T);
     if (!c || !gf || !gc || !coef || !b || !u || !bc || gf->dim != 3)
-        return fail(MGK_EINVAL, "mgk_residual_restrict_f64: bad arguments (3-D only)");
+        return fail(MGK_EINVAL, "mgk_residual_restrict: bad arguments (3-D only)");
     XferArgs x;
     int rc = xfer_args(gf, gc, x);
     if (rc) return rc;
-    if (gf->nz != 2 * gc->nz + 1) return fail(MGK_EINVAL, "mgk_residual_restrict_f64: whole grids only (nzf = 2 nzc + 1); slabs use residual + restrict");
-    if (gf->nx + 1 > 1024) return fail(MGK_EINVAL, "mgk_residual_restrict_f64: nx + 1 > 1024 is not built");
-    RRArgs a; memset(&a, 0, sizeof(a));
+    if (gf->nz != 2 * gc->nz + 1) return fail(MGK_EINVAL, "mgk_residual_restrict: whole grids only (nzf = 2 nzc + 1); slabs use residual + restrict");
+    if (gf->nx + 1 > 1024) return fail(MGK_EINVAL, "mgk_residual_restrict: nx + 1 > 1024 is not built");
+    RRArgs<T> a; memset(&a, 0, sizeof(a));
     a.u = u + gf->org; a.b = b + gf->org; a.bc = bc + gc->org;
     a.nx = gf->nx; a.ny = gf->ny; a.nz = gf->nz; a.nxc = gc->nx; a.nyc = gc->ny; a.nzc = gc->nz;
     a.rs = gf->pitch; a.ms = gf->plane; a.crs = gc->pitch; a.cms = gc->plane;
-    a.a0 = coef[0]; a.a1 = coef[1]; a.a2 = coef[2]; a.a3 = coef[3]; a.a4 = coef[4]; a.a5 = coef[5]; a.a6 = coef[6];
+    a.a0 = (T)coef[0]; a.a1 = (T)coef[1]; a.a2 = (T)coef[2]; a.a3 = (T)coef[3]; a.a4 = (T)coef[4]; a.a5 = (T)coef[5]; a.a6 = (T)coef[6];
     a.nty = (gf->ny - 1 + 3) / 4;                 // tiles of 5 rows at stride 4; ny = 2 nyc + 1
     if (a.nty < 1) a.nty = 1;
     long nch = (a.nty >= 256) ? 1 : (512 + a.nty - 1) / a.nty;
@@ -1617,13 +1639,21 @@ extern "C" int mgk_residual_restrict_f64(mgk_ctx *c, const mgk_geom *gf, const m
     const long ntz = (gc->nz + kcc - 1) / kcc;
     const unsigned nblk = (unsigned)(a.nty * ntz);
     hipStream_t s = S(c, stream);
-    const int w = (gf->nx + 1 + 127) / 128;
-    if (w <= 1) hipLaunchKernelGGL(k_resrestrict<1>, dim3(nblk), dim3(64), 0, s, a);
-    else if (w <= 2) hipLaunchKernelGGL(k_resrestrict<2>, dim3(nblk), dim3(128), 0, s, a);
-    else if (w <= 4) hipLaunchKernelGGL(k_resrestrict<4>, dim3(nblk), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_resrestrict<8>, dim3(nblk), dim3(512), 0, s, a);
+    const int w = (gf->nx + 1 + 64 * VX - 1) / (64 * VX);       // waves needed for a full row
+    if (w <= 1) hipLaunchKernelGGL((k_resrestrict<T, 1>), dim3(nblk), dim3(64), 0, s, a);
+    else if (w <= 2) hipLaunchKernelGGL((k_resrestrict<T, 2>), dim3(nblk), dim3(128), 0, s, a);
+    else if (w <= 4) hipLaunchKernelGGL((k_resrestrict<T, 4>), dim3(nblk), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_resrestrict<T, 8>), dim3(nblk), dim3(512), 0, s, a);
     HIPCHK(hipGetLastError());
     return 0;
+}
+extern "C" int mgk_residual_restrict_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
+                                         const double *b, const double *u, double *bc, void *stream) {
+    return residual_restrict<double>(c, gf, gc, coef, b, u, bc, stream);
+}
+extern "C" int mgk_residual_restrict_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
+                                         const float *b, const float *u, float *bc, void *stream) {
+    return residual_restrict<float>(c, gf, gc, coef, b, u, bc, stream);
 }
 
 // ------------------------------------------------------------------------------------------

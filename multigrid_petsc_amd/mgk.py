@@ -65,6 +65,7 @@ def _sigs(L):
         "mgk_unpack_f32": (i, [vp, G, vp, vp, vp]),
         "mgk_apply_f64": (i, [vp, G, c_dp, vp, vp, vp]),
         "mgk_residual_restrict_f64": (i, [vp, G, G, c_dp, vp, vp, vp, vp]),
+        "mgk_residual_restrict_f32": (i, [vp, G, G, c_dp, vp, vp, vp, vp]),
         "mgk_flat_dot": (i, [vp, C.c_long, vp, vp, C.POINTER(d), vp]),
         "mgk_flat_axpy": (i, [vp, C.c_long, d, vp, vp, vp]),
         "mgk_flat_scale": (i, [vp, C.c_long, d, vp, vp]),

@@ -96,3 +96,22 @@ def test_mixed_solve_matches_oracle_and_fp64_answer(orc, npts, levels):
     kat = 3 * math.pi ** 2 / ((12 / h ** 2) * math.sin(math.pi * h / 2) ** 2) - 1.0
     assert abs(s.error_norms()[0] - kat) <= 5e-7
     s.close()
+
+
+@pytest.mark.parametrize("nf", [3, 7, 31, 127, 255])
+def test_fused_residual_restrict_fp32_bit_exact(mgk, orc, nf):
+    rng = np.random.default_rng(50 + nf)
+    nc = (nf - 1) // 2
+    As = orc.level_stencil(3, nf + 2, 0)[0]
+    u, b = rng.uniform(-1, 1, nf ** 3).astype(np.float32), rng.uniform(-1, 1, nf ** 3).astype(np.float32)
+    gf, gc = mgk.geom32(nf), mgk.geom32(nc)
+    du, db, dbc = mgk.to_field32(gf, u), mgk.to_field32(gf, b), mgk.alloc(4 * gc.total)
+    want = orc.restrict32(nf, orc.residual32(nf, As, b, u))
+    for zc in (-1, 5):
+        mgk.L.mgk_set_tuning(-1, zc)
+        mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dbc, 4 * gc.total, None))
+        mgk._chk(mgk.L.mgk_residual_restrict_f32(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), db, du, dbc, None))
+        assert np.array_equal(mgk.from_field32(gc, dbc), want)
+    mgk.L.mgk_set_tuning(-1, -1)
+    for p in (du, db, dbc):
+        mgk.free(p)
