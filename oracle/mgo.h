@@ -19,7 +19,9 @@
  *    instead by (i) the closed-form discrete-eigenvector known answer,
  *    (ii) bit-equality of two independent restatements in this file
  *    (assembled-CSR path that follows solver.c's MatSetValue loops, and a
- *    matrix-free stencil path), see tests/test_oracle.py.
+ *    matrix-free stencil path), (iii) committed vectors from a scipy.sparse
+ *    restatement (tests/golden/make_golden.py -> vcycle_golden.npz), see
+ *    tests/test_oracle.py.
  *  - 3-D has no reference implementation at all (DIMENSION is 2,
  *    include/mesh.h:17); the 3-D branches extend the 2-D semantics by analogy
  *    and are marked "3-D extension".

@@ -186,3 +186,48 @@ def test_slab_operators_match_whole_grid(orc):
         parts.append(orc.jacobi(3, n, As, 0.8, np.ascontiguousarray(B[a:e]).ravel(),
                                 np.ascontiguousarray(U[a:e]).ravel(), nz=e - a, zlo=zlo, zhi=zhi))
     assert np.array_equal(np.concatenate(parts), whole)
+
+
+# ---- third restatement: committed scipy.sparse vectors (tests/golden/make_golden.py) ----
+from golden_cases import GOLD as NPZ, CYCLE_KEYS, cycle_case
+
+GOLD_RTOL = 1e-12      # bar of BASELINE.json north_star; observed: bit-identical fields
+
+
+@pytest.mark.parametrize("key", CYCLE_KEYS)
+@pytest.mark.parametrize("use_csr", [0, 1])
+def test_oracle_cycle_matches_committed_scipy_vectors(orc, key, use_csr):
+    g = cycle_case(key)
+    r = orc.vcycle(g["dim"], g["npts"], g["levels"], g["v0"], g["v1"], maxiter=g["maxiter"], scale=g["scale"], use_csr=use_csr)
+    assert r["iters"] == g["iters"]
+    assert abs(r["bnorm"] - g["bnorm"]) <= GOLD_RTOL * g["bnorm"]
+    assert np.abs(r["rnorm"] - g["rnorm"]).max() <= GOLD_RTOL * g["rnorm"][0]
+    assert np.abs(r["rnorm"] / g["rnorm"] - 1).max() <= 1e-9          # per entry, down to 1e-8 of rnorm[0]
+    assert np.abs(r["u"] - g["u"]).max() <= GOLD_RTOL * np.abs(g["u"]).max()
+    err = orc.error_norms(g["dim"], g["npts"], r["u"])
+    assert np.abs(np.asarray(err) / g["err"] - 1).max() <= 1e-11
+
+
+@pytest.mark.parametrize("dim,npts", [(2, 17), (2, 33), (2, 129), (3, 9), (3, 17), (3, 33)])
+def test_oracle_rhs_matches_committed_vectors(orc, dim, npts):
+    assert np.abs(orc.rhs(dim, npts) - NPZ["b0_d%d_n%d" % (dim, npts)]).max() <= 1e-13 * dim * math.pi ** 2
+
+
+@pytest.mark.parametrize("dim,nf", [(2, 31), (3, 15)])
+def test_oracle_operators_match_committed_vectors(orc, dim, nf):
+    x, xc, y = NPZ["xfer_d%d_fine" % dim], NPZ["xfer_d%d_coarse" % dim], NPZ["xfer_d%d_base" % dim]
+    As = orc.level_stencil(dim, nf + 2, 0)[0]
+    assert np.array_equal(orc.restrict(dim, nf, x), NPZ["xfer_d%d_restricted" % dim])
+    assert np.array_equal(orc.prolong_add(dim, nf, xc, y.copy()), NPZ["xfer_d%d_prolonged" % dim])
+    assert np.array_equal(orc.apply(dim, nf, As, x), NPZ["xfer_d%d_applied" % dim])
+    assert np.array_equal(orc.residual(dim, nf, As, y, x), NPZ["xfer_d%d_residual" % dim])
+
+
+@pytest.mark.parametrize("npts,levels", [(9, 3), (17, 4), (33, 5)])
+@pytest.mark.parametrize("procs", [1, 2, 4, 8])
+def test_ranges_match_committed_vectors(orc, npts, levels, procs):
+    want = NPZ["ranges_n%d_p%d" % (npts, procs)]
+    for l in range(levels):
+        for style in (0, 1, 2):
+            _, _, ranges = _maps(orc, npts, levels, levels, style, procs, l)
+            assert list(ranges) == list(want[l])
