@@ -50,6 +50,40 @@ def cpu_baseline(args):
                       f"{levels} levels, {cycles} cycles, solve loop only ({r['seconds']:.2f} s)"}
 
 
+def stream_ceiling(device, n_doubles):
+    """Measured HBM ceiling on this box: STREAM triad a = b + s*c over arrays of the fine field's
+    size, 24 B per element like a Jacobi sweep, HIP-event timed; best of a few launch shapes."""
+    import ctypes as C
+    from multigrid_petsc_amd.mgk import Mgk
+    m = Mgk(device)
+    n = int(n_doubles) & ~1
+    a, b, c = (m.alloc(8 * n) for _ in range(3))
+    m._chk(m.L.mgk_flat_fill(m.ctx, n, 1.0, b, None))
+    m._chk(m.L.mgk_flat_fill(m.ctx, n, 2.0, c, None))
+    t = C.c_void_p()
+    m._chk(m.L.mgk_timer_create(m.ctx, C.byref(t)))
+    best = None
+    for blocks in (256, 4096, 65536):
+        for nt in (1, 0):
+            m._chk(m.L.mgk_stream_triad_f64(m.ctx, n, a, b, c, 0.5, blocks, nt, None))       # warm-up
+            reps = 5
+            m._chk(m.L.mgk_timer_start(m.ctx, t, None))
+            for _ in range(reps):
+                m._chk(m.L.mgk_stream_triad_f64(m.ctx, n, a, b, c, 0.5, blocks, nt, None))
+            m._chk(m.L.mgk_timer_stop(m.ctx, t, None))
+            ms = C.c_double()
+            m._chk(m.L.mgk_timer_elapsed_ms(m.ctx, t, C.byref(ms)))
+            gbs = 24.0 * n * reps / (ms.value * 1e-3) / 1e9
+            if best is None or gbs > best["GB/s"]:
+                best = {"GB/s": gbs, "blocks": blocks, "nontemporal": bool(nt)}
+    m.L.mgk_timer_destroy(m.ctx, t)
+    for p_ in (a, b, c):
+        m.free(p_)
+    m.close()
+    best["kernel"] = "STREAM triad a=b+s*c, fp64, 24 B/element, arrays of the fine field's size"
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,7 +97,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-npts", type=int, default=257)
     ap.add_argument("--cpu-levels", type=int, default=8)
-    ap.add_argument("--cpu-cycles", type=int, default=40)
+    ap.add_argument("--cpu-cycles", type=int, default=120)
     ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
 
@@ -176,6 +210,13 @@ def main():
         }
     s.close()
     if rank == 0:
+        if world == 1 and achieved:
+            try:
+                tri = stream_ceiling(local_rank, local_unknowns)
+                tri["sweep_over_triad"] = achieved / tri["GB/s"]
+                out["roofline"]["measured_ceiling"] = tri
+            except Exception as e:   # reporting only
+                out["roofline"]["measured_ceiling"] = {"error": str(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args)

@@ -167,6 +167,9 @@ int  mgk_flat_axpbypcz(mgk_ctx *ctx, long n, double a, double b, double g, const
 int  mgk_flat_fill(mgk_ctx *ctx, long n, double a, double *z, void *stream);                        /* VecSet (src/solver.c:1514) */
 int  mgk_flat_scale(mgk_ctx *ctx, long n, double a, double *z, void *stream);
 int  mgk_flat_pointwise_mult(mgk_ctx *ctx, long n, const double *x, const double *y, double *z, void *stream);
+/* bandwidth probe: a = b + s*c over n doubles (n even, 16-byte aligned), `blocks` workgroups of 1024 lanes */
+int  mgk_stream_triad_f64(mgk_ctx *ctx, long n, double *a, const double *b, const double *c, double s,
+                          int blocks, int nontemporal, void *stream);
 int  mgk_flat_dot(mgk_ctx *ctx, long n, const double *x, const double *y, double *dot_host, void *stream);   /* VecDot / VecNorm^2 */
 /* generic assembled AIJ: y = A x, or y = addto + alpha*(A x) when addto != NULL (rows: ascending columns).
  * `col` holds element offsets into x (translated by the caller when x is a padded field); when y/addto are padded

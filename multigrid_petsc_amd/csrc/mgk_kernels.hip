@@ -1245,6 +1245,44 @@ __global__ void __launch_bounds__(256) k_csr_mult(long nrows, const long *rowptr
         y[o] = addto ? addto[o] + alpha * sum : sum;
     }
 }
+// Measured-ceiling probe: STREAM triad a = b + s*c with the access mix and hints of a Jacobi sweep
+// (two streamed reads, one streamed write, 24 B per element; 16-B lane vectors; contiguous chunk per block).
+template <int NT>
+__global__ void __launch_bounds__(1024) k_triad(long nvec, double *a, const double *b, const double *c, double s) {
+    constexpr int U = 4;                          // independent 16-B loads in flight per lane and stream
+    // grid-stride: at any moment the resident blocks cover one contiguous window that moves through the arrays
+    // (like the sweep's plane march), so the accesses spread over every HBM channel
+    const long q1 = nvec;
+    const d2v *bv = reinterpret_cast<const d2v *>(b), *cv = reinterpret_cast<const d2v *>(c);
+    d2v *av = reinterpret_cast<d2v *>(a);
+    for (long base = (long)blockIdx.x * U * blockDim.x + threadIdx.x; base < q1; base += (long)gridDim.x * U * blockDim.x) {
+        d2v x[U], y[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const long q = base + (long)k * blockDim.x;
+            if (q < q1) {
+                if (NT) { x[k] = __builtin_nontemporal_load(bv + q); y[k] = __builtin_nontemporal_load(cv + q); }
+                else { x[k] = bv[q]; y[k] = cv[q]; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const long q = base + (long)k * blockDim.x;
+            if (q < q1) {
+                d2v r; r.x = x[k].x + s * y[k].x; r.y = x[k].y + s * y[k].y;
+                if (NT) __builtin_nontemporal_store(r, av + q); else av[q] = r;
+            }
+        }
+    }
+}
+extern "C" int mgk_stream_triad_f64(mgk_ctx *c, long n, double *a, const double *b, const double *cc, double s,
+                                    int blocks, int nontemporal, void *stream) {
+    if (!c || !a || !b || !cc || n < 2 || (n & 1) || blocks < 1) return fail(MGK_EINVAL, "mgk_stream_triad_f64: bad arguments (n even)");
+    if (nontemporal) hipLaunchKernelGGL(k_triad<1>, dim3((unsigned)blocks), dim3(1024), 0, S(c, stream), n / 2, a, b, cc, s);
+    else hipLaunchKernelGGL(k_triad<0>, dim3((unsigned)blocks), dim3(1024), 0, S(c, stream), n / 2, a, b, cc, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 static unsigned flat_grid(long n) {
     long b = (n + 255) / 256;
     if (b > 8192) b = 8192;

@@ -67,8 +67,13 @@ def _sigs(L):
         "mgk_residual_restrict_f64": (i, [vp, G, G, c_dp, vp, vp, vp, vp]),
         "mgk_residual_restrict_f32": (i, [vp, G, G, c_dp, vp, vp, vp, vp]),
         "mgk_flat_dot": (i, [vp, C.c_long, vp, vp, C.POINTER(d), vp]),
+        "mgk_stream_triad_f64": (i, [vp, C.c_long, vp, vp, vp, d, i, i, vp]),
         "mgk_flat_axpy": (i, [vp, C.c_long, d, vp, vp, vp]),
         "mgk_flat_scale": (i, [vp, C.c_long, d, vp, vp]),
+        "mgk_flat_fill": (i, [vp, C.c_long, d, vp, vp]),
+        "mgk_flat_aypx": (i, [vp, C.c_long, d, vp, vp, vp]),
+        "mgk_flat_axpbypcz": (i, [vp, C.c_long, d, d, d, vp, vp, vp, vp]),
+        "mgk_flat_pointwise_mult": (i, [vp, C.c_long, vp, vp, vp, vp]),
         "mgk_prolong_jacobi_f64": (i, [vp, G, G, c_dp, d, d, vp, vp, vp, vp, vp]),
         "mgk_prolong_jacobi_f32": (i, [vp, G, G, c_dp, d, d, vp, vp, vp, vp, vp]),
     }
