@@ -40,6 +40,8 @@ typedef struct mg_comm {
 /* rank 0 calls this and ships the bytes to the other ranks (bench.py uses torch.distributed for that) */
 int      mg_comm_rccl_unique_id(void *id_out);
 mg_comm *mg_comm_rccl_create(int rank, int nranks, const void *id, int device);
+/* test aid: grouped ncclSend/ncclRecv with this rank as its own peer (count elements of esz 8 or 4 bytes) */
+int  mg_comm_rccl_self_sendrecv(mg_comm *c, mgk_ctx *ctx, const void *src, void *dst, long count, int esz);
 
 /* loopback: create the shared state once, then one handle per rank-thread */
 void    *mg_comm_loopback_shared_create(int nranks);

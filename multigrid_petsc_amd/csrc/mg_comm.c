@@ -135,6 +135,21 @@ static int rccl_allgather_planes(mg_comm *c, mgk_ctx *ctx, void *field, const mg
     return 0;
 }
 
+/* Self-test of the point-to-point entry points: a grouped ncclSend/ncclRecv of `count` elements from src to dst
+ * with this rank as its own peer (the only send/recv a 1-GPU box can run).  Same call shape as rccl_halo. */
+int mg_comm_rccl_self_sendrecv(mg_comm *c, mgk_ctx *ctx, const void *src, void *dst, long count, int esz) {
+    if (!c || c->halo != rccl_halo) return cfail(MGK_EINVAL, "mg_comm_rccl_self_sendrecv", "not an RCCL communicator");
+    rccl_impl *im = (rccl_impl *)c->impl;
+    void *s = stream_of(ctx, NULL);
+    const int dt = (esz == 8) ? NCCL_FLOAT64 : NCCL_FLOAT32;
+    NCK(g_rccl.GroupStart());
+    NCK(g_rccl.Send(src, (size_t)count, dt, c->rank, im->comm, s));
+    NCK(g_rccl.Recv(dst, (size_t)count, dt, c->rank, im->comm, s));
+    NCK(g_rccl.GroupEnd());
+    CK(mgk_sync(ctx, s));
+    return 0;
+}
+
 static int rccl_allreduce_sum(mg_comm *c, mgk_ctx *ctx, double *vals, int n, void *stream) {
     rccl_impl *im = (rccl_impl *)c->impl;
     if (n > 64) return cfail(MGK_EINVAL, "allreduce_sum", "at most 64 values");

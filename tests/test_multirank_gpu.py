@@ -112,6 +112,23 @@ def test_rccl_backend_single_rank_plumbing(mgk):
     f = mgk.field(g)
     assert _lib().mg_comm_halo(c.handle, mgk.ctx, f, C.byref(g)) == 0     # no neighbours: no-op
     mgk.free(f)
+    # point-to-point entry points, this rank as its own peer: the call shape of the halo exchange
+    L = _lib()
+    L.mg_comm_rccl_self_sendrecv.restype = C.c_int
+    L.mg_comm_rccl_self_sendrecv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int]
+    src = np.random.default_rng(5).uniform(-1, 1, 4096)
+    for esz, arr in ((8, src), (4, src.astype(np.float32))):
+        a = mgk.alloc(arr.nbytes)
+        b = mgk.alloc(arr.nbytes)
+        mgk._chk(mgk.L.mgk_h2d(mgk.ctx, a, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+        mgk._chk(mgk.L.mgk_memset0(mgk.ctx, b, arr.nbytes, None))
+        rc = L.mg_comm_rccl_self_sendrecv(c.handle, mgk.ctx, a, b, arr.size, esz)
+        assert rc == 0, L.mg_comm_last_error()
+        out = np.empty_like(arr)
+        mgk._chk(mgk.L.mgk_d2h(mgk.ctx, out.ctypes.data_as(C.c_void_p), b, arr.nbytes))
+        assert np.array_equal(out, arr)
+        mgk.free(a)
+        mgk.free(b)
     c.close()
 
 
