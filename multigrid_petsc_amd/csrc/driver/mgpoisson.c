@@ -4,12 +4,17 @@
  *
  *   mgpoisson [-dim 2|3] [-npts N] [-levels L] [-iter M] [-v v0,v1] [-ksp_type richardson|chebyshev]
  *             [-ksp_richardson_scale s] [-ksp_chebyshev_eigenvalues emin,emax] [-precision fp64|mixed]
- *             [-device d] [-options_file poisson.in]
+ *             [-device d] [-options_file poisson.in] [-write_fields 0|1]
  *
  * Same option spelling as the reference where it has one (-npts -levels -iter -v; poisson.in syntax: '#'
  * comments, "-key value" lines); -grids is implied (= -levels: one grid per level), -cycle is 0, -mesh 0.
  * Output mirrors what the reference prints: the PrintInfo block (src/poisson.c:165-214), error[0..2]
- * (src/solver.c:1333), "Relative residual" (:1354), "Solver walltime" (:1572), and rData.dat (:1350-1353).
+ * (src/solver.c:1333), "Relative residual" (:1354), "Solver walltime" (:1572), and the five files of
+ * Postprocessing (src/solver.c:160-164,1331-1353): eData.dat, rData.dat, and -- the O(N) text dumps --
+ * uData.dat, XgridData.dat, YgridData.dat in the reference's formats ("%.16e    " / "%lf    ", one grid row per
+ * line; the grid files repeat coord[0][j], coord[1][i] with the UNSHIFTED index, as the reference does).
+ * The O(N) dumps are written by default up to 1025^2 unknowns (2-D); -write_fields 1/0 forces them on/off
+ * (3-D: rows of nx values, plane after plane; a "3-D extension", the reference is 2-D only).
  */
 #include "mgsolve.h"
 #include <stdio.h>
@@ -84,16 +89,48 @@ int main(int argc, char **argv) {
     printf("rank = [0]; Solver walltime:               %lf\n", mg_solver_solve_seconds(s));
     for (int q = 0; q < 3; q++) printf("\nerror[%d] = %.16e\n", q, err[q]);
     printf("Relative residual = %.16e ", rn[it] / rn[0]);
-    FILE *f = fopen("rData.dat", "w");
+    FILE *f = fopen("eData.dat", "w");
+    if (f) { for (int q = 0; q < 3; q++) fprintf(f, "%.16e\n", err[q]); fclose(f); }
+    f = fopen("rData.dat", "w");
     if (f) { for (int q = 0; q <= it; q++) fprintf(f, "%.16e ", rn[q] / rn[0]); fprintf(f, "\n"); fclose(f); }
+    const int n = c.npts - 2;
+    int dump = (c.dim == 2 && n <= 1023);
+    if ((v = get("-write_fields"))) dump = atoi(v) != 0;
+    if (dump) {
+        const size_t N = (c.dim == 3) ? (size_t)n * n * n : (size_t)n * n;
+        double *u = (double *)malloc(N * sizeof(double)), *x = (double *)malloc((size_t)c.npts * sizeof(double));
+        if (!u || !x || mg_solver_get_solution(s, u)) { fprintf(stderr, "mgpoisson: cannot fetch the solution: %s\n", mg_last_error()); return 1; }
+        x[0] = 0.0;                                       /* Coords, uniform branch: repeated addition (src/mesh.c:150-152) */
+        for (int q = 1; q < c.npts; q++) x[q] = x[q - 1] + 1.0 / (c.npts - 1);
+        FILE *fu = fopen("uData.dat", "w"), *fx = fopen("XgridData.dat", "w"), *fy = fopen("YgridData.dat", "w");
+        if (fu && fx && fy) {
+            const size_t rows = N / (size_t)n;
+            for (size_t r = 0; r < rows; r++) {
+                const int i = (int)(r % (size_t)n);
+                for (int j = 0; j < n; j++) {
+                    fprintf(fx, "%lf    ", x[j]);
+                    fprintf(fy, "%lf    ", x[i]);
+                    fprintf(fu, "%.16e    ", u[r * (size_t)n + j]);
+                }
+                fprintf(fx, "\n"); fprintf(fy, "\n"); fprintf(fu, "\n");
+            }
+        }
+        if (fu) fclose(fu);
+        if (fx) fclose(fx);
+        if (fy) fclose(fy);
+        free(u); free(x);
+    }
     printf("=============================================================\n");
     if (c.dim == 2) printf("Size:\t\t\t\t%d x %d\n", c.npts, c.npts); else printf("Size:\t\t\t\t%d x %d x %d\n", c.npts, c.npts, c.npts);
     printf("Mesh Type:\t\t\tUniform\n");
     printf("Number of grids:\t\t%d\n", c.levels);
     printf("Number of levels:\t\t%d\n", c.levels);
-    printf("Number of unknowns per level:\t");
+    printf("Number of grids per level:\t");
+    for (int l = 0; l < c.levels; l++) printf("1\t");
+    printf("\nNumber of unknowns per level:\t");
     for (int l = 0; l < c.levels; l++) { double n = mg_solver_level_n(s, l); printf("%.0f\t", c.dim == 3 ? n * n * n : n * n); }
-    printf("\nCycle :\t\t\t\tV-Cycle\n");
+    printf("\nMapping style :\t\t\tLocal grid after grid\n");     /* one grid per level: all three styles coincide */
+    printf("Cycle :\t\t\t\tV-Cycle\n");
     printf("Number of smoothing steps :\t%d(fine) %d(coarsest)\n", c.v[0], c.v[1]);
     printf("Number of processes:\t\t1\n");
     printf("Number of iterations:\t\t%d\n", it);

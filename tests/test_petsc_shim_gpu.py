@@ -250,3 +250,38 @@ def test_reference_driver_stretched_meshes(orc, tmp_path, mesh, npts, levels, en
     assert np.array_equal(u, ref["u"])
     assert np.allclose(e, orc.error_norms_mesh(npts, mesh, ref["u"]), rtol=1e-12, atol=0)
     assert ("assembled AIJ (generic CSR kernel)" if env else "row-dependent coefficients") in out
+
+
+MGPOISSON = os.path.join(ROOT, "multigrid_petsc_amd", "mgpoisson")
+
+
+@pytest.mark.skipif(not os.path.exists(REFDRV), reason="build/refdriver/poisson absent")
+@pytest.mark.parametrize("npts,levels", [(17, 2), (65, 5), (129, 7)])
+def test_own_driver_writes_the_reference_output_files(tmp_path, npts, levels):
+    """the product's own driver against the reference's own Postprocessing code (unmodified
+    src/solver.c:1317-1380 running over the shim): uData.dat, XgridData.dat, YgridData.dat byte for byte;
+    eData.dat / rData.dat number for number (their sums are reduced in another order: 1e-12); PrintInfo lines."""
+    opts = (f"-npts {npts}\n-mesh 0\n-iter 1000\n-grids {levels}\n-levels {levels}\n-cycle 0\n-map 2\n-v 3,3\n-moreNorm 0\n"
+            f"-pc_type jacobi\n-ksp_richardson_scale 0.8\n")
+    a, b = tmp_path / "ref", tmp_path / "own"
+    a.mkdir()
+    b.mkdir()
+    it, rdat, u, e, out_ref = _run_reference_driver(a, opts)
+    (b / "poisson.in").write_text(opts)
+    p = subprocess.run([MGPOISSON, "-dim", "2"], cwd=b, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:]
+    for name in ("uData.dat", "XgridData.dat", "YgridData.dat"):
+        assert (a / name).read_bytes() == (b / name).read_bytes(), name
+    for name in ("eData.dat", "rData.dat"):
+        x = np.array((a / name).read_text().split(), dtype=np.float64)
+        y = np.array((b / name).read_text().split(), dtype=np.float64)
+        assert x.shape == y.shape and np.max(np.abs(x - y) / np.abs(x)) <= 1e-12, name
+    assert (a / "eData.dat").read_text().count("\n") == (b / "eData.dat").read_text().count("\n") == 3
+
+    def info(txt):
+        blk = txt[txt.index("====="):]
+        return [ln for ln in blk.splitlines() if ln.split(":")[0].strip() in
+                ("Size", "Mesh Type", "Number of grids", "Number of levels", "Number of grids per level",
+                 "Number of unknowns per level", "Mapping style", "Cycle", "Number of smoothing steps",
+                 "Number of processes", "Number of iterations")]
+    assert info(out_ref) == info(p.stdout)
