@@ -647,6 +647,11 @@ PetscErrorCode MatMult(Mat A, Vec x, Vec y) {                       /* src/solve
 static Vec mat_work(Mat A, Vec like) { if (!A->work) VecDuplicate(like, &A->work); return A->work; }
 PetscErrorCode MatMultAdd(Mat A, Vec x, Vec y, Vec z) {            /* z = y + A x */
     if (A->kind == MAT_GENERIC) { csr_apply(A, x, z, 1.0, y, "MatMultAdd"); return 0; }
+    if (A->kind == MAT_PROLONG && z == y) {                       /* u_f += P u_c in one pass (MatInterpolateAdd) */
+        need_vec(x, 1, &A->gc, A->n, "MatMultAdd"); need_vec(y, 1, &A->gf, A->m, "MatMultAdd");
+        DEV(mgk_prolong_add_f64(G, &A->gf, &A->gc, vdev(x), vdev(y), NULL));
+        return 0;
+    }
     Vec t = mat_work(A, y);
     MatMult(A, x, t);
     if (z != y) VecCopy(y, z);
@@ -712,8 +717,16 @@ PetscErrorCode MatDestroy(Mat *pA) {
 /* KSP / PC                                                            */
 /* ------------------------------------------------------------------ */
 enum { K_RICHARDSON = 0, K_CHEBYSHEV = 1, K_OTHER = 2 };
-enum { P_DEFAULT = 0, P_JACOBI = 1, P_NONE = 2 };
-struct _p_PC { KSP ksp; };
+enum { P_DEFAULT = 0, P_JACOBI = 1, P_NONE = 2, P_MG = 3 };
+/* PCMG state (-cycle 8, src/solver.c:1918-1956).  PETSc numbers levels coarse-to-fine: 0 = coarsest. */
+typedef struct pcmg {
+    int levels;
+    KSP *smooth;                /* [0] coarse solve, [i>0] level smoother (used down and up) */
+    Mat *interp, *restr;        /* [i] between level i-1 and i */
+    Vec *b, *x, *r;             /* user-provided work vectors (PCMGSetRhs/X/R) or created on demand */
+    unsigned char *own_b, *own_x, *own_r;
+} pcmg;
+struct _p_PC { KSP ksp; pcmg *mg; };
 struct _p_KSP {
     Mat A;
     int type, pc;
@@ -725,6 +738,9 @@ struct _p_KSP {
     Vec b, x;                   /* vec_rhs / vec_sol of the last KSPSolve (KSPBuildResidual, src/solver.c:1534) */
     PetscInt its;
     char prefix[64];
+    double rtol, atol, dtol;    /* used only by the outer Richardson of -cycle 8 (norm type != NONE) */
+    PetscReal *hist; PetscInt nhist;
+    int type_from_user;
     struct _p_PC pcobj;
 };
 
@@ -734,6 +750,7 @@ PetscErrorCode KSPCreate(MPI_Comm comm, KSP *out) {
     KSP k = (KSP)calloc(1, sizeof(*k));
     k->type = K_OTHER;          /* PETSc's default is GMRES: a type must be chosen */
     k->pc = P_DEFAULT; k->scale = 1.0; k->maxits = 10000; k->normtype = KSP_NORM_DEFAULT;
+    k->rtol = 1.e-5; k->atol = 1.e-50; k->dtol = 1.e5;
     k->pcobj.ksp = k;
     *out = k;
     return 0;
@@ -749,11 +766,15 @@ static int pc_type_from(const char *t) {
     fprintf(stderr, "[mgpetsc] FATAL: -pc_type %s is not provided by this drop-in (available: jacobi, none)\n", t);
     exit(87);
 }
-PetscErrorCode KSPSetType(KSP k, KSPType t) { k->type = ksp_type_from(t); return 0; }
+PetscErrorCode KSPSetType(KSP k, KSPType t) { k->type = ksp_type_from(t); k->type_from_user = 1; return 0; }
 PetscErrorCode KSPSetOperators(KSP k, Mat A, Mat P) { (void)P; k->A = A; return 0; }
 PetscErrorCode KSPSetNormType(KSP k, KSPNormType n) { k->normtype = n; return 0; }
 PetscErrorCode KSPSetTolerances(KSP k, PetscReal rtol, PetscReal atol, PetscReal dtol, PetscInt maxits) {
-    (void)rtol; (void)atol; (void)dtol;          /* KSP_NORM_NONE: only max_it matters (src/solver.c:1473-1474) */
+    /* KSP_NORM_NONE (the smoothers): only max_it matters (src/solver.c:1473-1474); the tolerances are kept for the
+     * outer Richardson of -cycle 8 (src/solver.c:1924) */
+    if (rtol != PETSC_DEFAULT) k->rtol = rtol;
+    if (atol != PETSC_DEFAULT) k->atol = atol;
+    if (dtol != PETSC_DEFAULT) k->dtol = dtol;
     if (maxits != PETSC_DEFAULT) k->maxits = maxits;
     return 0;
 }
@@ -771,7 +792,7 @@ static const char *kopt(KSP k, const char *name) {
 }
 PetscErrorCode KSPSetFromOptions(KSP k) {                         /* src/solver.c:1476,1492,1509 */
     const char *v;
-    if ((v = kopt(k, "ksp_type")) && v[0]) k->type = ksp_type_from(v);
+    if ((v = kopt(k, "ksp_type")) && v[0]) { k->type = ksp_type_from(v); k->type_from_user = 1; }
     if ((v = kopt(k, "pc_type")) && v[0]) k->pc = pc_type_from(v);
     if ((v = kopt(k, "ksp_richardson_scale")) && v[0]) k->scale = strtod(v, NULL);
     if ((v = kopt(k, "ksp_max_it")) && v[0]) k->maxits = (PetscInt)strtol(v, NULL, 10);
@@ -781,28 +802,70 @@ PetscErrorCode KSPSetFromOptions(KSP k) {                         /* src/solver.
         while (*end == ',' || *end == ' ') end++;
         k->emax = strtod(end, NULL);
     }
+    if (k->pc == P_MG && k->pcobj.mg)            /* PCSetFromOptions_MG: the level solvers read -mg_coarse_* / -mg_levels_* */
+        for (int i = 0; i < k->pcobj.mg->levels; i++) KSPSetFromOptions(k->pcobj.mg->smooth[i]);
     return 0;
 }
 PetscErrorCode KSPSetInitialGuessNonzero(KSP k, PetscBool f) { k->guess_nonzero = (f == PETSC_TRUE); return 0; }
 PetscErrorCode KSPGetPC(KSP k, PC *pc) { *pc = &k->pcobj; return 0; }
 PetscErrorCode PCSetType(PC pc, PCType t) {
-    if (!strcmp(t, PCMG)) UNSUPPORTED("PCSetType(PCMG): PETSc's own multigrid is excluded (north star)");
+    if (!strcmp(t, PCMG)) { pc->ksp->pc = P_MG; return 0; }
     pc->ksp->pc = pc_type_from(t);
     return 0;
 }
 PetscErrorCode KSPGetIterationNumber(KSP k, PetscInt *its) { *its = k->its; return 0; }
-PetscErrorCode KSPSetResidualHistory(KSP k, PetscReal a[], PetscInt na, PetscBool r) { (void)k; (void)a; (void)na; (void)r; UNSUPPORTED("KSPSetResidualHistory"); return 1; }
+PetscErrorCode KSPSetResidualHistory(KSP k, PetscReal a[], PetscInt na, PetscBool r) {      /* src/solver.c:1923 */
+    (void)r; k->hist = a; k->nhist = na; return 0;
+}
 PetscErrorCode KSPMonitorSet(KSP k, PetscErrorCode (*m)(KSP, PetscInt, PetscReal, void *), void *c, PetscErrorCode (*d)(void **)) {
     (void)k; (void)m; (void)c; (void)d; UNSUPPORTED("KSPMonitorSet (delayed cycles)"); return 1;
 }
-PetscErrorCode PCMGSetLevels(PC pc, PetscInt l, MPI_Comm *c) { (void)pc; (void)l; (void)c; UNSUPPORTED("PCMG"); return 1; }
-PetscErrorCode PCMGGetCoarseSolve(PC pc, KSP *k) { (void)pc; (void)k; UNSUPPORTED("PCMG"); return 1; }
-PetscErrorCode PCMGGetSmoother(PC pc, PetscInt l, KSP *k) { (void)pc; (void)l; (void)k; UNSUPPORTED("PCMG"); return 1; }
-PetscErrorCode PCMGSetInterpolation(PC pc, PetscInt l, Mat m) { (void)pc; (void)l; (void)m; UNSUPPORTED("PCMG"); return 1; }
-PetscErrorCode PCMGSetRestriction(PC pc, PetscInt l, Mat m) { (void)pc; (void)l; (void)m; UNSUPPORTED("PCMG"); return 1; }
-PetscErrorCode PCMGSetR(PC pc, PetscInt l, Vec c) { (void)pc; (void)l; (void)c; UNSUPPORTED("PCMG"); return 1; }
-PetscErrorCode PCMGSetRhs(PC pc, PetscInt l, Vec c) { (void)pc; (void)l; (void)c; UNSUPPORTED("PCMG"); return 1; }
-PetscErrorCode PCMGSetX(PC pc, PetscInt l, Vec c) { (void)pc; (void)l; (void)c; UNSUPPORTED("PCMG"); return 1; }
+
+/* ---- PCMG (-cycle 8, MultigridPetscPCMG, src/solver.c:1884-1989) ----
+ * Multiplicative V-cycle, one cycle per application, the textbook PCMG recursion:
+ *   x_L = 0;  level i > 0:  smooth(b_i, x_i);  r_i = b_i - A_i x_i;  b_{i-1} = R_i r_i;  x_{i-1} = 0;  recurse;
+ *                           x_i += P_i x_{i-1};  smooth(b_i, x_i);       level 0:  coarse solve(b_0, x_0)
+ * Level solvers are ordinary KSPs of this shim (richardson / chebyshev + jacobi / none, KSP_NORM_NONE, max_it sweeps)
+ * configured through -mg_levels_* and -mg_coarse_*.  PETSc's defaults (chebyshev+SOR with estimated eigenvalues on the
+ * levels, LU on the coarsest grid) are not provided: without options the level solvers fall back, with a note, to
+ * richardson + jacobi, 2 sweeps.  The PETSc version is unpinned and PCMG's internals are version dependent:
+ * parity of this path is pinned only against the oracle's restatement of the recursion above (oracle/mgo.c, mgo_pcmg). */
+static pcmg *need_mg(PC pc, const char *who) {
+    if (pc->ksp->pc != P_MG || !pc->mg) { fprintf(stderr, "[mgpetsc] FATAL: %s before PCSetType(PCMG) + PCMGSetLevels\n", who); exit(86); }
+    return pc->mg;
+}
+static int mg_level(pcmg *mg, PetscInt l, const char *who) {
+    if (l < 0 || l >= mg->levels) { fprintf(stderr, "[mgpetsc] FATAL: %s: level %d outside 0..%d\n", who, (int)l, mg->levels - 1); exit(86); }
+    return (int)l;
+}
+PetscErrorCode PCMGSetLevels(PC pc, PetscInt l, MPI_Comm *c) {
+    (void)c;
+    if (pc->ksp->pc != P_MG) UNSUPPORTED("PCMGSetLevels on a PC that is not PCMG");
+    if (pc->mg) UNSUPPORTED("PCMGSetLevels called twice");
+    if (l < 1) UNSUPPORTED("PCMGSetLevels with fewer than one level");
+    pcmg *mg = (pcmg *)calloc(1, sizeof(pcmg));
+    mg->levels = (int)l;
+    mg->smooth = (KSP *)calloc((size_t)l, sizeof(KSP));
+    mg->interp = (Mat *)calloc((size_t)l, sizeof(Mat)); mg->restr = (Mat *)calloc((size_t)l, sizeof(Mat));
+    mg->b = (Vec *)calloc((size_t)l, sizeof(Vec)); mg->x = (Vec *)calloc((size_t)l, sizeof(Vec)); mg->r = (Vec *)calloc((size_t)l, sizeof(Vec));
+    mg->own_b = (unsigned char *)calloc((size_t)l, 1); mg->own_x = (unsigned char *)calloc((size_t)l, 1); mg->own_r = (unsigned char *)calloc((size_t)l, 1);
+    for (int i = 0; i < mg->levels; i++) {
+        KSPCreate(PETSC_COMM_WORLD, &mg->smooth[i]);
+        PetscObjectSetOptionsPrefix(mg->smooth[i], i == 0 ? "mg_coarse_" : "mg_levels_");
+        mg->smooth[i]->normtype = KSP_NORM_NONE;
+        mg->smooth[i]->maxits = 2;                        /* PETSc's default number of smoothing steps */
+        mg->smooth[i]->guess_nonzero = (i > 0);           /* x is zeroed explicitly by the cycle */
+    }
+    pc->mg = mg;
+    return 0;
+}
+PetscErrorCode PCMGGetCoarseSolve(PC pc, KSP *k) { *k = need_mg(pc, "PCMGGetCoarseSolve")->smooth[0]; return 0; }
+PetscErrorCode PCMGGetSmoother(PC pc, PetscInt l, KSP *k) { pcmg *mg = need_mg(pc, "PCMGGetSmoother"); *k = mg->smooth[mg_level(mg, l, "PCMGGetSmoother")]; return 0; }
+PetscErrorCode PCMGSetInterpolation(PC pc, PetscInt l, Mat m) { pcmg *mg = need_mg(pc, "PCMGSetInterpolation"); mg->interp[mg_level(mg, l, "PCMGSetInterpolation")] = m; return 0; }
+PetscErrorCode PCMGSetRestriction(PC pc, PetscInt l, Mat m) { pcmg *mg = need_mg(pc, "PCMGSetRestriction"); mg->restr[mg_level(mg, l, "PCMGSetRestriction")] = m; return 0; }
+PetscErrorCode PCMGSetR(PC pc, PetscInt l, Vec c) { pcmg *mg = need_mg(pc, "PCMGSetR"); mg->r[mg_level(mg, l, "PCMGSetR")] = c; return 0; }
+PetscErrorCode PCMGSetRhs(PC pc, PetscInt l, Vec c) { pcmg *mg = need_mg(pc, "PCMGSetRhs"); mg->b[mg_level(mg, l, "PCMGSetRhs")] = c; return 0; }
+PetscErrorCode PCMGSetX(PC pc, PetscInt l, Vec c) { pcmg *mg = need_mg(pc, "PCMGSetX"); mg->x[mg_level(mg, l, "PCMGSetX")] = c; return 0; }
 
 static int ksp_pc(KSP k) {
     if (k->pc == P_DEFAULT) {
@@ -822,10 +885,89 @@ static Vec ksp_work(KSP k, int q, Vec like) {
 }
 static void swap_dev(Vec a, Vec b) { double *t = a->dev; a->dev = b->dev; b->dev = t; }
 
+/* ---- PCMG application and the outer Richardson of -cycle 8 ---- */
+static Vec mg_vec(Vec *slot, unsigned char *own, Mat A, int want_rows) {
+    if (!*slot) {                                   /* not provided through PCMGSetRhs/X/R: create it */
+        if (want_rows) MatCreateVecs(A, NULL, slot); else MatCreateVecs(A, slot, NULL);
+        *own = 1;
+    }
+    return *slot;
+}
+static void mg_setup(KSP k) {
+    pcmg *mg = k->pcobj.mg;
+    static int noted = 0;
+    for (int i = 0; i < mg->levels; i++) {
+        KSP s = mg->smooth[i];
+        if (!s->A) { fprintf(stderr, "[mgpetsc] FATAL: PCMG level %d has no operators (KSPSetOperators on PCMGGetSmoother/CoarseSolve)\n", i); exit(86); }
+        if (i > 0 && (!mg->interp[i] || !mg->restr[i])) { fprintf(stderr, "[mgpetsc] FATAL: PCMG level %d lacks interpolation/restriction\n", i); exit(86); }
+        if (!s->type_from_user) {
+            if (!noted) {
+                fprintf(stderr, "[mgpetsc] note: PCMG's PETSc defaults (chebyshev+SOR smoothers, LU coarse solve) are not provided; "
+                                "level solvers without -mg_levels_ksp_type / -mg_coarse_ksp_type use richardson + jacobi, %d sweeps\n", (int)s->maxits);
+                noted = 1;
+            }
+            s->type = K_RICHARDSON;
+            if (s->pc == P_DEFAULT) s->pc = P_JACOBI;
+        }
+        if (s->pc == P_MG) UNSUPPORTED("nested PCMG");
+        s->normtype = KSP_NORM_NONE;
+        s->guess_nonzero = (i > 0);
+        if (i < mg->levels - 1) {                       /* the finest level's b and x are the arguments of the application */
+            mg_vec(&mg->b[i], &mg->own_b[i], s->A, 1);
+            mg_vec(&mg->x[i], &mg->own_x[i], s->A, 0);
+        }
+        if (i > 0) mg_vec(&mg->r[i], &mg->own_r[i], s->A, 1);
+    }
+}
+static void mg_cycle(pcmg *mg, int i, Vec b, Vec x) {       /* PCMGMCycle_Private, one cycle per level */
+    KSP s = mg->smooth[i];
+    if (i == 0) { KSPSolve(s, b, x); return; }            /* coarse solve (zero initial guess) */
+    KSPSolve(s, b, x);                                      /* pre-smoothing */
+    MatResidual(s->A, b, x, mg->r[i]);
+    MatMult(mg->restr[i], mg->r[i], mg->b[i - 1]);          /* MatRestrict */
+    VecSet(mg->x[i - 1], 0.0);
+    mg_cycle(mg, i - 1, mg->b[i - 1], mg->x[i - 1]);
+    MatMultAdd(mg->interp[i], mg->x[i - 1], x, x);          /* MatInterpolateAdd */
+    KSPSolve(s, b, x);                                      /* post-smoothing */
+}
+/* KSPSolve of the outer solver (src/solver.c:1963): Richardson, x += scale * M^{-1} r, unpreconditioned residual
+ * norm logged to the residual history, KSPConvergedDefault (rtol * ||b|| with a zero guess, atol, dtol). */
+static PetscErrorCode ksp_solve_mg(KSP k, Vec b, Vec x) {
+    Mat A = k->A;
+    pcmg *mg = k->pcobj.mg;
+    if (!mg) UNSUPPORTED("KSPSolve with PCMG before PCMGSetLevels");
+    if (k->type != K_RICHARDSON) UNSUPPORTED("PCMG under an outer Krylov type other than richardson");
+    need_same(b, x, "KSPSolve");
+    mg_setup(k);
+    k->b = b; k->x = x; k->its = 0;
+    (void)vdev(b); (void)vdev(x);
+    Vec r = ksp_work(k, 0, x), z = ksp_work(k, 1, x);
+    if (!k->guess_nonzero) { VecSet(x, 0.0); VecCopy(b, r); }
+    else MatResidual(A, b, x, r);
+    PetscReal rn = 0.0, rn0;
+    VecNorm(r, NORM_2, &rn);
+    rn0 = rn;
+    if (k->hist && k->nhist > 0) k->hist[0] = rn;
+    double ttol = k->rtol * rn0;
+    if (ttol < k->atol) ttol = k->atol;
+    const int top = mg->levels - 1;
+    while (k->its < k->maxits && rn > ttol && !(rn >= k->dtol * rn0) && rn == rn) {
+        VecSet(z, 0.0);
+        mg_cycle(mg, top, r, z);                                                /* z = M^{-1} r */
+        VecAXPY(x, k->scale, z);
+        MatResidual(A, b, x, r);
+        VecNorm(r, NORM_2, &rn);
+        k->its++;
+        if (k->hist && k->its < k->nhist) k->hist[k->its] = rn;
+    }
+    return 0;
+}
+
 /* KSPSolve, KSP_NORM_NONE: exactly max_it iterations (src/solver.c:1531,1536,1542) */
 PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
     Mat A = k->A;
     if (!A || !A->assembled) UNSUPPORTED("KSPSolve without assembled operators");
+    if (k->pc == P_MG) return ksp_solve_mg(k, b, x);
     if (k->type == K_OTHER) UNSUPPORTED("KSPSolve with a Krylov type other than richardson/chebyshev");
     need_same(b, x, "KSPSolve");
     const int pc = ksp_pc(k);
@@ -921,6 +1063,16 @@ PetscErrorCode KSPView(KSP k, PetscViewer viewer) {               /* src/solver.
     if (k->type == K_CHEBYSHEV) printf("    eigenvalue targets used: min %g, max %g\n", k->emin, k->emax);
     printf("  maximum iterations=%d, %s initial guess\n  using NONE norm type for convergence test\n", k->maxits,
            k->guess_nonzero ? "nonzero" : "zero");
+    if (k->pc == P_MG) {
+        pcmg *mg = k->pcobj.mg;
+        printf("PC Object: 1 MPI process\n  type: mg\n    type is MULTIPLICATIVE, levels=%d cycles=v\n", mg ? mg->levels : 0);
+        for (int i = 0; mg && i < mg->levels; i++) {
+            printf("  %s level %d -------------------------------\n", i == 0 ? "Coarse grid solver --" : "Down/up solver (pre/post-smoother) on", i);
+            KSPView(mg->smooth[i], viewer);
+        }
+        if (k->A) { printf("  linear system matrix = precond matrix:\n  "); MatView(k->A, viewer); }
+        return 0;
+    }
     printf("PC Object: 1 MPI process\n  type: %s\n", pn[k->pc]);
     if (k->A) { printf("  linear system matrix = precond matrix:\n  "); MatView(k->A, viewer); }
     printf("  backend: mgpetsc (MI355X / gfx950 HIP kernels, fp64, matrix-free where recognised)\n");
@@ -929,6 +1081,17 @@ PetscErrorCode KSPView(KSP k, PetscViewer viewer) {               /* src/solver.
 PetscErrorCode KSPDestroy(KSP *pk) {
     if (!pk || !*pk) return 0;
     for (int q = 0; q < 3; q++) if ((*pk)->work[q]) VecDestroy(&(*pk)->work[q]);
+    pcmg *mg = (*pk)->pcobj.mg;
+    if (mg) {
+        for (int i = 0; i < mg->levels; i++) {
+            KSPDestroy(&mg->smooth[i]);
+            if (mg->own_b[i]) VecDestroy(&mg->b[i]);
+            if (mg->own_x[i]) VecDestroy(&mg->x[i]);
+            if (mg->own_r[i]) VecDestroy(&mg->r[i]);
+        }
+        free(mg->smooth); free(mg->interp); free(mg->restr); free(mg->b); free(mg->x); free(mg->r);
+        free(mg->own_b); free(mg->own_x); free(mg->own_r); free(mg);
+    }
     free(*pk); *pk = NULL;
     return 0;
 }

@@ -925,3 +925,85 @@ int mgo_vcycle(const mgo_vcycle_cfg *c, double *rnorm, double *u_out, double *bn
     free(L);
     return iter;
 }
+
+
+/* ------------------------------------------------------------------ */
+/* -cycle 8: MultigridPetscPCMG, src/solver.c:1884-1989               */
+/* ------------------------------------------------------------------ */
+/* Outer KSPRICHARDSON (scale 1, KSP_NORM_UNPRECONDITIONED, rtol 1e-7, residual history, :1919-1924) preconditioned
+ * by PCMG (:1926-1956).  PCMG is PETSc-internal and its PETSc version is unpinned; restated here is the textbook
+ * multiplicative V-cycle PCMG documents (one cycle per application):
+ *     x_fine = 0;  level: pre-smooth; r = b - A x; b_coarse = R r; x_coarse = 0; recurse; x += P x_coarse; post-smooth;
+ *     coarsest: coarse solve from a zero guess.
+ * Level solvers: the smoother of cfg (Richardson/Chebyshev + Jacobi, KSP_NORM_NONE), v0 sweeps on the levels and v1 on
+ * the coarsest grid -- PETSc's own defaults (Chebyshev+SOR, LU) are NOT restated.  PARITY UNPINNED by the reference.
+ * Levels are indexed as in the rest of this file: 0 = finest. */
+static void pcmg_cycle(const mgo_vcycle_cfg *c, olevel *L, int l) {
+    int levels = c->levels, dim = c->dim;
+    if (l == levels - 1) { L[l].guess_nonzero = 0; smooth(c, &L[l], c->v1); return; }
+    L[l].guess_nonzero = 1;                                   /* x was zeroed explicitly */
+    smooth(c, &L[l], c->v0);
+    residual(c, &L[l]);
+    if (c->use_csr) mgo_csr_mult(L[l].R, L[l].rv, L[l + 1].b);
+    else mgo_st_restrict(dim, L[l].n, L[l].n, L[l + 1].n, L[l].rv, NULL, L[l + 1].b);
+    memset(L[l + 1].u, 0, sizeof(double) * L[l + 1].N);
+    pcmg_cycle(c, L, l + 1);
+    if (c->use_csr) {
+        mgo_csr_mult(L[l].P, L[l + 1].u, L[l].rv);
+        for (long q = 0; q < L[l].N; q++) L[l].u[q] = L[l].u[q] + L[l].rv[q];
+    } else {
+        mgo_st_prolong_add(dim, L[l].n, L[l].n, L[l + 1].n, L[l + 1].u, NULL, NULL, L[l].u);
+    }
+    smooth(c, &L[l], c->v0);
+}
+
+int mgo_pcmg(const mgo_vcycle_cfg *c, double *rnorm, double *u_out, double *bnorm_out, double *solve_seconds) {
+    int levels = c->levels, dim = c->dim;
+    olevel *L = (olevel *)calloc(levels, sizeof(olevel));
+    for (int l = 0; l < levels; l++) {
+        L[l].n = mgo_grid_n(c->npts, l);
+        L[l].N = dim == 3 ? (long)L[l].n * L[l].n * L[l].n : (long)L[l].n * L[l].n;
+        mgo_level_stencil(dim, c->npts, l, L[l].As, NULL);
+        L[l].u = (double *)calloc(L[l].N, sizeof(double));
+        L[l].b = (double *)calloc(L[l].N, sizeof(double));
+        L[l].rv = (double *)calloc(L[l].N, sizeof(double));
+        L[l].work = (double *)calloc(4 * L[l].N, sizeof(double));
+        if (c->use_csr) {
+            L[l].A = mgo_build_A(dim, c->npts, l);
+            L[l].dinv = (double *)malloc(sizeof(double) * L[l].N);
+            mgo_csr_diag_inv(L[l].A, L[l].dinv);
+            if (l < levels - 1) { L[l].R = mgo_build_R(dim, c->npts, l); L[l].P = mgo_build_P(dim, c->npts, l); }
+        }
+    }
+    const long N = L[0].N;
+    double *bf = (double *)malloc(sizeof(double) * N), *x = (double *)calloc(N, sizeof(double)), *r = (double *)malloc(sizeof(double) * N);
+    mgo_rhs(dim, c->npts, bf);
+    memcpy(r, bf, sizeof(double) * N);                        /* zero guess: r = b */
+    double rn = mgo_norm2(r, N), rn0 = rn;
+    double rtol = c->rtol > 0 ? c->rtol : 1.e-7, ttol = rtol * rn0;
+    if (ttol < 1.e-50) ttol = 1.e-50;
+    rnorm[0] = rn;
+    int its = 0;
+    double t0 = now_s();
+    while (its < c->maxiter && rn > ttol && !(rn >= 1.e5 * rn0)) {
+        memcpy(L[0].b, r, sizeof(double) * N);                /* z = M^{-1} r */
+        memset(L[0].u, 0, sizeof(double) * N);
+        pcmg_cycle(c, L, 0);
+        for (long q = 0; q < N; q++) x[q] = x[q] + 1.0 * L[0].u[q];      /* Richardson scale 1 */
+        if (c->use_csr) mgo_residual_csr(L[0].A, bf, x, r);
+        else mgo_st_residual(dim, L[0].n, L[0].n, L[0].As, bf, x, NULL, NULL, r);
+        rn = mgo_norm2(r, N);
+        its++;
+        rnorm[its] = rn;
+    }
+    double t1 = now_s();
+    if (solve_seconds) *solve_seconds = t1 - t0;
+    if (bnorm_out) *bnorm_out = rn0;
+    if (u_out) memcpy(u_out, x, sizeof(double) * N);
+    for (int l = 0; l < levels; l++) {
+        free(L[l].u); free(L[l].b); free(L[l].rv); free(L[l].work); free(L[l].dinv);
+        mgo_csr_free(L[l].A); mgo_csr_free(L[l].R); mgo_csr_free(L[l].P);
+    }
+    free(L); free(bf); free(x); free(r);
+    return its;
+}

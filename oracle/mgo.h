@@ -145,6 +145,10 @@ typedef struct mgo_vcycle_cfg {
  * returns number of cycles done (solver->numIter, solver.c:1558); bnorm_out = ||b0||. */
 int mgo_vcycle(const mgo_vcycle_cfg *cfg, double *rnorm_raw, double *u_out, double *bnorm_out,
                double *solve_seconds);
+/* -cycle 8 (src/solver.c:1884-1989): outer Richardson + textbook PCMG V-cycle with cfg's smoother on every level
+ * (v0 sweeps, v1 on the coarsest grid).  PETSc-internal semantics, version unpinned: PARITY UNPINNED. */
+int mgo_pcmg(const mgo_vcycle_cfg *cfg, double *rnorm_raw, double *u_out, double *bnorm_out,
+             double *solve_seconds);
 int mgo_num_threads(void);
 
 /* ---------------- fp32 leg (mgo_f32.c): mixed-precision cycle of BASELINE config 5, 3-D only ---------------- */

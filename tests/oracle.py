@@ -78,6 +78,8 @@ class Oracle:
         L.mgo_st_residual_f32.argtypes = [C.c_int] + [C.c_void_p] * 4
         L.mgo_st_restrict_f32.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         L.mgo_st_prolong_add_f32.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.mgo_pcmg.restype = C.c_int
+        L.mgo_pcmg.argtypes = [C.POINTER(VcycleCfg), C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.mgo_vcycle_mixed.restype = C.c_int
         L.mgo_vcycle_mixed.argtypes = [C.POINTER(VcycleCfg), C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
 
@@ -165,6 +167,15 @@ class Oracle:
         u = np.zeros((npts - 2) ** dim) if want_u else None
         bn, sec = C.c_double(), C.c_double()
         it = self.L.mgo_vcycle(C.byref(cfg), _p(rn), _p(u), C.byref(bn), C.byref(sec))
+        return {"iters": it, "rnorm": rn[:it + 1].copy(), "u": u, "bnorm": bn.value, "seconds": sec.value}
+
+    def pcmg(self, dim, npts, levels, v0=3, v1=3, maxiter=1000, ksp_type=0, scale=1.0, emin=0.0, emax=0.0, use_csr=0):
+        """-cycle 8 restatement (outer Richardson + PCMG V-cycle), see oracle/mgo.c: mgo_pcmg"""
+        cfg = VcycleCfg(dim, npts, levels, v0, v1, maxiter, ksp_type, scale, emin, emax, use_csr, 0, 0.0, 0)
+        rn = np.zeros(maxiter + 1)
+        u = np.zeros((npts - 2) ** dim)
+        bn, sec = C.c_double(), C.c_double()
+        it = self.L.mgo_pcmg(C.byref(cfg), _p(rn), _p(u), C.byref(bn), C.byref(sec))
         return {"iters": it, "rnorm": rn[:it + 1].copy(), "u": u, "bnorm": bn.value, "seconds": sec.value}
 
     # ---- fp32 leg ----

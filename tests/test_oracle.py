@@ -231,3 +231,18 @@ def test_ranges_match_committed_vectors(orc, npts, levels, procs):
         for style in (0, 1, 2):
             _, _, ranges = _maps(orc, npts, levels, levels, style, procs, l)
             assert list(ranges) == list(want[l])
+
+
+# ---- -cycle 8 (PCMG) restatement: SURVEY 8(f) N4 ----
+@pytest.mark.parametrize("dim,npts,levels,scale", [(2, 33, 5, 0.8), (2, 129, 7, 0.8), (2, 17, 2, 1.0), (3, 17, 4, 6.0 / 7.0)])
+def test_pcmg_restatement_is_the_vcycle_in_correction_form(orc, dim, npts, levels, scale):
+    """Outer Richardson(1) + one PCMG V-cycle per application is algebraically the -cycle 0 iteration written in
+    correction form (x += M r): same iterates up to rounding, hence same cycle count and residual history.
+    This cross-pins the PCMG restatement (parity unpinned by the reference: PETSc-internal) against the V-cycle."""
+    a = orc.vcycle(dim, npts, levels, 3, 3, maxiter=400, scale=scale)
+    b = orc.pcmg(dim, npts, levels, 3, 3, maxiter=400, scale=scale)
+    c = orc.pcmg(dim, npts, levels, 3, 3, maxiter=400, scale=scale, use_csr=1)
+    assert b["iters"] == c["iters"] and np.array_equal(b["rnorm"], c["rnorm"]) and np.array_equal(b["u"], c["u"])
+    assert a["iters"] == b["iters"]
+    assert np.abs(b["rnorm"] / a["rnorm"] - 1).max() <= 1e-6      # rounding differs between the two forms
+    assert np.abs(a["u"] - b["u"]).max() <= 1e-9 * np.abs(a["u"]).max()

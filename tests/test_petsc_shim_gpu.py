@@ -285,3 +285,33 @@ def test_own_driver_writes_the_reference_output_files(tmp_path, npts, levels):
                  "Number of unknowns per level", "Mapping style", "Cycle", "Number of smoothing steps",
                  "Number of processes", "Number of iterations")]
     assert info(out_ref) == info(p.stdout)
+
+
+@pytest.mark.skipif(not os.path.exists(REFDRV), reason="build/refdriver/poisson absent")
+@pytest.mark.parametrize("npts,levels,scale,ksp", [(17, 2, 1.0, "richardson"), (33, 5, 0.8, "richardson"), (129, 7, 0.8, "richardson"),
+                                                   (513, 9, 0.8, "richardson"), (65, 5, None, "chebyshev")])
+def test_reference_driver_cycle8_pcmg(orc, tmp_path, npts, levels, scale, ksp):
+    """-cycle 8 (MultigridPetscPCMG, src/solver.c:1884-1989) -- the reference's own code drives
+    PCMG through the drop-in: outer Richardson + multiplicative V-cycle with -mg_levels_* / -mg_coarse_* solvers.
+    Checked against the oracle's restatement of that recursion (bit-identical fields) -- parity with PETSc itself
+    is unpinned (PCMG internals are version dependent; see petsc_shim.c)."""
+    lv = (f"-mg_levels_ksp_type {ksp}\n-mg_levels_pc_type jacobi\n-mg_levels_ksp_max_it 3\n"
+          f"-mg_coarse_ksp_type {ksp}\n-mg_coarse_pc_type jacobi\n-mg_coarse_ksp_max_it 3\n")
+    if ksp == "richardson":
+        lv += f"-mg_levels_ksp_richardson_scale {scale!r}\n-mg_coarse_ksp_richardson_scale {scale!r}\n"
+        kw = dict(scale=scale)
+    else:
+        lv += "-mg_levels_ksp_chebyshev_eigenvalues 0.2,2.0\n-mg_coarse_ksp_chebyshev_eigenvalues 0.2,2.0\n"
+        kw = dict(ksp_type=1, emin=0.2, emax=2.0)
+    opts = f"-npts {npts}\n-mesh 0\n-iter 400\n-grids {levels}\n-levels {levels}\n-cycle 8\n-map 2\n-v 3,3\n-moreNorm 0\n" + lv
+    it, rdat, u, e, out = _run_reference_driver(tmp_path, opts)
+    ref = orc.pcmg(2, npts, levels, 3, 3, maxiter=400, **kw)
+    assert it == ref["iters"] < 400
+    want = ref["rnorm"] / ref["rnorm"][0]
+    assert rdat.size == it + 1
+    assert np.max(np.abs(rdat - want) / want) <= 1e-12
+    assert np.array_equal(u, ref["u"])
+    assert "Petsc-V-Cycle" in out and "type: mg" in out
+    if ksp == "richardson":          # and it is the -cycle 0 iteration in correction form
+        vc = orc.vcycle(2, npts, levels, 3, 3, maxiter=400, scale=scale)
+        assert vc["iters"] == it
