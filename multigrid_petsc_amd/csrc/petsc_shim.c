@@ -963,11 +963,46 @@ static PetscErrorCode ksp_solve_mg(KSP k, Vec b, Vec x) {
     return 0;
 }
 
+/* KSPSolve with KSP_NORM_UNPRECONDITIONED and an ordinary PC: the single-level iteration of -cycle 1
+ * (MultigridIcycle, src/solver.c:1991-2060): x += scale * B (b - A x), ||b - A x||_2 logged after every iteration,
+ * KSPConvergedDefault's test.  One sweep at a time through the KSP_NORM_NONE path below, so the arithmetic is the
+ * smoother's. */
+static PetscErrorCode ksp_solve_monitored(KSP k, Vec b, Vec x) {
+    Mat A = k->A;
+    if (k->type != K_RICHARDSON) UNSUPPORTED("a monitored (KSP_NORM_UNPRECONDITIONED) solve with a Krylov type other than richardson");
+    need_same(b, x, "KSPSolve");
+    const PetscInt maxits = k->maxits;
+    const int guess = k->guess_nonzero;
+    Vec r = ksp_work(k, 2, x);
+    (void)vdev(b); (void)vdev(x);
+    if (!guess) { VecSet(x, 0.0); VecCopy(b, r); } else MatResidual(A, b, x, r);
+    PetscReal rn = 0.0, rn0;
+    VecNorm(r, NORM_2, &rn);
+    rn0 = rn;
+    if (k->hist && k->nhist > 0) k->hist[0] = rn;
+    double ttol = k->rtol * rn0;
+    if (ttol < k->atol) ttol = k->atol;
+    PetscInt its = 0;
+    k->normtype = KSP_NORM_NONE; k->maxits = 1;
+    while (its < maxits && rn > ttol && !(rn >= k->dtol * rn0) && rn == rn) {
+        k->guess_nonzero = (guess || its > 0);
+        KSPSolve(k, b, x);
+        MatResidual(A, b, x, r);
+        VecNorm(r, NORM_2, &rn);
+        its++;
+        if (k->hist && its < k->nhist) k->hist[its] = rn;
+    }
+    k->normtype = KSP_NORM_UNPRECONDITIONED; k->maxits = maxits; k->guess_nonzero = guess; k->its = its;
+    k->b = b; k->x = x;
+    return 0;
+}
+
 /* KSPSolve, KSP_NORM_NONE: exactly max_it iterations (src/solver.c:1531,1536,1542) */
 PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
     Mat A = k->A;
     if (!A || !A->assembled) UNSUPPORTED("KSPSolve without assembled operators");
     if (k->pc == P_MG) return ksp_solve_mg(k, b, x);
+    if (k->normtype == KSP_NORM_UNPRECONDITIONED) return ksp_solve_monitored(k, b, x);
     if (k->type == K_OTHER) UNSUPPORTED("KSPSolve with a Krylov type other than richardson/chebyshev");
     need_same(b, x, "KSPSolve");
     const int pc = ksp_pc(k);
@@ -1061,8 +1096,8 @@ PetscErrorCode KSPView(KSP k, PetscViewer viewer) {               /* src/solver.
     printf("KSP Object: 1 MPI process\n  type: %s\n", tn[k->type]);
     if (k->type == K_RICHARDSON) printf("    damping factor=%g\n", k->scale);
     if (k->type == K_CHEBYSHEV) printf("    eigenvalue targets used: min %g, max %g\n", k->emin, k->emax);
-    printf("  maximum iterations=%d, %s initial guess\n  using NONE norm type for convergence test\n", k->maxits,
-           k->guess_nonzero ? "nonzero" : "zero");
+    printf("  maximum iterations=%d, %s initial guess\n  using %s norm type for convergence test\n", k->maxits,
+           k->guess_nonzero ? "nonzero" : "zero", (k->normtype == KSP_NORM_UNPRECONDITIONED || k->pc == P_MG) ? "UNPRECONDITIONED" : "NONE");
     if (k->pc == P_MG) {
         pcmg *mg = k->pcobj.mg;
         printf("PC Object: 1 MPI process\n  type: mg\n    type is MULTIPLICATIVE, levels=%d cycles=v\n", mg ? mg->levels : 0);

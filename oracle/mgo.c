@@ -1007,3 +1007,46 @@ int mgo_pcmg(const mgo_vcycle_cfg *c, double *rnorm, double *u_out, double *bnor
     free(L); free(bf); free(x); free(r);
     return its;
 }
+
+
+/* ------------------------------------------------------------------ */
+/* -cycle 1 with one grid: MultigridIcycle, src/solver.c:1991-2060     */
+/* ------------------------------------------------------------------ */
+/* One KSPRICHARDSON on the level-0 operator, KSP_NORM_UNPRECONDITIONED, rtol 1e-7, residual history (:2011-2019):
+ * x += scale * B (b - A x) with ||b - A x|| logged after every iteration.  Restated for one grid per level
+ * (-grids 1 -levels 1); the multi-grid-per-level operator of :255-487 is not restated here. */
+int mgo_icycle(const mgo_vcycle_cfg *c, double *rnorm, double *u_out, double *bnorm_out) {
+    int dim = c->dim, n = mgo_grid_n(c->npts, 0);
+    long N = dim == 3 ? (long)n * n * n : (long)n * n;
+    double As[7];
+    mgo_level_stencil(dim, c->npts, 0, As, NULL);
+    double *b = (double *)malloc(sizeof(double) * N), *x = (double *)calloc(N, sizeof(double));
+    double *y = (double *)malloc(sizeof(double) * N), *r = (double *)malloc(sizeof(double) * N);
+    mgo_csr *A = c->use_csr ? mgo_build_A(dim, c->npts, 0) : NULL;
+    double *dinv = NULL, *work = NULL;
+    if (A) { dinv = (double *)malloc(sizeof(double) * N); mgo_csr_diag_inv(A, dinv); work = (double *)malloc(sizeof(double) * 2 * N); }
+    mgo_rhs(dim, c->npts, b);
+    memcpy(r, b, sizeof(double) * N);
+    double rn = mgo_norm2(r, N), rn0 = rn;
+    double rtol = c->rtol > 0 ? c->rtol : 1.e-7, ttol = rtol * rn0;
+    if (ttol < 1.e-50) ttol = 1.e-50;
+    rnorm[0] = rn;
+    int its = 0;
+    while (its < c->maxiter && rn > ttol && !(rn >= 1.e5 * rn0)) {
+        if (A) {
+            mgo_richardson_csr(A, dinv, b, x, 1, c->scale, its > 0, work);
+            mgo_residual_csr(A, b, x, r);
+        } else {
+            mgo_st_jacobi(dim, n, n, As, c->scale, b, x, NULL, NULL, y, its == 0);
+            double *t = x; x = y; y = t;
+            mgo_st_residual(dim, n, n, As, b, x, NULL, NULL, r);
+        }
+        rn = mgo_norm2(r, N);
+        its++;
+        rnorm[its] = rn;
+    }
+    if (bnorm_out) *bnorm_out = rn0;
+    if (u_out) memcpy(u_out, x, sizeof(double) * N);
+    free(b); free(x); free(y); free(r); free(dinv); free(work); mgo_csr_free(A);
+    return its;
+}

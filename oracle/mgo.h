@@ -149,6 +149,8 @@ int mgo_vcycle(const mgo_vcycle_cfg *cfg, double *rnorm_raw, double *u_out, doub
  * (v0 sweeps, v1 on the coarsest grid).  PETSc-internal semantics, version unpinned: PARITY UNPINNED. */
 int mgo_pcmg(const mgo_vcycle_cfg *cfg, double *rnorm_raw, double *u_out, double *bnorm_out,
              double *solve_seconds);
+/* -cycle 1 with one grid (src/solver.c:1991-2060): monitored Richardson + Jacobi on the fine operator */
+int mgo_icycle(const mgo_vcycle_cfg *cfg, double *rnorm_raw, double *u_out, double *bnorm_out);
 int mgo_num_threads(void);
 
 /* ---------------- fp32 leg (mgo_f32.c): mixed-precision cycle of BASELINE config 5, 3-D only ---------------- */

@@ -80,6 +80,8 @@ class Oracle:
         L.mgo_st_prolong_add_f32.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         L.mgo_pcmg.restype = C.c_int
         L.mgo_pcmg.argtypes = [C.POINTER(VcycleCfg), C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.mgo_icycle.restype = C.c_int
+        L.mgo_icycle.argtypes = [C.POINTER(VcycleCfg), C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
         L.mgo_vcycle_mixed.restype = C.c_int
         L.mgo_vcycle_mixed.argtypes = [C.POINTER(VcycleCfg), C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
 
@@ -177,6 +179,15 @@ class Oracle:
         bn, sec = C.c_double(), C.c_double()
         it = self.L.mgo_pcmg(C.byref(cfg), _p(rn), _p(u), C.byref(bn), C.byref(sec))
         return {"iters": it, "rnorm": rn[:it + 1].copy(), "u": u, "bnorm": bn.value, "seconds": sec.value}
+
+    def icycle(self, dim, npts, maxiter=1000, scale=1.0, use_csr=0):
+        """-cycle 1, one grid: monitored Richardson + Jacobi (oracle/mgo.c: mgo_icycle)"""
+        cfg = VcycleCfg(dim, npts, 1, 0, 0, maxiter, 0, scale, 0.0, 0.0, use_csr, 0, 0.0, 0)
+        rn = np.zeros(maxiter + 1)
+        u = np.zeros((npts - 2) ** dim)
+        bn = C.c_double()
+        it = self.L.mgo_icycle(C.byref(cfg), _p(rn), _p(u), C.byref(bn))
+        return {"iters": it, "rnorm": rn[:it + 1].copy(), "u": u, "bnorm": bn.value}
 
     # ---- fp32 leg ----
     def jacobi32(self, n, As, scale, b, u, zero_guess=False):

@@ -246,3 +246,14 @@ def test_pcmg_restatement_is_the_vcycle_in_correction_form(orc, dim, npts, level
     assert a["iters"] == b["iters"]
     assert np.abs(b["rnorm"] / a["rnorm"] - 1).max() <= 1e-6      # rounding differs between the two forms
     assert np.abs(a["u"] - b["u"]).max() <= 1e-9 * np.abs(a["u"]).max()
+
+
+def test_icycle_restatement(orc):
+    """-cycle 1, one grid: both legs agree bit for bit; 9x9 grid converges to the discrete solution (KAT)."""
+    a = orc.icycle(2, 9, maxiter=2000, scale=0.8)
+    b = orc.icycle(2, 9, maxiter=2000, scale=0.8, use_csr=1)
+    assert a["iters"] == b["iters"] < 2000 and np.array_equal(a["rnorm"], b["rnorm"]) and np.array_equal(a["u"], b["u"])
+    h = 1.0 / 8
+    kat = 2 * math.pi ** 2 / ((8 / h ** 2) * math.sin(math.pi * h / 2) ** 2) - 1.0
+    assert abs(orc.error_norms(2, 9, a["u"])[0] - kat) <= 5e-7
+    assert np.all(np.diff(a["rnorm"]) < 0)

@@ -315,3 +315,62 @@ def test_reference_driver_cycle8_pcmg(orc, tmp_path, npts, levels, scale, ksp):
     if ksp == "richardson":          # and it is the -cycle 0 iteration in correction form
         vc = orc.vcycle(2, npts, levels, 3, 3, maxiter=400, scale=scale)
         assert vc["iters"] == it
+
+
+@pytest.mark.skipif(not os.path.exists(REFDRV), reason="build/refdriver/poisson absent")
+@pytest.mark.parametrize("npts,scale,env", [(9, 0.8, None), (17, 1.0, None), (33, 0.8, None), (17, 0.8, {"MGPETSC_NO_RECOGNITION": "1"})])
+def test_reference_driver_cycle1_single_grid(orc, tmp_path, npts, scale, env):
+    """-cycle 1 (MultigridIcycle, src/solver.c:1991-2060) with one grid: a monitored Richardson +
+    Jacobi iteration on the fine operator.  Bit-identical to the oracle's restatement (mgo_icycle)."""
+    opts = (f"-npts {npts}\n-mesh 0\n-iter 20000\n-grids 1\n-levels 1\n-cycle 1\n-map 2\n-v 3,3\n-moreNorm 0\n"
+            f"-pc_type jacobi\n-ksp_richardson_scale {scale!r}\n")
+    it, rdat, u, e, out = _run_reference_driver(tmp_path, opts, env)
+    ref = orc.icycle(2, npts, maxiter=20000, scale=scale)
+    assert it == ref["iters"] < 20000
+    assert np.max(np.abs(rdat - ref["rnorm"] / ref["rnorm"][0]) / rdat) <= 1e-12
+    assert np.array_equal(u, ref["u"])
+    assert "I-Cycle" in out
+
+
+def _dense(orc, which, npts, l):
+    m = orc.build(which, 2, npts, l)
+    rows = orc.csr_rows(m)
+    nr, nc = orc.L.mgo_csr_nrows(m), orc.L.mgo_csr_ncols(m)
+    d = np.zeros((nr, nc))
+    for r, (cols, vals) in enumerate(rows):
+        d[r, list(cols)] = vals
+    return d
+
+
+@pytest.mark.skipif(not os.path.exists(REFDRV), reason="build/refdriver/poisson absent")
+@pytest.mark.parametrize("npts,iters", [(9, 25), (17, 25)])
+def test_reference_driver_cycle1_two_grids_in_one_level(orc, tmp_path, npts, iters):
+    """-cycle 1 with two grids in ONE level: the reference assembles its coupled level operator (src/solver.c:255-487)
+    with its own unmodified code; the drop-in keeps it as an assembled AIJ matrix and iterates with the generic CSR kernels.
+    Restated here in dense numpy from the oracle's A, R, P:   M = [[A_h, (A_h P) masked to P's 3x3 window], [R A_h, A_H]],
+    b = [f, R f] (levelvecb, :558-620), x += s D^-1 (b - M x).  Point-Jacobi Richardson does not converge on this
+    operator (the author's runs rely on PETSc PCs the drop-in does not provide), so a fixed number of iterations
+    is compared: residual history to 1e-9, fine-grid part of x to 1e-9.  Parity with PETSc itself: unpinned."""
+    s = 0.3
+    opts = (f"-npts {npts}\n-mesh 0\n-iter {iters}\n-grids 2\n-levels 1\n-cycle 1\n-map 2\n-v 3,3\n-moreNorm 0\n"
+            f"-pc_type jacobi\n-ksp_richardson_scale {s!r}\n")
+    it, rdat, u, e, out = _run_reference_driver(tmp_path, opts)
+    assert it == iters and rdat.size == iters + 1
+    assert "assembled AIJ (generic CSR kernel)" in out
+    Ah, AH, R, P = _dense(orc, "A", npts, 0), _dense(orc, "A", npts, 1), _dense(orc, "R", npts, 0), _dense(orc, "P", npts, 0)
+    nf, nc = Ah.shape[0], AH.shape[0]
+    M = np.block([[Ah, (Ah @ P) * (P != 0)], [R @ Ah, AH]])
+    f = orc.rhs(2, npts)
+    b = np.concatenate([f, R @ f])
+    dinv = 1.0 / np.diag(M)
+    x = np.zeros(nf + nc)
+    hist = [np.linalg.norm(b)]
+    for _ in range(iters):
+        x = x + s * (dinv * (b - M @ x))
+        hist.append(np.linalg.norm(b - M @ x))
+    hist = np.array(hist) / hist[0]
+    # KSPSetResidualHistory(ksp, rnorm, numIter, ...) (src/solver.c:2017): a buffer of numIter entries holds the norms of
+    # iterations 0..numIter-1 (PETSc stops logging when the buffer is full); entry numIter is never written when the
+    # solve runs out of iterations
+    assert np.max(np.abs(rdat[:-1] / hist[:-1] - 1)) <= 1e-9
+    assert np.max(np.abs(u - x[:nf])) <= 1e-9 * np.abs(x[:nf]).max()
