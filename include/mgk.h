@@ -112,6 +112,10 @@ int  mgk_residual_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef,
 /* K2+K6 fused: sum over the slab of (b - A u)^2, r is not written.  *sumsq_host is valid after return. */
 int  mgk_residual_sumsq_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef,
                             const double *b, const double *u, double *sumsq_host, void *stream);
+/* one Jacobi sweep unew = u + scale*dinv*(b - A u) that also returns ||b - A u||^2 (residual of the INPUT u): the norm
+ * that closes a cycle (src/solver.c:1545-1546) fused with the first sweep of the next one (:1531) */
+int  mgk_jacobi_sumsq_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale,
+                          const double *b, const double *u, double *unew, double *sumsq_host, void *stream);
 
 /* K2+K3 fused: b_coarse = R (b - A u), the fine residual is never written (src/solver.c:1534-1535).
  * Whole grids only (gf->nz == 2*gc->nz + 1); a slab uses mgk_residual_f64 + halo + mgk_restrict_fw_f64.  3-D. */

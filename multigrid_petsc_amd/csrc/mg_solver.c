@@ -96,6 +96,7 @@ struct mg_solver {
     int iter;
     double bnorm, rchk;
     int started;
+    int spec_valid;         /* level-0 tmp holds Jacobi(u): made by the sweep+norm kernel that closed the last cycle */
     double solve_seconds;
     int lgraph;             /* levels >= lgraph form the launch-bound coarse part replayed as one HIP graph (0: off) */
     void *coarse_graph[2];  /* one recording per precision */
@@ -239,7 +240,7 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
     s->cfg = *cfg;
     if (s->cfg.rtol <= 0) s->cfg.rtol = 1.e-7;
     if (s->cfg.dist_min_n <= 0) s->cfg.dist_min_n = 127;
-    if (s->cfg.fuse < 0) s->cfg.fuse = 7;
+    if (s->cfg.fuse < 0) s->cfg.fuse = 15;
     if (s->cfg.overlap < 0) s->cfg.overlap = 1;
     if (s->cfg.graph < 0) s->cfg.graph = 1;
     if (s->cfg.nranks < 1) s->cfg.nranks = 1;
@@ -514,7 +515,15 @@ static int smooth(mg_solver *s, int P, int l, int maxit) {
         CHK(mgk_memset0(s->ctx, F->u, (size_t)O->esz * (size_t)F->g.total, NULL));
         F->u_ghost_ok = 0; F->u_ghost_pending = 0;
     }
-    for (int it = 0; it < maxit; it++) {
+    int it0 = 0;
+    if (l == 0 && P == 0 && s->spec_valid && maxit >= 1 && F->guess_nonzero) {
+        /* the first sweep was already made by the kernel that evaluated the previous cycle's residual norm */
+        swap_ptr(&F->u, &F->tmp);
+        F->u_ghost_ok = 0; F->u_ghost_pending = 0;
+        s->spec_valid = 0;
+        it0 = 1;
+    }
+    for (int it = it0; it < maxit; it++) {
         if (it == 0 && !F->guess_nonzero) {
             /* r = b, x = 0 + scale*(B b): u is not read */
             CHK(O->jacobi_zero(s->ctx, &F->g, L->dinv, s->cfg.scale, F->b, F->tmp, NULL));
@@ -708,7 +717,14 @@ static int vcycle_once(mg_solver *s) {
         CHK(cycle_body(s, 0, s->iter == 0));
         /* :1545-1546  r0 = b0 - A0 u0 ; ||r0|| */
         CHK(ensure_u_ghosts(s, 0, L));
-        if (s->cfg.fuse & 1) CHK(mgk_residual_sumsq_f64(s->ctx, &F->g, L->coef, (const double *)F->b, (const double *)F->u, &ss, NULL));
+        if ((s->cfg.fuse & 8) && (s->cfg.fuse & 1) && s->cfg.ksp_type == MG_KSP_RICHARDSON && s->cfg.v[0] >= 1) {
+            /* ||b - A u|| and, speculatively, the first pre-smoothing sweep of the next cycle in one pass over u and b
+             * (both form the same residual).  The sweep lands in tmp and is adopted by smooth() only if another
+             * cycle follows; u itself is untouched, so stopping here leaves the solution as the reference has it. */
+            CHK(mgk_jacobi_sumsq_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u,
+                                     (double *)F->tmp, &ss, NULL));
+            s->spec_valid = 1;
+        } else if (s->cfg.fuse & 1) CHK(mgk_residual_sumsq_f64(s->ctx, &F->g, L->coef, (const double *)F->b, (const double *)F->u, &ss, NULL));
         else {
             CHK(mgk_residual_f64(s->ctx, &F->g, L->coef, (const double *)F->b, (const double *)F->u, (double *)F->rv, NULL));
             CHK(mgk_sumsq_f64(s->ctx, &F->g, (const double *)F->rv, &ss, NULL));
@@ -735,6 +751,7 @@ static int start(mg_solver *s) {
         CHK(mgk_residual_f64_to_f32(s->ctx, &F->g, &L->f[1].g, L->coef, (const double *)F->b, (const double *)F->u, (float *)L->f[1].b, &ss, NULL));
     else CHK(mgk_residual_sumsq_f64(s->ctx, &F->g, L->coef, (const double *)F->b, (const double *)F->u, &ss, NULL));
     CHK(norm_from_sumsq(s, ss, &s->rchk));
+    s->spec_valid = 0;
     s->iter = 0;
     s->rnorm[0] = s->rchk;                                              /* :1520 */
     s->started = 1;

@@ -342,7 +342,8 @@ struct StArgs {
     T dinv, scale, ckm1, ck, cz;
 };
 
-enum { MODE_JACOBI = 0, MODE_RESIDUAL = 1, MODE_CHEBY = 2, MODE_RESNORM = 3, MODE_APPLY = 4, MODE_RES32 = 5, MODE_PJACOBI = 6 };
+enum { MODE_JACOBI = 0, MODE_RESIDUAL = 1, MODE_CHEBY = 2, MODE_RESNORM = 3, MODE_APPLY = 4, MODE_RES32 = 5, MODE_PJACOBI = 6,
+       MODE_JNORM = 7 };   // Jacobi sweep that also accumulates ||b - A u||^2 of its INPUT (norm of cycle k + first sweep of cycle k+1)
 
 // Interpolated coarse correction (row of pro, src/solver.c:1140-1148) at the VX fine points (k, i, x0..x0+VX-1),
 // x0 a multiple of VX: parents summed in ascending coarse index (kc, ic, jc) exactly like k_prolong_add.
@@ -523,7 +524,7 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
         }
     }
 
-    double acc = 0.0;   // MODE_RESNORM / MODE_RES32
+    double acc = 0.0;   // MODE_RESNORM / MODE_RES32 / MODE_JNORM
     const int ic_base = PJ ? (ty * TY) / 2 - 1 : 0, jc_base = PJ ? (tx * TX) / 2 - 1 : 0;
     T cnew[NL];
     int kc_new = -2;                             // coarse plane held in cnew (none)
@@ -603,7 +604,7 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
         for (int r = 0; r < RY; r++) {
             const VT s2 = (r == 0) ? Sn : uc[r > 0 ? r - 1 : 0];
             const VT n2 = (r == RY - 1) ? Nn : uc[r < RY - 1 ? r + 1 : r];
-            VT o;
+            VT o, rsq;
 #pragma unroll
             for (int e = 0; e < VX; e++) {
                 const T wv = (e == 0) ? Wn[r] : uc[r].v[e > 0 ? e - 1 : 0];
@@ -616,7 +617,8 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
                 if (DIM == 3) t = t + a.a5 * n2.v[e];
                 t = t + c6 * up[r].v[e];
                 const T res = bc[r].v[e] - t;
-                if (MODE == MODE_JACOBI || MODE == MODE_PJACOBI) {
+                if (MODE == MODE_JNORM) rsq.v[e] = res;
+                if (MODE == MODE_JACOBI || MODE == MODE_PJACOBI || MODE == MODE_JNORM) {
                     const T zz = res * dv;
                     o.v[e] = uc[r].v[e] + a.scale * zz;
                 } else if (MODE == MODE_CHEBY) {
@@ -630,12 +632,16 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
             }
             if (lastvec) {                       // the vector straddles the end of the row: ghost / padding stay 0
 #pragma unroll
-                for (int e = 0; e < VX; e++) if (x0 + e >= a.nx) o.v[e] = (T)0;
+                for (int e = 0; e < VX; e++) if (x0 + e >= a.nx) { o.v[e] = (T)0; if (MODE == MODE_JNORM) rsq.v[e] = (T)0; }
             }
             if (rok[r]) {
                 if (MODE == MODE_RESNORM || MODE == MODE_RES32) {
 #pragma unroll
                     for (int e = 0; e < VX; e++) acc += (double)o.v[e] * (double)o.v[e];
+                }
+                if (MODE == MODE_JNORM) {
+#pragma unroll
+                    for (int e = 0; e < VX; e++) acc += (double)rsq.v[e] * (double)rsq.v[e];
                 }
                 if (MODE == MODE_RES32) {
                     float2 f; f.x = (float)o.v[0]; f.y = (float)o.v[VX - 1];     // T == double here (VX == 2)
@@ -679,7 +685,7 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
         }
     }
 
-    if (MODE == MODE_RESNORM || MODE == MODE_RES32) {
+    if (MODE == MODE_RESNORM || MODE == MODE_RES32 || MODE == MODE_JNORM) {
         __shared__ double red[16];
         double s = block_sum(acc, red);
         if (threadIdx.x == 0) a.partials[blockIdx.x] = s;
@@ -712,7 +718,7 @@ template <typename T, int DIM, int WX, int WY, int RY, int MODE>
 static int launch_st(mgk_ctx *c, StArgs<T> &a, int nrows, hipStream_t s, int *nblocks_out) {
     constexpr int VX = 16 / sizeof(T);
     constexpr int TX = 64 * VX * WX, TY = (DIM == 3) ? WY * RY : 1;
-    constexpr bool REDUCE = (MODE == MODE_RESNORM || MODE == MODE_RES32);
+    constexpr bool REDUCE = (MODE == MODE_RESNORM || MODE == MODE_RES32 || MODE == MODE_JNORM);
     a.ntx = (a.nx + 1 + TX - 1) / TX;
     a.nty = (DIM == 3) ? (nrows + TY - 1) / TY : 1;
     long tiles = (long)a.ntx * a.nty;
@@ -873,6 +879,20 @@ extern "C" int mgk_residual_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const doubl
     set_coef(a, g, coef);
     int nblk = 0;
     int rc = dispatch_st<MODE_RESNORM>(c, g, a, S(c, stream), &nblk);
+    if (rc) return rc;
+    return finish_to_host(c, nblk, 1, S(c, stream), sumsq_host);
+}
+
+// Jacobi sweep of u that also returns ||b - A u||^2: the residual norm that closes cycle k (src/solver.c:1545-1546)
+// and the first pre-smoothing sweep of cycle k+1 (:1531) read the same u and b and form the same residual.
+extern "C" int mgk_jacobi_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
+                                    const double *b, const double *u, double *unew, double *sumsq_host, void *stream) {
+    if (!c || !g || !coef || !b || !u || !unew || u == unew || !sumsq_host) return fail(MGK_EINVAL, "mgk_jacobi_sumsq_f64: bad arguments");
+    StArgs<double> a; memset(&a, 0, sizeof(a));
+    a.u = u + g->org; a.b = b + g->org; a.out = unew + g->org; a.partials = c->partials;
+    set_coef(a, g, coef); a.dinv = dinv; a.scale = scale;
+    int nblk = 0;
+    int rc = dispatch_st<MODE_JNORM>(c, g, a, S(c, stream), &nblk);
     if (rc) return rc;
     return finish_to_host(c, nblk, 1, S(c, stream), sumsq_host);
 }

@@ -203,3 +203,24 @@ def test_fused_residual_restrict_bit_exact(mgk, orc, nf):
     mgk.L.mgk_set_tuning(-1, -1)
     for p in (du, db, dbc):
         mgk.free(p)
+
+
+@pytest.mark.parametrize("dim,n,variant", [(3, 7, 0), (3, 31, 2), (3, 127, 1), (3, 255, 6), (2, 127, 0), (2, 1023, 2)])
+def test_sweep_with_input_residual_norm_bit_exact(mgk, orc, dim, n, variant):
+    """mgk_jacobi_sumsq_f64: the sweep is the plain Jacobi sweep, the sum is ||b - A u||^2 of the INPUT field"""
+    rng = np.random.default_rng(4000 + n)
+    As = _stencil(orc, dim, n)
+    dinv = 1.0 / As[3 if dim == 3 else 2]
+    u, b = _rand(rng, n ** dim), _rand(rng, n ** dim)
+    g = mgk.geom(dim, n)
+    du, db, dout = mgk.to_field(g, u), mgk.to_field(g, b), mgk.field(g)
+    ss = C.c_double()
+    for zc in (-1, 5):
+        mgk.L.mgk_set_tuning(variant, zc)
+        mgk._chk(mgk.L.mgk_jacobi_sumsq_f64(mgk.ctx, C.byref(g), mgk.coef(As), dinv, 0.8, db, du, dout, C.byref(ss), None))
+        assert np.array_equal(mgk.from_field(g, dout), orc.jacobi(dim, n, As, 0.8, b, u))
+        want = orc.sumsq(orc.residual(dim, n, As, b, u))
+        assert abs(ss.value - want) <= 1e-13 * want
+    mgk.L.mgk_set_tuning(-1, -1)
+    for p in (du, db, dout):
+        mgk.free(p)

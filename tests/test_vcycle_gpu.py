@@ -178,3 +178,29 @@ def test_own_c_driver_prints_reference_style_summary(orc, tmp_path):
     assert e0 == orc.error_norms(3, 65, ref["u"])[0]
     rdat = np.array((tmp_path / "rData.dat").read_text().split(), dtype=np.float64)
     assert np.max(np.abs(rdat - ref["rnorm"] / ref["rnorm"][0]) / rdat) <= 1e-12
+
+
+@pytest.mark.parametrize("dim,npts,levels", [(3, 65, 6), (2, 257, 8), (3, 33, 1)])
+def test_speculative_first_sweep_changes_nothing(dim, npts, levels):
+    """fuse bit 3: the kernel that evaluates ||r|| at the end of cycle k also makes the first sweep of cycle k+1.
+    Same fields, same history; the solution left behind when the iteration stops is u, not the speculative sweep;
+    fixed-count cycling (bench.py's path) agrees with the convergence-driven loop."""
+    from multigrid_petsc_amd.solver import Solver
+    scale = 6.0 / 7.0 if dim == 3 else 0.8
+    res = {}
+    for fuse in (7, 15):
+        s = Solver(dim, npts, levels, v=(3, 3), maxiter=60, scale=scale, fuse=fuse)
+        s.set_rhs_problem()
+        it = s.solve()
+        res[fuse] = (it, s.rnorm.copy(), s.solution())
+        s.close()
+    assert res[7][0] == res[15][0]
+    assert np.abs(res[7][1] / res[15][1] - 1).max() <= 1e-13
+    assert np.array_equal(res[7][2], res[15][2])
+    s = Solver(dim, npts, levels, v=(3, 3), maxiter=60, scale=scale, fuse=15)
+    s.set_rhs_problem()
+    s.cycles(2)
+    s.cycles(res[15][0] - 2)
+    s.sync()
+    assert np.array_equal(s.solution(), res[15][2]) and np.abs(s.rnorm / res[15][1] - 1).max() <= 1e-13
+    s.close()

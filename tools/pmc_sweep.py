@@ -30,5 +30,7 @@ uc, bc = m.field(gc), m.field(gc)
 for _ in range(2):
     m._chk(L.mgk_restrict_fw_f64(m.ctx, C.byref(g), C.byref(gc), out, bc, None))
     m._chk(L.mgk_prolong_add_f64(m.ctx, C.byref(g), C.byref(gc), uc, u, None))
+    m._chk(L.mgk_residual_restrict_f64(m.ctx, C.byref(g), C.byref(gc), coef, b, u, bc, None))
+    m._chk(L.mgk_prolong_jacobi_f64(m.ctx, C.byref(g), C.byref(gc), coef, dinv, 6.0 / 7.0, b, uc, u, out, None))
 m.sync()
 m.close()
