@@ -201,6 +201,10 @@ int  mgk_residual_restrict_f32(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom 
 int  mgk_residual_f64_to_f32(mgk_ctx *ctx, const mgk_geom *g, const mgk_geom *g32, const double *coef,
                              const double *b, const double *u, float *r32, double *sumsq_host, void *stream);
 /* u64 += (double) e32 */
+/* both of the above in one pass: unew = u + (double) e32, r32 = (float)(b - A unew), *sumsq_host = sum r^2 (32 B/unknown) */
+int  mgk_correct_residual_f64_f32(mgk_ctx *ctx, const mgk_geom *g, const mgk_geom *g32, const double *coef,
+                                  const double *b, const double *u, const float *e32, double *unew, float *r32,
+                                  double *sumsq_host, void *stream);
 int  mgk_correct_f64_from_f32(mgk_ctx *ctx, const mgk_geom *g, const mgk_geom *g32, const float *e32, double *u, void *stream);
 int  mgk_pack_f32(mgk_ctx *ctx, const mgk_geom *g32, const double *compact_dev, float *padded_dev, void *stream);
 int  mgk_unpack_f32(mgk_ctx *ctx, const mgk_geom *g32, const float *padded_dev, double *compact_dev, void *stream);

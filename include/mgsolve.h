@@ -40,7 +40,8 @@ typedef struct mg_config {
     int fuse;           /* bit 0: final residual fused with its norm (no rv write); bit 1: prolongation fused into the
                          * first post-smoothing sweep; bit 2: pre-restriction residual fused with the restriction (whole grids);
                          * bit 3: the residual norm that closes a cycle is evaluated by the kernel that also makes the first
-                         * pre-smoothing sweep of the next cycle (adopted only if a next cycle runs); default (-1): all on */
+                         * pre-smoothing sweep of the next cycle (adopted only if a next cycle runs); bit 4 (mixed precision): the
+                         * fp64 correction u += e and the fp64 residual -> fp32 in one pass; default (-1): all on */
     int overlap;        /* nranks > 1: halo of sweep k on the comm stream while sweep k's interior runs; default on (-1) */
     int graph;          /* replay the launch-bound coarse levels as one captured HIP graph; default on (-1) */
 } mg_config;

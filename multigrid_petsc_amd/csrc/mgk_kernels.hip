@@ -329,7 +329,8 @@ struct StArgs {
     long crs, cms;
     int nxc, nyc, nzc;
     T *out;
-    float *out32;          // MODE_RES32: float copy of the fp64 residual (own strides below)
+    float *out32;          // MODE_RES32 / MODE_CRES32: float copy of the fp64 residual (own strides below)
+    const float *e32;      // MODE_CRES32: fp32 correction added to u on the fly (same fp32 geometry as out32)
     double *partials;
     int nx, ny, nm;       // nm: number of marching planes (nz in 3-D, ny in 2-D)
     long rs, ms;          // row stride (3-D: pitch), marching stride (3-D: plane, 2-D: pitch)
@@ -343,7 +344,8 @@ struct StArgs {
 };
 
 enum { MODE_JACOBI = 0, MODE_RESIDUAL = 1, MODE_CHEBY = 2, MODE_RESNORM = 3, MODE_APPLY = 4, MODE_RES32 = 5, MODE_PJACOBI = 6,
-       MODE_JNORM = 7 };   // Jacobi sweep that also accumulates ||b - A u||^2 of its INPUT (norm of cycle k + first sweep of cycle k+1)
+       MODE_JNORM = 7,     // Jacobi sweep that also accumulates ||b - A u||^2 of its INPUT (norm of cycle k + first sweep of cycle k+1)
+       MODE_CRES32 = 8 };  // mixed precision outer step in one pass: u' = u + (double)e32 (written), r32 = (float)(b - A u'), sum r^2
 
 // Interpolated coarse correction (row of pro, src/solver.c:1140-1148) at the VX fine points (k, i, x0..x0+VX-1),
 // x0 a multiple of VX: parents summed in ascending coarse index (kc, ic, jc) exactly like k_prolong_add.
@@ -388,6 +390,33 @@ __device__ __forceinline__ T prolong_one(const T *uc, long crs, long cms, int k,
         for (int qi = 0; qi < nic; qi++)
             for (int qj = 0; qj < njc; qj++) s += w * cr[(long)qk * cms + (long)qi * crs + qj];
     return s;
+}
+// MODE_CRES32: the fp32 correction at the VX fine points (k, i, x0..) / at one point, widened to T (ghost cells hold 0)
+template <typename T>
+__device__ __forceinline__ V16<T> e32_vec(const float *e, long ers, long ems, int k, int i, int x0) {
+    constexpr int VX = 16 / sizeof(T);
+    const float *p = e + (long)k * ems + (long)i * ers + x0;
+    V16<T> s;
+#pragma unroll
+    for (int q = 0; q < VX; q += 2) {
+        const float2 f = *reinterpret_cast<const float2 *>(p + q);
+        s.v[q] = (T)f.x; s.v[q + 1] = (T)f.y;
+    }
+    return s;
+}
+// raw fp32 values of one lane vector (kept unconverted while the load is in flight)
+template <int VX>
+__device__ __forceinline__ void e32_raw(const float *p, float (&dst)[VX], bool ok) {
+#pragma unroll
+    for (int q = 0; q < VX; q += 2) {
+        float2 f = make_float2(0.f, 0.f);
+        if (ok) f = *reinterpret_cast<const float2 *>(p + q);
+        dst[q] = f.x; dst[q + 1] = f.y;
+    }
+}
+template <typename T>
+__device__ __forceinline__ T e32_one(const float *e, long ers, long ems, int k, int i, int x) {
+    return (T)e[(long)k * ems + (long)i * ers + x];
 }
 // The same sum with the parents taken from the block's LDS ring of coarse plane tiles (MODE_PJACOBI marching loop):
 // cl[slot][row][col], slot = (kc+3)%3, row = ic - ic_base, col = jc - jc_base; `xh2` = (local x of the vector)/2.
@@ -438,6 +467,10 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
     // interpolation of the planes the loop brings in; loaded cooperatively one step ahead of its first use
     // (only for blocks of <= 512 threads: a 1024-thread block is capped at 128 VGPRs and would spill)
     constexpr bool PJ = (MODE == MODE_PJACOBI) && (DIM == 3) && (64 * WX * WY <= 512);
+    // modes that read u through an additive correction (coarse interpolant / fp32 correction) at every point they touch
+    constexpr bool ADDU = (MODE == MODE_PJACOBI || MODE == MODE_CRES32);
+#define ADDV(zz, yy, xx) ((MODE == MODE_CRES32) ? e32_vec<T>(a.e32, a.ors, a.oms, zz, yy, xx) : prolong_vec(a.uc, a.crs, a.cms, zz, yy, xx))
+#define ADD1(zz, yy, xx) ((MODE == MODE_CRES32) ? e32_one<T>(a.e32, a.ors, a.oms, zz, yy, xx) : prolong_one(a.uc, a.crs, a.cms, zz, yy, xx))
     constexpr int TYC = PJ ? (TY / 2 + 2) : 1, CW = PJ ? (TX / 2 + 2) : 1, CWP = PJ ? (CW + 2) : 1;
     constexpr int NTHR = 64 * WX * WY, NLC = PJ ? ((CW + NTHR - 1) / NTHR) : 1, NL = TYC * NLC;   // thread t loads column t (+k*NTHR) of every tile row
     static_assert(!PJ || (TY % 2 == 0), "fused prolongation needs an even tile height");
@@ -501,15 +534,15 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
         const bool hok = xhok && (DIM == 2 || yb + r < a.ny);
         T xc = hok ? hp_[(long)z0 * a.ms + ro] : (T)0;
         xp[r] = hok ? hp_[(long)(z0 + 1) * a.ms + ro] : (T)0;
-        if (MODE == MODE_PJACOBI) {          // u := u + P e on everything this block reads
+        if (ADDU) {                          // u := u + P e (or + e32) on everything this block reads
             if (rok[r]) {
-                um[r] = vadd(um[r], prolong_vec(a.uc, a.crs, a.cms, z0 - 1, yb + r, x0));
-                uc[r] = vadd(uc[r], prolong_vec(a.uc, a.crs, a.cms, z0, yb + r, x0));
-                up[r] = vadd(up[r], prolong_vec(a.uc, a.crs, a.cms, z0 + 1, yb + r, x0));
+                um[r] = vadd(um[r], ADDV(z0 - 1, yb + r, x0));
+                uc[r] = vadd(uc[r], ADDV(z0, yb + r, x0));
+                up[r] = vadd(up[r], ADDV(z0 + 1, yb + r, x0));
             }
             if (hok) {
-                xc = xc + prolong_one(a.uc, a.crs, a.cms, z0, yb + r, xh);
-                xp[r] = xp[r] + prolong_one(a.uc, a.crs, a.cms, z0 + 1, yb + r, xh);
+                xc = xc + ADD1(z0, yb + r, xh);
+                xp[r] = xp[r] + ADD1(z0 + 1, yb + r, xh);
             }
         }
         *reinterpret_cast<VT *>(&lds[0][lrow + r][xl + VX]) = uc[r];
@@ -518,12 +551,14 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
     if (DIM == 3) {
         hS = ldv(up_ + (long)z0 * a.ms - a.rs, okS);
         hN = ldv(up_ + (long)z0 * a.ms + (long)RY * a.rs, okN);
-        if (MODE == MODE_PJACOBI) {
-            if (okS) hS = vadd(hS, prolong_vec(a.uc, a.crs, a.cms, z0, yb - 1, x0));
-            if (okN) hN = vadd(hN, prolong_vec(a.uc, a.crs, a.cms, z0, yb + RY, x0));
+        if (ADDU) {
+            if (okS) hS = vadd(hS, ADDV(z0, yb - 1, x0));
+            if (okN) hN = vadd(hN, ADDV(z0, yb + RY, x0));
         }
     }
 
+    // MODE_CRES32: fp32 corrections of the plane being brought in, loaded one step ahead like u itself
+    float erw[RY][VX], ehSr[VX], ehNr[VX], exr[RY];
     double acc = 0.0;   // MODE_RESNORM / MODE_RES32 / MODE_JNORM
     const int ic_base = PJ ? (ty * TY) / 2 - 1 : 0, jc_base = PJ ? (tx * TX) / 2 - 1 : 0;
     T cnew[NL];
@@ -562,6 +597,17 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
             if (DIM == 3) {
                 hSn = ldv(up_ + (long)(z + 1) * a.ms - a.rs, okS);
                 hNn = ldv(up_ + (long)(z + 1) * a.ms + (long)RY * a.rs, okN);
+            }
+            if (MODE == MODE_CRES32) {
+                const float *ep = a.e32 + (long)(z + 2) * a.oms + (long)yb * a.ors + x0;
+#pragma unroll
+                for (int r = 0; r < RY; r++) {
+                    e32_raw<VX>(ep + (long)r * a.ors, erw[r], rok[r]);
+                    const bool hok = xhok && (DIM == 2 || yb + r < a.ny);
+                    exr[r] = hok ? a.e32[(long)(z + 2) * a.oms + (long)(yb + r) * a.ors + xh] : 0.f;
+                }
+                e32_raw<VX>(ep - a.oms - a.ors, ehSr, okS);
+                e32_raw<VX>(ep - a.oms + (long)RY * a.ors, ehNr, okN);
             }
             if (PJ && (z & 1)) {                 // coarse plane (z+1)/2+1: first needed at step z+1
                 kc_new = (z + 1) / 2 + 1;
@@ -635,7 +681,7 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
                 for (int e = 0; e < VX; e++) if (x0 + e >= a.nx) { o.v[e] = (T)0; if (MODE == MODE_JNORM) rsq.v[e] = (T)0; }
             }
             if (rok[r]) {
-                if (MODE == MODE_RESNORM || MODE == MODE_RES32) {
+                if (MODE == MODE_RESNORM || MODE == MODE_RES32 || MODE == MODE_CRES32) {
 #pragma unroll
                     for (int e = 0; e < VX; e++) acc += (double)o.v[e] * (double)o.v[e];
                 }
@@ -643,9 +689,10 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
 #pragma unroll
                     for (int e = 0; e < VX; e++) acc += (double)rsq.v[e] * (double)rsq.v[e];
                 }
-                if (MODE == MODE_RES32) {
+                if (MODE == MODE_RES32 || MODE == MODE_CRES32) {
                     float2 f; f.x = (float)o.v[0]; f.y = (float)o.v[VX - 1];     // T == double here (VX == 2)
                     *reinterpret_cast<float2 *>(a.out32 + (DIM == 3 ? (long)yb * a.ors : 0) + x0 + (long)z * a.oms + (long)r * a.ors) = f;
+                    if (MODE == MODE_CRES32) stv_stream(a.out + rowoff + x0 + (long)z * a.ms + (long)r * a.rs, uc[r]);   // the corrected u
                 } else if (MODE != MODE_RESNORM) {
                     stv_stream(a.out + rowoff + x0 + (long)z * a.ms + (long)r * a.rs, o);
                 }
@@ -661,16 +708,22 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
                 um[r] = uc[r]; uc[r] = up[r]; up[r] = uq[r];
                 bc[r] = bn[r]; xp[r] = xq[r];
                 if (MODE == MODE_CHEBY) ac[r] = an[r];
-                if (MODE == MODE_PJACOBI) {
-                    if (rok[r]) up[r] = vadd(up[r], PJ ? prolong_vec_lds(cl, ic_base, z + 2, yb + r, xl / 2)
-                                                        : prolong_vec(a.uc, a.crs, a.cms, z + 2, yb + r, x0));
-                    if (xhok && (DIM == 2 || yb + r < a.ny)) xp[r] = xp[r] + prolong_one(a.uc, a.crs, a.cms, z + 2, yb + r, xh);
+                if (MODE == MODE_CRES32) {
+#pragma unroll
+                    for (int e = 0; e < VX; e++) up[r].v[e] = up[r].v[e] + (T)erw[r][e];
+                    xp[r] = xp[r] + (T)exr[r];
+                } else if (ADDU) {
+                    if (rok[r]) up[r] = vadd(up[r], PJ ? prolong_vec_lds(cl, ic_base, z + 2, yb + r, xl / 2) : ADDV(z + 2, yb + r, x0));
+                    if (xhok && (DIM == 2 || yb + r < a.ny)) xp[r] = xp[r] + ADD1(z + 2, yb + r, xh);
                 }
             }
             hS = hSn; hN = hNn;
-            if (MODE == MODE_PJACOBI) {
-                if (okS) hS = vadd(hS, PJ ? prolong_vec_lds(cl, ic_base, z + 1, yb - 1, xl / 2) : prolong_vec(a.uc, a.crs, a.cms, z + 1, yb - 1, x0));
-                if (okN) hN = vadd(hN, PJ ? prolong_vec_lds(cl, ic_base, z + 1, yb + RY, xl / 2) : prolong_vec(a.uc, a.crs, a.cms, z + 1, yb + RY, x0));
+            if (MODE == MODE_CRES32) {
+#pragma unroll
+                for (int e = 0; e < VX; e++) { hS.v[e] = hS.v[e] + (T)ehSr[e]; hN.v[e] = hN.v[e] + (T)ehNr[e]; }
+            } else if (ADDU) {
+                if (okS) hS = vadd(hS, PJ ? prolong_vec_lds(cl, ic_base, z + 1, yb - 1, xl / 2) : ADDV(z + 1, yb - 1, x0));
+                if (okN) hN = vadd(hN, PJ ? prolong_vec_lds(cl, ic_base, z + 1, yb + RY, xl / 2) : ADDV(z + 1, yb + RY, x0));
                 if (PJ && kc_new >= -1) {        // publish the coarse plane fetched at the top of this step
                     const int slot = (kc_new + 3) % 3;
 #pragma unroll
@@ -685,11 +738,13 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
         }
     }
 
-    if (MODE == MODE_RESNORM || MODE == MODE_RES32 || MODE == MODE_JNORM) {
+    if (MODE == MODE_RESNORM || MODE == MODE_RES32 || MODE == MODE_JNORM || MODE == MODE_CRES32) {
         __shared__ double red[16];
         double s = block_sum(acc, red);
         if (threadIdx.x == 0) a.partials[blockIdx.x] = s;
     }
+#undef ADDV
+#undef ADD1
 }
 
 // sum `n` partials in a fixed order (one block) -> out[slot]
@@ -718,7 +773,7 @@ template <typename T, int DIM, int WX, int WY, int RY, int MODE>
 static int launch_st(mgk_ctx *c, StArgs<T> &a, int nrows, hipStream_t s, int *nblocks_out) {
     constexpr int VX = 16 / sizeof(T);
     constexpr int TX = 64 * VX * WX, TY = (DIM == 3) ? WY * RY : 1;
-    constexpr bool REDUCE = (MODE == MODE_RESNORM || MODE == MODE_RES32 || MODE == MODE_JNORM);
+    constexpr bool REDUCE = (MODE == MODE_RESNORM || MODE == MODE_RES32 || MODE == MODE_JNORM || MODE == MODE_CRES32);
     a.ntx = (a.nx + 1 + TX - 1) / TX;
     a.nty = (DIM == 3) ? (nrows + TY - 1) / TY : 1;
     long tiles = (long)a.ntx * a.nty;
@@ -768,7 +823,7 @@ static int dispatch_st(mgk_ctx *c, const mgk_geom *g, StArgs<double> &a, hipStre
         a.ny = g->ny; a.nm = g->nz; a.rs = g->pitch; a.ms = g->plane;
         int v = g_variant;
         if (v < 0) v = (MODE == MODE_RESNORM && g->nx >= 255) ? 3
-                     : (g->nx >= 1023) ? (MODE == MODE_PJACOBI ? 9 : 12)      // fused prolongation: 512-thread blocks (LDS-staged parents)
+                     : (g->nx >= 1023) ? ((MODE == MODE_PJACOBI || MODE == MODE_CRES32) ? 9 : 12)   // on-the-fly corrections: 512-thread blocks (a 1024-thread block is capped at 128 VGPRs and spills)
                      : (g->nx >= 511) ? 6 : (g->nx >= 255) ? 2 : (g->nx >= 127 ? 1 : 0);
         switch (v) {
             case 0: return launch_st<double, 3, 1, 2, 2, MODE>(c, a, g->ny, s, nblocks);   // 128 x 4, 128 thr
@@ -1429,6 +1484,26 @@ extern "C" int mgk_residual_f64_to_f32(mgk_ctx *c, const mgk_geom *g, const mgk_
     set_coef(a, g, coef);
     int nblk = 0;
     int rc = dispatch_st<MODE_RES32>(c, g, a, S(c, stream), &nblk);
+    if (rc) return rc;
+    return finish_to_host(c, nblk, 1, S(c, stream), sumsq_host);
+}
+
+// The whole outer step of the mixed-precision iteration in one pass: unew = u + (double) e32 (written), r32 = (float)(b - A unew),
+// sum r^2.  Every u value the block touches is corrected on the fly, like the fused prolongation sweep does with the
+// coarse interpolant: 8 (u) + 4 (e32) + 8 (b) read, 8 (unew) + 4 (r32) written = 32 B instead of 20 + 20.
+extern "C" int mgk_correct_residual_f64_f32(mgk_ctx *c, const mgk_geom *g, const mgk_geom *g32, const double *coef,
+                                            const double *b, const double *u, const float *e32, double *unew, float *r32,
+                                            double *sumsq_host, void *stream) {
+    if (!c || !g || !g32 || !coef || !b || !u || !e32 || !unew || !r32 || !sumsq_host || u == unew || (const float *)r32 == e32 ||
+        g->dim != 3 || g->nx != g32->nx || g->ny != g32->ny || g->nz != g32->nz)
+        return fail(MGK_EINVAL, "mgk_correct_residual_f64_f32: bad arguments");
+    StArgs<double> a; memset(&a, 0, sizeof(a));
+    a.u = u + g->org; a.b = b + g->org; a.out = unew + g->org;
+    a.out32 = r32 + g32->org; a.e32 = e32 + g32->org; a.ors = g32->pitch; a.oms = g32->plane;
+    a.partials = c->partials;
+    set_coef(a, g, coef);
+    int nblk = 0;
+    int rc = dispatch_st<MODE_CRES32>(c, g, a, S(c, stream), &nblk);
     if (rc) return rc;
     return finish_to_host(c, nblk, 1, S(c, stream), sumsq_host);
 }

@@ -62,6 +62,7 @@ def _sigs(L):
         "mgk_prolong_add_f32": (i, [vp, G, G, vp, vp, vp]),
         "mgk_residual_f64_to_f32": (i, [vp, G, G, c_dp, vp, vp, vp, C.POINTER(d), vp]),
         "mgk_correct_f64_from_f32": (i, [vp, G, G, vp, vp, vp]),
+        "mgk_correct_residual_f64_f32": (i, [vp, G, G, c_dp, vp, vp, vp, vp, vp, C.POINTER(d), vp]),
         "mgk_pack_f32": (i, [vp, G, vp, vp, vp]),
         "mgk_unpack_f32": (i, [vp, G, vp, vp, vp]),
         "mgk_apply_f64": (i, [vp, G, c_dp, vp, vp, vp]),

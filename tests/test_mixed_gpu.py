@@ -115,3 +115,43 @@ def test_fused_residual_restrict_fp32_bit_exact(mgk, orc, nf):
     mgk.L.mgk_set_tuning(-1, -1)
     for p in (du, db, dbc):
         mgk.free(p)
+
+
+@pytest.mark.parametrize("n,variant", [(1, -1), (3, -1), (7, 0), (31, 2), (63, 1), (127, 6), (255, 9), (255, 3)])
+def test_fused_correction_and_residual_bit_exact(mgk, orc, n, variant):
+    """mgk_correct_residual_f64_f32 == mgk_correct_f64_from_f32 followed by mgk_residual_f64_to_f32"""
+    rng = np.random.default_rng(900 + n)
+    N = n ** 3
+    As = orc.level_stencil(3, n + 2, 0)[0]
+    u, b, e = rng.uniform(-1, 1, N), rng.uniform(-1, 1, N), rng.uniform(-1, 1, N).astype(np.float32)
+    g, g32 = mgk.geom(3, n), mgk.geom32(n)
+    du, db, dun = mgk.to_field(g, u), mgk.to_field(g, b), mgk.field(g)
+    de, dr32 = mgk.to_field32(g32, e), mgk.alloc(4 * g32.total)
+    mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dr32, 4 * g32.total, None))
+    ss = C.c_double()
+    ucorr = u + e.astype(np.float64)
+    r = orc.residual(3, n, As, b, ucorr)
+    for zc in (-1, 3):
+        mgk.L.mgk_set_tuning(variant, zc)
+        mgk._chk(mgk.L.mgk_correct_residual_f64_f32(mgk.ctx, C.byref(g), C.byref(g32), mgk.coef(As), db, du, de, dun, dr32, C.byref(ss), None))
+        assert np.array_equal(mgk.from_field(g, dun), ucorr)
+        assert np.array_equal(mgk.from_field32(g32, dr32), r.astype(np.float32))
+        assert abs(ss.value - orc.sumsq(r)) <= 1e-13 * orc.sumsq(r)
+        raw = mgk.raw_field(g, dun)                      # ghosts of the corrected field stay zero
+        assert abs(np.abs(raw).sum() - np.abs(ucorr).sum()) <= 1e-9 * np.abs(ucorr).sum()
+    mgk.L.mgk_set_tuning(-1, -1)
+    for p in (du, db, dun, de, dr32):
+        mgk.free(p)
+
+
+def test_mixed_fused_outer_step_changes_nothing():
+    from multigrid_petsc_amd.solver import Solver
+    res = {}
+    for fuse in (15, 31):
+        s = Solver(3, 65, 6, scale=6.0 / 7.0, maxiter=60, precision="mixed", fuse=fuse)
+        s.set_rhs_problem()
+        it = s.solve()
+        res[fuse] = (it, s.rnorm.copy(), s.solution())
+        s.close()
+    assert res[15][0] == res[31][0] and np.array_equal(res[15][2], res[31][2])
+    assert np.abs(res[15][1] / res[31][1] - 1).max() <= 1e-13
