@@ -787,7 +787,8 @@ static int launch_st(mgk_ctx *c, StArgs<T> &a, int nrows, hipStream_t s, int *nb
         // so does the 2-D kernel (a tile is one row segment: little work per marching step).
         long nch = (MODE == MODE_RESNORM) ? (4096 + tiles - 1) / tiles
                  : (DIM == 2)             ? (1024 + tiles - 1) / tiles
-                 : (tiles >= 256)         ? 1 : (512 + tiles - 1) / tiles;
+                 : (tiles >= 256)         ? ((64 * WX * WY <= 256) ? 2 : 1)     // small blocks: two per CU (fp32 PJ 3.45 -> 2.96 ms)
+                                          : (512 + tiles - 1) / tiles;
         zc = (int)((nmr + nch - 1) / nch);
         // 2-D: a marching step is one row segment, so a small level only fills the chip when it is cut into many short
         // chunks (measured at 255^2..1023^2: 16-row chunks left 32-128 blocks, 18-20 us per sweep; 4097^2 cycle 1.57 -> 1.12 ms)
@@ -854,7 +855,7 @@ static int dispatch_st(mgk_ctx *c, const mgk_geom *g, StArgs<float> &a, hipStrea
     if (g->dim != 3) return fail(MGK_EINVAL, "fp32 stencil kernels are built for 3-D only");
     a.ny = g->ny; a.nm = g->nz; a.rs = g->pitch; a.ms = g->plane;
     int v = g_variant;
-    if (v < 0) v = (g->nx >= 1023) ? 2 : (g->nx >= 511) ? 1 : 0;
+    if (v < 0) v = (g->nx >= 1023) ? (MODE == MODE_PJACOBI ? 3 : 2) : (g->nx >= 511) ? 1 : 0;
     switch (v) {
         case 0: return launch_st<float, 3, 1, 2, 2, MODE>(c, a, g->ny, s, nblocks);   // 256 x 4, 128 thr
         case 1: return launch_st<float, 3, 2, 2, 2, MODE>(c, a, g->ny, s, nblocks);   // 512 x 4, 256 thr
@@ -1766,7 +1767,9 @@ static int residual_restrict(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc,
     a.a0 = (T)coef[0]; a.a1 = (T)coef[1]; a.a2 = (T)coef[2]; a.a3 = (T)coef[3]; a.a4 = (T)coef[4]; a.a5 = (T)coef[5]; a.a6 = (T)coef[6];
     a.nty = (gf->ny - 1 + 3) / 4;                 // tiles of 5 rows at stride 4; ny = 2 nyc + 1
     if (a.nty < 1) a.nty = 1;
-    long nch = (a.nty >= 256) ? 1 : (512 + a.nty - 1) / a.nty;
+    const int w = (gf->nx + 1 + 64 * VX - 1) / (64 * VX);       // waves needed for a full row
+    // blocks of <= 256 threads (fp32 rows) leave room for two per CU: cut z in two (fp32 at 1023^3: 2.78 -> 1.82 ms)
+    long nch = (a.nty >= 256) ? ((w <= 4) ? 2 : 1) : (512 + a.nty - 1) / a.nty;
     if (g_zchunk > 0) nch = (gc->nz + g_zchunk - 1) / g_zchunk;
     int kcc = (int)((gc->nz + nch - 1) / nch);
     if (kcc < 4) kcc = 4;
@@ -1775,7 +1778,6 @@ static int residual_restrict(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc,
     const long ntz = (gc->nz + kcc - 1) / kcc;
     const unsigned nblk = (unsigned)(a.nty * ntz);
     hipStream_t s = S(c, stream);
-    const int w = (gf->nx + 1 + 64 * VX - 1) / (64 * VX);       // waves needed for a full row
     if (w <= 1) hipLaunchKernelGGL((k_resrestrict<T, 1>), dim3(nblk), dim3(64), 0, s, a);
     else if (w <= 2) hipLaunchKernelGGL((k_resrestrict<T, 2>), dim3(nblk), dim3(128), 0, s, a);
     else if (w <= 4) hipLaunchKernelGGL((k_resrestrict<T, 4>), dim3(nblk), dim3(256), 0, s, a);
