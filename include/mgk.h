@@ -119,6 +119,16 @@ int  mgk_jacobi_sumsq_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, d
 
 /* K2+K3 fused: b_coarse = R (b - A u), the fine residual is never written (src/solver.c:1534-1535).
  * Whole grids only (gf->nz == 2*gc->nz + 1); a slab uses mgk_residual_f64 + halo + mgk_restrict_fw_f64.  3-D. */
+/* residual on the planes (3-D) / rows (2-D) [zbeg, zend) only */
+int  mgk_residual_range_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, const double *b, const double *u, double *r,
+                            int zbeg, int zend, void *stream);
+int  mgk_residual_range_f32(mgk_ctx *ctx, const mgk_geom *g, const double *coef, const float *b, const float *u, float *r,
+                            int zbeg, int zend, void *stream);
+/* z-slab of a rank that is not the last (nzf = 2 nzc): mgk_residual_restrict_* leaves the last coarse plane partial (its
+ * dk = 0, 1 terms); this adds the dk = 2 terms from r's hi ghost plane (the neighbour's first residual plane) in the order
+ * of the row of res, so the result equals the whole-grid sum bit for bit */
+int  mgk_restrict_finish_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *r, double *bc, void *stream);
+int  mgk_restrict_finish_f32(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const float *r, float *bc, void *stream);
 int  mgk_residual_restrict_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
                                const double *b, const double *u, double *bc, void *stream);
 

@@ -36,7 +36,8 @@ typedef struct mg_config {
     int device;         /* HIP device ordinal */
     int precision;      /* mg_precision */
     int rank, nranks;   /* z-slab decomposition over `nranks` GPUs (1: whole grid) */
-    int dist_min_n;     /* levels with n >= dist_min_n stay distributed, coarser ones are replicated; <=0: default 127 */
+    int dist_min_n;     /* levels with n >= dist_min_n stay distributed, coarser ones are replicated; <=0: default 255
+                         * (below that a slab sweep is shorter than the latency of its halo exchange) */
     int fuse;           /* bit 0: final residual fused with its norm (no rv write); bit 1: prolongation fused into the
                          * first post-smoothing sweep; bit 2: pre-restriction residual fused with the restriction (whole grids);
                          * bit 3: the residual norm that closes a cycle is evaluated by the kernel that also makes the first

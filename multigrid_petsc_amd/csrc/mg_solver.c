@@ -61,6 +61,8 @@ typedef struct mg_ops {
     int (*prolong_add)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const void *, void *, void *);
     int (*prolong_jacobi)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const double *, double, double, const void *, const void *, const void *, void *, void *);
     int (*residual_restrict)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const double *, const void *, const void *, void *, void *);   /* NULL: not built */
+    int (*residual_range)(mgk_ctx *, const mgk_geom *, const double *, const void *, const void *, void *, int, int, void *);
+    int (*restrict_finish)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const void *, void *, void *);
 } mg_ops;
 
 #define W64(name) static int name##_64
@@ -79,9 +81,13 @@ W64(pj)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, dou
 W32(pj)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, double d, double sc, const void *b, const void *uc, const void *u, void *o, void *st) { return mgk_prolong_jacobi_f32(c, gf, gc, k, d, sc, (const float *)b, (const float *)uc, (const float *)u, (float *)o, st); }
 W64(rr)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, const void *b, const void *u, void *bc, void *st) { return mgk_residual_restrict_f64(c, gf, gc, k, (const double *)b, (const double *)u, (double *)bc, st); }
 W32(rr)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, const void *b, const void *u, void *bc, void *st) { return mgk_residual_restrict_f32(c, gf, gc, k, (const float *)b, (const float *)u, (float *)bc, st); }
+W64(rg)(mgk_ctx *c, const mgk_geom *g, const double *k, const void *b, const void *u, void *r, int z0, int z1, void *st) { return mgk_residual_range_f64(c, g, k, (const double *)b, (const double *)u, (double *)r, z0, z1, st); }
+W32(rg)(mgk_ctx *c, const mgk_geom *g, const double *k, const void *b, const void *u, void *r, int z0, int z1, void *st) { return mgk_residual_range_f32(c, g, k, (const float *)b, (const float *)u, (float *)r, z0, z1, st); }
+W64(fin)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const void *r, void *bc, void *st) { return mgk_restrict_finish_f64(c, gf, gc, (const double *)r, (double *)bc, st); }
+W32(fin)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const void *r, void *bc, void *st) { return mgk_restrict_finish_f32(c, gf, gc, (const float *)r, (float *)bc, st); }
 static const mg_ops OPS[2] = {
-    {8, jr_64, jz_64, rs_64, rf_64, pa_64, pj_64, rr_64},
-    {4, jr_32, jz_32, rs_32, rf_32, pa_32, pj_32, rr_32},
+    {8, jr_64, jz_64, rs_64, rf_64, pa_64, pj_64, rr_64, rg_64, fin_64},
+    {4, jr_32, jz_32, rs_32, rf_32, pa_32, pj_32, rr_32, rg_32, fin_32},
 };
 
 struct mg_solver {
@@ -201,7 +207,7 @@ void mg_config_default(mg_config *c) {
     c->emin = 0.0; c->emax = 0.0;
     c->rtol = 1.e-7;                             /* src/solver.c:1530 */
     c->device = 0; c->precision = MG_PREC_FP64;
-    c->rank = 0; c->nranks = 1; c->dist_min_n = 127;
+    c->rank = 0; c->nranks = 1; c->dist_min_n = 0;
     c->fuse = -1;
     c->overlap = -1;
     c->graph = -1;
@@ -239,7 +245,10 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
     mg_solver *s = (mg_solver *)calloc(1, sizeof(mg_solver));
     s->cfg = *cfg;
     if (s->cfg.rtol <= 0) s->cfg.rtol = 1.e-7;
-    if (s->cfg.dist_min_n <= 0) s->cfg.dist_min_n = 127;
+    if (s->cfg.dist_min_n <= 0) {               /* default; a fine grid smaller than that is still cut into slabs */
+        const int n0 = mg_grid_n(cfg->npts, 0);
+        s->cfg.dist_min_n = n0 < 255 ? n0 : 255;
+    }
     if (s->cfg.fuse < 0) s->cfg.fuse = 31;
     if (s->cfg.overlap < 0) s->cfg.overlap = 1;
     if (s->cfg.graph < 0) s->cfg.graph = 1;
@@ -651,6 +660,35 @@ static int descend(mg_solver *s, int P, int l) {
     if ((s->cfg.fuse & 4) && O->residual_restrict && s->cfg.dim == 3 && !Lf->distributed && Lf->n + 1 <= 1024) {
         /* :1534-1535 in one pass: b_l = R (b - A u), the fine residual is never written */
         CHK(O->residual_restrict(s->ctx, &Lf->f[P].g, &s->L[l].f[P].g, Lf->coef, Lf->f[P].b, Lf->f[P].u, s->L[l].f[P].b, NULL));
+    } else if ((s->cfg.fuse & 4) && O->residual_restrict && s->cfg.dim == 3 && Lf->distributed && Lf->n + 1 <= 1024 &&
+               Lf->f[P].g.nz >= 2) {
+        /* the same on a z-slab.  The last coarse plane of every rank but the last needs the residual of the NEXT rank's
+         * first plane: each rank evaluates that one plane first and ships it (comm stream) while the fused kernel
+         * runs over the slab and leaves its last coarse plane partial; a small kernel then appends the missing terms in
+         * the order of the row of res. */
+        mg_level *Lc = &s->L[l];
+        mg_fset *F = &Lf->f[P], *Cq = &Lc->f[P];
+        void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
+        const int me = s->cfg.rank, last = (me == s->cfg.nranks - 1);
+        mgk_geom gc = Cq->g;
+        void *bc = Cq->b;
+        if (!Lc->distributed) {                 /* slab -> replicated: my coarse planes land in place, then all-gather */
+            const int c0 = s->zstart[me], c1 = s->zstart[me + 1];
+            gc.nz = c1 - c0;
+            bc = (char *)Cq->b + (size_t)O->esz * (size_t)c0 * (size_t)Cq->g.plane;
+        }
+        CHK(ensure_u_ghosts(s, P, Lf));
+        CHK(O->residual_range(s->ctx, &F->g, Lf->coef, F->b, F->u, F->rv, 0, 1, cs));
+        CHK(mgk_stream_wait(s->ctx, ms, cs));
+        CHK(s->comm->halo(s->comm, s->ctx, F->rv, &F->g, O->esz, ms));
+        CHK(O->residual_restrict(s->ctx, &F->g, &gc, Lf->coef, F->b, F->u, bc, cs));
+        CHK(mgk_stream_wait(s->ctx, cs, ms));
+        if (!last) CHK(O->restrict_finish(s->ctx, &F->g, &gc, F->rv, bc, cs));
+        if (!Lc->distributed) {
+            CHK(mgk_stream_wait(s->ctx, ms, cs));
+            CHK(s->comm->allgather_planes(s->comm, s->ctx, Cq->b, &Cq->g, s->zstart, O->esz, ms));
+            CHK(mgk_stream_wait(s->ctx, cs, ms));
+        }
     } else {
         CHK(residual(s, P, l - 1));                                     /* :1534 */
         CHK(restrict_to(s, P, l));                                      /* :1535 */

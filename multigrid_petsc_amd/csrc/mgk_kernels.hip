@@ -902,13 +902,21 @@ extern "C" int mgk_cheby_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, 
     return dispatch_st<MODE_CHEBY>(c, g, a, S(c, stream), nullptr);
 }
 
-extern "C" int mgk_residual_f64(mgk_ctx *c, const mgk_geom *g, const double *coef,
-                                const double *b, const double *u, double *r, void *stream) {
+extern "C" int mgk_residual_range_f64(mgk_ctx *c, const mgk_geom *g, const double *coef,
+                                      const double *b, const double *u, double *r, int zbeg, int zend, void *stream) {
     if (!c || !g || !coef || !b || !u || !r || u == r) return fail(MGK_EINVAL, "mgk_residual_f64: bad arguments");
+    const int nm = (g->dim == 3) ? g->nz : g->ny;
+    if (zbeg < 0 || zend > nm || zbeg >= zend) return fail(MGK_EINVAL, "mgk_residual_range_f64: empty or out-of-range plane range");
     StArgs<double> a; memset(&a, 0, sizeof(a));
     a.u = u + g->org; a.b = b + g->org; a.out = r + g->org;
     set_coef(a, g, coef);
+    a.zbeg = zbeg; a.zend = zend;
     return dispatch_st<MODE_RESIDUAL>(c, g, a, S(c, stream), nullptr);
+}
+extern "C" int mgk_residual_f64(mgk_ctx *c, const mgk_geom *g, const double *coef,
+                                const double *b, const double *u, double *r, void *stream) {
+    if (!g) return fail(MGK_EINVAL, "mgk_residual_f64: bad arguments");
+    return mgk_residual_range_f64(c, g, coef, b, u, r, 0, (g->dim == 3) ? g->nz : g->ny, stream);
 }
 
 extern "C" int mgk_apply_f64(mgk_ctx *c, const mgk_geom *g, const double *coef,
@@ -1426,13 +1434,20 @@ extern "C" int mgk_jacobi_f32(mgk_ctx *c, const mgk_geom *g, const double *coef,
     if (!g) return fail(MGK_EINVAL, "mgk_jacobi_f32: bad arguments");
     return mgk_jacobi_range_f32(c, g, coef, dinv, scale, b, u, unew, 0, g->nz, stream);
 }
-extern "C" int mgk_residual_f32(mgk_ctx *c, const mgk_geom *g, const double *coef,
-                                const float *b, const float *u, float *r, void *stream) {
+extern "C" int mgk_residual_range_f32(mgk_ctx *c, const mgk_geom *g, const double *coef,
+                                      const float *b, const float *u, float *r, int zbeg, int zend, void *stream) {
     if (!c || !g || !coef || !b || !u || !r || u == r) return fail(MGK_EINVAL, "mgk_residual_f32: bad arguments");
+    if (zbeg < 0 || zend > g->nz || zbeg >= zend) return fail(MGK_EINVAL, "mgk_residual_range_f32: empty or out-of-range plane range");
     StArgs<float> a; memset(&a, 0, sizeof(a));
     a.u = u + g->org; a.b = b + g->org; a.out = r + g->org;
     set_coef(a, g, coef);
+    a.zbeg = zbeg; a.zend = zend;
     return dispatch_st<MODE_RESIDUAL>(c, g, a, S(c, stream), nullptr);
+}
+extern "C" int mgk_residual_f32(mgk_ctx *c, const mgk_geom *g, const double *coef,
+                                const float *b, const float *u, float *r, void *stream) {
+    if (!g) return fail(MGK_EINVAL, "mgk_residual_f32: bad arguments");
+    return mgk_residual_range_f32(c, g, coef, b, u, r, 0, g->nz, stream);
 }
 extern "C" int mgk_jacobi_zero_f32(mgk_ctx *c, const mgk_geom *g, double dinv, double scale,
                                    const float *b, float *unew, void *stream) {
@@ -1630,7 +1645,11 @@ __global__ void __launch_bounds__(64 * WX) k_resrestrict(const RRArgs<T> a) {
     const int yb = 4 * ty;
     const int kc0 = tz * a.kcc, kc1 = min(kc0 + a.kcc, a.nzc);
     if (kc0 >= kc1) return;
-    const int z0 = 2 * kc0, z1 = 2 * kc1 + 1;    // fine planes z0 .. z1-1 (= 2*kc1, shared with the next chunk)
+    const int z0 = 2 * kc0, z1u = 2 * kc1 + 1;   // fine planes z0 .. z1u-1 (= 2*kc1, shared with the next chunk)
+    // z-slab of a rank that is not the last one: nz = 2 nzc, the closing plane 2 nzc belongs to the next rank.  The last
+    // coarse plane is then left PARTIAL (its dk = 0, 1 terms); k_restrict_finish adds the dk = 2 terms from the
+    // neighbour's residual plane in the same order, so the sum is the one of the whole grid.
+    const int z1 = min(z1u, a.nz);
     const bool xok = x0 < a.nx;
     const bool lastvec = (x0 + VX > a.nx);
     bool rok[RR];
@@ -1747,6 +1766,33 @@ __global__ void __launch_bounds__(64 * WX) k_resrestrict(const RRArgs<T> a) {
             hS = hSn; hN = hNn;
         }
     }
+    if (z1u > z1) {                               // slab: partial last coarse plane (planes 2 kc, 2 kc + 1 of kc = kc1 - 1)
+#pragma unroll
+        for (int cl = 0; cl < 2; cl++)
+#pragma unroll
+            for (int q = 0; q < NCJ; q++)
+                if ((cl == 0 ? crow0 : crow1) && jc0 + q < a.nxc)
+                    a.bc[(long)(kc1 - 1) * a.cms + (long)(2 * ty + cl) * a.crs + jc0 + q] = acc[cl][q];
+    }
+}
+
+// closes the partial last coarse plane of a slab: bc(last) += sum_{di,dj} (1/4 w2[di][dj]) r(ghost plane), ascending (di, dj):
+// the dk = 2 terms of the row of res, appended to the running sum exactly as the whole-grid kernel would.
+template <typename T>
+__global__ void __launch_bounds__(256) k_restrict_finish(XferArgs a, const T *rghost, T *bclast) {
+    const int jc = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ic = blockIdx.y;
+    if (jc >= a.nxc || ic >= a.nyc) return;
+    const T w2[3][3] = {{(T)0.0625, (T)0.125, (T)0.0625}, {(T)0.125, (T)0.25, (T)0.125}, {(T)0.0625, (T)0.125, (T)0.0625}};
+    const T wk = (T)0.25;
+    T acc = bclast[(long)ic * a.pc + jc];
+#pragma unroll
+    for (int di = 0; di < 3; di++) {
+        const T *row = rghost + (long)(2 * ic + di) * a.pf + 2 * jc;
+#pragma unroll
+        for (int dj = 0; dj < 3; dj++) acc += (wk * w2[di][dj]) * row[dj];
+    }
+    bclast[(long)ic * a.pc + jc] = acc;
 }
 
 template <typename T>
@@ -1758,7 +1804,8 @@ static int residual_restrict(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc,
     XferArgs x;
     int rc = xfer_args(gf, gc, x);
     if (rc) return rc;
-    if (gf->nz != 2 * gc->nz + 1) return fail(MGK_EINVAL, "mgk_residual_restrict: whole grids only (nzf = 2 nzc + 1); slabs use residual + restrict");
+    if (gf->nz != 2 * gc->nz + 1 && gf->nz != 2 * gc->nz)
+        return fail(MGK_EINVAL, "mgk_residual_restrict: nzf must be 2 nzc + 1 (whole grid, last slab) or 2 nzc (inner slab: partial last plane)");
     if (gf->nx + 1 > 1024) return fail(MGK_EINVAL, "mgk_residual_restrict: nx + 1 > 1024 is not built");
     RRArgs<T> a; memset(&a, 0, sizeof(a));
     a.u = u + gf->org; a.b = b + gf->org; a.bc = bc + gc->org;
@@ -1792,6 +1839,26 @@ extern "C" int mgk_residual_restrict_f64(mgk_ctx *c, const mgk_geom *gf, const m
 extern "C" int mgk_residual_restrict_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
                                          const float *b, const float *u, float *bc, void *stream) {
     return residual_restrict<float>(c, gf, gc, coef, b, u, bc, stream);
+}
+template <typename T>
+static int restrict_finish(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const T *r, T *bc, void *stream) {
+    if (!c || !gf || !gc || !r || !bc || gf->dim != 3 || gf->nz != 2 * gc->nz)
+        return fail(MGK_EINVAL, "mgk_restrict_finish: inner slabs only (nzf = 2 nzc)");
+    XferArgs x;
+    int rc = xfer_args(gf, gc, x);
+    if (rc) return rc;
+    dim3 block(256), grid((gc->nx + 255) / 256, gc->ny);
+    // r's hi ghost plane (index nz) holds the neighbour's first residual plane; the last coarse plane is nzc - 1
+    hipLaunchKernelGGL((k_restrict_finish<T>), grid, block, 0, S(c, stream), x, r + gf->org + (long)gf->nz * gf->plane,
+                       bc + gc->org + (long)(gc->nz - 1) * gc->plane);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int mgk_restrict_finish_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *r, double *bc, void *stream) {
+    return restrict_finish<double>(c, gf, gc, r, bc, stream);
+}
+extern "C" int mgk_restrict_finish_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const float *r, float *bc, void *stream) {
+    return restrict_finish<float>(c, gf, gc, r, bc, stream);
 }
 
 // ------------------------------------------------------------------------------------------

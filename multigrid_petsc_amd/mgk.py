@@ -68,6 +68,10 @@ def _sigs(L):
         "mgk_apply_f64": (i, [vp, G, c_dp, vp, vp, vp]),
         "mgk_residual_restrict_f64": (i, [vp, G, G, c_dp, vp, vp, vp, vp]),
         "mgk_residual_restrict_f32": (i, [vp, G, G, c_dp, vp, vp, vp, vp]),
+        "mgk_residual_range_f64": (i, [vp, G, c_dp, vp, vp, vp, i, i, vp]),
+        "mgk_residual_range_f32": (i, [vp, G, c_dp, vp, vp, vp, i, i, vp]),
+        "mgk_restrict_finish_f64": (i, [vp, G, G, vp, vp, vp]),
+        "mgk_restrict_finish_f32": (i, [vp, G, G, vp, vp, vp]),
         "mgk_flat_dot": (i, [vp, C.c_long, vp, vp, C.POINTER(d), vp]),
         "mgk_stream_triad_f64": (i, [vp, C.c_long, vp, vp, vp, d, i, i, vp]),
         "mgk_flat_axpy": (i, [vp, C.c_long, d, vp, vp, vp]),

@@ -224,3 +224,52 @@ def test_sweep_with_input_residual_norm_bit_exact(mgk, orc, dim, n, variant):
     mgk.L.mgk_set_tuning(-1, -1)
     for p in (du, db, dout):
         mgk.free(p)
+
+
+def _slab_field(mgk, g, whole, n, z0):
+    """padded fp64 field of the z-slab [z0, z0 + g.nz) of a whole n^3 grid, ghost planes taken from the neighbours"""
+    w = whole.reshape(n, n, n)
+    pad = np.zeros(g.total)
+    for k in range(-1, g.nz + 1):
+        kz = z0 + k
+        if 0 <= kz < n:
+            for i in range(n):
+                o = g.org + k * g.plane + i * g.pitch
+                pad[o:o + n] = w[kz, i]
+    return mgk.upload(pad)
+
+
+@pytest.mark.parametrize("n,cut", [(31, 7), (15, 1), (63, 20)])
+def test_fused_residual_restrict_on_slabs_bit_exact(mgk, orc, n, cut):
+    """two z-slabs (coarse planes [0, cut) and [cut, nc)): the inner slab's fused kernel leaves its last coarse plane partial,
+    mgk_restrict_finish_f64 closes it with the neighbour's first residual plane; the result is the whole-grid restriction"""
+    rng = np.random.default_rng(77 + n)
+    nc = (n - 1) // 2
+    As = _stencil(orc, 3, n)
+    u, b = _rand(rng, n ** 3), _rand(rng, n ** 3)
+    want = orc.restrict(3, n, orc.residual(3, n, As, b, u)).reshape(nc, nc, nc)
+    L = mgk.L
+    coef = mgk.coef(As)
+    got = []
+    # slab 1 (last rank) first: its residual plane 0 is what slab 0 needs as hi ghost
+    g1, gc1 = mgk.geom(3, n, n, n - 2 * cut), mgk.geom(3, nc, nc, nc - cut)
+    u1, b1, r1, bc1 = _slab_field(mgk, g1, u, n, 2 * cut), _slab_field(mgk, g1, b, n, 2 * cut), mgk.field(g1), mgk.field(gc1)
+    mgk._chk(L.mgk_residual_range_f64(mgk.ctx, C.byref(g1), coef, b1, u1, r1, 0, 1, None))
+    mgk._chk(L.mgk_residual_restrict_f64(mgk.ctx, C.byref(g1), C.byref(gc1), coef, b1, u1, bc1, None))
+    r1_plane0 = mgk.from_field(g1, r1).reshape(g1.nz, n, n)[0]
+    assert np.array_equal(r1_plane0, orc.residual(3, n, As, b, u).reshape(n, n, n)[2 * cut])
+    # slab 0 (inner): partial + finish
+    g0, gc0 = mgk.geom(3, n, n, 2 * cut), mgk.geom(3, nc, nc, cut)
+    u0, b0, bc0 = _slab_field(mgk, g0, u, n, 0), _slab_field(mgk, g0, b, n, 0), mgk.field(gc0)
+    rpad = np.zeros(g0.total)
+    for i in range(n):
+        o = g0.org + g0.nz * g0.plane + i * g0.pitch
+        rpad[o:o + n] = r1_plane0[i]
+    r0 = mgk.upload(rpad)
+    mgk._chk(L.mgk_residual_restrict_f64(mgk.ctx, C.byref(g0), C.byref(gc0), coef, b0, u0, bc0, None))
+    mgk._chk(L.mgk_restrict_finish_f64(mgk.ctx, C.byref(g0), C.byref(gc0), r0, bc0, None))
+    got0 = mgk.from_field(gc0, bc0).reshape(cut, nc, nc)
+    got1 = mgk.from_field(gc1, bc1).reshape(nc - cut, nc, nc)
+    assert np.array_equal(got0, want[:cut]) and np.array_equal(got1, want[cut:])
+    for p in (u1, b1, r1, bc1, u0, b0, bc0, r0):
+        mgk.free(p)
