@@ -631,7 +631,7 @@ static int prolong_smooth(mg_solver *s, int P, int l) {
     mg_fset *F = &Lf->f[P], *Cq = &Lc->f[P];
     const mg_ops *O = &OPS[P];
     const int v0 = s->cfg.v[0];
-    if (!(s->cfg.fuse & 2) || s->cfg.dim != 3 || s->cfg.ksp_type != MG_KSP_RICHARDSON || v0 < 1) {
+    if (!(s->cfg.fuse & 2) || s->cfg.ksp_type != MG_KSP_RICHARDSON || v0 < 1) {
         CHK(prolong_from(s, P, l));
         return smooth(s, P, l, v0);
     }

@@ -391,6 +391,46 @@ __device__ __forceinline__ T prolong_one(const T *uc, long crs, long cms, int k,
             for (int qj = 0; qj < njc; qj++) s += w * cr[(long)qk * cms + (long)qi * crs + qj];
     return s;
 }
+// 2-D fused prolongation: the parents of fine row i (x0..x0+VX-1) fetched raw one marching step ahead, summed later in
+// the order of prolong_vec (k odd: one parent plane of weight 1, 1*(wi*wj) == wi*wj)
+template <typename T>
+__device__ __forceinline__ void prolong2d_raw(const T *uc, long crs, int i, int x0, bool ok, T (&pr)[2][3]) {
+    constexpr int VX = 16 / sizeof(T);
+    const int iodd = i & 1;
+    const int ic0 = iodd ? (i - 1) / 2 : i / 2 - 1, nic = iodd ? 1 : 2;
+    const T *cr = uc + (long)ic0 * crs + (x0 / 2 - 1);
+#pragma unroll
+    for (int qi = 0; qi < 2; qi++) {
+        const bool use = ok && qi < nic;
+        pr[qi][0] = use ? cr[(long)qi * crs] : (T)0;
+        pr[qi][1] = use ? cr[(long)qi * crs + 1] : (T)0;
+        pr[qi][2] = (use && VX == 4) ? cr[(long)qi * crs + 2] : (T)0;
+    }
+}
+template <typename T>
+__device__ __forceinline__ V16<T> prolong2d_sum(const T (&pr)[2][3], int i) {
+    constexpr int VX = 16 / sizeof(T);
+    const int iodd = i & 1, nic = iodd ? 1 : 2;
+    const T wi = iodd ? (T)1 : (T)0.5;
+    const T wh = (T)1 * (wi * (T)0.5), w1 = (T)1 * (wi * (T)1);
+    V16<T> s = v16_zero<T>();
+#pragma unroll
+    for (int qi = 0; qi < 2; qi++) {
+        if (qi < nic) {
+            const T c0 = pr[qi][0], c1 = pr[qi][1];
+            s.v[0] += wh * c0;
+            s.v[0] += wh * c1;
+            s.v[1] += w1 * c1;
+            if (VX == 4) {
+                const T c2 = pr[qi][2];
+                s.v[VX - 2] += wh * c1;
+                s.v[VX - 2] += wh * c2;
+                s.v[VX - 1] += w1 * c2;
+            }
+        }
+    }
+    return s;
+}
 // MODE_CRES32: the fp32 correction at the VX fine points (k, i, x0..) / at one point, widened to T (ghost cells hold 0)
 template <typename T>
 __device__ __forceinline__ V16<T> e32_vec(const float *e, long ers, long ems, int k, int i, int x0) {
@@ -469,8 +509,12 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
     constexpr bool PJ = (MODE == MODE_PJACOBI) && (DIM == 3) && (64 * WX * WY <= 512);
     // modes that read u through an additive correction (coarse interpolant / fp32 correction) at every point they touch
     constexpr bool ADDU = (MODE == MODE_PJACOBI || MODE == MODE_CRES32);
-#define ADDV(zz, yy, xx) ((MODE == MODE_CRES32) ? e32_vec<T>(a.e32, a.ors, a.oms, zz, yy, xx) : prolong_vec(a.uc, a.crs, a.cms, zz, yy, xx))
-#define ADD1(zz, yy, xx) ((MODE == MODE_CRES32) ? e32_one<T>(a.e32, a.ors, a.oms, zz, yy, xx) : prolong_one(a.uc, a.crs, a.cms, zz, yy, xx))
+    // (2-D: the marching index is the grid row; the interpolation helpers are called with a fixed odd plane index, whose
+    //  single parent plane has weight 1: 1*(wi*wj) == wi*wj bit for bit; a.cms is then the coarse ROW stride)
+#define ADDV(zz, yy, xx) ((MODE == MODE_CRES32) ? e32_vec<T>(a.e32, a.ors, a.oms, zz, yy, xx) \
+                          : (DIM == 3) ? prolong_vec(a.uc, a.crs, a.cms, zz, yy, xx) : prolong_vec(a.uc, a.cms, 0L, 1, zz, xx))
+#define ADD1(zz, yy, xx) ((MODE == MODE_CRES32) ? e32_one<T>(a.e32, a.ors, a.oms, zz, yy, xx) \
+                          : (DIM == 3) ? prolong_one(a.uc, a.crs, a.cms, zz, yy, xx) : prolong_one(a.uc, a.cms, 0L, 1, zz, xx))
     constexpr int TYC = PJ ? (TY / 2 + 2) : 1, CW = PJ ? (TX / 2 + 2) : 1, CWP = PJ ? (CW + 2) : 1;
     constexpr int NTHR = 64 * WX * WY, NLC = PJ ? ((CW + NTHR - 1) / NTHR) : 1, NL = TYC * NLC;   // thread t loads column t (+k*NTHR) of every tile row
     static_assert(!PJ || (TY % 2 == 0), "fused prolongation needs an even tile height");
@@ -559,6 +603,7 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
 
     // MODE_CRES32: fp32 corrections of the plane being brought in, loaded one step ahead like u itself
     float erw[RY][VX], ehSr[VX], ehNr[VX], exr[RY];
+    T praw[2][3];       // MODE_PJACOBI in 2-D: raw parents of the row being brought in
     double acc = 0.0;   // MODE_RESNORM / MODE_RES32 / MODE_JNORM
     const int ic_base = PJ ? (ty * TY) / 2 - 1 : 0, jc_base = PJ ? (tx * TX) / 2 - 1 : 0;
     T cnew[NL];
@@ -598,6 +643,7 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
                 hSn = ldv(up_ + (long)(z + 1) * a.ms - a.rs, okS);
                 hNn = ldv(up_ + (long)(z + 1) * a.ms + (long)RY * a.rs, okN);
             }
+            if (MODE == MODE_PJACOBI && DIM == 2) prolong2d_raw(a.uc, a.cms, z + 2, x0, rok[0], praw);
             if (MODE == MODE_CRES32) {
                 const float *ep = a.e32 + (long)(z + 2) * a.oms + (long)yb * a.ors + x0;
 #pragma unroll
@@ -712,6 +758,9 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
 #pragma unroll
                     for (int e = 0; e < VX; e++) up[r].v[e] = up[r].v[e] + (T)erw[r][e];
                     xp[r] = xp[r] + (T)exr[r];
+                } else if (MODE == MODE_PJACOBI && DIM == 2) {
+                    if (rok[r]) up[r] = vadd(up[r], prolong2d_sum(praw, z + 2));
+                    if (xhok) xp[r] = xp[r] + ADD1(z + 2, yb + r, xh);
                 } else if (ADDU) {
                     if (rok[r]) up[r] = vadd(up[r], PJ ? prolong_vec_lds(cl, ic_base, z + 2, yb + r, xl / 2) : ADDV(z + 2, yb + r, x0));
                     if (xhok && (DIM == 2 || yb + r < a.ny)) xp[r] = xp[r] + ADD1(z + 2, yb + r, xh);
@@ -1585,14 +1634,14 @@ extern "C" int mgk_unpack_f32(mgk_ctx *c, const mgk_geom *g32, const float *padd
 template <typename T>
 static int prolong_jacobi(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
                           const T *b, const T *ucoarse, const T *u, T *unew, void *stream) {
-    if (!c || !gf || !gc || !coef || !b || !ucoarse || !u || !unew || u == unew || gf->dim != 3)
-        return fail(MGK_EINVAL, "mgk_prolong_jacobi: bad arguments (3-D only)");
+    if (!c || !gf || !gc || !coef || !b || !ucoarse || !u || !unew || u == unew || (gf->dim != 3 && sizeof(T) != 8))
+        return fail(MGK_EINVAL, "mgk_prolong_jacobi: bad arguments (fp32: 3-D only)");
     XferArgs x;
     int rc = xfer_args(gf, gc, x);
     if (rc) return rc;
     StArgs<T> a; memset(&a, 0, sizeof(a));
     a.u = u + gf->org; a.b = b + gf->org; a.out = unew + gf->org;
-    a.uc = ucoarse + gc->org; a.crs = gc->pitch; a.cms = gc->plane;
+    a.uc = ucoarse + gc->org; a.crs = gc->pitch; a.cms = (gf->dim == 3) ? gc->plane : gc->pitch;
     a.nxc = gc->nx; a.nyc = gc->ny; a.nzc = gc->nz;
     set_coef(a, gf, coef); a.dinv = (T)dinv; a.scale = (T)scale;
     return dispatch_st<MODE_PJACOBI>(c, gf, a, S(c, stream), nullptr);

@@ -273,3 +273,23 @@ def test_fused_residual_restrict_on_slabs_bit_exact(mgk, orc, n, cut):
     assert np.array_equal(got0, want[:cut]) and np.array_equal(got1, want[cut:])
     for p in (u1, b1, r1, bc1, u0, b0, bc0, r0):
         mgk.free(p)
+
+
+@pytest.mark.parametrize("nf,variant", [(3, -1), (7, 0), (127, 0), (255, 1), (1023, 2), (1023, 0)])
+def test_fused_prolong_jacobi_2d_bit_exact(mgk, orc, nf, variant):
+    rng = np.random.default_rng(500 + nf)
+    nc = (nf - 1) // 2
+    As = _stencil(orc, 2, nf)
+    dinv = 1.0 / As[2]
+    u, b, uc = _rand(rng, nf ** 2), _rand(rng, nf ** 2), _rand(rng, nc ** 2)
+    gf, gc = mgk.geom(2, nf), mgk.geom(2, nc)
+    du, db, duc, dout = mgk.to_field(gf, u), mgk.to_field(gf, b), mgk.to_field(gc, uc), mgk.field(gf)
+    want = orc.jacobi(2, nf, As, 0.8, b, orc.prolong_add(2, nf, uc, u))
+    for zc in (-1, 3):
+        mgk.L.mgk_set_tuning(variant, zc)
+        mgk._chk(mgk.L.mgk_prolong_jacobi_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), dinv, 0.8, db, duc, du, dout, None))
+        got = mgk.from_field(gf, dout)
+        assert np.array_equal(got, want), f"max diff {np.abs(got - want).max()}"
+    mgk.L.mgk_set_tuning(-1, -1)
+    for p in (du, db, duc, dout):
+        mgk.free(p)
