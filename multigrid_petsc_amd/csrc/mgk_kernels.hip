@@ -1720,7 +1720,8 @@ __global__ void __launch_bounds__(64 * WX) k_resrestrict(const RRArgs<T> a) {
         um[r] = ldv(up_ + (long)(z0 - 1) * a.ms + ro, rok[r]);
         uc[r] = ldv(up_ + (long)z0 * a.ms + ro, rok[r]);
         up[r] = ldv(up_ + (long)(z0 + 1) * a.ms + ro, rok[r]);
-        bcur[r] = ldv_stream(bp_ + (long)z0 * a.ms + ro, rok[r]);
+        // rows 0 and RR-1 are shared with the neighbouring tiles: cached loads, so the second reader hits L2
+        bcur[r] = (r == 0 || r == RR - 1) ? ldv(bp_ + (long)z0 * a.ms + ro, rok[r]) : ldv_stream(bp_ + (long)z0 * a.ms + ro, rok[r]);
         *reinterpret_cast<VT *>(&lds[0][r][xl + VX]) = uc[r];
     }
     if (tid == 0) {
@@ -1744,7 +1745,7 @@ __global__ void __launch_bounds__(64 * WX) k_resrestrict(const RRArgs<T> a) {
             for (int r = 0; r < RR; r++) {
                 const long ro = (long)r * a.rs;
                 uq[r] = ldv(up_ + (long)(z + 2) * a.ms + ro, rok[r]);
-                bn[r] = ldv_stream(bp_ + (long)(z + 1) * a.ms + ro, rok[r]);
+                bn[r] = (r == 0 || r == RR - 1) ? ldv(bp_ + (long)(z + 1) * a.ms + ro, rok[r]) : ldv_stream(bp_ + (long)(z + 1) * a.ms + ro, rok[r]);
             }
             hSn = ldv(up_ + (long)(z + 1) * a.ms - a.rs, okS);
             hNn = ldv(up_ + (long)(z + 1) * a.ms + (long)RR * a.rs, okN);
