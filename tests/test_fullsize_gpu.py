@@ -92,3 +92,23 @@ def test_full_size_operator_properties(mgk):
     assert ss.value == 0.0                                                                        # scaling by 2 is exact
     for p in (one_f, one_c, a, b, out, ca, cb, r2, *xs, *ys):
         mgk.free(p)
+
+
+@pytest.mark.parametrize("precision", ["fp64", "mixed"])
+def test_full_size_fused_cycle_equals_unfused_cycle(precision):
+    """At 1023^3 every fusion of the cycle (residual+norm, prolongation+sweep, residual+restriction, norm+next first sweep,
+    mixed-precision correction+residual) must leave the fields bit for bit as the plain kernel-per-call cycle does:
+    identical solution checksums, residual histories equal up to the summation order of the norm."""
+    from multigrid_petsc_amd.solver import Solver
+    out = {}
+    for fuse in (0, 31):
+        s = Solver(3, 1025, 10, scale=6.0 / 7.0, maxiter=12, precision=precision, fuse=fuse)
+        s.set_rhs_problem()
+        s.cycles(5)
+        s.sync()
+        e = s.error_norms()             # max, sum, sqrt(sum of squares) of |u - exact|: three checksums of the field
+        out[fuse] = (s.rnorm.copy(), e)
+        s.close()
+    assert np.abs(out[0][0] / out[31][0] - 1).max() <= 1e-12
+    assert out[0][1][0] == out[31][1][0]
+    assert abs(out[0][1][1] - out[31][1][1]) <= 1e-13 * out[0][1][1] and abs(out[0][1][2] - out[31][1][2]) <= 1e-13 * out[0][1][2]
