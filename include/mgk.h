@@ -117,8 +117,6 @@ int  mgk_residual_sumsq_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef,
 int  mgk_jacobi_sumsq_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale,
                           const double *b, const double *u, double *unew, double *sumsq_host, void *stream);
 
-/* K2+K3 fused: b_coarse = R (b - A u), the fine residual is never written (src/solver.c:1534-1535).
- * Whole grids only (gf->nz == 2*gc->nz + 1); a slab uses mgk_residual_f64 + halo + mgk_restrict_fw_f64.  3-D. */
 /* residual on the planes (3-D) / rows (2-D) [zbeg, zend) only */
 int  mgk_residual_range_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, const double *b, const double *u, double *r,
                             int zbeg, int zend, void *stream);
@@ -129,6 +127,9 @@ int  mgk_residual_range_f32(mgk_ctx *ctx, const mgk_geom *g, const double *coef,
  * of the row of res, so the result equals the whole-grid sum bit for bit */
 int  mgk_restrict_finish_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *r, double *bc, void *stream);
 int  mgk_restrict_finish_f32(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const float *r, float *bc, void *stream);
+/* K2+K3 fused: b_coarse = R (b - A u), the fine residual is never written (src/solver.c:1534-1535).
+ * Whole grids and last slabs (gf->nz == 2*gc->nz + 1) complete; inner z-slabs (gf->nz == 2*gc->nz) leave the last coarse plane
+ * partial, to be closed by mgk_restrict_finish_* (above).  3-D. */
 int  mgk_residual_restrict_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
                                const double *b, const double *u, double *bc, void *stream);
 

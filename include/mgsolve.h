@@ -39,7 +39,7 @@ typedef struct mg_config {
     int dist_min_n;     /* levels with n >= dist_min_n stay distributed, coarser ones are replicated; <=0: default 255
                          * (below that a slab sweep is shorter than the latency of its halo exchange) */
     int fuse;           /* bit 0: final residual fused with its norm (no rv write); bit 1: prolongation fused into the
-                         * first post-smoothing sweep; bit 2: pre-restriction residual fused with the restriction (whole grids);
+                         * first post-smoothing sweep; bit 2: pre-restriction residual fused with the restriction;
                          * bit 3: the residual norm that closes a cycle is evaluated by the kernel that also makes the first
                          * pre-smoothing sweep of the next cycle (adopted only if a next cycle runs); bit 4 (mixed precision): the
                          * fp64 correction u += e and the fp64 residual -> fp32 in one pass; default (-1): all on */
