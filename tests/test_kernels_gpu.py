@@ -28,7 +28,7 @@ def _stencil(orc, dim, n):
 
 
 CASES_3D = [(3, n, v) for n in (1, 3, 7, 31) for v in (0, 2)] + \
-           [(3, 63, v) for v in (0, 1, 2, 3, 6, 9, 12)] + [(3, 127, v) for v in (1, 2, 3, 6, 9, 12)]
+           [(3, 63, v) for v in (0, 1, 2, 3, 6, 9, 12, 13)] + [(3, 127, v) for v in (1, 2, 3, 6, 9, 12, 13)]
 CASES_2D = [(2, n, v) for n in (1, 3, 15, 127) for v in (0, 1)] + [(2, 255, v) for v in (0, 1, 2)] + \
            [(2, 1023, 2), (2, 2047, 2)]
 
@@ -160,7 +160,7 @@ def test_rhs_fill_and_error_sums(mgk, orc, dim, npts):
         mgk.free(p)
 
 
-@pytest.mark.parametrize("nf,variant", [(3, -1), (7, 0), (31, 1), (63, 2), (63, 6), (127, 3), (127, 12), (255, -1)])
+@pytest.mark.parametrize("nf,variant", [(3, -1), (7, 0), (31, 1), (63, 2), (63, 6), (127, 3), (127, 12), (255, -1), (63, 13), (255, 13), (255, 9)])
 def test_fused_prolong_jacobi_bit_exact(mgk, orc, nf, variant):
     """unew = Jacobi(u + P uc) in one pass == prolong_add followed by a sweep (src/solver.c:1540-1542)"""
     rng = np.random.default_rng(400 + nf)
