@@ -185,6 +185,9 @@ int  mgk_flat_pointwise_mult(mgk_ctx *ctx, long n, const double *x, const double
 /* bandwidth probe: a = b + s*c over n doubles (n even, 16-byte aligned), `blocks` workgroups of 1024 lanes */
 int  mgk_stream_triad_f64(mgk_ctx *ctx, long n, double *a, const double *b, const double *c, double s,
                           int blocks, int nontemporal, void *stream);
+/* deferred reductions: while `slot_dev` is non-NULL every single-value reduction below (…_sumsq_…, mgk_flat_dot, the fused
+ * residual norms) writes its result to that device double in stream order and returns 0.0 without synchronising */
+int  mgk_defer_result(mgk_ctx *ctx, double *slot_dev);
 int  mgk_flat_dot(mgk_ctx *ctx, long n, const double *x, const double *y, double *dot_host, void *stream);   /* VecDot / VecNorm^2 */
 /* generic assembled AIJ: y = A x, or y = addto + alpha*(A x) when addto != NULL (rows: ascending columns).
  * `col` holds element offsets into x (translated by the caller when x is a padded field); when y/addto are padded

@@ -102,6 +102,8 @@ struct mg_solver {
     int iter;
     double bnorm, rchk;
     int started;
+    int deferring;          /* mg_solver_cycles: norms are deposited on the device and read once at the end */
+    double *d_norms; int d_norms_cap;
     int spec_valid;         /* level-0 tmp holds Jacobi(u): made by the sweep+norm kernel that closed the last cycle */
     double solve_seconds;
     int lgraph;             /* levels >= lgraph form the launch-bound coarse part replayed as one HIP graph (0: off) */
@@ -332,6 +334,7 @@ void mg_solver_destroy(mg_solver *s) {
     if (s->ctx) {
         mgk_sync(s->ctx, NULL);
         for (int q = 0; q < s->ntimers_created; q++) mgk_timer_destroy(s->ctx, s->timers[q]);
+        if (s->d_norms) mgk_free(s->ctx, s->d_norms);
         for (int p = 0; p < 2; p++) if (s->coarse_graph[p]) mgk_graph_destroy(s->ctx, s->coarse_graph[p]);
         for (int l = 0; l < s->levels; l++) {
             mg_level *L = &s->L[l];
@@ -781,7 +784,7 @@ static int vcycle_once(mg_solver *s) {
             CHK(mgk_sumsq_f64(s->ctx, &F->g, (const double *)F->rv, &ss, NULL));
         }
     }
-    CHK(norm_from_sumsq(s, ss, &s->rchk));
+    if (!s->deferring) CHK(norm_from_sumsq(s, ss, &s->rchk));
     s->iter++;
     if (s->iter < s->rnorm_cap) s->rnorm[s->iter] = s->rchk;            /* :1549 */
     return 0;
@@ -836,7 +839,33 @@ int mg_solver_cycles(mg_solver *s, int ncycles) {
         if (!r) return mgfail(MGK_EINVAL, "mg_solver_cycles: out of host memory");
         s->rnorm = r; s->rnorm_cap = cap;
     }
-    for (int q = 0; q < ncycles; q++) CHK(vcycle_once(s));
+    /* a fixed number of cycles needs no norm on the host in between: every cycle deposits its sum of squares in a device
+     * slot (no synchronisation, the host runs ahead), one copy and -- on N ranks -- one all-reduce per 64 cycles at the end */
+    if (ncycles > s->d_norms_cap) {
+        if (s->d_norms) mgk_free(s->ctx, s->d_norms);
+        void *q = NULL;
+        CHK(mgk_malloc(s->ctx, &q, sizeof(double) * (size_t)ncycles));
+        s->d_norms = (double *)q; s->d_norms_cap = ncycles;
+    }
+    const int it0 = s->iter;
+    s->deferring = 1;
+    int rc = 0;
+    for (int q = 0; q < ncycles && !rc; q++) {
+        rc = mgk_defer_result(s->ctx, s->d_norms + q);
+        if (!rc) rc = vcycle_once(s);
+    }
+    mgk_defer_result(s->ctx, NULL);
+    s->deferring = 0;
+    if (rc) return rc;
+    double *ss = (double *)malloc(sizeof(double) * (size_t)(ncycles > 0 ? ncycles : 1));
+    if (!ss) return mgfail(MGK_EINVAL, "mg_solver_cycles: out of host memory");
+    rc = ncycles > 0 ? mgk_d2h(s->ctx, ss, s->d_norms, sizeof(double) * (size_t)ncycles) : 0;      /* synchronises */
+    for (int q = 0; q < ncycles && !rc && s->cfg.nranks > 1; q += 64)
+        rc = s->comm->allreduce_sum(s->comm, s->ctx, ss + q, ncycles - q < 64 ? ncycles - q : 64, NULL);
+    if (rc) { free(ss); return mgfail(rc, "mg_solver_cycles: reading the deferred norms"); }
+    for (int q = 0; q < ncycles; q++) s->rnorm[it0 + 1 + q] = sqrt(ss[q]);
+    if (ncycles > 0) s->rchk = s->rnorm[it0 + ncycles];
+    free(ss);
     return 0;
 }
 

@@ -41,6 +41,7 @@ struct mgk_ctx {
     int max_partials;
     hipEvent_t ev[32];     // ring of dependency events for mgk_stream_wait (no create/destroy on the hot path)
     int ev_next;
+    double *defer_slot;    // non-null: the next single-value reductions deposit here (device) instead of syncing to the host
 };
 
 extern "C" const char *mgk_last_error(void) { return g_err; }
@@ -979,7 +980,21 @@ extern "C" int mgk_apply_f64(mgk_ctx *c, const mgk_geom *g, const double *coef,
     return dispatch_st<MODE_APPLY>(c, g, a, S(c, stream), nullptr);
 }
 
+// mgk_defer_result(ctx, slot): until reset with slot = NULL, every single-value reduction (sum of squares, dot) writes its
+// result to the device double `slot` in stream order and returns 0.0 to the host WITHOUT synchronising; the caller reads the
+// slots later in one copy.  Used by the fixed-count cycling loop, which needs no norm on the host between cycles.
+extern "C" int mgk_defer_result(mgk_ctx *c, double *slot_dev) {
+    if (!c) return fail(MGK_EINVAL, "mgk_defer_result: null context");
+    c->defer_slot = slot_dev;
+    return 0;
+}
 static int finish_to_host(mgk_ctx *c, int nparts, int nslots, hipStream_t s, double *host_out) {
+    if (c->defer_slot && nslots == 1) {
+        hipLaunchKernelGGL(k_finish_sum, dim3(1), dim3(256), 0, s, c->partials, nparts, c->defer_slot, 0);
+        HIPCHK(hipGetLastError());
+        host_out[0] = 0.0;
+        return 0;
+    }
     for (int q = 0; q < nslots; q++)
         hipLaunchKernelGGL(k_finish_sum, dim3(1), dim3(256), 0, s, c->partials + (long)q * c->max_partials, nparts, c->result_dev, q);
     HIPCHK(hipGetLastError());

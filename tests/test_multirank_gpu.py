@@ -182,3 +182,31 @@ def test_bench_two_processes_host_staged_transport(tmp_path):
     assert j2["n_gpus"] == 2 and j2["scaling"] == "strong" and "host" in j2["config"]["decomposition"]
     assert j2["config"]["dof_updates_per_cycle"] == j1["config"]["dof_updates_per_cycle"]
     assert abs(j2["residual_reduction_per_cycle"] - j1["residual_reduction_per_cycle"]) <= 1e-12
+
+
+@pytest.mark.timeout(300)
+def test_fixed_count_cycling_defers_the_norms_on_slabs():
+    """mg_solver_cycles (bench.py's loop): the per-cycle sums of squares stay on the device and are all-reduced once at the
+    end; history and fields equal the convergence-driven loop of a single rank"""
+    from multigrid_petsc_amd.solver import Solver
+    from multigrid_petsc_amd.comm import LoopbackWorld
+    it1, rn1, u1, _ = _solve_single(65, 5, 6.0 / 7.0, 40)
+    world = LoopbackWorld(3)
+
+    def fn(rank, comm):
+        s = Solver(3, 65, 5, scale=6.0 / 7.0, maxiter=40, rank=rank, nranks=3, comm=comm, dist_min_n=15)
+        s.set_rhs_problem()
+        s.cycles(2)
+        s.cycles(it1 - 2)
+        s.sync()
+        out = (s.rnorm.copy(), s.solution())
+        s.close()
+        return out
+
+    try:
+        res = world.run(fn)
+    finally:
+        world.close()
+    for rn, _ in res:
+        assert rn.shape == rn1.shape and np.abs(rn / rn1 - 1).max() <= 1e-13
+    assert np.array_equal(np.concatenate([r[1] for r in res]), u1)
