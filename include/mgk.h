@@ -112,6 +112,10 @@ int  mgk_residual_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef,
 /* K2+K6 fused: sum over the slab of (b - A u)^2, r is not written.  *sumsq_host is valid after return. */
 int  mgk_residual_sumsq_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef,
                             const double *b, const double *u, double *sumsq_host, void *stream);
+/* TWO Jacobi sweeps in one pass, unew = J(J(u)) (temporal blocking: the intermediate field lives in LDS only); 3-D, whole
+ * grids, nx + 1 <= 1024; bit-identical to two mgk_jacobi_f64 calls */
+int  mgk_jacobi2_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale,
+                     const double *b, const double *u, double *unew, void *stream);
 /* one Jacobi sweep unew = u + scale*dinv*(b - A u) that also returns ||b - A u||^2 (residual of the INPUT u): the norm
  * that closes a cycle (src/solver.c:1545-1546) fused with the first sweep of the next one (:1531) */
 int  mgk_jacobi_sumsq_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale,

@@ -42,7 +42,8 @@ typedef struct mg_config {
                          * first post-smoothing sweep; bit 2: pre-restriction residual fused with the restriction;
                          * bit 3: the residual norm that closes a cycle is evaluated by the kernel that also makes the first
                          * pre-smoothing sweep of the next cycle (adopted only if a next cycle runs); bit 4 (mixed precision): the
-                         * fp64 correction u += e and the fp64 residual -> fp32 in one pass; default (-1): all on */
+                         * fp64 correction u += e and the fp64 residual -> fp32 in one pass; bit 5: pairs of sweeps in one pass
+                         * (temporal blocking, whole 3-D grids >= 511^3); default (-1): all on */
     int overlap;        /* nranks > 1: halo of sweep k on the comm stream while sweep k's interior runs; default on (-1) */
     int graph;          /* replay the launch-bound coarse levels as one captured HIP graph; default on (-1) */
 } mg_config;
@@ -92,6 +93,8 @@ int  mg_solver_error_norms(mg_solver *s, double err[3]);
 /* per-kernel event timing of the fine-level smoother sweeps (bench.py roofline leg) */
 int  mg_solver_profile(mg_solver *s, int enable);
 int  mg_solver_profile_read(mg_solver *s, double *total_ms, int *launches);
+/* the same for one kind of launch: 0 = plain fine-level sweeps, 1 = two-sweeps-in-one-pass launches */
+int  mg_solver_profile_read_kind(mg_solver *s, int kind, double *total_ms, int *launches);
 
 /* integer half of the reference (src/matbuild.c), implicit form */
 void mg_get_ranges(int totaln, int procs, int *ranges);             /* matbuild.c:120-144 */

@@ -111,6 +111,7 @@ struct mg_solver {
     /* profiling */
     int prof_on, prof_n;
     void *timers[MG_MAX_TIMERS];
+    unsigned char timer_kind[MG_MAX_TIMERS];
     int ntimers_created;
 };
 
@@ -251,7 +252,7 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
         const int n0 = mg_grid_n(cfg->npts, 0);
         s->cfg.dist_min_n = n0 < 255 ? n0 : 255;
     }
-    if (s->cfg.fuse < 0) s->cfg.fuse = 31;
+    if (s->cfg.fuse < 0) s->cfg.fuse = 63;
     if (s->cfg.overlap < 0) s->cfg.overlap = 1;
     if (s->cfg.graph < 0) s->cfg.graph = 1;
     if (s->cfg.nranks < 1) s->cfg.nranks = 1;
@@ -468,12 +469,14 @@ static int ensure_u_ghosts(mg_solver *s, int P, mg_level *L) {
     return 0;
 }
 
+static int g_prof_kind = 0;      /* kind of the next timer: 0 plain sweep, 1 two sweeps in one pass */
 static void *prof_begin(mg_solver *s, int level) {
     if (!s->prof_on || level != 0 || s->prof_n >= MG_MAX_TIMERS) return NULL;
     if (s->prof_n >= s->ntimers_created) {
         if (mgk_timer_create(s->ctx, &s->timers[s->ntimers_created])) return NULL;
         s->ntimers_created++;
     }
+    s->timer_kind[s->prof_n] = (unsigned char)g_prof_kind;
     void *t = s->timers[s->prof_n++];
     mgk_timer_start(s->ctx, t, NULL);
     return t;
@@ -481,14 +484,20 @@ static void *prof_begin(mg_solver *s, int level) {
 static void prof_end(mg_solver *s, void *t) { if (t) mgk_timer_stop(s->ctx, t, NULL); }
 
 int mg_solver_profile(mg_solver *s, int enable) { s->prof_on = enable; s->prof_n = 0; return 0; }
-int mg_solver_profile_read(mg_solver *s, double *total_ms, int *launches) {
+int mg_solver_profile_read_kind(mg_solver *s, int kind, double *total_ms, int *launches) {
     double tot = 0.0, ms;
-    for (int q = 0; q < s->prof_n; q++) { CHK(mgk_timer_elapsed_ms(s->ctx, s->timers[q], &ms)); tot += ms; }
-    *total_ms = tot; *launches = s->prof_n;
-    s->prof_n = 0;
+    int n = 0;
+    for (int q = 0; q < s->prof_n; q++) {
+        if (s->timer_kind[q] != kind) continue;
+        CHK(mgk_timer_elapsed_ms(s->ctx, s->timers[q], &ms));
+        tot += ms; n++;
+    }
+    *total_ms = tot; *launches = n;
     return 0;
 }
-
+int mg_solver_profile_read(mg_solver *s, double *total_ms, int *launches) {
+    return mg_solver_profile_read_kind(s, 0, total_ms, launches);
+}
 static void swap_ptr(void **a, void **b) { void *t = *a; *a = *b; *b = t; }
 
 /* KSPSolve(ksp[l], b[l], u[l]) with KSPCHEBYSHEV (fp64 only), classic three-term recurrence (oracle/mgo.c) */
@@ -540,10 +549,22 @@ static int smooth(mg_solver *s, int P, int l, int maxit) {
         s->spec_valid = 0;
         it0 = 1;
     }
+    /* two sweeps per pass (temporal blocking) where it pays: whole 3-D grids of 511^3 and more.  Not on the level whose
+     * buffers the coarse-level HIP graph refers to (a pass swaps u/tmp once, not twice: see coarse_part) */
+    const int pair_ok = (s->cfg.fuse & 32) && P == 0 && s->cfg.dim == 3 && !L->distributed && L->n >= 511 && L->n + 1 <= 1024 &&
+                        (s->lgraph == 0 || l < s->lgraph - 1);
     for (int it = it0; it < maxit; it++) {
         if (it == 0 && !F->guess_nonzero) {
             /* r = b, x = 0 + scale*(B b): u is not read */
             CHK(O->jacobi_zero(s->ctx, &F->g, L->dinv, s->cfg.scale, F->b, F->tmp, NULL));
+        } else if (pair_ok && maxit - it >= 2) {
+            g_prof_kind = 1;
+            void *t = prof_begin(s, l);
+            g_prof_kind = 0;
+            CHK(mgk_jacobi2_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u,
+                                (double *)F->tmp, NULL));
+            prof_end(s, t);
+            it++;                                   /* this pass made sweeps it and it + 1 */
         } else if (L->distributed && s->cfg.overlap && F->g.nz >= 3) {
             /* boundary planes first, ship them on the comm stream, sweep the interior meanwhile */
             void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);

@@ -1031,6 +1031,210 @@ extern "C" int mgk_jacobi_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const double 
 }
 
 // ------------------------------------------------------------------------------------------
+// two Jacobi sweeps in one pass (temporal blocking): out = J(J(u)), 24 B + halo re-reads instead of 48 B per unknown
+// ------------------------------------------------------------------------------------------
+// Block = one full-row tile of TY = 4 rows marching along z, 64*WX lanes, lane t owns the column pair x = 2t, 2t+1 of ALL
+// rows of the tile.  Stage 1 (first sweep) is evaluated on the tile plus one halo row either side (6 rows) for plane
+// z+1 from u rows yb-2 .. yb+5 held in registers (planes z, z+1, z+2, and z+3 in flight): y neighbours are the lane's own
+// registers, x neighbours come by wave shuffle (the two edge lanes of a wave: from a small LDS edge buffer), so stage 1
+// needs no barrier.  Its output u' goes to an LDS ring of three planes; stage 2 (second sweep) reads the seven u'
+// neighbours of plane z from the ring and stores the result.  The halo rows of u' are recomputed by the neighbouring
+// tile (1.5x stage-1 arithmetic, 2x u row loads that mostly hit L2); u' never goes to memory.  Each stage performs
+// exactly the arithmetic of k_stencil<MODE_JACOBI>, so the result equals two separate sweeps bit for bit.
+struct J2Args {
+    const double *u, *b;
+    double *out;
+    int nx, ny, nz;
+    long rs, ms;
+    int nty, zc;
+    double a0, a1, a2, a3, a4, a5, a6, dinv, scale;
+};
+
+template <int WX>
+__global__ void __launch_bounds__(64 * WX) k_jacobi2(const J2Args a) {
+    constexpr int VX = 2, TY = 4, R1 = TY + 4, R2 = TY + 2, TX = 64 * VX * WX, LW = TX + 2 * VX;
+    __shared__ __attribute__((aligned(16))) double ring[3][R2][LW];
+    __shared__ double edgeW[2][R2][WX], edgeE[2][R2][WX];     // first / last element of every wave's row segment
+    using VT = V16<double>;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int ty = bid % a.nty, tz = bid / a.nty;
+    const int yb = TY * ty;
+    const int z0 = tz * a.zc, z1 = min(z0 + a.zc, a.nz);
+    if (z0 >= z1) return;
+    const int xl = VX * tid, x0 = xl;
+    const bool xok = x0 < a.nx;
+    const bool lastvec = (x0 + VX > a.nx);
+
+    bool uok[R1], s1ok[R2];
+#pragma unroll
+    for (int rr = 0; rr < R1; rr++) { const int y = yb - 2 + rr; uok[rr] = xok && y >= -1 && y <= a.ny; }
+#pragma unroll
+    for (int q = 0; q < R2; q++) { const int y = yb - 1 + q; s1ok[q] = y >= 0 && y < a.ny; }
+    const double *up_ = a.u + (long)(yb - 2) * a.rs + x0;     // row rr of plane p: up_ + p*ms + rr*rs
+    const double *bp_ = a.b + (long)(yb - 1) * a.rs + x0;     // row q  of plane p: bp_ + p*ms + q*rs
+
+    // zero the ring (u'(-1) and the padding columns are 0) -- one pass, strided over the block
+    for (int i = tid; i < 3 * R2 * LW; i += 64 * WX) (&ring[0][0][0])[i] = 0.0;
+
+    VT ua[R1], ub[R1], uc[R1], ud[R1], b1[R2], bn[R2], b0[TY];
+    const int t0 = z0 - 2;                                    // first step: stage 1 of plane z0 - 1
+#pragma unroll
+    for (int rr = 0; rr < R1; rr++) {
+        const long ro = (long)rr * a.rs;
+        ua[rr] = ldv(up_ + (long)t0 * a.ms + ro, uok[rr] && t0 >= -1);
+        ub[rr] = ldv(up_ + (long)(t0 + 1) * a.ms + ro, uok[rr] && t0 + 1 >= -1);
+        uc[rr] = ldv(up_ + (long)(t0 + 2) * a.ms + ro, uok[rr]);
+        ud[rr] = v16_zero<double>();
+    }
+#pragma unroll
+    for (int q = 0; q < R2; q++) {
+        const int p = t0 + 1;
+        b1[q] = ldv(bp_ + (long)p * a.ms + (long)q * a.rs, xok && s1ok[q] && p >= 0 && p < a.nz);
+        bn[q] = v16_zero<double>();
+    }
+#pragma unroll
+    for (int j = 0; j < TY; j++) b0[j] = v16_zero<double>();
+    // edges of the first centre plane (ub = plane t0 + 1)
+    if (lane == 0 || lane == 63) {
+#pragma unroll
+        for (int q = 0; q < R2; q++) {
+            if (lane == 0) edgeW[(t0 + 1) & 1][q][w] = ub[q + 1].v[0];
+            else edgeE[(t0 + 1) & 1][q][w] = ub[q + 1].v[VX - 1];
+        }
+    }
+    __syncthreads();
+
+    for (int t = t0; t < z1; t++) {
+        const int p = t + 1;                                  // plane of stage 1
+        // ---- loads consumed in the next step ----
+        {
+            const bool pu = (t + 3 <= a.nz), pb = (t + 2 < a.nz) && (t + 1 < z1);
+#pragma unroll
+            for (int rr = 0; rr < R1; rr++) ud[rr] = ldv(up_ + (long)(t + 3) * a.ms + (long)rr * a.rs, uok[rr] && pu);
+#pragma unroll
+            for (int q = 0; q < R2; q++) {
+                const double *bp = bp_ + (long)(t + 2) * a.ms + (long)q * a.rs;
+                const bool ok = xok && s1ok[q] && pb;
+                bn[q] = (q >= 2 && q < R2 - 2) ? ldv_stream(bp, ok) : ldv(bp, ok);     // rows shared with neighbours: cached
+            }
+        }
+        // ---- stage 1: u'(p) on rows yb-1 .. yb+TY ----
+        {
+            const bool pin = (p >= 0 && p < a.nz);
+            const int slot = (p + 3) % 3, eb = p & 1;
+#pragma unroll
+            for (int q = 0; q < R2; q++) {
+                const int rr = q + 1;
+                double Wv = __shfl_up(ub[rr].v[VX - 1], 1, 64), Ev = __shfl_down(ub[rr].v[0], 1, 64);
+                if (lane == 0) Wv = (w > 0) ? edgeE[eb][q][w - 1] : 0.0;
+                if (lane == 63) Ev = (w < WX - 1) ? edgeW[eb][q][w + 1] : 0.0;
+                VT o;
+#pragma unroll
+                for (int e = 0; e < VX; e++) {
+                    const double wv = (e == 0) ? Wv : ub[rr].v[e - 1 < 0 ? 0 : e - 1];
+                    const double ev = (e == VX - 1) ? Ev : ub[rr].v[e + 1 > VX - 1 ? VX - 1 : e + 1];
+                    double s = a.a0 * ua[rr].v[e];
+                    s = s + a.a1 * ub[rr - 1].v[e];
+                    s = s + a.a2 * wv;
+                    s = s + a.a3 * ub[rr].v[e];
+                    s = s + a.a4 * ev;
+                    s = s + a.a5 * ub[rr + 1].v[e];
+                    s = s + a.a6 * uc[rr].v[e];
+                    const double res = b1[q].v[e] - s;
+                    const double zz = res * a.dinv;
+                    o.v[e] = ub[rr].v[e] + a.scale * zz;
+                    if (!pin || !s1ok[q] || !xok || (lastvec && x0 + e >= a.nx)) o.v[e] = 0.0;
+                }
+                *reinterpret_cast<VT *>(&ring[slot][q][xl + VX]) = o;
+            }
+            // edges of the next centre plane (uc = plane p + 1), other buffer
+            if (lane == 0 || lane == 63) {
+#pragma unroll
+                for (int q = 0; q < R2; q++) {
+                    if (lane == 0) edgeW[eb ^ 1][q][w] = uc[q + 1].v[0];
+                    else edgeE[eb ^ 1][q][w] = uc[q + 1].v[VX - 1];
+                }
+            }
+        }
+        __syncthreads();                                      // u'(p) complete
+        // ---- stage 2: out(t) on rows yb .. yb+TY-1 from u'(t-1), u'(t), u'(t+1) ----
+        if (t >= z0) {
+            const int sm = (t + 2) % 3, sc = t % 3, sp = (t + 1) % 3;
+#pragma unroll
+            for (int j = 0; j < TY; j++) {
+                const int q = j + 1;
+                const VT c = *reinterpret_cast<const VT *>(&ring[sc][q][xl + VX]);
+                const VT dn = *reinterpret_cast<const VT *>(&ring[sm][q][xl + VX]);
+                const VT upv = *reinterpret_cast<const VT *>(&ring[sp][q][xl + VX]);
+                const VT sv = *reinterpret_cast<const VT *>(&ring[sc][q - 1][xl + VX]);
+                const VT nv = *reinterpret_cast<const VT *>(&ring[sc][q + 1][xl + VX]);
+                const double Wv = ring[sc][q][xl + VX - 1], Ev = ring[sc][q][xl + 2 * VX];
+                VT o;
+#pragma unroll
+                for (int e = 0; e < VX; e++) {
+                    const double wv = (e == 0) ? Wv : c.v[e - 1 < 0 ? 0 : e - 1];
+                    const double ev = (e == VX - 1) ? Ev : c.v[e + 1 > VX - 1 ? VX - 1 : e + 1];
+                    double s = a.a0 * dn.v[e];
+                    s = s + a.a1 * sv.v[e];
+                    s = s + a.a2 * wv;
+                    s = s + a.a3 * c.v[e];
+                    s = s + a.a4 * ev;
+                    s = s + a.a5 * nv.v[e];
+                    s = s + a.a6 * upv.v[e];
+                    const double res = b0[j].v[e] - s;
+                    const double zz = res * a.dinv;
+                    o.v[e] = c.v[e] + a.scale * zz;
+                    if (lastvec && x0 + e >= a.nx) o.v[e] = 0.0;
+                }
+                if (xok && yb + j < a.ny) stv_stream(a.out + (long)t * a.ms + (long)(yb + j) * a.rs + x0, o);
+            }
+        }
+        __syncthreads();                                      // ring slot (t-1)%3 is free for u'(t+2)
+        // ---- rotate ----
+#pragma unroll
+        for (int j = 0; j < TY; j++) b0[j] = b1[j + 1];
+#pragma unroll
+        for (int q = 0; q < R2; q++) b1[q] = bn[q];
+#pragma unroll
+        for (int rr = 0; rr < R1; rr++) { ua[rr] = ub[rr]; ub[rr] = uc[rr]; uc[rr] = ud[rr]; }
+    }
+}
+
+extern "C" int mgk_jacobi2_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
+                               const double *b, const double *u, double *unew, void *stream) {
+    if (!c || !g || !coef || !b || !u || !unew || u == unew || g->dim != 3) return fail(MGK_EINVAL, "mgk_jacobi2_f64: bad arguments (3-D)");
+    if (g->nx + 1 > 1024) return fail(MGK_EINVAL, "mgk_jacobi2_f64: nx + 1 > 1024 is not built");
+    J2Args a; memset(&a, 0, sizeof(a));
+    a.u = u + g->org; a.b = b + g->org; a.out = unew + g->org;
+    a.nx = g->nx; a.ny = g->ny; a.nz = g->nz; a.rs = g->pitch; a.ms = g->plane;
+    a.a0 = coef[0]; a.a1 = coef[1]; a.a2 = coef[2]; a.a3 = coef[3]; a.a4 = coef[4]; a.a5 = coef[5]; a.a6 = coef[6];
+    a.dinv = dinv; a.scale = scale;
+    a.nty = (g->ny + 3) / 4;
+    const int w = (g->nx + 1 + 127) / 128;                      // waves per full row
+    // one 512-thread block per CU (LDS) at 1023^3: 256 tiles, one chunk; 256-thread blocks (511^3): two per CU, 512 blocks
+    // (measured at 511^3: 128 blocks 0.83 ms, 512 blocks 0.57 ms); every chunk recomputes two planes of the first sweep
+    const long target = (w > 4) ? 256 : 512;
+    long nch = (a.nty >= target) ? 1 : (target + a.nty - 1) / a.nty;
+    if (g_zchunk > 0) nch = (g->nz + g_zchunk - 1) / g_zchunk;
+    int zc = (int)((g->nz + nch - 1) / nch);
+    if (zc < 8) zc = 8;
+    if (zc > g->nz) zc = g->nz;
+    a.zc = zc;
+    const long ntz = (g->nz + zc - 1) / zc;
+    const unsigned nblk = (unsigned)(a.nty * ntz);
+    hipStream_t s = S(c, stream);
+    if (w <= 1) hipLaunchKernelGGL((k_jacobi2<1>), dim3(nblk), dim3(64), 0, s, a);
+    else if (w <= 2) hipLaunchKernelGGL((k_jacobi2<2>), dim3(nblk), dim3(128), 0, s, a);
+    else if (w <= 4) hipLaunchKernelGGL((k_jacobi2<4>), dim3(nblk), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_jacobi2<8>), dim3(nblk), dim3(512), 0, s, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // row-wise elementwise / reduction kernels: one lane per aligned x pair, blocks stride over rows
 // ------------------------------------------------------------------------------------------
 // every block of a row kernel owns a CONTIGUOUS range of rows (long sequential streams per block keep

@@ -68,6 +68,8 @@ def _lib():
     L.mg_solver_profile.argtypes = [vp, i]
     L.mg_solver_profile_read.restype = i
     L.mg_solver_profile_read.argtypes = [vp, C.POINTER(d), C.POINTER(i)]
+    L.mg_solver_profile_read_kind.restype = i
+    L.mg_solver_profile_read_kind.argtypes = [vp, i, C.POINTER(d), C.POINTER(i)]
     L.mg_get_ranges.argtypes = [i, i, vp]
     L.mg_grid_n.restype = i
     L.mg_grid_n.argtypes = [i, i]
@@ -194,7 +196,9 @@ class Solver:
     def profile(self, on=True):
         self._chk(self.L.mg_solver_profile(self.h, int(on)))
 
-    def profile_read(self):
+    def profile_read(self, kind=0):
+        """(total ms, launches) of the fine-level launches timed since profile(True): kind 0 plain sweeps,
+        kind 1 two-sweeps-in-one-pass launches"""
         ms, n = C.c_double(), C.c_int()
-        self._chk(self.L.mg_solver_profile_read(self.h, C.byref(ms), C.byref(n)))
+        self._chk(self.L.mg_solver_profile_read_kind(self.h, kind, C.byref(ms), C.byref(n)))
         return ms.value, n.value

@@ -293,3 +293,27 @@ def test_fused_prolong_jacobi_2d_bit_exact(mgk, orc, nf, variant):
     mgk.L.mgk_set_tuning(-1, -1)
     for p in (du, db, duc, dout):
         mgk.free(p)
+
+
+@pytest.mark.parametrize("n", [1, 3, 5, 7, 15, 31, 63, 127, 255])
+def test_two_sweeps_in_one_pass_bit_exact(mgk, orc, n):
+    """mgk_jacobi2_f64 (temporal blocking, u' lives in LDS only) == two mgk_jacobi_f64 sweeps, bit for bit"""
+    rng = np.random.default_rng(6000 + n)
+    As = _stencil(orc, 3, n) if n > 2 else [float((n + 1) ** 2)] * 3 + [-6.0 * (n + 1) ** 2] + [float((n + 1) ** 2)] * 3
+    dinv = 1.0 / As[3]
+    u, b = _rand(rng, n ** 3), _rand(rng, n ** 3)
+    g = mgk.geom(3, n)
+    du, db, dout = mgk.to_field(g, u), mgk.to_field(g, b), mgk.field(g)
+    want = orc.jacobi(3, n, As, 0.8, b, orc.jacobi(3, n, As, 0.8, b, u))
+    for zc in (-1, 8, 13):
+        mgk.L.mgk_set_tuning(-1, zc)
+        mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dout, 8 * g.total, None))
+        mgk._chk(mgk.L.mgk_jacobi2_f64(mgk.ctx, C.byref(g), mgk.coef(As), dinv, 0.8, db, du, dout, None))
+        got = mgk.from_field(g, dout)
+        assert np.array_equal(got, want), f"zc={zc} max diff {np.abs(got - want).max()}"
+        raw = mgk.raw_field(g, dout)
+        assert abs(np.abs(raw).sum() - np.abs(got).sum()) <= 1e-9 * np.abs(got).sum()      # ghosts / padding stay zero
+    mgk.L.mgk_set_tuning(-1, -1)
+    assert np.array_equal(mgk.from_field(g, du), u)
+    for p in (du, db, dout):
+        mgk.free(p)
