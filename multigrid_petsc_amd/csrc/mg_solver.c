@@ -40,6 +40,9 @@ typedef struct mg_fset {
     int guess_nonzero;      /* KSPSetInitialGuessNonzero state of ksp[l] (src/solver.c:1532,1537,1543) */
     int u_ghost_ok;         /* z ghost planes of `u` hold the neighbours' current boundary planes */
     int u_ghost_pending;    /* ... but the exchange is still in flight on the comm stream */
+    int b_ghost_ok;         /* z ghost planes of `b` hold the neighbours' boundary planes (two-sweep passes on slabs) */
+    void *far;              /* distributed levels: field of geometry gfar = (nx, ny, 2) for the neighbours' SECOND planes of u */
+    mgk_geom gfar;
 } mg_fset;
 
 typedef struct mg_level {
@@ -63,6 +66,9 @@ typedef struct mg_ops {
     int (*residual_restrict)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const double *, const void *, const void *, void *, void *);   /* NULL: not built */
     int (*residual_range)(mgk_ctx *, const mgk_geom *, const double *, const void *, const void *, void *, int, int, void *);
     int (*restrict_finish)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const void *, void *, void *);
+    int (*jacobi2)(mgk_ctx *, const mgk_geom *, const double *, double, double, const void *, const void *, void *, void *);
+    int (*jacobi2_slab)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const double *, double, double, const void *, const void *, void *,
+                        const void *, int, int, void *);
 } mg_ops;
 
 #define W64(name) static int name##_64
@@ -85,9 +91,13 @@ W64(rg)(mgk_ctx *c, const mgk_geom *g, const double *k, const void *b, const voi
 W32(rg)(mgk_ctx *c, const mgk_geom *g, const double *k, const void *b, const void *u, void *r, int z0, int z1, void *st) { return mgk_residual_range_f32(c, g, k, (const float *)b, (const float *)u, (float *)r, z0, z1, st); }
 W64(fin)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const void *r, void *bc, void *st) { return mgk_restrict_finish_f64(c, gf, gc, (const double *)r, (double *)bc, st); }
 W32(fin)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const void *r, void *bc, void *st) { return mgk_restrict_finish_f32(c, gf, gc, (const float *)r, (float *)bc, st); }
+W64(j2)(mgk_ctx *c, const mgk_geom *g, const double *k, double d, double sc, const void *b, const void *u, void *o, void *st) { return mgk_jacobi2_f64(c, g, k, d, sc, (const double *)b, (const double *)u, (double *)o, st); }
+W32(j2)(mgk_ctx *c, const mgk_geom *g, const double *k, double d, double sc, const void *b, const void *u, void *o, void *st) { return mgk_jacobi2_f32(c, g, k, d, sc, (const float *)b, (const float *)u, (float *)o, st); }
+W64(j2s)(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gf, const double *k, double d, double sc, const void *b, const void *u, void *o, const void *far, int lo, int hi, void *st) { return mgk_jacobi2_slab_f64(c, g, gf, k, d, sc, (const double *)b, (const double *)u, (double *)o, (const double *)far, lo, hi, st); }
+W32(j2s)(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gf, const double *k, double d, double sc, const void *b, const void *u, void *o, const void *far, int lo, int hi, void *st) { return mgk_jacobi2_slab_f32(c, g, gf, k, d, sc, (const float *)b, (const float *)u, (float *)o, (const float *)far, lo, hi, st); }
 static const mg_ops OPS[2] = {
-    {8, jr_64, jz_64, rs_64, rf_64, pa_64, pj_64, rr_64, rg_64, fin_64},
-    {4, jr_32, jz_32, rs_32, rf_32, pa_32, pj_32, rr_32, rg_32, fin_32},
+    {8, jr_64, jz_64, rs_64, rf_64, pa_64, pj_64, rr_64, rg_64, fin_64, j2_64, j2s_64},
+    {4, jr_32, jz_32, rs_32, rf_32, pa_32, pj_32, rr_32, rg_32, fin_32, j2_32, j2s_32},
 };
 
 struct mg_solver {
@@ -214,6 +224,7 @@ void mg_config_default(mg_config *c) {
     c->fuse = -1;
     c->overlap = -1;
     c->graph = -1;
+    c->pair_min_n = 0;
 }
 
 static int alloc_fset(mg_solver *s, mg_fset *F, int esz, int all4) {
@@ -223,6 +234,20 @@ static int alloc_fset(mg_solver *s, mg_fset *F, int esz, int all4) {
         CHK(mgk_malloc(s->ctx, &q, (size_t)esz * (size_t)F->g.total));
         *f[k] = q;
     }
+    return 0;
+}
+
+/* distributed level: the (nx, ny, 2) field through which the neighbours' second planes of u travel (two-sweep passes) */
+static int alloc_far(mg_solver *s, mg_level *L, int P) {
+    mg_fset *F = &L->f[P];
+    if (!L->distributed || !(s->cfg.fuse & 32) || s->cfg.dim != 3) return 0;
+    int rc = (P == 0) ? mgk_geom_init(&F->gfar, 3, L->n, L->n, 2) : mgk_geom_init_f32(&F->gfar, 3, L->n, L->n, 2);
+    if (rc) return rc;
+    void *q = NULL;
+    const size_t bytes = (size_t)(P == 0 ? 8 : 4) * (size_t)F->gfar.total;
+    CHK(mgk_malloc(s->ctx, &q, bytes));
+    CHK(mgk_memset0(s->ctx, q, bytes, NULL));
+    F->far = q;
     return 0;
 }
 
@@ -253,6 +278,7 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
         s->cfg.dist_min_n = n0 < 255 ? n0 : 255;
     }
     if (s->cfg.fuse < 0) s->cfg.fuse = 63;
+    if (s->cfg.pair_min_n <= 0) s->cfg.pair_min_n = 511;
     if (s->cfg.overlap < 0) s->cfg.overlap = 1;
     if (s->cfg.graph < 0) s->cfg.graph = 1;
     if (s->cfg.nranks < 1) s->cfg.nranks = 1;
@@ -305,9 +331,11 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
             }
             if ((rc = mgk_geom_init_f32(&L->f[1].g, 3, L->n, L->n, L->nzl))) { mg_solver_destroy(s); return mgfail(rc, "mg_solver_create: fp32 geometry"); }
             if ((rc = alloc_fset(s, &L->f[1], 4, 1))) { mg_solver_destroy(s); return rc; }
+            if ((rc = alloc_far(s, L, 1))) { mg_solver_destroy(s); return rc; }
             continue;
         }
         if ((rc = alloc_fset(s, &L->f[0], 8, 1))) { mg_solver_destroy(s); return rc; }
+        if ((rc = alloc_far(s, L, 0))) { mg_solver_destroy(s); return rc; }
         if (cfg->ksp_type == MG_KSP_CHEBYSHEV) {
             void *q = NULL;
             if ((rc = mgk_malloc(s->ctx, &q, sizeof(double) * (size_t)L->f[0].g.total))) { mg_solver_destroy(s); return mgfail(rc, "mg_solver_create: field"); }
@@ -340,8 +368,8 @@ void mg_solver_destroy(mg_solver *s) {
         for (int l = 0; l < s->levels; l++) {
             mg_level *L = &s->L[l];
             for (int p = 0; p < 2; p++) {
-                void *f[4] = {L->f[p].u, L->f[p].b, L->f[p].rv, L->f[p].tmp};
-                for (int k = 0; k < 4; k++) if (f[k]) mgk_free(s->ctx, f[k]);
+                void *f[5] = {L->f[p].u, L->f[p].b, L->f[p].rv, L->f[p].tmp, L->f[p].far};
+                for (int k = 0; k < 5; k++) if (f[k]) mgk_free(s->ctx, f[k]);
             }
             if (L->p2) mgk_free(s->ctx, L->p2);
         }
@@ -551,19 +579,37 @@ static int smooth(mg_solver *s, int P, int l, int maxit) {
     }
     /* two sweeps per pass (temporal blocking) where it pays: whole 3-D grids of 511^3 and more.  Not on the level whose
      * buffers the coarse-level HIP graph refers to (a pass swaps u/tmp once, not twice: see coarse_part) */
-    const int pair_ok = (s->cfg.fuse & 32) && P == 0 && s->cfg.dim == 3 && !L->distributed && L->n >= 511 && L->n + 1 <= 1024 &&
-                        (s->lgraph == 0 || l < s->lgraph - 1);
+    const int pair_ok = (s->cfg.fuse & 32) && s->cfg.dim == 3 && L->n >= s->cfg.pair_min_n && L->n + 1 <= 1024 &&
+                        (!L->distributed || (F->far && F->g.nz >= 4)) && (s->lgraph == 0 || l < s->lgraph - 1);
     for (int it = it0; it < maxit; it++) {
         if (it == 0 && !F->guess_nonzero) {
             /* r = b, x = 0 + scale*(B b): u is not read */
             CHK(O->jacobi_zero(s->ctx, &F->g, L->dinv, s->cfg.scale, F->b, F->tmp, NULL));
         } else if (pair_ok && maxit - it >= 2) {
-            g_prof_kind = 1;
-            void *t = prof_begin(s, l);
-            g_prof_kind = 0;
-            CHK(mgk_jacobi2_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u,
-                                (double *)F->tmp, NULL));
-            prof_end(s, t);
+            if (L->distributed) {
+                /* slab: the second sweep of my first / last plane needs the first sweep of the neighbour's last / first plane,
+                 * i.e. TWO of its planes of u (one is the regular ghost plane) and its b on that plane */
+                const size_t pb = (size_t)O->esz * (size_t)F->g.plane;
+                const int nz = F->g.nz;
+                CHK(ensure_u_ghosts(s, P, L));
+                if (!F->b_ghost_ok) { CHK(halo(s, P, L, F->b)); F->b_ghost_ok = 1; }
+                CHK(mgk_d2d(s->ctx, (char *)F->far + pb, (char *)F->u + 2 * pb, pb, NULL));                       /* my plane 1 */
+                CHK(mgk_d2d(s->ctx, (char *)F->far + 2 * pb, (char *)F->u + (size_t)(nz - 1) * pb, pb, NULL));   /* my plane nz-2 */
+                {
+                    void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
+                    CHK(mgk_stream_wait(s->ctx, ms, cs));
+                    CHK(s->comm->halo(s->comm, s->ctx, F->far, &F->gfar, O->esz, ms));
+                    CHK(mgk_stream_wait(s->ctx, cs, ms));
+                }
+                CHK(O->jacobi2_slab(s->ctx, &F->g, &F->gfar, L->coef, L->dinv, s->cfg.scale, F->b, F->u, F->tmp, F->far,
+                                    s->cfg.rank > 0, s->cfg.rank < s->cfg.nranks - 1, NULL));
+            } else {
+                g_prof_kind = 1;
+                void *t = prof_begin(s, l);
+                g_prof_kind = 0;
+                CHK(O->jacobi2(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, F->b, F->u, F->tmp, NULL));
+                prof_end(s, t);
+            }
             it++;                                   /* this pass made sweeps it and it + 1 */
         } else if (L->distributed && s->cfg.overlap && F->g.nz >= 3) {
             /* boundary planes first, ship them on the comm stream, sweep the interior meanwhile */
@@ -613,6 +659,7 @@ static int restrict_to(mg_solver *s, int P, int l) {
     mg_level *Lf = &s->L[l - 1], *Lc = &s->L[l];
     mg_fset *F = &Lf->f[P], *Cq = &Lc->f[P];
     const mg_ops *O = &OPS[P];
+    Cq->b_ghost_ok = 0;
     CHK(halo(s, P, Lf, F->rv));
     if (Lf->distributed && !Lc->distributed) {
         /* slab -> replicated: produce my coarse planes in place, then all-gather them */
@@ -694,6 +741,7 @@ static int descend(mg_solver *s, int P, int l) {
         mg_fset *F = &Lf->f[P], *Cq = &Lc->f[P];
         void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
         const int me = s->cfg.rank, last = (me == s->cfg.nranks - 1);
+        Cq->b_ghost_ok = 0;
         mgk_geom gc = Cq->g;
         void *bc = Cq->b;
         if (!Lc->distributed) {                 /* slab -> replicated: my coarse planes land in place, then all-gather */
@@ -788,6 +836,7 @@ static int vcycle_once(mg_solver *s) {
             CHK(ensure_u_ghosts(s, 0, L));
             CHK(mgk_residual_f64_to_f32(s->ctx, &F->g, &E->g, L->coef, (const double *)F->b, (const double *)F->u, (float *)E->b, &ss, NULL));
         }
+        E->b_ghost_ok = 0;
     } else {
         CHK(cycle_body(s, 0, s->iter == 0));
         /* :1545-1546  r0 = b0 - A0 u0 ; ||r0|| */
@@ -819,7 +868,7 @@ static int start(mg_solver *s) {
     CHK(mgk_sumsq_f64(s->ctx, &F->g, (const double *)F->b, &ss, NULL)); /* VecNorm(b[0]) :1512 */
     CHK(norm_from_sumsq(s, ss, &s->bnorm));
     for (int l = 0; l < s->levels; l++)
-        for (int p = 0; p < 2; p++) { s->L[l].f[p].guess_nonzero = 0; s->L[l].f[p].u_ghost_ok = 0; s->L[l].f[p].u_ghost_pending = 0; }
+        for (int p = 0; p < 2; p++) { s->L[l].f[p].guess_nonzero = 0; s->L[l].f[p].u_ghost_ok = 0; s->L[l].f[p].u_ghost_pending = 0; s->L[l].f[p].b_ghost_ok = 0; }
     CHK(mgk_memset0(s->ctx, F->u, sizeof(double) * (size_t)F->g.total, NULL));   /* VecSet(u[0],0) :1514 */
     /* rv = A u - b with u = 0 (:1516-1517); ||A u - b|| = ||b - A u||, evaluated by the same residual kernel */
     if (s->cfg.precision == MG_PREC_MIXED)

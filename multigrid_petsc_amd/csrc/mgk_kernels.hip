@@ -1041,21 +1041,27 @@ extern "C" int mgk_jacobi_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const double 
 // neighbours of plane z from the ring and stores the result.  The halo rows of u' are recomputed by the neighbouring
 // tile (1.5x stage-1 arithmetic, 2x u row loads that mostly hit L2); u' never goes to memory.  Each stage performs
 // exactly the arithmetic of k_stencil<MODE_JACOBI>, so the result equals two separate sweeps bit for bit.
+template <typename T>
 struct J2Args {
-    const double *u, *b;
-    double *out;
+    const T *u, *b;
+    T *out;
     int nx, ny, nz;
     long rs, ms;
     int nty, zc;
-    double a0, a1, a2, a3, a4, a5, a6, dinv, scale;
+    T a0, a1, a2, a3, a4, a5, a6, dinv, scale;
+    // z-slab of a multi-GPU run: the second sweep of planes 0 / nz-1 needs the first sweep of the neighbour's last / first
+    // plane, hence TWO of its planes of u (plane -1 / nz is the field's own ghost plane, plane -2 / nz+1 comes in these
+    // separate plane buffers, same pitch, pointing at their interior origin) and b on the ghost planes.
+    const T *far_lo, *far_hi;
+    int has_lo, has_hi;
 };
 
-template <int WX>
-__global__ void __launch_bounds__(64 * WX) k_jacobi2(const J2Args a) {
-    constexpr int VX = 2, TY = 4, R1 = TY + 4, R2 = TY + 2, TX = 64 * VX * WX, LW = TX + 2 * VX;
-    __shared__ __attribute__((aligned(16))) double ring[3][R2][LW];
-    __shared__ double edgeW[2][R2][WX], edgeE[2][R2][WX];     // first / last element of every wave's row segment
-    using VT = V16<double>;
+template <typename T, int WX>
+__global__ void __launch_bounds__(64 * WX) k_jacobi2(const J2Args<T> a) {
+    constexpr int VX = 16 / sizeof(T), TY = 4, R1 = TY + 4, R2 = TY + 2, TX = 64 * VX * WX, LW = TX + 2 * VX;
+    __shared__ __attribute__((aligned(16))) T ring[3][R2][LW];
+    __shared__ T edgeW[2][R2][WX], edgeE[2][R2][WX];          // first / last element of every wave's row segment
+    using VT = V16<T>;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     int bid = blockIdx.x;
     const int nblk = gridDim.x;
@@ -1073,30 +1079,35 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2(const J2Args a) {
     for (int rr = 0; rr < R1; rr++) { const int y = yb - 2 + rr; uok[rr] = xok && y >= -1 && y <= a.ny; }
 #pragma unroll
     for (int q = 0; q < R2; q++) { const int y = yb - 1 + q; s1ok[q] = y >= 0 && y < a.ny; }
-    const double *up_ = a.u + (long)(yb - 2) * a.rs + x0;     // row rr of plane p: up_ + p*ms + rr*rs
-    const double *bp_ = a.b + (long)(yb - 1) * a.rs + x0;     // row q  of plane p: bp_ + p*ms + q*rs
+    const long uoff = (long)(yb - 2) * a.rs + x0;             // row rr of plane p: uplane(p) + rr*rs
+    const T *bp_ = a.b + (long)(yb - 1) * a.rs + x0;          // row q  of plane p: bp_ + p*ms + q*rs
+    const int pmin = a.has_lo ? -2 : -1, pmax = a.has_hi ? a.nz + 1 : a.nz;     // u planes that exist
+    const int smin = a.has_lo ? -1 : 0, smax = a.has_hi ? a.nz : a.nz - 1;      // planes on which the first sweep is real
+    auto uplane = [&](int p) -> const T * {
+        return (p == -2 ? a.far_lo : p == a.nz + 1 ? a.far_hi : a.u + (long)p * a.ms) + uoff;
+    };
 
     // zero the ring (u'(-1) and the padding columns are 0) -- one pass, strided over the block
-    for (int i = tid; i < 3 * R2 * LW; i += 64 * WX) (&ring[0][0][0])[i] = 0.0;
+    for (int i = tid; i < 3 * R2 * LW; i += 64 * WX) (&ring[0][0][0])[i] = (T)0;
 
     VT ua[R1], ub[R1], uc[R1], ud[R1], b1[R2], bn[R2], b0[TY];
     const int t0 = z0 - 2;                                    // first step: stage 1 of plane z0 - 1
 #pragma unroll
     for (int rr = 0; rr < R1; rr++) {
         const long ro = (long)rr * a.rs;
-        ua[rr] = ldv(up_ + (long)t0 * a.ms + ro, uok[rr] && t0 >= -1);
-        ub[rr] = ldv(up_ + (long)(t0 + 1) * a.ms + ro, uok[rr] && t0 + 1 >= -1);
-        uc[rr] = ldv(up_ + (long)(t0 + 2) * a.ms + ro, uok[rr]);
-        ud[rr] = v16_zero<double>();
+        ua[rr] = ldv(uplane(t0) + ro, uok[rr] && t0 >= pmin);
+        ub[rr] = ldv(uplane(t0 + 1) + ro, uok[rr] && t0 + 1 >= pmin);
+        uc[rr] = ldv(uplane(t0 + 2) + ro, uok[rr]);
+        ud[rr] = v16_zero<T>();
     }
 #pragma unroll
     for (int q = 0; q < R2; q++) {
         const int p = t0 + 1;
-        b1[q] = ldv(bp_ + (long)p * a.ms + (long)q * a.rs, xok && s1ok[q] && p >= 0 && p < a.nz);
-        bn[q] = v16_zero<double>();
+        b1[q] = ldv(bp_ + (long)p * a.ms + (long)q * a.rs, xok && s1ok[q] && p >= smin && p <= smax);
+        bn[q] = v16_zero<T>();
     }
 #pragma unroll
-    for (int j = 0; j < TY; j++) b0[j] = v16_zero<double>();
+    for (int j = 0; j < TY; j++) b0[j] = v16_zero<T>();
     // edges of the first centre plane (ub = plane t0 + 1)
     if (lane == 0 || lane == 63) {
 #pragma unroll
@@ -1111,42 +1122,43 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2(const J2Args a) {
         const int p = t + 1;                                  // plane of stage 1
         // ---- loads consumed in the next step ----
         {
-            const bool pu = (t + 3 <= a.nz), pb = (t + 2 < a.nz) && (t + 1 < z1);
+            const bool pu = (t + 3 <= pmax), pb = (t + 2 <= smax) && (t + 1 < z1);
+            const T *un = uplane(t + 3);
 #pragma unroll
-            for (int rr = 0; rr < R1; rr++) ud[rr] = ldv(up_ + (long)(t + 3) * a.ms + (long)rr * a.rs, uok[rr] && pu);
+            for (int rr = 0; rr < R1; rr++) ud[rr] = ldv(un + (long)rr * a.rs, uok[rr] && pu);
 #pragma unroll
             for (int q = 0; q < R2; q++) {
-                const double *bp = bp_ + (long)(t + 2) * a.ms + (long)q * a.rs;
+                const T *bp = bp_ + (long)(t + 2) * a.ms + (long)q * a.rs;
                 const bool ok = xok && s1ok[q] && pb;
                 bn[q] = (q >= 2 && q < R2 - 2) ? ldv_stream(bp, ok) : ldv(bp, ok);     // rows shared with neighbours: cached
             }
         }
         // ---- stage 1: u'(p) on rows yb-1 .. yb+TY ----
         {
-            const bool pin = (p >= 0 && p < a.nz);
+            const bool pin = (p >= smin && p <= smax);
             const int slot = (p + 3) % 3, eb = p & 1;
 #pragma unroll
             for (int q = 0; q < R2; q++) {
                 const int rr = q + 1;
-                double Wv = __shfl_up(ub[rr].v[VX - 1], 1, 64), Ev = __shfl_down(ub[rr].v[0], 1, 64);
-                if (lane == 0) Wv = (w > 0) ? edgeE[eb][q][w - 1] : 0.0;
-                if (lane == 63) Ev = (w < WX - 1) ? edgeW[eb][q][w + 1] : 0.0;
+                T Wv = __shfl_up(ub[rr].v[VX - 1], 1, 64), Ev = __shfl_down(ub[rr].v[0], 1, 64);
+                if (lane == 0) Wv = (w > 0) ? edgeE[eb][q][w - 1] : (T)0;
+                if (lane == 63) Ev = (w < WX - 1) ? edgeW[eb][q][w + 1] : (T)0;
                 VT o;
 #pragma unroll
                 for (int e = 0; e < VX; e++) {
-                    const double wv = (e == 0) ? Wv : ub[rr].v[e - 1 < 0 ? 0 : e - 1];
-                    const double ev = (e == VX - 1) ? Ev : ub[rr].v[e + 1 > VX - 1 ? VX - 1 : e + 1];
-                    double s = a.a0 * ua[rr].v[e];
+                    const T wv = (e == 0) ? Wv : ub[rr].v[e - 1 < 0 ? 0 : e - 1];
+                    const T ev = (e == VX - 1) ? Ev : ub[rr].v[e + 1 > VX - 1 ? VX - 1 : e + 1];
+                    T s = a.a0 * ua[rr].v[e];
                     s = s + a.a1 * ub[rr - 1].v[e];
                     s = s + a.a2 * wv;
                     s = s + a.a3 * ub[rr].v[e];
                     s = s + a.a4 * ev;
                     s = s + a.a5 * ub[rr + 1].v[e];
                     s = s + a.a6 * uc[rr].v[e];
-                    const double res = b1[q].v[e] - s;
-                    const double zz = res * a.dinv;
+                    const T res = b1[q].v[e] - s;
+                    const T zz = res * a.dinv;
                     o.v[e] = ub[rr].v[e] + a.scale * zz;
-                    if (!pin || !s1ok[q] || !xok || (lastvec && x0 + e >= a.nx)) o.v[e] = 0.0;
+                    if (!pin || !s1ok[q] || !xok || (lastvec && x0 + e >= a.nx)) o.v[e] = (T)0;
                 }
                 *reinterpret_cast<VT *>(&ring[slot][q][xl + VX]) = o;
             }
@@ -1171,23 +1183,23 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2(const J2Args a) {
                 const VT upv = *reinterpret_cast<const VT *>(&ring[sp][q][xl + VX]);
                 const VT sv = *reinterpret_cast<const VT *>(&ring[sc][q - 1][xl + VX]);
                 const VT nv = *reinterpret_cast<const VT *>(&ring[sc][q + 1][xl + VX]);
-                const double Wv = ring[sc][q][xl + VX - 1], Ev = ring[sc][q][xl + 2 * VX];
+                const T Wv = ring[sc][q][xl + VX - 1], Ev = ring[sc][q][xl + 2 * VX];
                 VT o;
 #pragma unroll
                 for (int e = 0; e < VX; e++) {
-                    const double wv = (e == 0) ? Wv : c.v[e - 1 < 0 ? 0 : e - 1];
-                    const double ev = (e == VX - 1) ? Ev : c.v[e + 1 > VX - 1 ? VX - 1 : e + 1];
-                    double s = a.a0 * dn.v[e];
+                    const T wv = (e == 0) ? Wv : c.v[e - 1 < 0 ? 0 : e - 1];
+                    const T ev = (e == VX - 1) ? Ev : c.v[e + 1 > VX - 1 ? VX - 1 : e + 1];
+                    T s = a.a0 * dn.v[e];
                     s = s + a.a1 * sv.v[e];
                     s = s + a.a2 * wv;
                     s = s + a.a3 * c.v[e];
                     s = s + a.a4 * ev;
                     s = s + a.a5 * nv.v[e];
                     s = s + a.a6 * upv.v[e];
-                    const double res = b0[j].v[e] - s;
-                    const double zz = res * a.dinv;
+                    const T res = b0[j].v[e] - s;
+                    const T zz = res * a.dinv;
                     o.v[e] = c.v[e] + a.scale * zz;
-                    if (lastvec && x0 + e >= a.nx) o.v[e] = 0.0;
+                    if (lastvec && x0 + e >= a.nx) o.v[e] = (T)0;
                 }
                 if (xok && yb + j < a.ny) stv_stream(a.out + (long)t * a.ms + (long)(yb + j) * a.rs + x0, o);
             }
@@ -1203,19 +1215,23 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2(const J2Args a) {
     }
 }
 
-extern "C" int mgk_jacobi2_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
-                               const double *b, const double *u, double *unew, void *stream) {
-    if (!c || !g || !coef || !b || !u || !unew || u == unew || g->dim != 3) return fail(MGK_EINVAL, "mgk_jacobi2_f64: bad arguments (3-D)");
-    if (g->nx + 1 > 1024) return fail(MGK_EINVAL, "mgk_jacobi2_f64: nx + 1 > 1024 is not built");
-    J2Args a; memset(&a, 0, sizeof(a));
+template <typename T>
+static int jacobi2(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
+                   const T *b, const T *u, T *unew, const T *far_lo, const T *far_hi, void *stream) {
+    constexpr int VX = 16 / sizeof(T);
+    if (!c || !g || !coef || !b || !u || !unew || u == unew || g->dim != 3) return fail(MGK_EINVAL, "mgk_jacobi2: bad arguments (3-D)");
+    if (g->nx + 1 > 1024) return fail(MGK_EINVAL, "mgk_jacobi2: nx + 1 > 1024 is not built");
+    J2Args<T> a; memset(&a, 0, sizeof(a));
     a.u = u + g->org; a.b = b + g->org; a.out = unew + g->org;
     a.nx = g->nx; a.ny = g->ny; a.nz = g->nz; a.rs = g->pitch; a.ms = g->plane;
-    a.a0 = coef[0]; a.a1 = coef[1]; a.a2 = coef[2]; a.a3 = coef[3]; a.a4 = coef[4]; a.a5 = coef[5]; a.a6 = coef[6];
-    a.dinv = dinv; a.scale = scale;
+    a.a0 = (T)coef[0]; a.a1 = (T)coef[1]; a.a2 = (T)coef[2]; a.a3 = (T)coef[3]; a.a4 = (T)coef[4]; a.a5 = (T)coef[5]; a.a6 = (T)coef[6];
+    a.dinv = (T)dinv; a.scale = (T)scale;
+    a.far_lo = far_lo; a.far_hi = far_hi; a.has_lo = far_lo != nullptr; a.has_hi = far_hi != nullptr;
     a.nty = (g->ny + 3) / 4;
-    const int w = (g->nx + 1 + 127) / 128;                      // waves per full row
-    // one 512-thread block per CU (LDS) at 1023^3: 256 tiles, one chunk; 256-thread blocks (511^3): two per CU, 512 blocks
-    // (measured at 511^3: 128 blocks 0.83 ms, 512 blocks 0.57 ms); every chunk recomputes two planes of the first sweep
+    const int w = (g->nx + 1 + 64 * VX - 1) / (64 * VX);        // waves per full row
+    // one 512-thread block per CU (LDS) for fp64 at 1023^3: 256 tiles, one chunk; blocks of <= 256 threads (fp64 511^3, fp32):
+    // two per CU, 512 blocks (measured, fp64 511^3: 128 blocks 0.83 ms, 512 blocks 0.57 ms); every chunk recomputes two
+    // planes of the first sweep
     const long target = (w > 4) ? 256 : 512;
     long nch = (a.nty >= target) ? 1 : (target + a.nty - 1) / a.nty;
     if (g_zchunk > 0) nch = (g->nz + g_zchunk - 1) / g_zchunk;
@@ -1226,12 +1242,41 @@ extern "C" int mgk_jacobi2_f64(mgk_ctx *c, const mgk_geom *g, const double *coef
     const long ntz = (g->nz + zc - 1) / zc;
     const unsigned nblk = (unsigned)(a.nty * ntz);
     hipStream_t s = S(c, stream);
-    if (w <= 1) hipLaunchKernelGGL((k_jacobi2<1>), dim3(nblk), dim3(64), 0, s, a);
-    else if (w <= 2) hipLaunchKernelGGL((k_jacobi2<2>), dim3(nblk), dim3(128), 0, s, a);
-    else if (w <= 4) hipLaunchKernelGGL((k_jacobi2<4>), dim3(nblk), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_jacobi2<8>), dim3(nblk), dim3(512), 0, s, a);
+    if (w <= 1) hipLaunchKernelGGL((k_jacobi2<T, 1>), dim3(nblk), dim3(64), 0, s, a);
+    else if (w <= 2) hipLaunchKernelGGL((k_jacobi2<T, 2>), dim3(nblk), dim3(128), 0, s, a);
+    else if (w <= 4) hipLaunchKernelGGL((k_jacobi2<T, 4>), dim3(nblk), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_jacobi2<T, 8>), dim3(nblk), dim3(512), 0, s, a);
     HIPCHK(hipGetLastError());
     return 0;
+}
+extern "C" int mgk_jacobi2_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
+                               const double *b, const double *u, double *unew, void *stream) {
+    return jacobi2<double>(c, g, coef, dinv, scale, b, u, unew, nullptr, nullptr, stream);
+}
+extern "C" int mgk_jacobi2_f32(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
+                               const float *b, const float *u, float *unew, void *stream) {
+    return jacobi2<float>(c, g, coef, dinv, scale, b, u, unew, nullptr, nullptr, stream);
+}
+// The same on a z-slab.  `far` is a field of geometry (nx, ny, nz = 2) whose ghost planes hold the neighbours' second plane
+// (lo ghost: plane nz-2 of the rank below, hi ghost: plane 1 of the rank above; mgk_geom of it in gfar); u's own ghost
+// planes hold their last / first plane and b's ghost planes their b.  has_lo / has_hi: a neighbour exists on that side.
+template <typename T>
+static int jacobi2_slab(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gfar, const double *coef, double dinv, double scale,
+                        const T *b, const T *u, T *unew, const T *far, int has_lo, int has_hi, void *stream) {
+    if (!g || !gfar || !far || gfar->dim != 3 || gfar->nz != 2 || gfar->nx != g->nx || gfar->ny != g->ny || gfar->pitch != g->pitch ||
+        g->nz < 2)
+        return fail(MGK_EINVAL, "mgk_jacobi2_slab: the far-plane field must have the geometry (nx, ny, 2) of the slab");
+    const T *lo = has_lo ? far + gfar->org - gfar->plane : nullptr;
+    const T *hi = has_hi ? far + gfar->org + 2 * gfar->plane : nullptr;
+    return jacobi2<T>(c, g, coef, dinv, scale, b, u, unew, lo, hi, stream);
+}
+extern "C" int mgk_jacobi2_slab_f64(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gfar, const double *coef, double dinv, double scale,
+                                    const double *b, const double *u, double *unew, const double *far, int has_lo, int has_hi, void *stream) {
+    return jacobi2_slab<double>(c, g, gfar, coef, dinv, scale, b, u, unew, far, has_lo, has_hi, stream);
+}
+extern "C" int mgk_jacobi2_slab_f32(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gfar, const double *coef, double dinv, double scale,
+                                    const float *b, const float *u, float *unew, const float *far, int has_lo, int has_hi, void *stream) {
+    return jacobi2_slab<float>(c, g, gfar, coef, dinv, scale, b, u, unew, far, has_lo, has_hi, stream);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -155,3 +155,23 @@ def test_mixed_fused_outer_step_changes_nothing():
         s.close()
     assert res[15][0] == res[31][0] and np.array_equal(res[15][2], res[31][2])
     assert np.abs(res[15][1] / res[31][1] - 1).max() <= 1e-13
+
+
+@pytest.mark.parametrize("n", [1, 3, 7, 31, 63, 127, 255])
+def test_two_fp32_sweeps_in_one_pass_bit_exact(mgk, orc, n):
+    rng = np.random.default_rng(7000 + n)
+    As = orc.level_stencil(3, n + 2, 0)[0]
+    dinv = 1.0 / As[3]
+    u, b = rng.uniform(-1, 1, n ** 3).astype(np.float32), rng.uniform(-1, 1, n ** 3).astype(np.float32)
+    g = mgk.geom32(n)
+    du, db, dout = mgk.to_field32(g, u), mgk.to_field32(g, b), mgk.alloc(4 * g.total)
+    s = 6.0 / 7.0
+    want = orc.jacobi32(n, As, s, b, orc.jacobi32(n, As, s, b, u))
+    for zc in (-1, 8, 13):
+        mgk.L.mgk_set_tuning(-1, zc)
+        mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dout, 4 * g.total, None))
+        mgk._chk(mgk.L.mgk_jacobi2_f32(mgk.ctx, C.byref(g), mgk.coef(As), dinv, s, db, du, dout, None))
+        assert np.array_equal(mgk.from_field32(g, dout), want)
+    mgk.L.mgk_set_tuning(-1, -1)
+    for p in (du, db, dout):
+        mgk.free(p)

@@ -210,3 +210,20 @@ def test_fixed_count_cycling_defers_the_norms_on_slabs():
     for rn, _ in res:
         assert rn.shape == rn1.shape and np.abs(rn / rn1 - 1).max() <= 1e-13
     assert np.array_equal(np.concatenate([r[1] for r in res]), u1)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("P,npts,levels,dist_min_n,precision", [
+    (2, 65, 5, 15, "fp64"), (3, 65, 5, 15, "fp64"), (4, 129, 6, 31, "fp64"), (8, 129, 6, 63, "fp64"), (2, 65, 3, 15, "fp64"),
+    (2, 65, 5, 15, "mixed"), (4, 129, 6, 31, "mixed"),
+])
+def test_two_sweep_passes_on_slabs(P, npts, levels, dist_min_n, precision):
+    """fuse bit 5 on distributed levels: the pair kernel runs on every slab with the neighbours' two boundary planes of u
+    (regular ghost plane + the far-plane field) and their b ghost plane; fields equal the single-rank, one-sweep-per-launch
+    solve bit for bit"""
+    it1, rn1, u1, _ = _solve_single(npts, levels, 6.0 / 7.0, 60, precision=precision, fuse=0)
+    res = _solve_ranks(P, npts, levels, 6.0 / 7.0, 60, dist_min_n, precision=precision, pair_min_n=15)
+    assert all(r[0] == it1 for r in res)
+    for r in res:
+        assert np.abs(r[1] / rn1 - 1).max() <= 1e-12
+    assert np.array_equal(np.concatenate([r[2] for r in res]), u1)

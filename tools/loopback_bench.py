@@ -10,7 +10,7 @@ npts = int(sys.argv[1]) if len(sys.argv) > 1 else 513
 Ps = [int(x) for x in sys.argv[2:]] or [1, 2, 4, 8]
 levels = {1025: 10, 513: 9, 257: 8, 129: 7}[npts]
 for P in Ps:
-    for fuse in (27, 31):                         # 27: without the fused residual+restriction
+    for fuse in (31, 63):                         # 31: one sweep per launch; 63: sweeps in pairs where possible
         def fn(rank, comm):
             s = Solver(3, npts, levels, scale=6 / 7, maxiter=40, rank=rank, nranks=P, comm=comm, fuse=fuse)
             s.set_rhs_problem(); s.cycles(2); s.sync()
