@@ -1215,6 +1215,166 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2(const J2Args<T> a) {
     }
 }
 
+// Variant of k_jacobi2 with ONE barrier per marching step: the first-sweep values a lane needs again at its own columns
+// (planes t-1 and t+1 of the second sweep) stay in its registers; LDS holds only the centre plane u'(t) that the x / y
+// neighbours of the second sweep are read from, double buffered (written in step t-1, read in step t while u'(t+1) goes
+// to the other buffer).  The plane of u brought in for the next step is loaded straight into the registers of the plane
+// the first sweep has just finished with.
+template <typename T, int WX>
+__global__ void __launch_bounds__(64 * WX) k_jacobi2r(const J2Args<T> a) {
+    constexpr int VX = 16 / sizeof(T), TY = 4, R1 = TY + 4, R2 = TY + 2, TX = 64 * VX * WX, LW = TX + 2 * VX;
+    __shared__ __attribute__((aligned(16))) T cen[2][R2][LW];
+    __shared__ T edgeW[2][R2][WX], edgeE[2][R2][WX];
+    using VT = V16<T>;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int ty = bid % a.nty, tz = bid / a.nty;
+    const int yb = TY * ty;
+    const int z0 = tz * a.zc, z1 = min(z0 + a.zc, a.nz);
+    if (z0 >= z1) return;
+    const int xl = VX * tid, x0 = xl;
+    const bool xok = x0 < a.nx;
+    const bool lastvec = (x0 + VX > a.nx);
+
+    bool uok[R1], s1ok[R2];
+#pragma unroll
+    for (int rr = 0; rr < R1; rr++) { const int y = yb - 2 + rr; uok[rr] = xok && y >= -1 && y <= a.ny; }
+#pragma unroll
+    for (int q = 0; q < R2; q++) { const int y = yb - 1 + q; s1ok[q] = y >= 0 && y < a.ny; }
+    const long uoff = (long)(yb - 2) * a.rs + x0;
+    const T *bp_ = a.b + (long)(yb - 1) * a.rs + x0;
+    const int pmin = a.has_lo ? -2 : -1, pmax = a.has_hi ? a.nz + 1 : a.nz;
+    const int smin = a.has_lo ? -1 : 0, smax = a.has_hi ? a.nz : a.nz - 1;
+    auto uplane = [&](int p) -> const T * {
+        return (p == -2 ? a.far_lo : p == a.nz + 1 ? a.far_hi : a.u + (long)p * a.ms) + uoff;
+    };
+    for (int i = tid; i < 2 * R2 * LW; i += 64 * WX) (&cen[0][0][0])[i] = (T)0;
+
+    VT ua[R1], ub[R1], uc[R1], b1[R2], bn[R2], b0[TY], wm[TY], wc[TY], wp[TY];
+    const int t0 = z0 - 2;
+#pragma unroll
+    for (int rr = 0; rr < R1; rr++) {
+        const long ro = (long)rr * a.rs;
+        ua[rr] = ldv(uplane(t0) + ro, uok[rr] && t0 >= pmin);
+        ub[rr] = ldv(uplane(t0 + 1) + ro, uok[rr] && t0 + 1 >= pmin);
+        uc[rr] = ldv(uplane(t0 + 2) + ro, uok[rr]);
+    }
+#pragma unroll
+    for (int q = 0; q < R2; q++) {
+        const int p = t0 + 1;
+        b1[q] = ldv(bp_ + (long)p * a.ms + (long)q * a.rs, xok && s1ok[q] && p >= smin && p <= smax);
+        bn[q] = v16_zero<T>();
+    }
+#pragma unroll
+    for (int j = 0; j < TY; j++) { b0[j] = v16_zero<T>(); wm[j] = b0[j]; wc[j] = b0[j]; wp[j] = b0[j]; }
+    if (lane == 0 || lane == 63) {
+#pragma unroll
+        for (int q = 0; q < R2; q++) {
+            if (lane == 0) edgeW[(t0 + 1) & 1][q][w] = ub[q + 1].v[0];
+            else edgeE[(t0 + 1) & 1][q][w] = ub[q + 1].v[VX - 1];
+        }
+    }
+    __syncthreads();
+
+    for (int t = t0; t < z1; t++) {
+        const int p = t + 1;
+        {   // b of the next step (u of the next step is issued after the first sweep, into the registers it frees)
+            const bool pb = (t + 2 <= smax) && (t + 1 < z1);
+#pragma unroll
+            for (int q = 0; q < R2; q++) {
+                const T *bp = bp_ + (long)(t + 2) * a.ms + (long)q * a.rs;
+                const bool ok = xok && s1ok[q] && pb;
+                bn[q] = (q >= 2 && q < R2 - 2) ? ldv_stream(bp, ok) : ldv(bp, ok);
+            }
+        }
+        // ---- second sweep of plane t: neighbours in x / y from cen[t & 1] (written in step t-1), z neighbours wm / wp ... ----
+        // (wp = u'(t+1) is produced by the first sweep below, so the first sweep goes first)
+        {
+            const bool pin = (p >= smin && p <= smax);
+            const int eb = p & 1, cb = p & 1;
+#pragma unroll
+            for (int q = 0; q < R2; q++) {
+                const int rr = q + 1;
+                T Wv = __shfl_up(ub[rr].v[VX - 1], 1, 64), Ev = __shfl_down(ub[rr].v[0], 1, 64);
+                if (lane == 0) Wv = (w > 0) ? edgeE[eb][q][w - 1] : (T)0;
+                if (lane == 63) Ev = (w < WX - 1) ? edgeW[eb][q][w + 1] : (T)0;
+                VT o;
+#pragma unroll
+                for (int e = 0; e < VX; e++) {
+                    const T wv = (e == 0) ? Wv : ub[rr].v[e - 1 < 0 ? 0 : e - 1];
+                    const T ev = (e == VX - 1) ? Ev : ub[rr].v[e + 1 > VX - 1 ? VX - 1 : e + 1];
+                    T s = a.a0 * ua[rr].v[e];
+                    s = s + a.a1 * ub[rr - 1].v[e];
+                    s = s + a.a2 * wv;
+                    s = s + a.a3 * ub[rr].v[e];
+                    s = s + a.a4 * ev;
+                    s = s + a.a5 * ub[rr + 1].v[e];
+                    s = s + a.a6 * uc[rr].v[e];
+                    const T res = b1[q].v[e] - s;
+                    const T zz = res * a.dinv;
+                    o.v[e] = ub[rr].v[e] + a.scale * zz;
+                    if (!pin || !s1ok[q] || !xok || (lastvec && x0 + e >= a.nx)) o.v[e] = (T)0;
+                }
+                *reinterpret_cast<VT *>(&cen[cb][q][xl + VX]) = o;
+                if (q >= 1 && q <= TY) wp[q - 1] = o;
+            }
+            if (lane == 0 || lane == 63) {
+#pragma unroll
+                for (int q = 0; q < R2; q++) {
+                    if (lane == 0) edgeW[eb ^ 1][q][w] = uc[q + 1].v[0];
+                    else edgeE[eb ^ 1][q][w] = uc[q + 1].v[VX - 1];
+                }
+            }
+        }
+        // plane t+3 of u into the registers of plane t (the first sweep is done with them)
+        {
+            const bool pu = (t + 3 <= pmax);
+            const T *un = uplane(t + 3);
+#pragma unroll
+            for (int rr = 0; rr < R1; rr++) ua[rr] = ldv(un + (long)rr * a.rs, uok[rr] && pu);
+        }
+        if (t >= z0) {
+            const int cb = t & 1;
+#pragma unroll
+            for (int j = 0; j < TY; j++) {
+                const int q = j + 1;
+                const VT sv = *reinterpret_cast<const VT *>(&cen[cb][q - 1][xl + VX]);
+                const VT nv = *reinterpret_cast<const VT *>(&cen[cb][q + 1][xl + VX]);
+                const T Wv = cen[cb][q][xl + VX - 1], Ev = cen[cb][q][xl + 2 * VX];
+                VT o;
+#pragma unroll
+                for (int e = 0; e < VX; e++) {
+                    const T wv = (e == 0) ? Wv : wc[j].v[e - 1 < 0 ? 0 : e - 1];
+                    const T ev = (e == VX - 1) ? Ev : wc[j].v[e + 1 > VX - 1 ? VX - 1 : e + 1];
+                    T s = a.a0 * wm[j].v[e];
+                    s = s + a.a1 * sv.v[e];
+                    s = s + a.a2 * wv;
+                    s = s + a.a3 * wc[j].v[e];
+                    s = s + a.a4 * ev;
+                    s = s + a.a5 * nv.v[e];
+                    s = s + a.a6 * wp[j].v[e];
+                    const T res = b0[j].v[e] - s;
+                    const T zz = res * a.dinv;
+                    o.v[e] = wc[j].v[e] + a.scale * zz;
+                    if (lastvec && x0 + e >= a.nx) o.v[e] = (T)0;
+                }
+                if (xok && yb + j < a.ny) stv_stream(a.out + (long)t * a.ms + (long)(yb + j) * a.rs + x0, o);
+            }
+        }
+        __syncthreads();            // cen[(t+1)&1] = u'(t+1) complete for the next step; cen[t&1] free for u'(t+2)
+#pragma unroll
+        for (int j = 0; j < TY; j++) { b0[j] = b1[j + 1]; wm[j] = wc[j]; wc[j] = wp[j]; }
+#pragma unroll
+        for (int q = 0; q < R2; q++) b1[q] = bn[q];
+#pragma unroll
+        for (int rr = 0; rr < R1; rr++) { VT tmpv = ua[rr]; ua[rr] = ub[rr]; ub[rr] = uc[rr]; uc[rr] = tmpv; }
+    }
+}
+
+
+
 template <typename T>
 static int jacobi2(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
                    const T *b, const T *u, T *unew, const T *far_lo, const T *far_hi, void *stream) {
@@ -1242,10 +1402,21 @@ static int jacobi2(mgk_ctx *c, const mgk_geom *g, const double *coef, double din
     const long ntz = (g->nz + zc - 1) / zc;
     const unsigned nblk = (unsigned)(a.nty * ntz);
     hipStream_t s = S(c, stream);
-    if (w <= 1) hipLaunchKernelGGL((k_jacobi2<T, 1>), dim3(nblk), dim3(64), 0, s, a);
-    else if (w <= 2) hipLaunchKernelGGL((k_jacobi2<T, 2>), dim3(nblk), dim3(128), 0, s, a);
-    else if (w <= 4) hipLaunchKernelGGL((k_jacobi2<T, 4>), dim3(nblk), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_jacobi2<T, 8>), dim3(nblk), dim3(512), 0, s, a);
+    // one 512-thread block per CU (fp64, 1023^3): the one-barrier variant (4.51 vs 5.15 ms per pass); smaller blocks run two
+    // per CU and hide the second barrier, and prefer the ring variant's full-step prefetch distance (fp64 511^3: 0.66 vs
+    // 0.72 ms; fp32 1023^3: 3.98 vs 7.29 ms, the register variant is at the 256-VGPR limit there)
+    const bool ring = (g_variant == 1) || (g_variant != 2 && !(sizeof(T) == 8 && w > 4));
+    if (ring) {
+        if (w <= 1) hipLaunchKernelGGL((k_jacobi2<T, 1>), dim3(nblk), dim3(64), 0, s, a);
+        else if (w <= 2) hipLaunchKernelGGL((k_jacobi2<T, 2>), dim3(nblk), dim3(128), 0, s, a);
+        else if (w <= 4) hipLaunchKernelGGL((k_jacobi2<T, 4>), dim3(nblk), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_jacobi2<T, 8>), dim3(nblk), dim3(512), 0, s, a);
+    } else {
+        if (w <= 1) hipLaunchKernelGGL((k_jacobi2r<T, 1>), dim3(nblk), dim3(64), 0, s, a);
+        else if (w <= 2) hipLaunchKernelGGL((k_jacobi2r<T, 2>), dim3(nblk), dim3(128), 0, s, a);
+        else if (w <= 4) hipLaunchKernelGGL((k_jacobi2r<T, 4>), dim3(nblk), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_jacobi2r<T, 8>), dim3(nblk), dim3(512), 0, s, a);
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }

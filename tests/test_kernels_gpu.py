@@ -305,12 +305,12 @@ def test_two_sweeps_in_one_pass_bit_exact(mgk, orc, n):
     g = mgk.geom(3, n)
     du, db, dout = mgk.to_field(g, u), mgk.to_field(g, b), mgk.field(g)
     want = orc.jacobi(3, n, As, 0.8, b, orc.jacobi(3, n, As, 0.8, b, u))
-    for zc in (-1, 8, 13):
-        mgk.L.mgk_set_tuning(-1, zc)
+    for var, zc in [(v, z) for v in (-1, 1, 2) for z in (-1, 8, 13)]:      # default choice, ring variant, one-barrier variant
+        mgk.L.mgk_set_tuning(var, zc)
         mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dout, 8 * g.total, None))
         mgk._chk(mgk.L.mgk_jacobi2_f64(mgk.ctx, C.byref(g), mgk.coef(As), dinv, 0.8, db, du, dout, None))
         got = mgk.from_field(g, dout)
-        assert np.array_equal(got, want), f"zc={zc} max diff {np.abs(got - want).max()}"
+        assert np.array_equal(got, want), f"variant={var} zc={zc} max diff {np.abs(got - want).max()}"
         raw = mgk.raw_field(g, dout)
         assert abs(np.abs(raw).sum() - np.abs(got).sum()) <= 1e-9 * np.abs(got).sum()      # ghosts / padding stay zero
     mgk.L.mgk_set_tuning(-1, -1)

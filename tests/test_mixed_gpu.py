@@ -167,8 +167,8 @@ def test_two_fp32_sweeps_in_one_pass_bit_exact(mgk, orc, n):
     du, db, dout = mgk.to_field32(g, u), mgk.to_field32(g, b), mgk.alloc(4 * g.total)
     s = 6.0 / 7.0
     want = orc.jacobi32(n, As, s, b, orc.jacobi32(n, As, s, b, u))
-    for zc in (-1, 8, 13):
-        mgk.L.mgk_set_tuning(-1, zc)
+    for var, zc in [(v, z) for v in (-1, 2) for z in (-1, 8, 13)]:
+        mgk.L.mgk_set_tuning(var, zc)
         mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dout, 4 * g.total, None))
         mgk._chk(mgk.L.mgk_jacobi2_f32(mgk.ctx, C.byref(g), mgk.coef(As), dinv, s, db, du, dout, None))
         assert np.array_equal(mgk.from_field32(g, dout), want)
