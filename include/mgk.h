@@ -122,9 +122,11 @@ int  mgk_jacobi2_f32(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double
  * rank below / plane 1 of the rank above (exchange it like any field after copying this rank's planes 1 and nz-2 into its two
  * interior planes); u's ghost planes hold the neighbours' last / first plane, b's ghost planes their b */
 int  mgk_jacobi2_slab_f64(mgk_ctx *ctx, const mgk_geom *g, const mgk_geom *gfar, const double *coef, double dinv, double scale,
-                          const double *b, const double *u, double *unew, const double *far, int has_lo, int has_hi, void *stream);
+                          const double *b, const double *u, double *unew, const double *far, int has_lo, int has_hi,
+                          int zbeg, int zend, void *stream);   /* output planes [zbeg, zend): planes 2 .. nz-3 need no ghost data */
 int  mgk_jacobi2_slab_f32(mgk_ctx *ctx, const mgk_geom *g, const mgk_geom *gfar, const double *coef, double dinv, double scale,
-                          const float *b, const float *u, float *unew, const float *far, int has_lo, int has_hi, void *stream);
+                          const float *b, const float *u, float *unew, const float *far, int has_lo, int has_hi,
+                          int zbeg, int zend, void *stream);
 /* one Jacobi sweep unew = u + scale*dinv*(b - A u) that also returns ||b - A u||^2 (residual of the INPUT u): the norm
  * that closes a cycle (src/solver.c:1545-1546) fused with the first sweep of the next one (:1531) */
 int  mgk_jacobi_sumsq_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale,

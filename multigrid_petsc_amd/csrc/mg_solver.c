@@ -68,7 +68,7 @@ typedef struct mg_ops {
     int (*restrict_finish)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const void *, void *, void *);
     int (*jacobi2)(mgk_ctx *, const mgk_geom *, const double *, double, double, const void *, const void *, void *, void *);
     int (*jacobi2_slab)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const double *, double, double, const void *, const void *, void *,
-                        const void *, int, int, void *);
+                        const void *, int, int, int, int, void *);
 } mg_ops;
 
 #define W64(name) static int name##_64
@@ -93,8 +93,8 @@ W64(fin)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const void *r, void
 W32(fin)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const void *r, void *bc, void *st) { return mgk_restrict_finish_f32(c, gf, gc, (const float *)r, (float *)bc, st); }
 W64(j2)(mgk_ctx *c, const mgk_geom *g, const double *k, double d, double sc, const void *b, const void *u, void *o, void *st) { return mgk_jacobi2_f64(c, g, k, d, sc, (const double *)b, (const double *)u, (double *)o, st); }
 W32(j2)(mgk_ctx *c, const mgk_geom *g, const double *k, double d, double sc, const void *b, const void *u, void *o, void *st) { return mgk_jacobi2_f32(c, g, k, d, sc, (const float *)b, (const float *)u, (float *)o, st); }
-W64(j2s)(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gf, const double *k, double d, double sc, const void *b, const void *u, void *o, const void *far, int lo, int hi, void *st) { return mgk_jacobi2_slab_f64(c, g, gf, k, d, sc, (const double *)b, (const double *)u, (double *)o, (const double *)far, lo, hi, st); }
-W32(j2s)(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gf, const double *k, double d, double sc, const void *b, const void *u, void *o, const void *far, int lo, int hi, void *st) { return mgk_jacobi2_slab_f32(c, g, gf, k, d, sc, (const float *)b, (const float *)u, (float *)o, (const float *)far, lo, hi, st); }
+W64(j2s)(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gf, const double *k, double d, double sc, const void *b, const void *u, void *o, const void *far, int lo, int hi, int z0, int z1, void *st) { return mgk_jacobi2_slab_f64(c, g, gf, k, d, sc, (const double *)b, (const double *)u, (double *)o, (const double *)far, lo, hi, z0, z1, st); }
+W32(j2s)(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gf, const double *k, double d, double sc, const void *b, const void *u, void *o, const void *far, int lo, int hi, int z0, int z1, void *st) { return mgk_jacobi2_slab_f32(c, g, gf, k, d, sc, (const float *)b, (const float *)u, (float *)o, (const float *)far, lo, hi, z0, z1, st); }
 static const mg_ops OPS[2] = {
     {8, jr_64, jz_64, rs_64, rf_64, pa_64, pj_64, rr_64, rg_64, fin_64, j2_64, j2s_64},
     {4, jr_32, jz_32, rs_32, rf_32, pa_32, pj_32, rr_32, rg_32, fin_32, j2_32, j2s_32},
@@ -590,19 +590,26 @@ static int smooth(mg_solver *s, int P, int l, int maxit) {
                 /* slab: the second sweep of my first / last plane needs the first sweep of the neighbour's last / first plane,
                  * i.e. TWO of its planes of u (one is the regular ghost plane) and its b on that plane */
                 const size_t pb = (size_t)O->esz * (size_t)F->g.plane;
-                const int nz = F->g.nz;
-                CHK(ensure_u_ghosts(s, P, L));
-                if (!F->b_ghost_ok) { CHK(halo(s, P, L, F->b)); F->b_ghost_ok = 1; }
+                const int nz = F->g.nz, lo = s->cfg.rank > 0, hi = s->cfg.rank < s->cfg.nranks - 1;
+                void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
                 CHK(mgk_d2d(s->ctx, (char *)F->far + pb, (char *)F->u + 2 * pb, pb, NULL));                       /* my plane 1 */
                 CHK(mgk_d2d(s->ctx, (char *)F->far + 2 * pb, (char *)F->u + (size_t)(nz - 1) * pb, pb, NULL));   /* my plane nz-2 */
-                {
-                    void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
-                    CHK(mgk_stream_wait(s->ctx, ms, cs));
-                    CHK(s->comm->halo(s->comm, s->ctx, F->far, &F->gfar, O->esz, ms));
-                    CHK(mgk_stream_wait(s->ctx, cs, ms));
+                /* all exchanges of this pass on the comm stream ... */
+                CHK(mgk_stream_wait(s->ctx, ms, cs));
+                if (!F->u_ghost_pending && !F->u_ghost_ok) CHK(s->comm->halo(s->comm, s->ctx, F->u, &F->g, O->esz, ms));
+                if (!F->b_ghost_ok) CHK(s->comm->halo(s->comm, s->ctx, F->b, &F->g, O->esz, ms));
+                CHK(s->comm->halo(s->comm, s->ctx, F->far, &F->gfar, O->esz, ms));
+                /* ... while the planes 2 .. nz-3, which need no ghost data, are already being swept */
+                if (s->cfg.overlap && nz >= 6)
+                    CHK(O->jacobi2_slab(s->ctx, &F->g, &F->gfar, L->coef, L->dinv, s->cfg.scale, F->b, F->u, F->tmp, F->far, lo, hi, 2, nz - 2, cs));
+                CHK(mgk_stream_wait(s->ctx, cs, ms));
+                F->u_ghost_pending = 0; F->u_ghost_ok = 1; F->b_ghost_ok = 1;
+                if (s->cfg.overlap && nz >= 6) {
+                    CHK(O->jacobi2_slab(s->ctx, &F->g, &F->gfar, L->coef, L->dinv, s->cfg.scale, F->b, F->u, F->tmp, F->far, lo, hi, 0, 2, cs));
+                    CHK(O->jacobi2_slab(s->ctx, &F->g, &F->gfar, L->coef, L->dinv, s->cfg.scale, F->b, F->u, F->tmp, F->far, lo, hi, nz - 2, nz, cs));
+                } else {
+                    CHK(O->jacobi2_slab(s->ctx, &F->g, &F->gfar, L->coef, L->dinv, s->cfg.scale, F->b, F->u, F->tmp, F->far, lo, hi, 0, nz, cs));
                 }
-                CHK(O->jacobi2_slab(s->ctx, &F->g, &F->gfar, L->coef, L->dinv, s->cfg.scale, F->b, F->u, F->tmp, F->far,
-                                    s->cfg.rank > 0, s->cfg.rank < s->cfg.nranks - 1, NULL));
             } else {
                 g_prof_kind = 1;
                 void *t = prof_begin(s, l);

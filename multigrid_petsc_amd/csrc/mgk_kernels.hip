@@ -1054,6 +1054,7 @@ struct J2Args {
     // separate plane buffers, same pitch, pointing at their interior origin) and b on the ghost planes.
     const T *far_lo, *far_hi;
     int has_lo, has_hi;
+    int zbeg, zend;          // output planes of this launch (whole grid / slab: 0, nz)
 };
 
 template <typename T, int WX>
@@ -1068,7 +1069,7 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2(const J2Args<T> a) {
     if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
     const int ty = bid % a.nty, tz = bid / a.nty;
     const int yb = TY * ty;
-    const int z0 = tz * a.zc, z1 = min(z0 + a.zc, a.nz);
+    const int z0 = a.zbeg + tz * a.zc, z1 = min(z0 + a.zc, a.zend);
     if (z0 >= z1) return;
     const int xl = VX * tid, x0 = xl;
     const bool xok = x0 < a.nx;
@@ -1232,7 +1233,7 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2r(const J2Args<T> a) {
     if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
     const int ty = bid % a.nty, tz = bid / a.nty;
     const int yb = TY * ty;
-    const int z0 = tz * a.zc, z1 = min(z0 + a.zc, a.nz);
+    const int z0 = a.zbeg + tz * a.zc, z1 = min(z0 + a.zc, a.zend);
     if (z0 >= z1) return;
     const int xl = VX * tid, x0 = xl;
     const bool xok = x0 < a.nx;
@@ -1377,7 +1378,7 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2r(const J2Args<T> a) {
 
 template <typename T>
 static int jacobi2(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
-                   const T *b, const T *u, T *unew, const T *far_lo, const T *far_hi, void *stream) {
+                   const T *b, const T *u, T *unew, const T *far_lo, const T *far_hi, int zbeg, int zend, void *stream) {
     constexpr int VX = 16 / sizeof(T);
     if (!c || !g || !coef || !b || !u || !unew || u == unew || g->dim != 3) return fail(MGK_EINVAL, "mgk_jacobi2: bad arguments (3-D)");
     if (g->nx + 1 > 1024) return fail(MGK_EINVAL, "mgk_jacobi2: nx + 1 > 1024 is not built");
@@ -1387,6 +1388,9 @@ static int jacobi2(mgk_ctx *c, const mgk_geom *g, const double *coef, double din
     a.a0 = (T)coef[0]; a.a1 = (T)coef[1]; a.a2 = (T)coef[2]; a.a3 = (T)coef[3]; a.a4 = (T)coef[4]; a.a5 = (T)coef[5]; a.a6 = (T)coef[6];
     a.dinv = (T)dinv; a.scale = (T)scale;
     a.far_lo = far_lo; a.far_hi = far_hi; a.has_lo = far_lo != nullptr; a.has_hi = far_hi != nullptr;
+    if (zbeg < 0 || zend > g->nz || zbeg >= zend) return fail(MGK_EINVAL, "mgk_jacobi2: empty or out-of-range plane range");
+    a.zbeg = zbeg; a.zend = zend;
+    const int nzr = zend - zbeg;
     a.nty = (g->ny + 3) / 4;
     const int w = (g->nx + 1 + 64 * VX - 1) / (64 * VX);        // waves per full row
     // one 512-thread block per CU (LDS) for fp64 at 1023^3: 256 tiles, one chunk; blocks of <= 256 threads (fp64 511^3, fp32):
@@ -1394,12 +1398,12 @@ static int jacobi2(mgk_ctx *c, const mgk_geom *g, const double *coef, double din
     // planes of the first sweep
     const long target = (w > 4) ? 256 : 512;
     long nch = (a.nty >= target) ? 1 : (target + a.nty - 1) / a.nty;
-    if (g_zchunk > 0) nch = (g->nz + g_zchunk - 1) / g_zchunk;
-    int zc = (int)((g->nz + nch - 1) / nch);
+    if (g_zchunk > 0) nch = (nzr + g_zchunk - 1) / g_zchunk;
+    int zc = (int)((nzr + nch - 1) / nch);
     if (zc < 8) zc = 8;
-    if (zc > g->nz) zc = g->nz;
+    if (zc > nzr) zc = nzr;
     a.zc = zc;
-    const long ntz = (g->nz + zc - 1) / zc;
+    const long ntz = (nzr + zc - 1) / zc;
     const unsigned nblk = (unsigned)(a.nty * ntz);
     hipStream_t s = S(c, stream);
     // one 512-thread block per CU (fp64, 1023^3): the one-barrier variant (4.51 vs 5.15 ms per pass); smaller blocks run two
@@ -1422,32 +1426,36 @@ static int jacobi2(mgk_ctx *c, const mgk_geom *g, const double *coef, double din
 }
 extern "C" int mgk_jacobi2_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
                                const double *b, const double *u, double *unew, void *stream) {
-    return jacobi2<double>(c, g, coef, dinv, scale, b, u, unew, nullptr, nullptr, stream);
+    if (!g) return fail(MGK_EINVAL, "mgk_jacobi2_f64: bad arguments");
+    return jacobi2<double>(c, g, coef, dinv, scale, b, u, unew, nullptr, nullptr, 0, g->nz, stream);
 }
 extern "C" int mgk_jacobi2_f32(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
                                const float *b, const float *u, float *unew, void *stream) {
-    return jacobi2<float>(c, g, coef, dinv, scale, b, u, unew, nullptr, nullptr, stream);
+    if (!g) return fail(MGK_EINVAL, "mgk_jacobi2_f32: bad arguments");
+    return jacobi2<float>(c, g, coef, dinv, scale, b, u, unew, nullptr, nullptr, 0, g->nz, stream);
 }
 // The same on a z-slab.  `far` is a field of geometry (nx, ny, nz = 2) whose ghost planes hold the neighbours' second plane
 // (lo ghost: plane nz-2 of the rank below, hi ghost: plane 1 of the rank above; mgk_geom of it in gfar); u's own ghost
 // planes hold their last / first plane and b's ghost planes their b.  has_lo / has_hi: a neighbour exists on that side.
 template <typename T>
 static int jacobi2_slab(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gfar, const double *coef, double dinv, double scale,
-                        const T *b, const T *u, T *unew, const T *far, int has_lo, int has_hi, void *stream) {
+                        const T *b, const T *u, T *unew, const T *far, int has_lo, int has_hi, int zbeg, int zend, void *stream) {
     if (!g || !gfar || !far || gfar->dim != 3 || gfar->nz != 2 || gfar->nx != g->nx || gfar->ny != g->ny || gfar->pitch != g->pitch ||
         g->nz < 2)
         return fail(MGK_EINVAL, "mgk_jacobi2_slab: the far-plane field must have the geometry (nx, ny, 2) of the slab");
     const T *lo = has_lo ? far + gfar->org - gfar->plane : nullptr;
     const T *hi = has_hi ? far + gfar->org + 2 * gfar->plane : nullptr;
-    return jacobi2<T>(c, g, coef, dinv, scale, b, u, unew, lo, hi, stream);
+    return jacobi2<T>(c, g, coef, dinv, scale, b, u, unew, lo, hi, zbeg, zend, stream);
 }
 extern "C" int mgk_jacobi2_slab_f64(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gfar, const double *coef, double dinv, double scale,
-                                    const double *b, const double *u, double *unew, const double *far, int has_lo, int has_hi, void *stream) {
-    return jacobi2_slab<double>(c, g, gfar, coef, dinv, scale, b, u, unew, far, has_lo, has_hi, stream);
+                                    const double *b, const double *u, double *unew, const double *far, int has_lo, int has_hi,
+                                    int zbeg, int zend, void *stream) {
+    return jacobi2_slab<double>(c, g, gfar, coef, dinv, scale, b, u, unew, far, has_lo, has_hi, zbeg, zend, stream);
 }
 extern "C" int mgk_jacobi2_slab_f32(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gfar, const double *coef, double dinv, double scale,
-                                    const float *b, const float *u, float *unew, const float *far, int has_lo, int has_hi, void *stream) {
-    return jacobi2_slab<float>(c, g, gfar, coef, dinv, scale, b, u, unew, far, has_lo, has_hi, stream);
+                                    const float *b, const float *u, float *unew, const float *far, int has_lo, int has_hi,
+                                    int zbeg, int zend, void *stream) {
+    return jacobi2_slab<float>(c, g, gfar, coef, dinv, scale, b, u, unew, far, has_lo, has_hi, zbeg, zend, stream);
 }
 
 // ------------------------------------------------------------------------------------------
