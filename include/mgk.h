@@ -118,6 +118,9 @@ int  mgk_jacobi2_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double
                      const double *b, const double *u, double *unew, void *stream);
 int  mgk_jacobi2_f32(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale,
                      const float *b, const float *u, float *unew, void *stream);
+/* 2-D version (constant coefficients; x tiles overlap by one lane, y chunks recompute two rows of the first sweep) */
+int  mgk_jacobi2_2d_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale,
+                        const double *b, const double *u, double *unew, void *stream);
 /* the same on a z-slab: `far` is a field of geometry gfar = (nx, ny, nz = 2) whose lo / hi ghost planes hold plane nz-2 of the
  * rank below / plane 1 of the rank above (exchange it like any field after copying this rank's planes 1 and nz-2 into its two
  * interior planes); u's ghost planes hold the neighbours' last / first plane, b's ghost planes their b */

@@ -46,7 +46,7 @@ typedef struct mg_config {
                          * (temporal blocking, whole 3-D grids >= 511^3); default (-1): all on */
     int overlap;        /* nranks > 1: halo of sweep k on the comm stream while sweep k's interior runs; default on (-1) */
     int graph;          /* replay the launch-bound coarse levels as one captured HIP graph; default on (-1) */
-    int pair_min_n;     /* levels with n >= pair_min_n run their sweeps two per pass (fuse bit 5); <=0: default 511 */
+    int pair_min_n;     /* levels with n >= pair_min_n run their sweeps two per pass (fuse bit 5); <=0: default 511 (3-D), 2047 (2-D) */
 } mg_config;
 
 void mg_config_default(mg_config *cfg);     /* poisson.in defaults + -pc_type jacobi -ksp_richardson_scale 1 */

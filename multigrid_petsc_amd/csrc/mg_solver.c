@@ -278,7 +278,7 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
         s->cfg.dist_min_n = n0 < 255 ? n0 : 255;
     }
     if (s->cfg.fuse < 0) s->cfg.fuse = 63;
-    if (s->cfg.pair_min_n <= 0) s->cfg.pair_min_n = 511;
+    if (s->cfg.pair_min_n <= 0) s->cfg.pair_min_n = (cfg->dim == 3) ? 511 : 2047;   /* where a two-sweep pass beats two sweeps */
     if (s->cfg.overlap < 0) s->cfg.overlap = 1;
     if (s->cfg.graph < 0) s->cfg.graph = 1;
     if (s->cfg.nranks < 1) s->cfg.nranks = 1;
@@ -579,8 +579,9 @@ static int smooth(mg_solver *s, int P, int l, int maxit) {
     }
     /* two sweeps per pass (temporal blocking) where it pays: whole 3-D grids of 511^3 and more.  Not on the level whose
      * buffers the coarse-level HIP graph refers to (a pass swaps u/tmp once, not twice: see coarse_part) */
-    const int pair_ok = (s->cfg.fuse & 32) && s->cfg.dim == 3 && L->n >= s->cfg.pair_min_n && L->n + 1 <= 1024 &&
-                        (!L->distributed || (F->far && F->g.nz >= 4)) && (s->lgraph == 0 || l < s->lgraph - 1);
+    const int pair_ok = (s->cfg.fuse & 32) && L->n >= s->cfg.pair_min_n && (s->lgraph == 0 || l < s->lgraph - 1) &&
+                        ((s->cfg.dim == 3 && L->n + 1 <= 1024 && (!L->distributed || (F->far && F->g.nz >= 4))) ||
+                         (s->cfg.dim == 2 && P == 0));
     for (int it = it0; it < maxit; it++) {
         if (it == 0 && !F->guess_nonzero) {
             /* r = b, x = 0 + scale*(B b): u is not read */
@@ -610,6 +611,9 @@ static int smooth(mg_solver *s, int P, int l, int maxit) {
                 } else {
                     CHK(O->jacobi2_slab(s->ctx, &F->g, &F->gfar, L->coef, L->dinv, s->cfg.scale, F->b, F->u, F->tmp, F->far, lo, hi, 0, nz, cs));
                 }
+            } else if (s->cfg.dim == 2) {
+                CHK(mgk_jacobi2_2d_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u,
+                                       (double *)F->tmp, NULL));
             } else {
                 g_prof_kind = 1;
                 void *t = prof_begin(s, l);

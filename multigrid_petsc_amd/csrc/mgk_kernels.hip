@@ -1458,6 +1458,118 @@ extern "C" int mgk_jacobi2_slab_f32(mgk_ctx *c, const mgk_geom *g, const mgk_geo
     return jacobi2_slab<float>(c, g, gfar, coef, dinv, scale, b, u, unew, far, has_lo, has_hi, zbeg, zend, stream);
 }
 
+// 2-D version of the two-sweep pass: blocks of 64*WX lanes march along y over an x tile of 128*WX columns; a lane owns one
+// column pair, rows y-1 .. y+2 of u and the three live rows of the first sweep stay in its registers, x neighbours come by
+// wave shuffle (wave edges through LDS, written one step ahead: one barrier per row).  Tiles overlap by one lane on either
+// side: every lane makes the first sweep, the inner lanes the second one.
+struct J2dArgs {
+    const double *u, *b;
+    double *out;
+    int nx, ny;
+    long rs;
+    int ntx, yc;
+    double a0, a2, a3, a4, a6, dinv, scale;
+};
+template <int WX>
+__global__ void __launch_bounds__(64 * WX) k_jacobi2_2d(const J2dArgs a) {
+    constexpr int VX = 2, NT = 64 * WX, TXE = VX * (NT - 2);          // columns a block produces
+    __shared__ double eUW[2][WX], eUE[2][WX], ePW[2][WX], ePE[2][WX];   // wave-edge values of u(row) / u'(row), double buffered
+    using VT = V16<double>;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tx = blockIdx.x % a.ntx, tyc = blockIdx.x / a.ntx;
+    const int x0 = tx * TXE - VX + VX * tid;                          // may be -2 (left of the grid) on the first lane
+    const int y0 = tyc * a.yc, y1 = min(y0 + a.yc, a.ny);
+    if (y0 >= y1) return;
+    const bool xin = x0 >= 0 && x0 < a.nx;                            // the pair holds at least one grid column
+    const bool lastvec = (x0 + VX > a.nx);
+    const bool outl = xin && tid >= 1 && tid <= NT - 2;               // this lane stores second-sweep values
+    const double *up_ = a.u + x0, *bp_ = a.b + x0;
+    auto ldu = [&](int r) -> VT { return ldv(up_ + (long)r * a.rs, xin && r >= -1 && r <= a.ny); };
+    auto ldb = [&](int r) -> VT { return ldv(bp_ + (long)r * a.rs, xin && r >= 0 && r < a.ny); };
+
+    const int t0 = y0 - 2;
+    VT ua = ldu(t0), ub = ldu(t0 + 1), uc = ldu(t0 + 2), ud = v16_zero<double>();
+    VT b1 = ldb(t0 + 1), bn = v16_zero<double>(), b0 = bn;
+    VT wm = bn, wc = bn, wp = bn;                                     // first-sweep rows t-1, t, t+1
+    if (lane == 0) { eUW[(t0 + 1) & 1][w] = ub.v[0]; ePW[t0 & 1][w] = 0.0; }
+    if (lane == 63) { eUE[(t0 + 1) & 1][w] = ub.v[VX - 1]; ePE[t0 & 1][w] = 0.0; }
+    __syncthreads();
+    for (int t = t0; t < y1; t++) {
+        const int p = t + 1;
+        ud = ldu(t + 3);
+        bn = (t + 1 < y1) ? ldb(t + 2) : v16_zero<double>();
+        // ---- first sweep of row p ----
+        {
+            double Wv = __shfl_up(ub.v[VX - 1], 1, 64), Ev = __shfl_down(ub.v[0], 1, 64);
+            if (lane == 0) Wv = (w > 0) ? eUE[p & 1][w - 1] : 0.0;
+            if (lane == 63) Ev = (w < WX - 1) ? eUW[p & 1][w + 1] : 0.0;
+            const bool pin = (p >= 0 && p < a.ny);
+#pragma unroll
+            for (int e = 0; e < VX; e++) {
+                const double wv = (e == 0) ? Wv : ub.v[0];
+                const double ev = (e == VX - 1) ? Ev : ub.v[VX - 1];
+                double s = a.a0 * ua.v[e];
+                s = s + a.a2 * wv;
+                s = s + a.a3 * ub.v[e];
+                s = s + a.a4 * ev;
+                s = s + a.a6 * uc.v[e];
+                const double res = b1.v[e] - s;
+                const double zz = res * a.dinv;
+                wp.v[e] = ub.v[e] + a.scale * zz;
+                if (!pin || !xin || (lastvec && x0 + e >= a.nx)) wp.v[e] = 0.0;
+            }
+        }
+        // ---- second sweep of row t (x neighbours of u'(t): shuffles of wc, wave edges written in the previous step) ----
+        if (t >= y0) {
+            double Wv = __shfl_up(wc.v[VX - 1], 1, 64), Ev = __shfl_down(wc.v[0], 1, 64);
+            if (lane == 0) Wv = (w > 0) ? ePE[t & 1][w - 1] : 0.0;
+            if (lane == 63) Ev = (w < WX - 1) ? ePW[t & 1][w + 1] : 0.0;
+            VT o;
+#pragma unroll
+            for (int e = 0; e < VX; e++) {
+                const double wv = (e == 0) ? Wv : wc.v[0];
+                const double ev = (e == VX - 1) ? Ev : wc.v[VX - 1];
+                double s = a.a0 * wm.v[e];
+                s = s + a.a2 * wv;
+                s = s + a.a3 * wc.v[e];
+                s = s + a.a4 * ev;
+                s = s + a.a6 * wp.v[e];
+                const double res = b0.v[e] - s;
+                const double zz = res * a.dinv;
+                o.v[e] = wc.v[e] + a.scale * zz;
+                if (lastvec && x0 + e >= a.nx) o.v[e] = 0.0;
+            }
+            if (outl) stv_stream(a.out + (long)t * a.rs + x0, o);
+        }
+        // wave edges for the next step: u(row p+1) = uc, u'(row p) = wp
+        if (lane == 0) { eUW[(p + 1) & 1][w] = uc.v[0]; ePW[p & 1][w] = wp.v[0]; }
+        if (lane == 63) { eUE[(p + 1) & 1][w] = uc.v[VX - 1]; ePE[p & 1][w] = wp.v[VX - 1]; }
+        __syncthreads();
+        b0 = b1; b1 = bn; wm = wc; wc = wp; ua = ub; ub = uc; uc = ud;
+    }
+}
+extern "C" int mgk_jacobi2_2d_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
+                                  const double *b, const double *u, double *unew, void *stream) {
+    if (!c || !g || !coef || !b || !u || !unew || u == unew || g->dim != 2) return fail(MGK_EINVAL, "mgk_jacobi2_2d_f64: bad arguments (2-D)");
+    J2dArgs a; memset(&a, 0, sizeof(a));
+    a.u = u + g->org; a.b = b + g->org; a.out = unew + g->org;
+    a.nx = g->nx; a.ny = g->ny; a.rs = g->pitch;
+    a.a0 = coef[0]; a.a2 = coef[1]; a.a3 = coef[2]; a.a4 = coef[3]; a.a6 = coef[4];
+    a.dinv = dinv; a.scale = scale;
+    constexpr int WX = 4, TXE = 2 * (64 * WX - 2);
+    a.ntx = (g->nx + TXE - 1) / TXE;
+    long nch = (2048 + a.ntx - 1) / a.ntx;
+    if (g_zchunk > 0) nch = (g->ny + g_zchunk - 1) / g_zchunk;
+    int yc = (int)((g->ny + nch - 1) / nch);
+    if (yc < 16) yc = 16;
+    if (yc > g->ny) yc = g->ny;
+    a.yc = yc;
+    const long nty = (g->ny + yc - 1) / yc;
+    hipLaunchKernelGGL((k_jacobi2_2d<WX>), dim3((unsigned)(a.ntx * nty)), dim3(64 * WX), 0, S(c, stream), a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // row-wise elementwise / reduction kernels: one lane per aligned x pair, blocks stride over rows
 // ------------------------------------------------------------------------------------------

@@ -49,6 +49,7 @@ def _sigs(L):
         "mgk_residual_sumsq_f64": (i, [vp, G, c_dp, vp, vp, C.POINTER(d), vp]),
         "mgk_jacobi2_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp, vp]),
         "mgk_jacobi2_f32": (i, [vp, G, c_dp, d, d, vp, vp, vp, vp]),
+        "mgk_jacobi2_2d_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp, vp]),
         "mgk_jacobi_sumsq_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp, C.POINTER(d), vp]),
         "mgk_restrict_fw_f64": (i, [vp, G, G, vp, vp, vp]),
         "mgk_prolong_add_f64": (i, [vp, G, G, vp, vp, vp]),

@@ -317,3 +317,26 @@ def test_two_sweeps_in_one_pass_bit_exact(mgk, orc, n):
     assert np.array_equal(mgk.from_field(g, du), u)
     for p in (du, db, dout):
         mgk.free(p)
+
+
+@pytest.mark.parametrize("n", [1, 3, 7, 63, 127, 255, 507, 509, 511, 1023, 2047])
+def test_two_sweeps_in_one_pass_2d_bit_exact(mgk, orc, n):
+    rng = np.random.default_rng(8000 + n)
+    q = float((n + 1) ** 2)
+    As = [q, q, -4.0 * q, q, q]
+    dinv = 1.0 / As[2]
+    u, b = _rand(rng, n ** 2), _rand(rng, n ** 2)
+    g = mgk.geom(2, n)
+    du, db, dout = mgk.to_field(g, u), mgk.to_field(g, b), mgk.field(g)
+    want = orc.jacobi(2, n, As, 0.8, b, orc.jacobi(2, n, As, 0.8, b, u))
+    for zc in (-1, 16, 37):
+        mgk.L.mgk_set_tuning(-1, zc)
+        mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dout, 8 * g.total, None))
+        mgk._chk(mgk.L.mgk_jacobi2_2d_f64(mgk.ctx, C.byref(g), mgk.coef(As), dinv, 0.8, db, du, dout, None))
+        got = mgk.from_field(g, dout)
+        assert np.array_equal(got, want), f"zc={zc} max diff {np.abs(got - want).max()}"
+        raw = mgk.raw_field(g, dout)
+        assert abs(np.abs(raw).sum() - np.abs(got).sum()) <= 1e-9 * np.abs(got).sum()
+    mgk.L.mgk_set_tuning(-1, -1)
+    for p in (du, db, dout):
+        mgk.free(p)

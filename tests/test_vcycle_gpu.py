@@ -204,3 +204,21 @@ def test_speculative_first_sweep_changes_nothing(dim, npts, levels):
     s.sync()
     assert np.array_equal(s.solution(), res[15][2]) and np.abs(s.rnorm / res[15][1] - 1).max() <= 1e-13
     s.close()
+
+
+@pytest.mark.parametrize("dim,npts,levels", [(2, 257, 8), (2, 129, 3), (3, 65, 6), (3, 33, 2)])
+def test_two_sweep_passes_change_nothing(dim, npts, levels):
+    """fuse bit 5 with a low pair_min_n: pre- and post-smoothing sweeps 2 and 3 run as one pass on every level the
+    coarse-level graph allows; fields and history equal the one-sweep-per-launch cycle"""
+    from multigrid_petsc_amd.solver import Solver
+    scale = 6.0 / 7.0 if dim == 3 else 0.8
+    res = {}
+    for fuse, pmin in ((31, 0), (63, 7)):
+        s = Solver(dim, npts, levels, v=(3, 3), maxiter=60, scale=scale, fuse=fuse, pair_min_n=pmin)
+        s.set_rhs_problem()
+        it = s.solve()
+        res[fuse] = (it, s.rnorm.copy(), s.solution())
+        s.close()
+    assert res[31][0] == res[63][0]
+    assert np.abs(res[31][1] / res[63][1] - 1).max() <= 1e-13
+    assert np.array_equal(res[31][2], res[63][2])
