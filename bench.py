@@ -231,14 +231,15 @@ def main():
             # cannot avoid -- read u, read b, write the twice-swept field: 24 B/unknown per launch (SURVEY 8 d3 counts
             # 24 B per SWEEP, 48 B for what this launch does: reported beside it as per_sweep_equivalent).
             t_ms = pair_ms / pair_n
-            comp = JACOBI_BYTES_PER_DOF * local_unknowns
+            comp = bytes_per_dof * local_unknowns
             ach = comp / (t_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k_jacobi2<WX>: two fine-level Jacobi sweeps in one pass (temporal blocking)",
+            roof = {"bound": "hbm", "kernel": f"k_jacobi2{'r' if args.precision == 'fp64' else ''}<{'double' if args.precision == 'fp64' else 'float'},WX>: "
+                                              "two fine-level Jacobi sweeps in one pass (temporal blocking)",
                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "launches": pair_n, "avg_launch_ms": t_ms, "algorithmic_bytes_per_launch": comp,
-                    "traffic": tj.get("jacobi2_hbm_bytes_per_launch") if (world == 1 and args.npts == 1025) else None,
+                    "traffic": tj.get("jacobi2_hbm_bytes_per_launch") if (world == 1 and args.npts == 1025 and args.precision == "fp64") else None,
                     "per_sweep_equivalent": {"bytes_per_launch": 2 * comp, "GB/s": 2 * ach,
-                                             "note": "SURVEY 8(d3) accounting: 24 B per unknown and SWEEP, two sweeps per launch"}}
+                                             "note": f"SURVEY 8(d3) accounting: {bytes_per_dof:g} B per unknown and SWEEP, two sweeps per launch"}}
         else:
             roof = {"bound": "hbm", "kernel": f"k_stencil<{'double' if args.precision == 'fp64' else 'float'},{args.dim},..,MODE_JACOBI> fine-level Jacobi sweep",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -265,7 +266,7 @@ def main():
         }
     s.close()
     if rank == 0:
-        if world == 1 and pair_n and args.dim == 3:
+        if world == 1 and pair_n and args.dim == 3 and args.precision == "fp64":
             try:     # the plain one-sweep kernel beside it (north_star: >= 70 % of 8 TB/s on the fp64 smoother sweep)
                 ps = plain_sweep_probe(local_rank, n0)
                 ps["traffic"] = tj.get("jacobi_sweep_hbm_bytes_per_launch") if args.npts == 1025 else None
