@@ -175,3 +175,17 @@ def test_two_fp32_sweeps_in_one_pass_bit_exact(mgk, orc, n):
     mgk.L.mgk_set_tuning(-1, -1)
     for p in (du, db, dout):
         mgk.free(p)
+
+
+def test_mixed_cycle_with_fp32_two_sweep_passes_changes_nothing():
+    """fuse bit 6 (+ a low pair_min_n) runs the fp32 legs' sweeps two per pass: same fields as one sweep per launch"""
+    from multigrid_petsc_amd.solver import Solver
+    res = {}
+    for fuse, pmin in ((31, 0), (127, 7)):
+        s = Solver(3, 65, 6, scale=6.0 / 7.0, maxiter=60, precision="mixed", fuse=fuse, pair_min_n=pmin)
+        s.set_rhs_problem()
+        it = s.solve()
+        res[fuse] = (it, s.rnorm.copy(), s.solution())
+        s.close()
+    assert res[31][0] == res[127][0] and np.array_equal(res[31][2], res[127][2])
+    assert np.abs(res[31][1] / res[127][1] - 1).max() <= 1e-13

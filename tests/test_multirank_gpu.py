@@ -222,7 +222,7 @@ def test_two_sweep_passes_on_slabs(P, npts, levels, dist_min_n, precision):
     (regular ghost plane + the far-plane field) and their b ghost plane; fields equal the single-rank, one-sweep-per-launch
     solve bit for bit"""
     it1, rn1, u1, _ = _solve_single(npts, levels, 6.0 / 7.0, 60, precision=precision, fuse=0)
-    res = _solve_ranks(P, npts, levels, 6.0 / 7.0, 60, dist_min_n, precision=precision, pair_min_n=15)
+    res = _solve_ranks(P, npts, levels, 6.0 / 7.0, 60, dist_min_n, precision=precision, pair_min_n=15, fuse=127)
     assert all(r[0] == it1 for r in res)
     for r in res:
         assert np.abs(r[1] / rn1 - 1).max() <= 1e-12
