@@ -122,6 +122,7 @@ struct mg_solver {
     int prof_on, prof_n;
     void *timers[MG_MAX_TIMERS];
     unsigned char timer_kind[MG_MAX_TIMERS];
+    int prof_kind;          /* kind of the next timer: 0 plain sweep, 1 two sweeps in one pass */
     int ntimers_created;
 };
 
@@ -497,14 +498,13 @@ static int ensure_u_ghosts(mg_solver *s, int P, mg_level *L) {
     return 0;
 }
 
-static int g_prof_kind = 0;      /* kind of the next timer: 0 plain sweep, 1 two sweeps in one pass */
 static void *prof_begin(mg_solver *s, int level) {
     if (!s->prof_on || level != 0 || s->prof_n >= MG_MAX_TIMERS) return NULL;
     if (s->prof_n >= s->ntimers_created) {
         if (mgk_timer_create(s->ctx, &s->timers[s->ntimers_created])) return NULL;
         s->ntimers_created++;
     }
-    s->timer_kind[s->prof_n] = (unsigned char)g_prof_kind;
+    s->timer_kind[s->prof_n] = (unsigned char)s->prof_kind;
     void *t = s->timers[s->prof_n++];
     mgk_timer_start(s->ctx, t, NULL);
     return t;
@@ -616,9 +616,9 @@ static int smooth(mg_solver *s, int P, int l, int maxit) {
                 CHK(mgk_jacobi2_2d_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u,
                                        (double *)F->tmp, NULL));
             } else {
-                g_prof_kind = 1;
+                s->prof_kind = 1;
                 void *t = prof_begin(s, l);
-                g_prof_kind = 0;
+                s->prof_kind = 0;
                 CHK(O->jacobi2(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, F->b, F->u, F->tmp, NULL));
                 prof_end(s, t);
             }
