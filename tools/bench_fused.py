@@ -2,6 +2,9 @@
 import ctypes as C, sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multigrid_petsc_amd import _lib
+if os.environ.get("MGK_LIB"):
+    _lib._cache["mgk"] = C.CDLL(os.environ["MGK_LIB"], mode=C.RTLD_GLOBAL)
 from multigrid_petsc_amd.mgk import Mgk
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1023
 m = Mgk(0); L = m.L
