@@ -222,3 +222,20 @@ def test_two_sweep_passes_change_nothing(dim, npts, levels):
     assert res[31][0] == res[63][0]
     assert np.abs(res[31][1] / res[63][1] - 1).max() <= 1e-13
     assert np.array_equal(res[31][2], res[63][2])
+
+
+@pytest.mark.parametrize("dim,npts,levels,v", [(3, 33, 4, (1, 1)), (3, 33, 4, (2, 3)), (3, 65, 5, (4, 2)), (3, 65, 6, (5, 5)),
+                                                 (2, 129, 6, (2, 1)), (2, 257, 7, (4, 4))])
+def test_other_sweep_counts_with_all_fusions(orc, dim, npts, levels, v):
+    """-v v0,v1 other than 3,3 with every fusion on (speculative first sweep, two-sweep passes from a low pair_min_n,
+    fused transfers, graph replay): the pass/swap bookkeeping must hold for odd and even counts alike"""
+    from multigrid_petsc_amd.solver import Solver
+    scale = 6.0 / 7.0 if dim == 3 else 0.8
+    s = Solver(dim, npts, levels, v=v, maxiter=80, scale=scale, pair_min_n=7)
+    s.set_rhs_problem()
+    it = s.solve()
+    ref = orc.vcycle(dim, npts, levels, v[0], v[1], maxiter=80, scale=scale)
+    assert it == ref["iters"]
+    assert np.abs(s.rnorm / ref["rnorm"] - 1).max() <= RTOL
+    assert np.array_equal(s.solution(), ref["u"])
+    s.close()
