@@ -580,8 +580,7 @@ static int smooth(mg_solver *s, int P, int l, int maxit) {
     /* two sweeps per pass (temporal blocking) where it pays: whole 3-D grids of 511^3 and more.  Not on the level whose
      * buffers the coarse-level HIP graph refers to (a pass swaps u/tmp once, not twice: see coarse_part) */
     const int pair_ok = (s->cfg.fuse & 32) && L->n >= s->cfg.pair_min_n && (s->lgraph == 0 || l < s->lgraph - 1) &&
-                        ((s->cfg.dim == 3 && L->n + 1 <= 1024 && (!L->distributed || (F->far && F->g.nz >= 4)) &&
-                          (P == 0 || (s->cfg.fuse & 64))) ||      /* fp32: the pass is arithmetic bound and gains nothing (bit 6 forces it) */
+                        ((s->cfg.dim == 3 && L->n + 1 <= 1024 && (!L->distributed || (F->far && F->g.nz >= 4))) ||
                          (s->cfg.dim == 2 && P == 0));
     for (int it = it0; it < maxit; it++) {
         if (it == 0 && !F->guess_nonzero) {

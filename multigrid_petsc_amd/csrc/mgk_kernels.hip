@@ -1041,6 +1041,52 @@ extern "C" int mgk_jacobi_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const double 
 // neighbours of plane z from the ring and stores the result.  The halo rows of u' are recomputed by the neighbouring
 // tile (1.5x stage-1 arithmetic, 2x u row loads that mostly hit L2); u' never goes to memory.  Each stage performs
 // exactly the arithmetic of k_stencil<MODE_JACOBI>, so the result equals two separate sweeps bit for bit.
+// one Jacobi update of a lane vector: o = c + scale * ((b - A.(dn, s, w, c, e, n, up)) * dinv), terms in the canonical order.
+// The float overload works on the 4-wide vector type so that the compiler issues packed fp32 instructions (v_pk_mul_f32 /
+// v_pk_add_f32: two lanes of the lane vector per instruction); every lane sees the same IEEE operations in the same order.
+template <typename T>
+__device__ __forceinline__ V16<T> jac7(T a0, T a1, T a2, T a3, T a4, T a5, T a6, T dinv, T scale, const V16<T> &dn, const V16<T> &sv,
+                                       const V16<T> &c, const V16<T> &nv, const V16<T> &upv, T Wv, T Ev, const V16<T> &b) {
+    constexpr int VX = 16 / sizeof(T);
+    V16<T> o;
+#pragma unroll
+    for (int e = 0; e < VX; e++) {
+        const T wv = (e == 0) ? Wv : c.v[e - 1 < 0 ? 0 : e - 1];
+        const T ev = (e == VX - 1) ? Ev : c.v[e + 1 > VX - 1 ? VX - 1 : e + 1];
+        T s = a0 * dn.v[e];
+        s = s + a1 * sv.v[e];
+        s = s + a2 * wv;
+        s = s + a3 * c.v[e];
+        s = s + a4 * ev;
+        s = s + a5 * nv.v[e];
+        s = s + a6 * upv.v[e];
+        const T res = b.v[e] - s;
+        const T zz = res * dinv;
+        o.v[e] = c.v[e] + scale * zz;
+    }
+    return o;
+}
+__device__ __forceinline__ V16<float> jac7(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float dinv, float scale,
+                                           const V16<float> &dn, const V16<float> &sv, const V16<float> &c, const V16<float> &nv,
+                                           const V16<float> &upv, float Wv, float Ev, const V16<float> &b) {
+    auto ld = [](const V16<float> &x) { f4v r; r.x = x.v[0]; r.y = x.v[1]; r.z = x.v[2]; r.w = x.v[3]; return r; };
+    const f4v C = ld(c);
+    f4v W; W.x = Wv; W.y = c.v[0]; W.z = c.v[1]; W.w = c.v[2];
+    f4v E; E.x = c.v[1]; E.y = c.v[2]; E.z = c.v[3]; E.w = Ev;
+    f4v s = a0 * ld(dn);
+    s = s + a1 * ld(sv);
+    s = s + a2 * W;
+    s = s + a3 * C;
+    s = s + a4 * E;
+    s = s + a5 * ld(nv);
+    s = s + a6 * ld(upv);
+    const f4v res = ld(b) - s;
+    const f4v zz = res * dinv;
+    const f4v o4 = C + scale * zz;
+    V16<float> o; o.v[0] = o4.x; o.v[1] = o4.y; o.v[2] = o4.z; o.v[3] = o4.w;
+    return o;
+}
+
 template <typename T>
 struct J2Args {
     const T *u, *b;
@@ -1144,23 +1190,10 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2(const J2Args<T> a) {
                 T Wv = __shfl_up(ub[rr].v[VX - 1], 1, 64), Ev = __shfl_down(ub[rr].v[0], 1, 64);
                 if (lane == 0) Wv = (w > 0) ? edgeE[eb][q][w - 1] : (T)0;
                 if (lane == 63) Ev = (w < WX - 1) ? edgeW[eb][q][w + 1] : (T)0;
-                VT o;
+                VT o = jac7(a.a0, a.a1, a.a2, a.a3, a.a4, a.a5, a.a6, a.dinv, a.scale, ua[rr], ub[rr - 1], ub[rr], ub[rr + 1], uc[rr], Wv, Ev, b1[q]);
 #pragma unroll
-                for (int e = 0; e < VX; e++) {
-                    const T wv = (e == 0) ? Wv : ub[rr].v[e - 1 < 0 ? 0 : e - 1];
-                    const T ev = (e == VX - 1) ? Ev : ub[rr].v[e + 1 > VX - 1 ? VX - 1 : e + 1];
-                    T s = a.a0 * ua[rr].v[e];
-                    s = s + a.a1 * ub[rr - 1].v[e];
-                    s = s + a.a2 * wv;
-                    s = s + a.a3 * ub[rr].v[e];
-                    s = s + a.a4 * ev;
-                    s = s + a.a5 * ub[rr + 1].v[e];
-                    s = s + a.a6 * uc[rr].v[e];
-                    const T res = b1[q].v[e] - s;
-                    const T zz = res * a.dinv;
-                    o.v[e] = ub[rr].v[e] + a.scale * zz;
+                for (int e = 0; e < VX; e++)
                     if (!pin || !s1ok[q] || !xok || (lastvec && x0 + e >= a.nx)) o.v[e] = (T)0;
-                }
                 *reinterpret_cast<VT *>(&ring[slot][q][xl + VX]) = o;
             }
             // edges of the next centre plane (uc = plane p + 1), other buffer
@@ -1185,22 +1218,10 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2(const J2Args<T> a) {
                 const VT sv = *reinterpret_cast<const VT *>(&ring[sc][q - 1][xl + VX]);
                 const VT nv = *reinterpret_cast<const VT *>(&ring[sc][q + 1][xl + VX]);
                 const T Wv = ring[sc][q][xl + VX - 1], Ev = ring[sc][q][xl + 2 * VX];
-                VT o;
+                VT o = jac7(a.a0, a.a1, a.a2, a.a3, a.a4, a.a5, a.a6, a.dinv, a.scale, dn, sv, c, nv, upv, Wv, Ev, b0[j]);
+                if (lastvec) {
 #pragma unroll
-                for (int e = 0; e < VX; e++) {
-                    const T wv = (e == 0) ? Wv : c.v[e - 1 < 0 ? 0 : e - 1];
-                    const T ev = (e == VX - 1) ? Ev : c.v[e + 1 > VX - 1 ? VX - 1 : e + 1];
-                    T s = a.a0 * dn.v[e];
-                    s = s + a.a1 * sv.v[e];
-                    s = s + a.a2 * wv;
-                    s = s + a.a3 * c.v[e];
-                    s = s + a.a4 * ev;
-                    s = s + a.a5 * nv.v[e];
-                    s = s + a.a6 * upv.v[e];
-                    const T res = b0[j].v[e] - s;
-                    const T zz = res * a.dinv;
-                    o.v[e] = c.v[e] + a.scale * zz;
-                    if (lastvec && x0 + e >= a.nx) o.v[e] = (T)0;
+                    for (int e = 0; e < VX; e++) if (x0 + e >= a.nx) o.v[e] = (T)0;
                 }
                 if (xok && yb + j < a.ny) stv_stream(a.out + (long)t * a.ms + (long)(yb + j) * a.rs + x0, o);
             }
@@ -1396,7 +1417,7 @@ static int jacobi2(mgk_ctx *c, const mgk_geom *g, const double *coef, double din
     // one 512-thread block per CU (LDS) for fp64 at 1023^3: 256 tiles, one chunk; blocks of <= 256 threads (fp64 511^3, fp32):
     // two per CU, 512 blocks (measured, fp64 511^3: 128 blocks 0.83 ms, 512 blocks 0.57 ms); every chunk recomputes two
     // planes of the first sweep
-    const long target = (w > 4) ? 256 : 512;
+    const long target = (w > 4) ? 256 : (sizeof(T) == 4 ? 1024 : 512);      // fp32 1023^3: 1024 blocks 2.72 ms, 512 blocks 2.84 ms
     long nch = (a.nty >= target) ? 1 : (target + a.nty - 1) / a.nty;
     if (g_zchunk > 0) nch = (nzr + g_zchunk - 1) / g_zchunk;
     int zc = (int)((nzr + nch - 1) / nch);
