@@ -232,6 +232,9 @@ def main():
             # 24 B per SWEEP, 48 B for what this launch does: reported beside it as per_sweep_equivalent).
             t_ms = pair_ms / pair_n
             comp = bytes_per_dof * local_unknowns
+            if world > 1:          # on a slab the timed launch covers the interior planes 2 .. nz-3 (the rest waits for the halos)
+                nzl = s.level_planes(0)[1]
+                comp *= max(nzl - 4, 1) / float(nzl)
             ach = comp / (t_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": f"k_jacobi2{'r' if args.precision == 'fp64' else ''}<{'double' if args.precision == 'fp64' else 'float'},WX>: "
                                               "two fine-level Jacobi sweeps in one pass (temporal blocking)",

@@ -601,8 +601,13 @@ static int smooth(mg_solver *s, int P, int l, int maxit) {
                 if (!F->b_ghost_ok) CHK(s->comm->halo(s->comm, s->ctx, F->b, &F->g, O->esz, ms));
                 CHK(s->comm->halo(s->comm, s->ctx, F->far, &F->gfar, O->esz, ms));
                 /* ... while the planes 2 .. nz-3, which need no ghost data, are already being swept */
-                if (s->cfg.overlap && nz >= 6)
+                if (s->cfg.overlap && nz >= 6) {
+                    s->prof_kind = 1;                       /* timed: the interior planes 2 .. nz-3 of the slab */
+                    void *t = prof_begin(s, l);
+                    s->prof_kind = 0;
                     CHK(O->jacobi2_slab(s->ctx, &F->g, &F->gfar, L->coef, L->dinv, s->cfg.scale, F->b, F->u, F->tmp, F->far, lo, hi, 2, nz - 2, cs));
+                    prof_end(s, t);
+                }
                 CHK(mgk_stream_wait(s->ctx, cs, ms));
                 F->u_ghost_pending = 0; F->u_ghost_ok = 1; F->b_ghost_ok = 1;
                 if (s->cfg.overlap && nz >= 6) {
