@@ -1022,9 +1022,16 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
         const double dinv = (pc == P_JACOBI) ? 1.0 / A->coef[2] : 1.0;
         Vec w = ksp_work(k, 0, x);
         if (k->type == K_RICHARDSON) {
+            /* sweeps two per pass (temporal blocking) where that beats two launches: 2-D grids of 2047^2 and more
+             * (MGPETSC_PAIR_MIN_N overrides the threshold; bit-identical either way) */
+            static int pair_min_n = -1;
+            if (pair_min_n < 0) { const char *e = getenv("MGPETSC_PAIR_MIN_N"); pair_min_n = e ? atoi(e) : 2047; }
             for (PetscInt it = 0; it < maxit; it++) {
                 if (it == 0 && !k->guess_nonzero) DEV(mgk_jacobi_zero_f64(G, &A->gf, dinv, k->scale, b->dev, w->dev, NULL));
-                else DEV(mgk_jacobi_f64(G, &A->gf, A->coef, dinv, k->scale, b->dev, x->dev, w->dev, NULL));
+                else if (A->gf.dim == 2 && maxit - it >= 2 && A->gf.nx >= pair_min_n) {
+                    DEV(mgk_jacobi2_2d_f64(G, &A->gf, A->coef, dinv, k->scale, b->dev, x->dev, w->dev, NULL));
+                    it++;
+                } else DEV(mgk_jacobi_f64(G, &A->gf, A->coef, dinv, k->scale, b->dev, x->dev, w->dev, NULL));
                 swap_dev(x, w);
             }
             k->its = maxit;

@@ -203,6 +203,7 @@ def _run_reference_driver(tmp_path, opts, extra_env=None):
 @pytest.mark.parametrize("npts,levels,scale,env", [
     (17, 2, 0.8, None), (17, 2, 1.0, None), (129, 7, 0.8, None), (129, 6, 0.8, None), (513, 9, 0.8, None),
     (33, 4, 0.8, {"MGPETSC_NO_RECOGNITION": "1"}),
+    (257, 8, 0.8, {"MGPETSC_PAIR_MIN_N": "7"}),          # KSPSolve runs its sweeps two per pass
 ])
 def test_unmodified_reference_driver_on_the_gpu(orc, tmp_path, npts, levels, scale, env):
     opts = (f"-npts {npts}\n-mesh 0\n-iter 1000\n-grids {levels}\n-levels {levels}\n-cycle 0\n-map 2\n-v 3,3\n-moreNorm 0\n"
