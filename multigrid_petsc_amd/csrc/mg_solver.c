@@ -744,7 +744,9 @@ static int descend(mg_solver *s, int P, int l) {
     const int levels = s->levels, *v = s->cfg.v;
     mg_level *Lf = &s->L[l - 1];
     const mg_ops *O = &OPS[P];
-    if ((s->cfg.fuse & 4) && O->residual_restrict && s->cfg.dim == 3 && !Lf->distributed && Lf->n + 1 <= 1024) {
+    /* (below 255^3 the marching fused kernel is latency bound: residual + restriction as two short kernels are quicker) */
+    if ((s->cfg.fuse & 4) && O->residual_restrict && s->cfg.dim == 3 && !Lf->distributed && Lf->n + 1 <= 1024 &&
+        (Lf->n >= 255 || (s->cfg.fuse & 128))) {
         /* :1534-1535 in one pass: b_l = R (b - A u), the fine residual is never written */
         CHK(O->residual_restrict(s->ctx, &Lf->f[P].g, &s->L[l].f[P].g, Lf->coef, Lf->f[P].b, Lf->f[P].u, s->L[l].f[P].b, NULL));
     } else if ((s->cfg.fuse & 4) && O->residual_restrict && s->cfg.dim == 3 && Lf->distributed && Lf->n + 1 <= 1024 &&

@@ -239,3 +239,17 @@ def test_other_sweep_counts_with_all_fusions(orc, dim, npts, levels, v):
     assert np.abs(s.rnorm / ref["rnorm"] - 1).max() <= RTOL
     assert np.array_equal(s.solution(), ref["u"])
     s.close()
+
+
+@pytest.mark.parametrize("npts,levels,precision", [(33, 4, "fp64"), (65, 6, "fp64"), (65, 5, "mixed")])
+def test_fused_residual_restriction_on_small_levels(orc, npts, levels, precision):
+    """fuse bit 7 keeps the fused residual+restriction kernel on levels below 255^3 (by default two short kernels run
+    there): same cycle bit for bit"""
+    from multigrid_petsc_amd.solver import Solver
+    s = Solver(3, npts, levels, maxiter=80, scale=6.0 / 7.0, fuse=63 | 128, precision=precision)
+    s.set_rhs_problem()
+    it = s.solve()
+    ref = orc.vcycle(3, npts, levels, 3, 3, maxiter=80, scale=6.0 / 7.0) if precision == "fp64" else orc.vcycle_mixed(npts, levels, maxiter=80, scale=6.0 / 7.0)
+    assert it == ref["iters"] and np.array_equal(s.solution(), ref["u"])
+    assert np.abs(s.rnorm / ref["rnorm"] - 1).max() <= RTOL
+    s.close()
