@@ -165,7 +165,7 @@ def main():
             try:
                 comm = rccl_comm(rank, world, local_rank, dist)
             except Exception as e:          # every rank must take the same decision
-                print(f"[bench rank {rank}] RCCL communicator failed ({e}); falling back to the host-staged transport", flush=True)
+                print(f"[bench rank {rank}] RCCL communicator failed ({e}); falling back to the host-staged transport", file=sys.stderr, flush=True)
                 ok = 0
             flag = torch.tensor([ok], dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)

@@ -174,7 +174,7 @@ class HostStagedComm:
                 self._put(ctx, addr, t)
             return 0
         except Exception as e:      # noqa: BLE001 - reported through the C return code
-            print("[HostStagedComm.halo]", e, flush=True)
+            print("[HostStagedComm.halo]", e, file=sys.stderr, flush=True)
             return 10003
 
     def _gather(self, c, ctx, field, gptr, zstart, esz, stream):
@@ -193,7 +193,7 @@ class HostStagedComm:
                     self._put(ctx, addr, t)
             return 0
         except Exception as e:      # noqa: BLE001
-            print("[HostStagedComm.allgather]", e, flush=True)
+            print("[HostStagedComm.allgather]", e, file=sys.stderr, flush=True)
             return 10003
 
     def _reduce(self, c, ctx, vals, n, stream):
@@ -204,7 +204,7 @@ class HostStagedComm:
                 vals[q] = float(t[q])
             return 0
         except Exception as e:      # noqa: BLE001
-            print("[HostStagedComm.allreduce]", e, flush=True)
+            print("[HostStagedComm.allreduce]", e, file=sys.stderr, flush=True)
             return 10003
 
     def _barrier(self, c, ctx):
