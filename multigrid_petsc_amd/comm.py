@@ -4,6 +4,7 @@ rccl_comm()      one process per GPU (bench.py under torch.distributed.run); the
                  is created on rank 0 and shipped through the caller's control-plane group.
 LoopbackWorld    all ranks are threads of this process on one GPU (tests)."""
 import ctypes as C
+import sys
 import threading
 
 from ._lib import load_mgpetsc
