@@ -150,6 +150,12 @@ int  mgk_restrict_finish_f32(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *g
  * partial, to be closed by mgk_restrict_finish_* (above).  3-D. */
 int  mgk_residual_restrict_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
                                const double *b, const double *u, double *bc, void *stream);
+/* the same (whole grids), also writing the coarse level's first sweep from a zero guess, uc0 = scale_c * (bc * dinv_c): what
+ * mgk_jacobi_zero_* would compute from bc */
+int  mgk_residual_restrict_jz_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef, const double *b,
+                                  const double *u, double *bc, double *uc0, double dinv_c, double scale_c, void *stream);
+int  mgk_residual_restrict_jz_f32(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef, const float *b,
+                                  const float *u, float *bc, float *uc0, double dinv_c, double scale_c, void *stream);
 
 /* ---- K3: MatMult(res[l], r, b[l+1]) full weighting (src/solver.c:1535, matrix :1071-1092) ----
  * coarse (kc,ic,jc) gathers fine (2kc+dk, 2ic+di, 2jc+dj), d in {0,1,2}.  gc->nz coarse planes are

@@ -44,7 +44,8 @@ typedef struct mg_config {
                          * pre-smoothing sweep of the next cycle (adopted only if a next cycle runs); bit 4 (mixed precision): the
                          * fp64 correction u += e and the fp64 residual -> fp32 in one pass; bit 5: pairs of sweeps in one pass
                          * (temporal blocking, levels >= pair_min_n, both precisions); bit 7 (testing): bit 2 also below 255^3, where two short
-                         * kernels are quicker; default (-1): bits 0-5 on */
+                         * kernels are quicker; bit 8: the fused residual+restriction also writes the coarse level's first (zero-guess)
+                         * sweep; default (-1): bits 0-5 and 8 on */
     int overlap;        /* nranks > 1: halo of sweep k on the comm stream while sweep k's interior runs; default on (-1) */
     int graph;          /* replay the launch-bound coarse levels as one captured HIP graph; default on (-1) */
     int pair_min_n;     /* levels with n >= pair_min_n run their sweeps two per pass (fuse bit 5); <=0: default 511 (3-D), 2047 (2-D) */

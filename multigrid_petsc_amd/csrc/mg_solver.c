@@ -40,6 +40,7 @@ typedef struct mg_fset {
     int guess_nonzero;      /* KSPSetInitialGuessNonzero state of ksp[l] (src/solver.c:1532,1537,1543) */
     int u_ghost_ok;         /* z ghost planes of `u` hold the neighbours' current boundary planes */
     int u_ghost_pending;    /* ... but the exchange is still in flight on the comm stream */
+    int jz_ready;           /* tmp already holds the first sweep from a zero guess (written by the fused residual+restriction) */
     int b_ghost_ok;         /* z ghost planes of `b` hold the neighbours' boundary planes (two-sweep passes on slabs) */
     void *far;              /* distributed levels: field of geometry gfar = (nx, ny, 2) for the neighbours' SECOND planes of u */
     mgk_geom gfar;
@@ -66,6 +67,8 @@ typedef struct mg_ops {
     int (*residual_restrict)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const double *, const void *, const void *, void *, void *);   /* NULL: not built */
     int (*residual_range)(mgk_ctx *, const mgk_geom *, const double *, const void *, const void *, void *, int, int, void *);
     int (*restrict_finish)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const void *, void *, void *);
+    int (*residual_restrict_jz)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const double *, const void *, const void *, void *, void *,
+                                double, double, void *);
     int (*jacobi2)(mgk_ctx *, const mgk_geom *, const double *, double, double, const void *, const void *, void *, void *);
     int (*jacobi2_slab)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const double *, double, double, const void *, const void *, void *,
                         const void *, int, int, int, int, void *);
@@ -95,9 +98,11 @@ W64(j2)(mgk_ctx *c, const mgk_geom *g, const double *k, double d, double sc, con
 W32(j2)(mgk_ctx *c, const mgk_geom *g, const double *k, double d, double sc, const void *b, const void *u, void *o, void *st) { return mgk_jacobi2_f32(c, g, k, d, sc, (const float *)b, (const float *)u, (float *)o, st); }
 W64(j2s)(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gf, const double *k, double d, double sc, const void *b, const void *u, void *o, const void *far, int lo, int hi, int z0, int z1, void *st) { return mgk_jacobi2_slab_f64(c, g, gf, k, d, sc, (const double *)b, (const double *)u, (double *)o, (const double *)far, lo, hi, z0, z1, st); }
 W32(j2s)(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gf, const double *k, double d, double sc, const void *b, const void *u, void *o, const void *far, int lo, int hi, int z0, int z1, void *st) { return mgk_jacobi2_slab_f32(c, g, gf, k, d, sc, (const float *)b, (const float *)u, (float *)o, (const float *)far, lo, hi, z0, z1, st); }
+W64(rrz)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, const void *b, const void *u, void *bc, void *uc0, double d, double sc, void *st) { return mgk_residual_restrict_jz_f64(c, gf, gc, k, (const double *)b, (const double *)u, (double *)bc, (double *)uc0, d, sc, st); }
+W32(rrz)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, const void *b, const void *u, void *bc, void *uc0, double d, double sc, void *st) { return mgk_residual_restrict_jz_f32(c, gf, gc, k, (const float *)b, (const float *)u, (float *)bc, (float *)uc0, d, sc, st); }
 static const mg_ops OPS[2] = {
-    {8, jr_64, jz_64, rs_64, rf_64, pa_64, pj_64, rr_64, rg_64, fin_64, j2_64, j2s_64},
-    {4, jr_32, jz_32, rs_32, rf_32, pa_32, pj_32, rr_32, rg_32, fin_32, j2_32, j2s_32},
+    {8, jr_64, jz_64, rs_64, rf_64, pa_64, pj_64, rr_64, rg_64, fin_64, rrz_64, j2_64, j2s_64},
+    {4, jr_32, jz_32, rs_32, rf_32, pa_32, pj_32, rr_32, rg_32, fin_32, rrz_32, j2_32, j2s_32},
 };
 
 struct mg_solver {
@@ -278,7 +283,7 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
         const int n0 = mg_grid_n(cfg->npts, 0);
         s->cfg.dist_min_n = n0 < 255 ? n0 : 255;
     }
-    if (s->cfg.fuse < 0) s->cfg.fuse = 63;
+    if (s->cfg.fuse < 0) s->cfg.fuse = 63 | 256;
     if (s->cfg.pair_min_n <= 0) s->cfg.pair_min_n = (cfg->dim == 3) ? 511 : 2047;   /* where a two-sweep pass beats two sweeps */
     if (s->cfg.overlap < 0) s->cfg.overlap = 1;
     if (s->cfg.graph < 0) s->cfg.graph = 1;
@@ -582,10 +587,12 @@ static int smooth(mg_solver *s, int P, int l, int maxit) {
     const int pair_ok = (s->cfg.fuse & 32) && L->n >= s->cfg.pair_min_n && (s->lgraph == 0 || l < s->lgraph - 1) &&
                         ((s->cfg.dim == 3 && L->n + 1 <= 1024 && (!L->distributed || (F->far && F->g.nz >= 4))) ||
                          (s->cfg.dim == 2 && P == 0));
+    if (maxit < 1 || F->guess_nonzero) F->jz_ready = 0;
     for (int it = it0; it < maxit; it++) {
         if (it == 0 && !F->guess_nonzero) {
-            /* r = b, x = 0 + scale*(B b): u is not read */
-            CHK(O->jacobi_zero(s->ctx, &F->g, L->dinv, s->cfg.scale, F->b, F->tmp, NULL));
+            /* r = b, x = 0 + scale*(B b): u is not read (already in tmp when the fused residual+restriction wrote it) */
+            if (!F->jz_ready) CHK(O->jacobi_zero(s->ctx, &F->g, L->dinv, s->cfg.scale, F->b, F->tmp, NULL));
+            F->jz_ready = 0;
         } else if (pair_ok && maxit - it >= 2) {
             if (L->distributed) {
                 /* slab: the second sweep of my first / last plane needs the first sweep of the neighbour's last / first plane,
@@ -748,7 +755,16 @@ static int descend(mg_solver *s, int P, int l) {
     if ((s->cfg.fuse & 4) && O->residual_restrict && s->cfg.dim == 3 && !Lf->distributed && Lf->n + 1 <= 1024 &&
         (Lf->n >= 255 || (s->cfg.fuse & 128))) {
         /* :1534-1535 in one pass: b_l = R (b - A u), the fine residual is never written */
-        CHK(O->residual_restrict(s->ctx, &Lf->f[P].g, &s->L[l].f[P].g, Lf->coef, Lf->f[P].b, Lf->f[P].u, s->L[l].f[P].b, NULL));
+        mg_fset *Cq = &s->L[l].f[P];
+        const int sweeps = (l == levels - 1) ? v[1] : v[0];
+        if ((s->cfg.fuse & 256) && s->cfg.ksp_type == MG_KSP_RICHARDSON && sweeps >= 1 && !Cq->guess_nonzero) {
+            /* ... and the coarse level's first sweep from its zero guess comes out of the same kernel (saves re-reading b_l) */
+            CHK(O->residual_restrict_jz(s->ctx, &Lf->f[P].g, &Cq->g, Lf->coef, Lf->f[P].b, Lf->f[P].u, Cq->b, Cq->tmp, s->L[l].dinv,
+                                        s->cfg.scale, NULL));
+            Cq->jz_ready = 1;
+        } else {
+            CHK(O->residual_restrict(s->ctx, &Lf->f[P].g, &Cq->g, Lf->coef, Lf->f[P].b, Lf->f[P].u, Cq->b, NULL));
+        }
     } else if ((s->cfg.fuse & 4) && O->residual_restrict && s->cfg.dim == 3 && Lf->distributed && Lf->n + 1 <= 1024 &&
                Lf->f[P].g.nz >= 2) {
         /* the same on a z-slab.  The last coarse plane of every rank but the last needs the residual of the NEXT rank's
@@ -886,7 +902,7 @@ static int start(mg_solver *s) {
     CHK(mgk_sumsq_f64(s->ctx, &F->g, (const double *)F->b, &ss, NULL)); /* VecNorm(b[0]) :1512 */
     CHK(norm_from_sumsq(s, ss, &s->bnorm));
     for (int l = 0; l < s->levels; l++)
-        for (int p = 0; p < 2; p++) { s->L[l].f[p].guess_nonzero = 0; s->L[l].f[p].u_ghost_ok = 0; s->L[l].f[p].u_ghost_pending = 0; s->L[l].f[p].b_ghost_ok = 0; }
+        for (int p = 0; p < 2; p++) { s->L[l].f[p].guess_nonzero = 0; s->L[l].f[p].u_ghost_ok = 0; s->L[l].f[p].u_ghost_pending = 0; s->L[l].f[p].b_ghost_ok = 0; s->L[l].f[p].jz_ready = 0; }
     CHK(mgk_memset0(s->ctx, F->u, sizeof(double) * (size_t)F->g.total, NULL));   /* VecSet(u[0],0) :1514 */
     /* rv = A u - b with u = 0 (:1516-1517); ||A u - b|| = ||b - A u||, evaluated by the same residual kernel */
     if (s->cfg.precision == MG_PREC_MIXED)

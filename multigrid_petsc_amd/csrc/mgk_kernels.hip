@@ -2253,6 +2253,8 @@ struct RRArgs {
     long rs, ms, crs, cms;   // fine / coarse row and plane strides
     int kcc, nty;            // coarse planes per chunk, tiles in y
     T a0, a1, a2, a3, a4, a5, a6;
+    T *uc0;                  // optional: the coarse level's first sweep from a zero guess, uc0 = scale_c * (bc * dinv_c)
+    T dinv_c, scale_c;
 };
 
 template <typename T, int WX>
@@ -2379,8 +2381,11 @@ __global__ void __launch_bounds__(64 * WX) k_resrestrict(const RRArgs<T> a) {
                 for (int cl = 0; cl < 2; cl++)
 #pragma unroll
                     for (int q = 0; q < NCJ; q++) {
-                        if (kc >= kc0 && (cl == 0 ? crow0 : crow1) && jc0 + q < a.nxc)
-                            a.bc[(long)kc * a.cms + (long)(2 * ty + cl) * a.crs + jc0 + q] = acc[cl][q];
+                        if (kc >= kc0 && (cl == 0 ? crow0 : crow1) && jc0 + q < a.nxc) {
+                            const long oc = (long)kc * a.cms + (long)(2 * ty + cl) * a.crs + jc0 + q;
+                            a.bc[oc] = acc[cl][q];
+                            if (a.uc0) { const T z = acc[cl][q] * a.dinv_c; a.uc0[oc] = a.scale_c * z; }   // k_jacobi_zero's arithmetic
+                        }
                         acc[cl][q] = accn[cl][q]; accn[cl][q] = (T)0;
                     }
             }
@@ -2425,7 +2430,7 @@ __global__ void __launch_bounds__(256) k_restrict_finish(XferArgs a, const T *rg
 
 template <typename T>
 static int residual_restrict(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
-                             const T *b, const T *u, T *bc, void *stream) {
+                             const T *b, const T *u, T *bc, T *uc0, double dinv_c, double scale_c, void *stream) {
     constexpr int VX = 16 / sizeof(T);
     if (!c || !gf || !gc || !coef || !b || !u || !bc || gf->dim != 3)
         return fail(MGK_EINVAL, "mgk_residual_restrict: bad arguments (3-D only)");
@@ -2440,6 +2445,8 @@ static int residual_restrict(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc,
     a.nx = gf->nx; a.ny = gf->ny; a.nz = gf->nz; a.nxc = gc->nx; a.nyc = gc->ny; a.nzc = gc->nz;
     a.rs = gf->pitch; a.ms = gf->plane; a.crs = gc->pitch; a.cms = gc->plane;
     a.a0 = (T)coef[0]; a.a1 = (T)coef[1]; a.a2 = (T)coef[2]; a.a3 = (T)coef[3]; a.a4 = (T)coef[4]; a.a5 = (T)coef[5]; a.a6 = (T)coef[6];
+    if (uc0 && gf->nz != 2 * gc->nz + 1) return fail(MGK_EINVAL, "mgk_residual_restrict_jz: whole grids only");
+    a.uc0 = uc0 ? uc0 + gc->org : nullptr; a.dinv_c = (T)dinv_c; a.scale_c = (T)scale_c;
     a.nty = (gf->ny - 1 + 3) / 4;                 // tiles of 5 rows at stride 4; ny = 2 nyc + 1
     if (a.nty < 1) a.nty = 1;
     const int w = (gf->nx + 1 + 64 * VX - 1) / (64 * VX);       // waves needed for a full row
@@ -2462,11 +2469,23 @@ static int residual_restrict(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc,
 }
 extern "C" int mgk_residual_restrict_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
                                          const double *b, const double *u, double *bc, void *stream) {
-    return residual_restrict<double>(c, gf, gc, coef, b, u, bc, stream);
+    return residual_restrict<double>(c, gf, gc, coef, b, u, bc, nullptr, 0.0, 0.0, stream);
 }
 extern "C" int mgk_residual_restrict_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
                                          const float *b, const float *u, float *bc, void *stream) {
-    return residual_restrict<float>(c, gf, gc, coef, b, u, bc, stream);
+    return residual_restrict<float>(c, gf, gc, coef, b, u, bc, nullptr, 0.0, 0.0, stream);
+}
+// the same, also writing the coarse level's first sweep from a zero guess (uc0 = scale_c * (bc * dinv_c), what mgk_jacobi_zero_*
+// would compute from bc): saves that kernel's read of bc
+extern "C" int mgk_residual_restrict_jz_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, const double *b,
+                                            const double *u, double *bc, double *uc0, double dinv_c, double scale_c, void *stream) {
+    if (!uc0) return fail(MGK_EINVAL, "mgk_residual_restrict_jz_f64: null uc0");
+    return residual_restrict<double>(c, gf, gc, coef, b, u, bc, uc0, dinv_c, scale_c, stream);
+}
+extern "C" int mgk_residual_restrict_jz_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, const float *b,
+                                            const float *u, float *bc, float *uc0, double dinv_c, double scale_c, void *stream) {
+    if (!uc0) return fail(MGK_EINVAL, "mgk_residual_restrict_jz_f32: null uc0");
+    return residual_restrict<float>(c, gf, gc, coef, b, u, bc, uc0, dinv_c, scale_c, stream);
 }
 template <typename T>
 static int restrict_finish(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const T *r, T *bc, void *stream) {

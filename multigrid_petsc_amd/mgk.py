@@ -71,6 +71,8 @@ def _sigs(L):
         "mgk_apply_f64": (i, [vp, G, c_dp, vp, vp, vp]),
         "mgk_residual_restrict_f64": (i, [vp, G, G, c_dp, vp, vp, vp, vp]),
         "mgk_residual_restrict_f32": (i, [vp, G, G, c_dp, vp, vp, vp, vp]),
+        "mgk_residual_restrict_jz_f64": (i, [vp, G, G, c_dp, vp, vp, vp, vp, d, d, vp]),
+        "mgk_residual_restrict_jz_f32": (i, [vp, G, G, c_dp, vp, vp, vp, vp, d, d, vp]),
         "mgk_residual_range_f64": (i, [vp, G, c_dp, vp, vp, vp, i, i, vp]),
         "mgk_residual_range_f32": (i, [vp, G, c_dp, vp, vp, vp, i, i, vp]),
         "mgk_restrict_finish_f64": (i, [vp, G, G, vp, vp, vp]),

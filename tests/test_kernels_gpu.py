@@ -340,3 +340,23 @@ def test_two_sweeps_in_one_pass_2d_bit_exact(mgk, orc, n):
     mgk.L.mgk_set_tuning(-1, -1)
     for p in (du, db, dout):
         mgk.free(p)
+
+
+@pytest.mark.parametrize("nf", [7, 63, 255])
+def test_fused_residual_restrict_with_coarse_first_sweep(mgk, orc, nf):
+    """mgk_residual_restrict_jz_f64: b_c as before, plus the coarse level's first sweep from a zero guess (what
+    mgk_jacobi_zero_f64 computes from b_c)"""
+    rng = np.random.default_rng(9100 + nf)
+    nc = (nf - 1) // 2
+    As, Asc = _stencil(orc, 3, nf), _stencil(orc, 3, nc)
+    u, b = _rand(rng, nf ** 3), _rand(rng, nf ** 3)
+    gf, gc = mgk.geom(3, nf), mgk.geom(3, nc)
+    du, db, dbc, duc = mgk.to_field(gf, u), mgk.to_field(gf, b), mgk.field(gc), mgk.field(gc)
+    mgk._chk(mgk.L.mgk_memset0(mgk.ctx, duc, 8 * gc.total, None))
+    dinvc = 1.0 / Asc[3]
+    mgk._chk(mgk.L.mgk_residual_restrict_jz_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), db, du, dbc, duc, dinvc, 0.8, None))
+    bc = orc.restrict(3, nf, orc.residual(3, nf, As, b, u))
+    assert np.array_equal(mgk.from_field(gc, dbc), bc)
+    assert np.array_equal(mgk.from_field(gc, duc), orc.jacobi(3, nc, Asc, 0.8, bc, np.zeros(nc ** 3), zero_guess=True))
+    for p in (du, db, dbc, duc):
+        mgk.free(p)
