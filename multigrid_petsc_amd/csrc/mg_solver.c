@@ -49,6 +49,8 @@ typedef struct mg_fset {
 typedef struct mg_level {
     int n;                  /* unknowns per side of the whole grid */
     int z0, nzl;            /* owned planes [z0, z0+nzl) (3-D); whole grid when replicated / 2-D */
+    int nz_min;             /* fewest planes any rank owns on this level: every choice between code paths that differ in their
+                             * exchanges is made on it, never on the own slab size, so that all ranks take the same path */
     int distributed;
     double coef[7], dinv, h;
     mg_fset f[2];
@@ -323,6 +325,12 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
             mg_slab_range(cfg->npts, s->ldist, l, s->cfg.rank, s->cfg.nranks, &a, &b);
             L->z0 = a; L->nzl = b - a;
         }
+        L->nz_min = L->nzl;
+        for (int r = 0; L->distributed && r < s->cfg.nranks; r++) {
+            int a, b;
+            mg_slab_range(cfg->npts, s->ldist, l, r, s->cfg.nranks, &a, &b);
+            if (b - a < L->nz_min) L->nz_min = b - a;
+        }
         rc = mgk_geom_init(&L->f[0].g, cfg->dim, L->n, L->n, L->nzl);
         if (rc) { mg_solver_destroy(s); return mgfail(rc, "mg_solver_create: geometry"); }
         level_stencil(cfg->dim, L->n, L->coef, &L->h);
@@ -585,7 +593,7 @@ static int smooth(mg_solver *s, int P, int l, int maxit) {
     /* two sweeps per pass (temporal blocking) where it pays: whole 3-D grids of 511^3 and more.  Not on the level whose
      * buffers the coarse-level HIP graph refers to (a pass swaps u/tmp once, not twice: see coarse_part) */
     const int pair_ok = (s->cfg.fuse & 32) && L->n >= s->cfg.pair_min_n && (s->lgraph == 0 || l < s->lgraph - 1) &&
-                        ((s->cfg.dim == 3 && L->n + 1 <= 1024 && (!L->distributed || (F->far && F->g.nz >= 4))) ||
+                        ((s->cfg.dim == 3 && L->n + 1 <= 1024 && (!L->distributed || (F->far && L->nz_min >= 4))) ||
                          (s->cfg.dim == 2 && P == 0));
     if (maxit < 1 || F->guess_nonzero) F->jz_ready = 0;
     for (int it = it0; it < maxit; it++) {
@@ -608,7 +616,7 @@ static int smooth(mg_solver *s, int P, int l, int maxit) {
                 if (!F->b_ghost_ok) CHK(s->comm->halo(s->comm, s->ctx, F->b, &F->g, O->esz, ms));
                 CHK(s->comm->halo(s->comm, s->ctx, F->far, &F->gfar, O->esz, ms));
                 /* ... while the planes 2 .. nz-3, which need no ghost data, are already being swept */
-                if (s->cfg.overlap && nz >= 6) {
+                if (s->cfg.overlap && L->nz_min >= 6) {
                     s->prof_kind = 1;                       /* timed: the interior planes 2 .. nz-3 of the slab */
                     void *t = prof_begin(s, l);
                     s->prof_kind = 0;
@@ -617,7 +625,7 @@ static int smooth(mg_solver *s, int P, int l, int maxit) {
                 }
                 CHK(mgk_stream_wait(s->ctx, cs, ms));
                 F->u_ghost_pending = 0; F->u_ghost_ok = 1; F->b_ghost_ok = 1;
-                if (s->cfg.overlap && nz >= 6) {
+                if (s->cfg.overlap && L->nz_min >= 6) {
                     CHK(O->jacobi2_slab(s->ctx, &F->g, &F->gfar, L->coef, L->dinv, s->cfg.scale, F->b, F->u, F->tmp, F->far, lo, hi, 0, 2, cs));
                     CHK(O->jacobi2_slab(s->ctx, &F->g, &F->gfar, L->coef, L->dinv, s->cfg.scale, F->b, F->u, F->tmp, F->far, lo, hi, nz - 2, nz, cs));
                 } else {
@@ -634,7 +642,7 @@ static int smooth(mg_solver *s, int P, int l, int maxit) {
                 prof_end(s, t);
             }
             it++;                                   /* this pass made sweeps it and it + 1 */
-        } else if (L->distributed && s->cfg.overlap && F->g.nz >= 3) {
+        } else if (L->distributed && s->cfg.overlap && L->nz_min >= 3) {
             /* boundary planes first, ship them on the comm stream, sweep the interior meanwhile */
             void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
             const int nz = F->g.nz;
@@ -766,7 +774,7 @@ static int descend(mg_solver *s, int P, int l) {
             CHK(O->residual_restrict(s->ctx, &Lf->f[P].g, &Cq->g, Lf->coef, Lf->f[P].b, Lf->f[P].u, Cq->b, NULL));
         }
     } else if ((s->cfg.fuse & 4) && O->residual_restrict && s->cfg.dim == 3 && Lf->distributed && Lf->n + 1 <= 1024 &&
-               Lf->f[P].g.nz >= 2) {
+               Lf->nz_min >= 2) {
         /* the same on a z-slab.  The last coarse plane of every rank but the last needs the residual of the NEXT rank's
          * first plane: each rank evaluates that one plane first and ships it (comm stream) while the fused kernel
          * runs over the slab and leaves its last coarse plane partial; a small kernel then appends the missing terms in

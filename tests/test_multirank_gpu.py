@@ -216,6 +216,8 @@ def test_fixed_count_cycling_defers_the_norms_on_slabs():
 @pytest.mark.parametrize("P,npts,levels,dist_min_n,precision", [
     (2, 65, 5, 15, "fp64"), (3, 65, 5, 15, "fp64"), (4, 129, 6, 31, "fp64"), (8, 129, 6, 63, "fp64"), (2, 65, 3, 15, "fp64"),
     (2, 65, 5, 15, "mixed"), (4, 129, 6, 31, "mixed"),
+    (8, 129, 6, 31, "fp64"),      # level 31: slabs of 4,4,...,3 planes -- every rank must take the same (one-sweep) path there
+    (8, 65, 4, 15, "fp64"),       # slabs of 2 planes and 3 on the last rank
 ])
 def test_two_sweep_passes_on_slabs(P, npts, levels, dist_min_n, precision):
     """fuse bit 5 on distributed levels: the pair kernel runs on every slab with the neighbours' two boundary planes of u
