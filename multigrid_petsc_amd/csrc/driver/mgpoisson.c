@@ -7,7 +7,7 @@
  *             [-device d] [-options_file poisson.in] [-write_fields 0|1]
  *
  * Same option spelling as the reference where it has one (-npts -levels -iter -v; poisson.in syntax: '#'
- * comments, "-key value" lines); -grids is implied (= -levels: one grid per level), -cycle is 0, -mesh 0.
+ * comments, "-key value" lines); -grids is implied (= -levels: one grid per level), -cycle is 0; -mesh 0|1|2 (1, 2: 2-D).
  * Output mirrors what the reference prints: the PrintInfo block (src/poisson.c:165-214), error[0..2]
  * (src/solver.c:1333), "Relative residual" (:1354), "Solver walltime" (:1572), and the five files of
  * Postprocessing (src/solver.c:160-164,1331-1353): eData.dat, rData.dat, and -- the O(N) text dumps --
@@ -20,6 +20,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 
 typedef struct { char key[64], val[128]; } kv;
 static kv g_kv[128];
@@ -76,7 +77,7 @@ int main(int argc, char **argv) {
     if ((v = get("-device"))) c.device = atoi(v);
     if ((v = get("-pc_type")) && strcmp(v, "jacobi")) { fprintf(stderr, "mgpoisson: only -pc_type jacobi is built\n"); return 2; }
     if ((v = get("-cycle")) && atoi(v) != 0) { fprintf(stderr, "mgpoisson: only -cycle 0 (V-cycle) is built\n"); return 2; }
-    if ((v = get("-mesh")) && atoi(v) != 0) { fprintf(stderr, "mgpoisson: only -mesh 0 (uniform) is built in this driver\n"); return 2; }
+    if ((v = get("-mesh"))) c.mesh = atoi(v);
 
     mg_solver *s = NULL;
     if (mg_solver_create(&s, &c, NULL)) { fprintf(stderr, "mgpoisson: %s\n", mg_last_error()); return 1; }
@@ -100,8 +101,15 @@ int main(int argc, char **argv) {
         const size_t N = (c.dim == 3) ? (size_t)n * n * n : (size_t)n * n;
         double *u = (double *)malloc(N * sizeof(double)), *x = (double *)malloc((size_t)c.npts * sizeof(double));
         if (!u || !x || mg_solver_get_solution(s, u)) { fprintf(stderr, "mgpoisson: cannot fetch the solution: %s\n", mg_last_error()); return 1; }
+        double *y = (double *)malloc((size_t)c.npts * sizeof(double));
         x[0] = 0.0;                                       /* Coords, uniform branch: repeated addition (src/mesh.c:150-152) */
-        for (int q = 1; q < c.npts; q++) x[q] = x[q - 1] + 1.0 / (c.npts - 1);
+        for (int q = 1; q < c.npts - 1; q++) x[q] = x[q - 1] + 1.0 / (c.npts - 1);
+        x[c.npts - 1] = 1.0;
+        for (int q = 0; q < c.npts; q++) y[q] = x[q];
+        for (int q = 1; q < c.npts - 1 && c.mesh; q++) {  /* y of the stretched meshes (src/mesh.c:165-169) */
+            const double eta = q / (double)(c.npts - 1);
+            y[q] = (c.mesh == 1) ? 1.0 - 1.0 * (cos(3.14159265358979323846 * 0.5 * eta)) : 0.0 + 1.0 * ((exp(2 * eta) - 1) / (exp(2) - 1));
+        }
         FILE *fu = fopen("uData.dat", "w"), *fx = fopen("XgridData.dat", "w"), *fy = fopen("YgridData.dat", "w");
         if (fu && fx && fy) {
             const size_t rows = N / (size_t)n;
@@ -109,7 +117,7 @@ int main(int argc, char **argv) {
                 const int i = (int)(r % (size_t)n);
                 for (int j = 0; j < n; j++) {
                     fprintf(fx, "%lf    ", x[j]);
-                    fprintf(fy, "%lf    ", x[i]);
+                    fprintf(fy, "%lf    ", y[i]);
                     fprintf(fu, "%.16e    ", u[r * (size_t)n + j]);
                 }
                 fprintf(fx, "\n"); fprintf(fy, "\n"); fprintf(fu, "\n");
@@ -118,11 +126,12 @@ int main(int argc, char **argv) {
         if (fu) fclose(fu);
         if (fx) fclose(fx);
         if (fy) fclose(fy);
-        free(u); free(x);
+        free(u); free(x); free(y);
     }
     printf("=============================================================\n");
     if (c.dim == 2) printf("Size:\t\t\t\t%d x %d\n", c.npts, c.npts); else printf("Size:\t\t\t\t%d x %d x %d\n", c.npts, c.npts, c.npts);
-    printf("Mesh Type:\t\t\tUniform\n");
+    if (c.mesh == 0) printf("Mesh Type:\t\t\tUniform\n");          /* the reference prints no line for -mesh 2 (src/poisson.c:179-180) */
+    if (c.mesh == 1) printf("Mesh Type:\t\t\tNon Uniform\n");
     printf("Number of grids:\t\t%d\n", c.levels);
     printf("Number of levels:\t\t%d\n", c.levels);
     printf("Number of grids per level:\t");

@@ -53,6 +53,7 @@ typedef struct mg_level {
                              * exchanges is made on it, never on the own slab size, so that all ranks take the same path */
     int distributed;
     double coef[7], dinv, h;
+    double *ctab, *dtab;    /* -mesh 1/2 (2-D): device tables, 5 coefficients {(i-1), W, C, E, (i+1)} and 1/diag per grid row */
     mg_fset f[2];
     double *p2;             /* Chebyshev: third recurrence vector (fp64) */
 } mg_level;
@@ -191,6 +192,58 @@ static void coords_uniform(int npts, double *c) {
     for (int j = 1; j < npts - 1; j++) c[j] = c[j - 1] + d;
 }
 
+/* y coordinates of the stretched meshes (x stays uniform): src/mesh.c:154-176 */
+static void coords_mesh_y(int npts, int mesh, double *c) {
+    if (mesh == 0) { coords_uniform(npts, c); return; }
+    c[0] = 0.0; c[npts - 1] = 1.0;
+    const double length = c[npts - 1] - c[0];
+    for (int j = 1; j < npts - 1; j++) {
+        if (mesh == 1) c[j] = 1.0 - length * (cos(MG_PI * 0.5 * (j / (double)(npts - 1))));          /* :165-166 */
+        else { double eta = (j / (double)(npts - 1)); c[j] = 0.0 + length * ((exp(2 * eta) - 1) / (exp(2) - 1)); }   /* :168-169 */
+    }
+}
+/* metric coefficients at height y on [0,1]^2: MetricsNonUniform1 / 2, src/mesh.c:45-75 / 77-107 */
+static void metrics_mesh(int mesh, double y, double *m) {
+    const double b0 = 0.0, b1 = 1.0, b2 = 0.0, b3 = 1.0;
+    if (mesh == 1) {
+        double temp = ((b3 - b2) * (b3 - b2) - (b3 - y) * (b3 - y));
+        m[0] = 1.0;
+        m[1] = 4.0 / (MG_PI * MG_PI * temp);
+        m[2] = 0.0;
+        m[3] = (-2.0 * (b3 - y)) / (MG_PI * sqrt(temp * temp * temp));
+        m[4] = 0.0;
+        return;
+    }
+    double temp = ((exp(2) - 1) * (exp(2) - 1)) / (((y - b2) * (exp(2) - 1) + (b3 - b2)) * ((y - b2) * (exp(2) - 1) + (b3 - b2)));
+    m[0] = 1.0 / ((b1 - b0) * (b1 - b0));
+    m[1] = 0.25 * temp;
+    m[2] = 0.0;
+    m[3] = (-0.5) * temp;
+    m[4] = 0.0;
+}
+/* rows of level l on a stretched mesh: metrics at the fine-grid point of grid row i (src/solver.c:227-232), OpA with the level's
+ * computational spacing (src/problem.c:3-22).  ctab: n x 5, dtab: n (host) */
+static void level_row_tables(int npts, int mesh, int l, int n, double *ctab, double *dtab) {
+    double *cy = (double *)malloc(sizeof(double) * (size_t)npts);
+    coords_mesh_y(npts, mesh, cy);
+    const double h[2] = {1.0 / (n + 1), 1.0 / (n + 1)};
+    const double hx2 = h[0] * h[0], hy2 = h[1] * h[1];
+    const int f = 1 << l;
+    for (int i = 0; i < n; i++) {
+        double m[5];
+        const int ifine = f * (i + 1) - 1;
+        metrics_mesh(mesh, cy[ifine + 1], m);
+        double *As = ctab + 5 * (size_t)i;
+        As[0] = (m[1] / hy2) - (m[3] / (2 * h[1]));
+        As[1] = (m[0] / hx2) - (m[2] / (2 * h[0]));
+        As[2] = -2.0 * ((m[0] / hx2) + (m[1] / hy2));
+        As[3] = (m[0] / hx2) + (m[2] / (2 * h[0]));
+        As[4] = (m[1] / hy2) + (m[3] / (2 * h[1]));
+        dtab[i] = 1.0 / As[2];
+    }
+    free(cy);
+}
+
 static void level_stencil(int dim, int n, double *As, double *h_out) {
     /* h: src/matbuild.c:99-104; OpA: src/problem.c:3-22 with MetricsUniform (src/mesh.c:29-43) */
     double h[3] = {1.0 / (n + 1), 1.0 / (n + 1), 1.0 / (n + 1)};
@@ -245,6 +298,8 @@ static int alloc_fset(mg_solver *s, mg_fset *F, int esz, int all4) {
     return 0;
 }
 
+static int upload(mg_solver *s, const double *h, size_t n, double **d);
+
 /* distributed level: the (nx, ny, 2) field through which the neighbours' second planes of u travel (two-sweep passes) */
 static int alloc_far(mg_solver *s, mg_level *L, int P) {
     mg_fset *F = &L->f[P];
@@ -273,6 +328,9 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
         if (n < 1 || (cfg->npts - 1) % f != 0 || (n & 1) == 0)
             return mgfail(MGK_EINVAL, "mg_solver_create: npts-1 must be 2^m with m >= levels (vertex-centred coarsening, src/matbuild.c:62-66)");
     }
+    if (cfg->mesh != 0 && (cfg->mesh < 0 || cfg->mesh > 2 || cfg->dim != 2 || cfg->precision != MG_PREC_FP64 || cfg->nranks > 1 ||
+                           cfg->ksp_type != MG_KSP_RICHARDSON))
+        return mgfail(MGK_EINVAL, "mg_solver_create: -mesh 1/2 is built for 2-D, fp64, one GPU, Richardson + Jacobi");
     if (cfg->nranks > 1 && (!comm || cfg->dim != 3))
         return mgfail(MGK_EINVAL, "mg_solver_create: nranks > 1 needs a communicator and dim == 3");
     if (cfg->ksp_type == MG_KSP_CHEBYSHEV && !(cfg->emax > cfg->emin && cfg->emin > 0.0))
@@ -287,6 +345,7 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
     }
     if (s->cfg.fuse < 0) s->cfg.fuse = 63 | 256;
     if (s->cfg.pair_min_n <= 0) s->cfg.pair_min_n = (cfg->dim == 3) ? 511 : 2047;   /* where a two-sweep pass beats two sweeps */
+    if (s->cfg.mesh) s->cfg.fuse = 0;           /* row-dependent coefficients: the kernel-per-operation cycle on the row-table kernels */
     if (s->cfg.overlap < 0) s->cfg.overlap = 1;
     if (s->cfg.graph < 0) s->cfg.graph = 1;
     if (s->cfg.nranks < 1) s->cfg.nranks = 1;
@@ -335,6 +394,14 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
         if (rc) { mg_solver_destroy(s); return mgfail(rc, "mg_solver_create: geometry"); }
         level_stencil(cfg->dim, L->n, L->coef, &L->h);
         L->dinv = 1.0 / L->coef[cfg->dim == 3 ? 3 : 2];      /* PCJACOBI: 1/diag(A) */
+        if (cfg->mesh) {
+            double *hc = (double *)malloc(sizeof(double) * 5 * (size_t)L->n), *hd = (double *)malloc(sizeof(double) * (size_t)L->n);
+            level_row_tables(cfg->npts, cfg->mesh, l, L->n, hc, hd);
+            rc = upload(s, hc, 5 * (size_t)L->n, &L->ctab);
+            if (!rc) rc = upload(s, hd, (size_t)L->n, &L->dtab);
+            free(hc); free(hd);
+            if (rc) { mg_solver_destroy(s); return mgfail(rc, "mg_solver_create: coefficient tables"); }
+        }
         if (mixed) {
             /* fp64 only where the outer defect correction lives (level 0: u, b); fp32 on every level */
             if (l == 0 && (rc = alloc_fset(s, &L->f[0], 8, 0))) { mg_solver_destroy(s); return rc; }
@@ -386,6 +453,8 @@ void mg_solver_destroy(mg_solver *s) {
                 for (int k = 0; k < 5; k++) if (f[k]) mgk_free(s->ctx, f[k]);
             }
             if (L->p2) mgk_free(s->ctx, L->p2);
+            if (L->ctab) mgk_free(s->ctx, L->ctab);
+            if (L->dtab) mgk_free(s->ctx, L->dtab);
         }
         mgk_ctx_destroy(s->ctx);
     }
@@ -421,6 +490,10 @@ static int sin_tables(mg_solver *s, double **cx, double **sx, double **sy, doubl
     int rc = 0;
     if (cx) rc = upload(s, tc, n, cx);
     if (!rc && sx) rc = upload(s, t, n, sx);
+    if (s->cfg.mesh) {                                   /* stretched in y: sin(pi y_i) at the mesh's own coordinates */
+        coords_mesh_y(npts, s->cfg.mesh, c);
+        for (int j = 0; j < n; j++) t[j] = sin(MG_PI * c[j + 1]);
+    }
     if (!rc) rc = upload(s, t, n, sy);
     if (!rc && s->cfg.dim == 3) rc = upload(s, t + L->z0, L->nzl, sz); else if (!rc) *sz = NULL;
     free(c); free(t); free(tc);
@@ -596,6 +669,17 @@ static int smooth(mg_solver *s, int P, int l, int maxit) {
                         ((s->cfg.dim == 3 && L->n + 1 <= 1024 && (!L->distributed || (F->far && L->nz_min >= 4))) ||
                          (s->cfg.dim == 2 && P == 0));
     if (maxit < 1 || F->guess_nonzero) F->jz_ready = 0;
+    if (s->cfg.mesh) {                                   /* -mesh 1/2: row-table kernels, one sweep per launch */
+        for (int it = 0; it < maxit; it++) {
+            if (it == 0 && !F->guess_nonzero)
+                CHK(mgk_jacobi_zero_rowcoef_f64(s->ctx, &F->g, L->dtab, s->cfg.scale, (const double *)F->b, (double *)F->tmp, NULL));
+            else
+                CHK(mgk_rowcoef_f64(s->ctx, &F->g, 0, L->ctab, L->dtab, s->cfg.scale, (const double *)F->b, (const double *)F->u,
+                                    (double *)F->tmp, NULL));
+            swap_ptr(&F->u, &F->tmp);
+        }
+        return 0;
+    }
     for (int it = it0; it < maxit; it++) {
         if (it == 0 && !F->guess_nonzero) {
             /* r = b, x = 0 + scale*(B b): u is not read (already in tmp when the fused residual+restriction wrote it) */
@@ -675,6 +759,7 @@ static int residual(mg_solver *s, int P, int l) {
     mg_level *L = &s->L[l];
     mg_fset *F = &L->f[P];
     CHK(ensure_u_ghosts(s, P, L));
+    if (s->cfg.mesh) return mgk_rowcoef_f64(s->ctx, &F->g, 1, L->ctab, L->dtab, 1.0, (const double *)F->b, (const double *)F->u, (double *)F->rv, NULL);
     CHK(OPS[P].residual(s->ctx, &F->g, L->coef, F->b, F->u, F->rv, NULL));
     return 0;
 }
@@ -892,7 +977,7 @@ static int vcycle_once(mg_solver *s) {
             s->spec_valid = 1;
         } else if (s->cfg.fuse & 1) CHK(mgk_residual_sumsq_f64(s->ctx, &F->g, L->coef, (const double *)F->b, (const double *)F->u, &ss, NULL));
         else {
-            CHK(mgk_residual_f64(s->ctx, &F->g, L->coef, (const double *)F->b, (const double *)F->u, (double *)F->rv, NULL));
+            CHK(residual(s, 0, 0));
             CHK(mgk_sumsq_f64(s->ctx, &F->g, (const double *)F->rv, &ss, NULL));
         }
     }

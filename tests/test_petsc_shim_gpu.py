@@ -257,12 +257,12 @@ MGPOISSON = os.path.join(ROOT, "multigrid_petsc_amd", "mgpoisson")
 
 
 @pytest.mark.skipif(not os.path.exists(REFDRV), reason="build/refdriver/poisson absent")
-@pytest.mark.parametrize("npts,levels", [(17, 2), (65, 5), (129, 7)])
-def test_own_driver_writes_the_reference_output_files(tmp_path, npts, levels):
+@pytest.mark.parametrize("npts,levels,mesh", [(17, 2, 0), (65, 5, 0), (129, 7, 0), (65, 5, 1), (129, 6, 2)])
+def test_own_driver_writes_the_reference_output_files(tmp_path, npts, levels, mesh):
     """the product's own driver against the reference's own Postprocessing code (unmodified
     src/solver.c:1317-1380 running over the shim): uData.dat, XgridData.dat, YgridData.dat byte for byte;
     eData.dat / rData.dat number for number (their sums are reduced in another order: 1e-12); PrintInfo lines."""
-    opts = (f"-npts {npts}\n-mesh 0\n-iter 1000\n-grids {levels}\n-levels {levels}\n-cycle 0\n-map 2\n-v 3,3\n-moreNorm 0\n"
+    opts = (f"-npts {npts}\n-mesh {mesh}\n-iter 1000\n-grids {levels}\n-levels {levels}\n-cycle 0\n-map 2\n-v 3,3\n-moreNorm 0\n"
             f"-pc_type jacobi\n-ksp_richardson_scale 0.8\n")
     a, b = tmp_path / "ref", tmp_path / "own"
     a.mkdir()

@@ -253,3 +253,20 @@ def test_fused_residual_restriction_on_small_levels(orc, npts, levels, precision
     assert it == ref["iters"] and np.array_equal(s.solution(), ref["u"])
     assert np.abs(s.rnorm / ref["rnorm"] - 1).max() <= RTOL
     s.close()
+
+
+@pytest.mark.parametrize("mesh,npts,levels", [(1, 33, 4), (2, 33, 4), (1, 129, 6), (2, 257, 7), (1, 513, 8)])
+def test_own_driver_on_stretched_meshes(orc, mesh, npts, levels):
+    """SURVEY 8(f) N1 in the own driver: -mesh 1/2 (src/mesh.c:45-107,165-169) -- per-row coefficient tables on every level,
+    the row-table kernels, the kernel-per-operation cycle.  Bit-identical to the oracle's assembled stretched-mesh leg."""
+    from multigrid_petsc_amd.solver import Solver
+    s = Solver(2, npts, levels, v=(3, 3), maxiter=1000, scale=0.8, mesh=mesh)
+    s.set_rhs_problem()
+    it = s.solve()
+    ref = orc.vcycle(2, npts, levels, 3, 3, maxiter=1000, scale=0.8, use_csr=1, mesh=mesh)
+    assert it == ref["iters"] < 1000
+    assert np.abs(s.rnorm / ref["rnorm"] - 1).max() <= RTOL
+    assert np.array_equal(s.solution(), ref["u"])
+    e, eref = s.error_norms(), orc.error_norms_mesh(npts, mesh, ref["u"])
+    assert e[0] == eref[0] and abs(e[1] - eref[1]) <= RTOL * eref[1] and abs(e[2] - eref[2]) <= RTOL * eref[2]
+    s.close()
