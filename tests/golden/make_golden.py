@@ -64,6 +64,52 @@ def level_operator(dim, n):
     return A
 
 
+def coords_y(npts, mesh):
+    """y coordinates of the stretched meshes, src/mesh.c:154-176 (x stays uniform)"""
+    if mesh == 0:
+        return coords(npts)
+    c = [0.0] * npts
+    c[-1] = 1.0
+    for j in range(1, npts - 1):
+        eta = j / float(npts - 1)
+        c[j] = 1.0 - 1.0 * math.cos(math.pi * 0.5 * eta) if mesh == 1 else 0.0 + 1.0 * ((math.exp(2 * eta) - 1) / (math.exp(2) - 1))
+    return c
+
+
+def metrics(mesh, y):
+    """MetricsNonUniform1 / 2 on [0,1]^2, src/mesh.c:45-107"""
+    if mesh == 1:
+        temp = (1.0 - 0.0) * (1.0 - 0.0) - (1.0 - y) * (1.0 - y)
+        return [1.0, 4.0 / (math.pi * math.pi * temp), 0.0, (-2.0 * (1.0 - y)) / (math.pi * math.sqrt(temp * temp * temp)), 0.0]
+    e2 = math.exp(2) - 1
+    temp = (e2 * e2) / (((y - 0.0) * e2 + 1.0) * ((y - 0.0) * e2 + 1.0))
+    return [1.0, 0.25 * temp, 0.0, (-0.5) * temp, 0.0]
+
+
+def level_operator_mesh(npts, l, mesh):
+    """rows of level l on a stretched mesh (2-D): metrics at the fine-grid point of the grid row (src/solver.c:227-232),
+    OpA with the level's computational spacing (src/problem.c:3-22)"""
+    n = (npts - 1) // 2 ** l - 1
+    h = 1.0 / (n + 1)
+    cy = coords_y(npts, mesh)
+    a = np.zeros((5, n))
+    for i in range(n):
+        m = metrics(mesh, cy[2 ** l * (i + 1)])
+        a[0, i] = (m[1] / (h * h)) - (m[3] / (2 * h))
+        a[1, i] = (m[0] / (h * h)) - (m[2] / (2 * h))
+        a[2, i] = -2.0 * ((m[0] / (h * h)) + (m[1] / (h * h)))
+        a[3, i] = (m[0] / (h * h)) + (m[2] / (2 * h))
+        a[4, i] = (m[1] / (h * h)) + (m[3] / (2 * h))
+    I = sp.identity(n, format="csr")
+    lo, up = sp.diags([np.ones(n - 1)], [-1], format="csr"), sp.diags([np.ones(n - 1)], [1], format="csr")
+    A = (sp.kron(sp.diags(a[0]) @ lo, I) + sp.kron(sp.diags(a[1]), lo) + sp.kron(sp.diags(a[2]), I)
+         + sp.kron(sp.diags(a[3]), up) + sp.kron(sp.diags(a[4]) @ up, I))
+    A = sp.csr_matrix(A)
+    A.sum_duplicates()
+    A.sort_indices()
+    return A
+
+
 def coords(npts):
     c = [0.0]
     d = 1.0 / (npts - 1)
@@ -88,6 +134,25 @@ def rhs(dim, npts):
                 for j in range(n):
                     b[(k * n + i) * n + j] = f * s[j] * s[i] * s[k]
     return b
+
+
+def rhs_mesh(npts, mesh):
+    cx, cy = coords(npts), coords_y(npts, mesh)
+    n = npts - 2
+    b = np.empty(n * n)
+    f = -2 * math.pi * math.pi
+    for i in range(n):
+        for j in range(n):
+            b[i * n + j] = f * math.sin(math.pi * cx[j + 1]) * math.sin(math.pi * cy[i + 1])
+    return b
+
+
+def exact_mesh(npts, mesh):
+    cx, cy = coords(npts), coords_y(npts, mesh)
+    n = npts - 2
+    sx = np.array([math.sin(math.pi * cx[j + 1]) for j in range(n)])
+    sy = np.array([math.sin(math.pi * cy[i + 1]) for i in range(n)])
+    return np.multiply.outer(sy, sx).ravel()
 
 
 def exact(dim, npts):
@@ -116,15 +181,15 @@ def richardson(A, dinv, b, x, maxit, scale, guess_nonzero):
     return x
 
 
-def vcycle(dim, npts, levels, v0, v1, scale, maxiter=400, rtol=1e-7):
+def vcycle(dim, npts, levels, v0, v1, scale, maxiter=400, rtol=1e-7, mesh=0):
     ns = [(npts - 1) // 2 ** l - 1 for l in range(levels)]
-    A = [level_operator(dim, n) for n in ns]
+    A = [level_operator(dim, n) for n in ns] if mesh == 0 else [level_operator_mesh(npts, l, mesh) for l in range(levels)]
     dinv = [1.0 / a.diagonal() for a in A]
     R = [kron_all([full_weighting_1d(ns[l])] * dim) for l in range(levels - 1)]
     P = [sp.csr_matrix((2.0 ** dim) * r.T) for r in R]
     for p in P:
         p.sort_indices()
-    b = [rhs(dim, npts)] + [None] * (levels - 1)
+    b = [rhs(dim, npts) if mesh == 0 else rhs_mesh(npts, mesh)] + [None] * (levels - 1)
     u = [np.zeros(n ** dim) for n in ns]
     bnorm = math.sqrt(float(np.dot(b[0], b[0])))
     r0 = b[0] - A[0] @ u[0]
@@ -189,6 +254,16 @@ def main():
         if levels == 2 and scale != 1.0:
             out["b0_d%d_n%d" % (dim, npts)] = r["b"]
         print(key, "cycles", r["iters"], "rel", r["rnorm"][-1] / r["rnorm"][0], "err", out[key + "_err"])
+    for mesh, npts, levels in ((1, 33, 4), (2, 33, 4), (1, 129, 6), (2, 65, 5)):
+        r = vcycle(2, npts, levels, 3, 3, 0.8, maxiter=1000, mesh=mesh)
+        key = "mesh%d_n%d_l%d" % (mesh, npts, levels)
+        d = np.abs(r["u"] - exact_mesh(npts, mesh))
+        out[key + "_meta"] = np.array([2, npts, levels, 3, 3, 1000, r["iters"], mesh], dtype=np.int64)
+        out[key + "_scale"] = np.array([0.8, r["bnorm"]])
+        out[key + "_rnorm"] = r["rnorm"]
+        out[key + "_err"] = np.array([d.max(), d.sum(), math.sqrt(float(np.dot(d, d)))])
+        out[key + "_u"] = r["u"]
+        print(key, "cycles", r["iters"], "rel", r["rnorm"][-1] / r["rnorm"][0])
     for dim, nf in ((2, 31), (3, 15)):
         x = rng.uniform(-1, 1, nf ** dim)
         nc = (nf - 1) // 2

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from golden_cases import GOLD, CYCLE_KEYS, cycle_case
+from golden_cases import GOLD, CYCLE_KEYS, MESH_KEYS, cycle_case, mesh_case
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-12
@@ -76,4 +76,17 @@ def test_rhs_fill_reproduces_committed_vectors(dim, npts):
     want = GOLD["b0_d%d_n%d" % (dim, npts)]
     wn = float(np.sqrt(np.dot(want, want)))
     assert abs(s.bnorm - wn) <= RTOL * wn and abs(s.rnorm[0] - wn) <= RTOL * wn      # u = 0: r = b
+    s.close()
+
+
+@pytest.mark.parametrize("key", MESH_KEYS)
+def test_solver_reproduces_committed_stretched_mesh_vectors(key):
+    from multigrid_petsc_amd.solver import Solver
+    g = mesh_case(key)
+    s = Solver(2, g["npts"], g["levels"], v=(g["v0"], g["v1"]), maxiter=g["maxiter"], scale=g["scale"], mesh=g["mesh"])
+    s.set_rhs_problem()
+    assert s.solve() == g["iters"]
+    assert np.abs(s.rnorm - g["rnorm"]).max() <= 1e-11 * g["rnorm"][0]
+    assert np.abs(s.solution() - g["u"]).max() <= 1e-11 * np.abs(g["u"]).max()
+    assert np.abs(np.asarray(s.error_norms()) / g["err"] - 1).max() <= 1e-9
     s.close()

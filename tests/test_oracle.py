@@ -189,7 +189,7 @@ def test_slab_operators_match_whole_grid(orc):
 
 
 # ---- third restatement: committed scipy.sparse vectors (tests/golden/make_golden.py) ----
-from golden_cases import GOLD as NPZ, CYCLE_KEYS, cycle_case
+from golden_cases import GOLD as NPZ, CYCLE_KEYS, MESH_KEYS, cycle_case, mesh_case
 
 GOLD_RTOL = 1e-12      # bar of BASELINE.json north_star; observed: bit-identical fields
 
@@ -257,3 +257,17 @@ def test_icycle_restatement(orc):
     kat = 2 * math.pi ** 2 / ((8 / h ** 2) * math.sin(math.pi * h / 2) ** 2) - 1.0
     assert abs(orc.error_norms(2, 9, a["u"])[0] - kat) <= 5e-7
     assert np.all(np.diff(a["rnorm"]) < 0)
+
+
+@pytest.mark.parametrize("key", MESH_KEYS)
+def test_oracle_stretched_mesh_cycle_matches_committed_scipy_vectors(orc, key):
+    """-mesh 1/2: the oracle's assembled leg against the scipy.sparse restatement (coordinates and metrics through Python's
+    math module: agreement to 1e-12, not bit for bit)"""
+    g = mesh_case(key)
+    r = orc.vcycle(2, g["npts"], g["levels"], g["v0"], g["v1"], maxiter=g["maxiter"], scale=g["scale"], use_csr=1, mesh=g["mesh"])
+    assert r["iters"] == g["iters"]
+    assert abs(r["bnorm"] - g["bnorm"]) <= GOLD_RTOL * g["bnorm"]
+    assert np.abs(r["rnorm"] - g["rnorm"]).max() <= 1e-11 * g["rnorm"][0]
+    assert np.abs(r["u"] - g["u"]).max() <= 1e-11 * np.abs(g["u"]).max()
+    err = orc.error_norms_mesh(g["npts"], g["mesh"], r["u"])
+    assert np.abs(np.asarray(err) / g["err"] - 1).max() <= 1e-9
