@@ -154,25 +154,53 @@ def main():
     dist = None
     comm = None
     transport = "none"
+    transport_fallback = False
     if world > 1:
         import torch.distributed as dist   # control plane only (id broadcast, barrier, max-reduce)
         import torch
-        from multigrid_petsc_amd.comm import rccl_comm, HostStagedComm
+        from multigrid_petsc_amd.comm import rccl_comm, HostStagedComm, selftest
+        from multigrid_petsc_amd.mgk import Mgk
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        transport = os.environ.get("MG_BENCH_TRANSPORT", "rccl")       # rccl (default) | host
+        requested = os.environ.get("MG_BENCH_TRANSPORT", "rccl")       # rccl (default) | host
+        transport = requested
+
+        def all_ok(ok):                     # every rank takes the same decision: MIN over ranks of a status flag
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag[0]) == 1
+
         if transport == "rccl":
-            ok = 1
+            # every rank makes the same sequence of control-plane collectives whatever fails where: rccl_comm broadcasts a
+            # (status, id) pair from rank 0; then one MIN for the communicator, one MIN for the first-run gate
+            why = ""
             try:
                 comm = rccl_comm(rank, world, local_rank, dist)
-            except Exception as e:          # every rank must take the same decision
-                print(f"[bench rank {rank}] RCCL communicator failed ({e}); falling back to the host-staged transport", file=sys.stderr, flush=True)
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag[0]) == 0:
+            except Exception as e:          # noqa: BLE001
+                why = f"communicator: {e}"
+            up = all_ok(comm is not None)
+            if up:
+                # first-run gate: rank-coded planes through every hook of the transport, checked on every rank, before
+                # anything is timed (a wrong neighbour, plane or element type shows up here, not as a wrong residual)
+                ok = True
+                try:
+                    m = Mgk(local_rank)
+                    try:
+                        selftest(comm.handle, m.ctx)
+                    finally:
+                        m.close()
+                except Exception as e:      # noqa: BLE001
+                    ok, why = False, f"self-test: {e}"
+                up = all_ok(ok)
+            if not up:
+                print(f"[bench rank {rank}] RCCL transport unusable ({why or 'another rank failed'})", file=sys.stderr, flush=True)
                 if comm is not None:
                     comm.close()
-                transport = "host"
+                    comm = None
+                if os.environ.get("MG_BENCH_ALLOW_FALLBACK", "1") != "1":
+                    raise SystemExit(3)
+                # the run continues on the host-staged (gloo) transport so that the job still yields a correct line, but the
+                # line says so at top level ("transport_fallback": true): it is NOT an RCCL/xGMI number
+                transport, transport_fallback = "host", True
         if transport == "host":
             comm = HostStagedComm(rank, world, dist)
 
@@ -256,6 +284,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "transport": transport, "transport_fallback": transport_fallback,
             "dtype": "f64" if args.precision == "fp64" else "f32 sweeps + f64 residual/correction", "data": "synthetic",
             "config": {"workload": f"{args.dim}-D {2 * args.dim + 1}-point Poisson, npts={args.npts} "
                                    f"({n0}^{args.dim} unknowns), {levels} levels, V(3,3), Richardson+Jacobi "

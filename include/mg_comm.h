@@ -8,9 +8,16 @@
  *
  * Back ends:
  *   rccl      ncclSend/ncclRecv (grouped) + ncclAllReduce over xGMI, librccl loaded with dlopen;
- *             communicator bootstrapped from a 128-byte unique id distributed by the launcher
+ *             communicator bootstrapped from a 128-byte unique id distributed by the launcher.
+ *             EVERY RCCL call of a communicator is issued on the comm stream of the context it is
+ *             used with (one communicator, one stream: one total order on every rank); a hook given
+ *             any other stream fails with MGK_EINVAL.
  *   loopback  all ranks are threads of ONE process sharing one GPU (device-to-device copies and
  *             a pthread barrier): exercises every line of the slab logic on a single-GPU box
+ *   phantom   ONE rank of an N-rank run alone on a GPU: ghost planes are filled by device copies of
+ *             the rank's own boundary planes and every exchange holds its stream for
+ *             latency + bytes / link bandwidth (mgk_delay_us): times one rank's share of the
+ *             N-GPU cycle, exchanges included, on a single GPU.  Results are meaningless.
  */
 #ifndef MG_COMM_H
 #define MG_COMM_H
@@ -34,6 +41,11 @@ typedef struct mg_comm {
     int (*allreduce_sum)(struct mg_comm *c, mgk_ctx *ctx, double *vals, int n, void *stream);
     int (*barrier)(struct mg_comm *c, mgk_ctx *ctx);
     void (*destroy)(struct mg_comm *c);
+    /* ---- optional hooks (NULL: mg_comm_halo_n / the solver fall back to the forms above) ---- */
+    /* the halo of `nf` fields (same element size) as ONE exchange: one ncclGroup, one latency */
+    int (*halo_n)(struct mg_comm *c, mgk_ctx *ctx, int nf, void *const *fields, const mgk_geom *const *geoms, int esz, void *stream);
+    /* in-place sum over ranks of n DEVICE doubles, queued on `stream`: no host synchronisation */
+    int (*allreduce_sum_dev)(struct mg_comm *c, mgk_ctx *ctx, double *dvals, int n, void *stream);
 } mg_comm;
 
 #define MG_RCCL_ID_BYTES 128
@@ -42,6 +54,15 @@ int      mg_comm_rccl_unique_id(void *id_out);
 mg_comm *mg_comm_rccl_create(int rank, int nranks, const void *id, int device);
 /* test aid: grouped ncclSend/ncclRecv with this rank as its own peer (count elements of esz 8 or 4 bytes) */
 int  mg_comm_rccl_self_sendrecv(mg_comm *c, mgk_ctx *ctx, const void *src, void *dst, long count, int esz);
+
+/* phantom: rank `rank` of `nranks` alone on its GPU (measurement aid, see above).  lat_us: latency of one exchange,
+ * link_gbs: one-directional bandwidth of one link; an exchange holds its stream for lat_us + bytes_per_direction/link_gbs */
+mg_comm *mg_comm_phantom_create(int rank, int nranks, double lat_us, double link_gbs);
+
+/* First-run gate of a transport: rank-coded planes through halo / halo_n / allgather_planes, known sums through both
+ * all-reduce forms, everything read back and compared on every rank.  0, or MGK_ECOMM with mg_comm_last_error() naming the
+ * first mismatch.  Collective: every rank of the communicator must call it. */
+int  mg_comm_selftest(mg_comm *c, mgk_ctx *ctx);
 
 /* loopback: create the shared state once, then one handle per rank-thread */
 void    *mg_comm_loopback_shared_create(int nranks);
@@ -53,6 +74,8 @@ void mg_comm_destroy(mg_comm *c);       /* calls c->destroy */
 /* plain-call forms of the hooks (bindings, tests) */
 int  mg_comm_halo(mg_comm *c, mgk_ctx *ctx, double *field, const mgk_geom *g);
 int  mg_comm_allreduce_sum(mg_comm *c, mgk_ctx *ctx, double *vals, int n);
+/* halo of several fields in one exchange where the back end can (halo_n), else one after the other */
+int  mg_comm_halo_n(mg_comm *c, mgk_ctx *ctx, int nf, void *const *fields, const mgk_geom *const *geoms, int esz, void *stream);
 
 #ifdef __cplusplus
 }

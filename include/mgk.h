@@ -68,6 +68,14 @@ int  mgk_h2d(mgk_ctx *ctx, void *dst, const void *src, size_t bytes);     /* syn
 int  mgk_d2h(mgk_ctx *ctx, void *dst, const void *src, size_t bytes);     /* synchronous */
 int  mgk_d2d(mgk_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream);
 int  mgk_sync(mgk_ctx *ctx, void *stream);                         /* NULL: whole device */
+/* pinned host memory + stream-ordered copies: a reduction result leaves the device without a device-wide synchronisation */
+int  mgk_host_alloc(mgk_ctx *ctx, void **hptr, size_t bytes);      /* zero-filled */
+int  mgk_host_free(mgk_ctx *ctx, void *hptr);
+int  mgk_d2h_async(mgk_ctx *ctx, void *dst_pinned, const void *src, size_t bytes, void *stream);
+int  mgk_h2d_async(mgk_ctx *ctx, void *dst, const void *src_pinned, size_t bytes, void *stream);
+/* one wavefront busy-waits `us` microseconds on `stream` (nothing else is touched): stands for the time a halo plane spends
+ * on a link when one rank's share of an N-GPU run is timed on one GPU (mg_comm phantom back end); never on the product path */
+int  mgk_delay_us(mgk_ctx *ctx, double us, void *stream);
 /* stream-ordered event timing for bench.py's roofline leg */
 int  mgk_timer_create(mgk_ctx *ctx, void **timer);
 int  mgk_timer_start(mgk_ctx *ctx, void *timer, void *stream);
@@ -135,6 +143,14 @@ int  mgk_jacobi2_slab_f32(mgk_ctx *ctx, const mgk_geom *g, const mgk_geom *gfar,
 int  mgk_jacobi_sumsq_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale,
                           const double *b, const double *u, double *unew, double *sumsq_host, void *stream);
 
+/* the same on the marching planes [zbeg, zend): per-block partial sums land in the context's partial buffer from slot
+ * part_off on (*nparts slots) and are NOT reduced; after the last range call mgk_partials_finish(nparts_total) reduces
+ * slots 0 .. nparts_total-1 in a fixed order.  Lets a slab rank sweep its interior while the ghost planes travel. */
+int  mgk_jacobi_sumsq_range_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale,
+                                const double *b, const double *u, double *unew, int zbeg, int zend,
+                                int part_off, int *nparts, void *stream);
+int  mgk_partials_finish(mgk_ctx *ctx, int nparts, double *sumsq_host, void *stream);
+
 /* residual on the planes (3-D) / rows (2-D) [zbeg, zend) only */
 int  mgk_residual_range_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, const double *b, const double *u, double *r,
                             int zbeg, int zend, void *stream);
@@ -150,6 +166,12 @@ int  mgk_restrict_finish_f32(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *g
  * partial, to be closed by mgk_restrict_finish_* (above).  3-D. */
 int  mgk_residual_restrict_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
                                const double *b, const double *u, double *bc, void *stream);
+/* the same for the coarse planes [kcbeg, kcend) only (reads the fine planes 2 kcbeg - 1 .. 2 kcend + 1): a slab rank restricts
+ * its inner coarse planes, which need no ghost plane of u, while the halo travels */
+int  mgk_residual_restrict_range_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
+                                     const double *b, const double *u, double *bc, int kcbeg, int kcend, void *stream);
+int  mgk_residual_restrict_range_f32(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
+                                     const float *b, const float *u, float *bc, int kcbeg, int kcend, void *stream);
 /* the same (whole grids), also writing the coarse level's first sweep from a zero guess, uc0 = scale_c * (bc * dinv_c): what
  * mgk_jacobi_zero_* would compute from bc */
 int  mgk_residual_restrict_jz_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef, const double *b,
@@ -173,6 +195,13 @@ int  mgk_prolong_jacobi_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc
                             double scale, const double *b, const double *uc, const double *u, double *unew, void *stream);
 int  mgk_prolong_jacobi_f32(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv,
                             double scale, const float *b, const float *uc, const float *u, float *unew, void *stream);
+/* output planes [zbeg, zend) only.  On an inner slab the planes 2 .. nz-2 read neither a ghost plane of u nor one of uc */
+int  mgk_prolong_jacobi_range_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv,
+                                  double scale, const double *b, const double *uc, const double *u, double *unew,
+                                  int zbeg, int zend, void *stream);
+int  mgk_prolong_jacobi_range_f32(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv,
+                                  double scale, const float *b, const float *uc, const float *u, float *unew,
+                                  int zbeg, int zend, void *stream);
 
 /* ---- K6: VecNorm(NORM_2) (src/solver.c:1512,1518,1546): returns sum of squares of the interior ---- */
 int  mgk_sumsq_f64(mgk_ctx *ctx, const mgk_geom *g, const double *x, double *sumsq_host, void *stream);

@@ -31,6 +31,10 @@ def _lib():
     L.mg_comm_halo.argtypes = [C.c_void_p] * 4
     L.mg_comm_allreduce_sum.restype = C.c_int
     L.mg_comm_allreduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.mg_comm_phantom_create.restype = C.c_void_p
+    L.mg_comm_phantom_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double]
+    L.mg_comm_selftest.restype = C.c_int
+    L.mg_comm_selftest.argtypes = [C.c_void_p, C.c_void_p]
     L._comm_sigs = True
     return L
 
@@ -47,6 +51,18 @@ class Comm:
             self.handle = None
 
 
+def selftest(comm_handle, ctx):
+    """mg_comm_selftest: rank-coded planes through every hook of the transport, checked on every rank (collective)."""
+    rc = _lib().mg_comm_selftest(comm_handle, ctx)
+    if rc:
+        raise RuntimeError(f"transport self-test failed (rc={rc}): " + _lib().mg_comm_last_error().decode())
+
+
+def phantom_comm(rank, world, lat_us=20.0, link_gbs=60.0):
+    """one rank of a `world`-rank run alone on its GPU: exchanges are device copies + a modelled link time (timing aid)"""
+    return Comm(_lib().mg_comm_phantom_create(rank, world, lat_us, link_gbs))
+
+
 def rccl_unique_id():
     buf = C.create_string_buffer(ID_BYTES)
     rc = _lib().mg_comm_rccl_unique_id(buf)
@@ -56,12 +72,21 @@ def rccl_unique_id():
 
 
 def rccl_comm(rank, world, device, dist=None, uid=None):
-    """dist: an initialised torch.distributed module (any backend) used only to broadcast the id"""
+    """dist: an initialised torch.distributed module (any backend) used only to broadcast the id.
+    Collective-safe: rank 0 ALWAYS broadcasts a (status, id) pair, so a failure to make the id on rank 0 reaches every rank
+    as an exception instead of leaving them in a broadcast that never comes."""
     if uid is None:
-        box = [rccl_unique_id() if rank == 0 else None]
+        box = [None]
+        if rank == 0:
+            try:
+                box = [("ok", rccl_unique_id())]
+            except Exception as e:      # noqa: BLE001 - shipped to every rank below
+                box = [("error", str(e))]
         if world > 1:
             dist.broadcast_object_list(box, src=0)
-        uid = box[0]
+        status, uid = box[0]
+        if status != "ok":
+            raise RuntimeError("rank 0 could not create the RCCL unique id: " + str(uid))
     return Comm(_lib().mg_comm_rccl_create(rank, world, uid, device))
 
 
@@ -120,8 +145,11 @@ _DESTROY = C.CFUNCTYPE(None, C.c_void_p)
 
 
 class _MgComm(C.Structure):
+    # mirrors struct mg_comm (include/mg_comm.h); the two optional hooks stay NULL: the C side then falls back to
+    # halo() per field and to the host all-reduce
     _fields_ = [("rank", C.c_int), ("nranks", C.c_int), ("impl", C.c_void_p), ("halo", _HALO),
-                ("allgather_planes", _GATHER), ("allreduce_sum", _REDUCE), ("barrier", _BARRIER), ("destroy", _DESTROY)]
+                ("allgather_planes", _GATHER), ("allreduce_sum", _REDUCE), ("barrier", _BARRIER), ("destroy", _DESTROY),
+                ("halo_n", C.c_void_p), ("allreduce_sum_dev", C.c_void_p)]
 
 
 class HostStagedComm:
@@ -139,7 +167,7 @@ class HostStagedComm:
         self.K.mgk_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         self.K.mgk_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         self._cb = (_HALO(self._halo), _GATHER(self._gather), _REDUCE(self._reduce), _BARRIER(self._barrier), _DESTROY(self._destroy))
-        self.struct = _MgComm(rank, world, None, *self._cb)
+        self.struct = _MgComm(rank, world, None, *self._cb, None, None)
         self.handle = C.c_void_p(C.addressof(self.struct))
 
     # device plane <-> host tensor

@@ -28,6 +28,12 @@ void mg_comm_destroy(mg_comm *c) { if (c && c->destroy) c->destroy(c); }
 
 int mg_comm_halo(mg_comm *c, mgk_ctx *ctx, double *field, const mgk_geom *g) { return c->halo(c, ctx, field, g, 8, NULL); }
 int mg_comm_allreduce_sum(mg_comm *c, mgk_ctx *ctx, double *vals, int n) { return c->allreduce_sum(c, ctx, vals, n, NULL); }
+int mg_comm_halo_n(mg_comm *c, mgk_ctx *ctx, int nf, void *const *fields, const mgk_geom *const *geoms, int esz, void *stream) {
+    if (nf < 1) return 0;
+    if (c->halo_n) return c->halo_n(c, ctx, nf, fields, geoms, esz, stream);
+    for (int q = 0; q < nf; q++) { int rc = c->halo(c, ctx, fields[q], geoms[q], esz, stream); if (rc) return rc; }
+    return 0;
+}
 
 static void *stream_of(mgk_ctx *ctx, void *stream) { return stream ? stream : mgk_stream_compute(ctx); }
 
@@ -83,7 +89,17 @@ typedef struct rccl_impl {
     nccl_comm_t comm;
     int device;
     double *scratch;       /* device, 64 doubles */
+    double *pin;           /* pinned host, 64 doubles */
 } rccl_impl;
+
+/* One communicator, one stream: every RCCL call goes to the comm stream of the context (NULL selects it; any other stream
+ * is refused, so that a new call site cannot drive the communicator from two streams by accident). */
+static int rccl_stream(mgk_ctx *ctx, void *stream, void **out) {
+    void *ms = mgk_stream_comm(ctx);
+    if (stream && stream != ms) return cfail(MGK_EINVAL, "rccl back end", "every RCCL call must be issued on the context's comm stream");
+    *out = ms;
+    return 0;
+}
 
 int mg_comm_rccl_unique_id(void *id_out) {
     int rc = rccl_load();
@@ -94,30 +110,43 @@ int mg_comm_rccl_unique_id(void *id_out) {
     return 0;
 }
 
-static int rccl_halo(mg_comm *c, mgk_ctx *ctx, void *field, const mgk_geom *g, int esz, void *stream) {
+/* the halos of nf fields as ONE group: per neighbour nf sends and nf receives, matched in field order on both sides */
+static int rccl_halo_n(mg_comm *c, mgk_ctx *ctx, int nf, void *const *fields, const mgk_geom *const *geoms, int esz, void *stream) {
     rccl_impl *im = (rccl_impl *)c->impl;
-    if (c->nranks == 1) return 0;
-    void *s = stream_of(ctx, stream);
-    const size_t cnt = (size_t)g->plane, pb = (size_t)esz * (size_t)g->plane;      /* elements / bytes per padded plane */
+    if (c->nranks == 1 || nf < 1) return 0;
+    void *s = NULL;
+    int rc = rccl_stream(ctx, stream, &s);
+    if (rc) return rc;
     const int dt = (esz == 8) ? NCCL_FLOAT64 : NCCL_FLOAT32;
-    char *f = (char *)field;
     NCK(g_rccl.GroupStart());
-    if (c->rank > 0) {
-        NCK(g_rccl.Send(f + pb, cnt, dt, c->rank - 1, im->comm, s));                       /* first interior plane */
-        NCK(g_rccl.Recv(f, cnt, dt, c->rank - 1, im->comm, s));                            /* lo ghost */
-    }
-    if (c->rank < c->nranks - 1) {
-        NCK(g_rccl.Send(f + (size_t)g->nz * pb, cnt, dt, c->rank + 1, im->comm, s));       /* last interior plane */
-        NCK(g_rccl.Recv(f + (size_t)(g->nz + 1) * pb, cnt, dt, c->rank + 1, im->comm, s)); /* hi ghost */
+    for (int q = 0; q < nf; q++) {
+        const mgk_geom *g = geoms[q];
+        const size_t cnt = (size_t)g->plane, pb = (size_t)esz * (size_t)g->plane;  /* elements / bytes per padded plane */
+        char *f = (char *)fields[q];
+        if (c->rank > 0) {
+            NCK(g_rccl.Send(f + pb, cnt, dt, c->rank - 1, im->comm, s));                       /* first interior plane */
+            NCK(g_rccl.Recv(f, cnt, dt, c->rank - 1, im->comm, s));                            /* lo ghost */
+        }
+        if (c->rank < c->nranks - 1) {
+            NCK(g_rccl.Send(f + (size_t)g->nz * pb, cnt, dt, c->rank + 1, im->comm, s));       /* last interior plane */
+            NCK(g_rccl.Recv(f + (size_t)(g->nz + 1) * pb, cnt, dt, c->rank + 1, im->comm, s)); /* hi ghost */
+        }
     }
     NCK(g_rccl.GroupEnd());
     return 0;
+}
+static int rccl_halo(mg_comm *c, mgk_ctx *ctx, void *field, const mgk_geom *g, int esz, void *stream) {
+    void *const f[1] = {field};
+    const mgk_geom *const gg[1] = {g};
+    return rccl_halo_n(c, ctx, 1, f, gg, esz, stream);
 }
 
 static int rccl_allgather_planes(mg_comm *c, mgk_ctx *ctx, void *field, const mgk_geom *gf, const int *zstart, int esz, void *stream) {
     rccl_impl *im = (rccl_impl *)c->impl;
     if (c->nranks == 1) return 0;
-    void *s = stream_of(ctx, stream);
+    void *s = NULL;
+    int rcs = rccl_stream(ctx, stream, &s);
+    if (rcs) return rcs;
     const int me = c->rank;
     const size_t pb = (size_t)esz * (size_t)gf->plane;
     const int dt = (esz == 8) ? NCCL_FLOAT64 : NCCL_FLOAT32;
@@ -140,7 +169,8 @@ static int rccl_allgather_planes(mg_comm *c, mgk_ctx *ctx, void *field, const mg
 int mg_comm_rccl_self_sendrecv(mg_comm *c, mgk_ctx *ctx, const void *src, void *dst, long count, int esz) {
     if (!c || c->halo != rccl_halo) return cfail(MGK_EINVAL, "mg_comm_rccl_self_sendrecv", "not an RCCL communicator");
     rccl_impl *im = (rccl_impl *)c->impl;
-    void *s = stream_of(ctx, NULL);
+    void *s = mgk_stream_comm(ctx);
+    CK(mgk_stream_wait(ctx, s, mgk_stream_compute(ctx)));        /* src was filled on the compute stream */
     const int dt = (esz == 8) ? NCCL_FLOAT64 : NCCL_FLOAT32;
     NCK(g_rccl.GroupStart());
     NCK(g_rccl.Send(src, (size_t)count, dt, c->rank, im->comm, s));
@@ -150,14 +180,33 @@ int mg_comm_rccl_self_sendrecv(mg_comm *c, mgk_ctx *ctx, const void *src, void *
     return 0;
 }
 
+/* in place on the device, queued on the comm stream: the caller ties it to the producer of dvals with mgk_stream_wait */
+static int rccl_allreduce_sum_dev(mg_comm *c, mgk_ctx *ctx, double *dvals, int n, void *stream) {
+    rccl_impl *im = (rccl_impl *)c->impl;
+    void *s = NULL;
+    int rc = rccl_stream(ctx, stream, &s);
+    if (rc) return rc;
+    if (n < 1) return 0;
+    NCK(g_rccl.AllReduce(dvals, dvals, (size_t)n, NCCL_FLOAT64, NCCL_SUM, im->comm, s));
+    return 0;
+}
+/* host values, blocking: staged through pinned memory, everything on the comm stream (it first waits for the compute
+ * stream, so the call is also ordered after all work queued so far); the only synchronisation is on the comm stream */
 static int rccl_allreduce_sum(mg_comm *c, mgk_ctx *ctx, double *vals, int n, void *stream) {
     rccl_impl *im = (rccl_impl *)c->impl;
     if (n > 64) return cfail(MGK_EINVAL, "allreduce_sum", "at most 64 values");
+    void *s = NULL;
+    int rc = rccl_stream(ctx, stream, &s);
+    if (rc) return rc;
     if (!im->scratch) { void *p = NULL; CK(mgk_malloc(ctx, &p, 64 * sizeof(double))); im->scratch = (double *)p; }
-    (void)stream;
-    CK(mgk_h2d(ctx, im->scratch, vals, sizeof(double) * (size_t)n));          /* ordered on the compute stream */
-    NCK(g_rccl.AllReduce(im->scratch, im->scratch, (size_t)n, NCCL_FLOAT64, NCCL_SUM, im->comm, mgk_stream_compute(ctx)));
-    CK(mgk_d2h(ctx, vals, im->scratch, sizeof(double) * (size_t)n));          /* synchronises */
+    if (!im->pin) { void *p = NULL; CK(mgk_host_alloc(ctx, &p, 64 * sizeof(double))); im->pin = (double *)p; }
+    CK(mgk_stream_wait(ctx, s, mgk_stream_compute(ctx)));
+    memcpy(im->pin, vals, sizeof(double) * (size_t)n);
+    CK(mgk_h2d_async(ctx, im->scratch, im->pin, sizeof(double) * (size_t)n, s));
+    NCK(g_rccl.AllReduce(im->scratch, im->scratch, (size_t)n, NCCL_FLOAT64, NCCL_SUM, im->comm, s));
+    CK(mgk_d2h_async(ctx, im->pin, im->scratch, sizeof(double) * (size_t)n, s));
+    CK(mgk_sync(ctx, s));
+    memcpy(vals, im->pin, sizeof(double) * (size_t)n);
     return 0;
 }
 
@@ -171,6 +220,7 @@ static void rccl_destroy(mg_comm *c) {
     rccl_impl *im = (rccl_impl *)c->impl;
     if (im) {
         if (im->comm) g_rccl.CommDestroy(im->comm);
+        if (im->pin) mgk_host_free(NULL, im->pin);
         free(im);     /* scratch is released with its context */
     }
     free(c);
@@ -189,6 +239,7 @@ mg_comm *mg_comm_rccl_create(int rank, int nranks, const void *id, int device) {
     c->rank = rank; c->nranks = nranks; c->impl = im;
     c->halo = rccl_halo; c->allgather_planes = rccl_allgather_planes;
     c->allreduce_sum = rccl_allreduce_sum; c->barrier = rccl_barrier; c->destroy = rccl_destroy;
+    c->halo_n = rccl_halo_n; c->allreduce_sum_dev = rccl_allreduce_sum_dev;
     return c;
 }
 
@@ -271,6 +322,21 @@ static int loop_allreduce_sum(mg_comm *c, mgk_ctx *ctx, double *vals, int n, voi
     return 0;
 }
 
+/* device values: read back, summed in rank order like the host form, written back (a test transport: it may block) */
+static int loop_allreduce_sum_dev(mg_comm *c, mgk_ctx *ctx, double *dvals, int n, void *stream) {
+    void *s = stream_of(ctx, stream);
+    if (n < 1) return 0;
+    double *h = (double *)malloc(sizeof(double) * (size_t)n);
+    if (!h) return cfail(MGK_EINVAL, "allreduce_sum_dev", "out of host memory");
+    int rc = mgk_sync(ctx, s);
+    if (!rc) rc = mgk_d2h(ctx, h, dvals, sizeof(double) * (size_t)n);
+    for (int q = 0; q < n && !rc; q += 64) rc = loop_allreduce_sum(c, ctx, h + q, n - q < 64 ? n - q : 64, NULL);
+    if (!rc) rc = mgk_h2d(ctx, dvals, h, sizeof(double) * (size_t)n);
+    free(h);
+    if (rc) return cfail(rc, "loopback allreduce_sum_dev", mgk_last_error());
+    return mgk_sync(ctx, NULL);
+}
+
 static int loop_barrier(mg_comm *c, mgk_ctx *ctx) {
     (void)ctx;
     pthread_barrier_wait(&((loop_impl *)c->impl)->sh->bar);
@@ -287,5 +353,196 @@ mg_comm *mg_comm_loopback_create(void *shared, int rank) {
     c->rank = rank; c->nranks = sh->nranks; c->impl = im;
     c->halo = loop_halo; c->allgather_planes = loop_allgather_planes;
     c->allreduce_sum = loop_allreduce_sum; c->barrier = loop_barrier; c->destroy = loop_destroy;
+    c->allreduce_sum_dev = loop_allreduce_sum_dev;
     return c;
+}
+
+/* ================================================================== */
+/* phantom: one rank of an N-rank run alone on its GPU (timing aid)    */
+/* ================================================================== */
+typedef struct phantom_impl { double lat_us, gbs; } phantom_impl;
+
+static int phantom_hold(mg_comm *c, mgk_ctx *ctx, double bytes_per_direction, void *s) {
+    const phantom_impl *im = (const phantom_impl *)c->impl;
+    double us = im->lat_us + (im->gbs > 0.0 ? bytes_per_direction / (im->gbs * 1.0e3) : 0.0);   /* GB/s = 1e3 B/us */
+    return mgk_delay_us(ctx, us, s);
+}
+static int phantom_halo_n(mg_comm *c, mgk_ctx *ctx, int nf, void *const *fields, const mgk_geom *const *geoms, int esz, void *stream) {
+    if (c->nranks == 1 || nf < 1) return 0;
+    void *s = stream_of(ctx, stream);
+    double bytes = 0.0;
+    for (int q = 0; q < nf; q++) {
+        const mgk_geom *g = geoms[q];
+        const size_t pb = (size_t)esz * (size_t)g->plane;
+        char *f = (char *)fields[q];
+        /* the neighbours' planes are stood in for by my own boundary planes (mirror): same bytes written, defined values */
+        if (c->rank > 0) CK(mgk_d2d(ctx, f, f + pb, pb, s));
+        if (c->rank < c->nranks - 1) CK(mgk_d2d(ctx, f + (size_t)(g->nz + 1) * pb, f + (size_t)g->nz * pb, pb, s));
+        bytes += (double)pb;                       /* the two directions use two links at once */
+    }
+    return phantom_hold(c, ctx, bytes, s);
+}
+static int phantom_halo(mg_comm *c, mgk_ctx *ctx, void *field, const mgk_geom *g, int esz, void *stream) {
+    void *const f[1] = {field};
+    const mgk_geom *const gg[1] = {g};
+    return phantom_halo_n(c, ctx, 1, f, gg, esz, stream);
+}
+static int phantom_allgather_planes(mg_comm *c, mgk_ctx *ctx, void *field, const mgk_geom *gf, const int *zstart, int esz, void *stream) {
+    if (c->nranks == 1) return 0;
+    void *s = stream_of(ctx, stream);
+    const size_t pb = (size_t)esz * (size_t)gf->plane;
+    const int me = c->rank, mine = zstart[me + 1] - zstart[me];
+    double most = 0.0;
+    for (int r = 0; r < c->nranks; r++) {
+        if (r == me) continue;
+        const int cnt = zstart[r + 1] - zstart[r];
+        /* fill the other ranks' planes with copies of mine (as many as fit), so that the gathered level is defined */
+        for (int k = 0; k < cnt && mine > 0; k++)
+            CK(mgk_d2d(ctx, (char *)field + (size_t)(zstart[r] + 1 + k) * pb, (char *)field + (size_t)(zstart[me] + 1 + k % mine) * pb, pb, s));
+        if ((double)cnt * (double)pb > most) most = (double)cnt * (double)pb;
+    }
+    return phantom_hold(c, ctx, most, s);          /* one chunk per link, all links at once */
+}
+static int phantom_allreduce_sum(mg_comm *c, mgk_ctx *ctx, double *vals, int n, void *stream) {
+    (void)stream;
+    for (int q = 0; q < n; q++) vals[q] *= (double)c->nranks;       /* every rank is taken to contribute what I do */
+    void *ms = mgk_stream_comm(ctx);
+    CK(mgk_stream_wait(ctx, ms, mgk_stream_compute(ctx)));
+    CK(phantom_hold(c, ctx, 0.0, ms));
+    CK(mgk_sync(ctx, ms));
+    return 0;
+}
+static int phantom_allreduce_sum_dev(mg_comm *c, mgk_ctx *ctx, double *dvals, int n, void *stream) {
+    void *s = stream_of(ctx, stream);
+    if (n < 1) return 0;
+    CK(mgk_flat_scale(ctx, (long)n, (double)c->nranks, dvals, s));
+    return phantom_hold(c, ctx, 0.0, s);
+}
+static int phantom_barrier(mg_comm *c, mgk_ctx *ctx) { (void)c; (void)ctx; return 0; }
+static void phantom_destroy(mg_comm *c) { if (c) { free(c->impl); free(c); } }
+
+mg_comm *mg_comm_phantom_create(int rank, int nranks, double lat_us, double link_gbs) {
+    if (nranks < 1 || rank < 0 || rank >= nranks || lat_us < 0.0 || link_gbs < 0.0) { cfail(MGK_EINVAL, "mg_comm_phantom_create", "bad arguments"); return NULL; }
+    phantom_impl *im = (phantom_impl *)calloc(1, sizeof(phantom_impl));
+    mg_comm *c = (mg_comm *)calloc(1, sizeof(mg_comm));
+    if (!im || !c) { free(im); free(c); cfail(MGK_EINVAL, "mg_comm_phantom_create", "out of host memory"); return NULL; }
+    im->lat_us = lat_us; im->gbs = link_gbs;
+    c->rank = rank; c->nranks = nranks; c->impl = im;
+    c->halo = phantom_halo; c->allgather_planes = phantom_allgather_planes;
+    c->allreduce_sum = phantom_allreduce_sum; c->barrier = phantom_barrier; c->destroy = phantom_destroy;
+    c->halo_n = phantom_halo_n; c->allreduce_sum_dev = phantom_allreduce_sum_dev;
+    return c;
+}
+
+/* ================================================================== */
+/* self-test of a transport (collective)                               */
+/* ================================================================== */
+static int st_fail(const char *what, int rank, double got, double want) {
+    char d[256];
+    snprintf(d, sizeof(d), "rank %d: %s: got %.17g, expected %.17g", rank, what, got, want);
+    return cfail(MGK_ECOMM, "mg_comm_selftest", d);
+}
+/* plane p (0 .. nz+1, ghosts included) of a field whose owner is `rank`, field number q */
+static double st_code(int rank, int q, int p) { return 1000.0 * (rank + 1) + 100.0 * q + p; }
+
+int mg_comm_selftest(mg_comm *c, mgk_ctx *ctx) {
+    if (!c || !ctx) return cfail(MGK_EINVAL, "mg_comm_selftest", "null argument");
+    snprintf(g_cerr, sizeof(g_cerr), "ok");
+    const int P = c->nranks, me = c->rank;
+    void *cs = mgk_stream_compute(ctx), *ms = mgk_stream_comm(ctx);
+    int rc = 0;
+    /* ---- halo (one field) and halo_n (two fields of different plane counts), fp64 and fp32 ---- */
+    for (int esz = 8; esz >= 4 && !rc; esz -= 4) {
+        mgk_geom g[2];
+        if (esz == 8) { mgk_geom_init(&g[0], 3, 15, 7, 3); mgk_geom_init(&g[1], 3, 15, 7, 2); }
+        else { mgk_geom_init_f32(&g[0], 3, 15, 7, 3); mgk_geom_init_f32(&g[1], 3, 15, 7, 2); }
+        void *d[2] = {NULL, NULL};
+        char *h[2] = {NULL, NULL};
+        for (int q = 0; q < 2 && !rc; q++) {
+            const size_t bytes = (size_t)esz * (size_t)g[q].total;
+            h[q] = (char *)calloc(1, bytes);
+            rc = mgk_malloc(ctx, &d[q], bytes);
+            if (rc || !h[q]) { rc = rc ? rc : MGK_EINVAL; break; }
+            for (int p = 0; p <= g[q].nz + 1; p++)
+                for (long e = 0; e < g[q].plane; e++) {
+                    const double v = (p == 0 || p == g[q].nz + 1) ? -1.0 : st_code(me, q, p);
+                    if (esz == 8) ((double *)h[q])[(long)p * g[q].plane + e] = v; else ((float *)h[q])[(long)p * g[q].plane + e] = (float)v;
+                }
+            rc = mgk_h2d(ctx, d[q], h[q], bytes);
+        }
+        for (int pass = 0; pass < 2 && !rc; pass++) {        /* pass 0: halo on field 0; pass 1: halo_n on both */
+            rc = mgk_stream_wait(ctx, ms, cs);
+            if (!rc && pass == 0) rc = c->halo(c, ctx, d[0], &g[0], esz, ms);
+            if (!rc && pass == 1) {
+                void *const ff[2] = {d[0], d[1]};
+                const mgk_geom *const gg[2] = {&g[0], &g[1]};
+                rc = mg_comm_halo_n(c, ctx, 2, ff, gg, esz, ms);
+            }
+            if (!rc) rc = mgk_stream_wait(ctx, cs, ms);
+            for (int q = 0; q < (pass ? 2 : 1) && !rc; q++) {
+                const size_t bytes = (size_t)esz * (size_t)g[q].total;
+                rc = mgk_d2h(ctx, h[q], d[q], bytes);
+                for (int p = 0; p <= g[q].nz + 1 && !rc; p++) {
+                    double want = st_code(me, q, p);
+                    if (p == 0) want = me > 0 ? st_code(me - 1, q, g[q].nz) : -1.0;
+                    if (p == g[q].nz + 1) want = me < P - 1 ? st_code(me + 1, q, 1) : -1.0;
+                    for (long e = 0; e < g[q].plane && !rc; e += (g[q].plane - 1 > 0 ? g[q].plane - 1 : 1)) {   /* first and last element */
+                        const double got = esz == 8 ? ((double *)h[q])[(long)p * g[q].plane + e] : (double)((float *)h[q])[(long)p * g[q].plane + e];
+                        if (got != want) rc = st_fail(pass ? "halo_n plane" : "halo plane", me, got, want);
+                    }
+                }
+            }
+        }
+        for (int q = 0; q < 2; q++) { if (d[q]) mgk_free(ctx, d[q]); free(h[q]); }
+        if (rc && !strncmp(g_cerr, "ok", 2)) cfail(rc, "mg_comm_selftest: halo", mgk_last_error());
+    }
+    /* ---- all-gather of planes: rank r produces planes [2r, 2r+2) of a level with 2P planes ---- */
+    if (!rc) {
+        mgk_geom g;
+        mgk_geom_init(&g, 3, 7, 7, 2 * P);
+        int *zs = (int *)calloc((size_t)P + 1, sizeof(int));
+        double *h = (double *)calloc((size_t)g.total, sizeof(double));
+        void *d = NULL;
+        rc = mgk_malloc(ctx, &d, sizeof(double) * (size_t)g.total);
+        if (!zs || !h) rc = rc ? rc : MGK_EINVAL;
+        if (!rc) {
+            for (int r = 0; r <= P; r++) zs[r] = 2 * r;
+            for (int p = zs[me]; p < zs[me + 1]; p++)
+                for (long e = 0; e < g.plane; e++) h[(long)(p + 1) * g.plane + e] = st_code(me, 7, p);
+            rc = mgk_h2d(ctx, d, h, sizeof(double) * (size_t)g.total);
+        }
+        if (!rc) rc = mgk_stream_wait(ctx, ms, cs);
+        if (!rc) rc = c->allgather_planes(c, ctx, d, &g, zs, 8, ms);
+        if (!rc) rc = mgk_stream_wait(ctx, cs, ms);
+        if (!rc) rc = mgk_d2h(ctx, h, d, sizeof(double) * (size_t)g.total);
+        for (int r = 0; r < P && !rc; r++)
+            for (int p = zs[r]; p < zs[r + 1] && !rc; p++) {
+                const double got = h[(long)(p + 1) * g.plane + g.plane - 1], want = st_code(r, 7, p);
+                if (got != want) rc = st_fail("all-gathered plane", me, got, want);
+            }
+        if (d) mgk_free(ctx, d);
+        free(zs); free(h);
+    }
+    /* ---- all-reduce: host form and device form ---- */
+    if (!rc) {
+        double v[3] = {(double)(me + 1), 1.0, 0.5};
+        rc = c->allreduce_sum(c, ctx, v, 3, NULL);
+        const double want[3] = {0.5 * P * (P + 1), (double)P, 0.5 * P};
+        for (int q = 0; q < 3 && !rc; q++) if (v[q] != want[q]) rc = st_fail("all-reduce (host values)", me, v[q], want[q]);
+    }
+    if (!rc && c->allreduce_sum_dev) {
+        double v[2] = {(double)(me + 1), 0.25};
+        void *d = NULL;
+        rc = mgk_malloc(ctx, &d, sizeof(v));
+        if (!rc) rc = mgk_h2d(ctx, d, v, sizeof(v));
+        if (!rc) rc = mgk_stream_wait(ctx, ms, cs);
+        if (!rc) rc = c->allreduce_sum_dev(c, ctx, (double *)d, 2, ms);
+        if (!rc) rc = mgk_stream_wait(ctx, cs, ms);
+        if (!rc) rc = mgk_d2h(ctx, v, d, sizeof(v));
+        const double want[2] = {0.5 * P * (P + 1), 0.25 * P};
+        for (int q = 0; q < 2 && !rc; q++) if (v[q] != want[q]) rc = st_fail("all-reduce (device values)", me, v[q], want[q]);
+        if (d) mgk_free(ctx, d);
+    }
+    if (rc && !strncmp(g_cerr, "ok", 2)) cfail(rc, "mg_comm_selftest", mgk_last_error());
+    return rc;
 }

@@ -75,6 +75,9 @@ typedef struct mg_ops {
     int (*jacobi2)(mgk_ctx *, const mgk_geom *, const double *, double, double, const void *, const void *, void *, void *);
     int (*jacobi2_slab)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const double *, double, double, const void *, const void *, void *,
                         const void *, int, int, int, int, void *);
+    int (*prolong_jacobi_range)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const double *, double, double, const void *, const void *, const void *,
+                                void *, int, int, void *);
+    int (*residual_restrict_range)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const double *, const void *, const void *, void *, int, int, void *);
 } mg_ops;
 
 #define W64(name) static int name##_64
@@ -103,9 +106,13 @@ W64(j2s)(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gf, const double *k, dou
 W32(j2s)(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gf, const double *k, double d, double sc, const void *b, const void *u, void *o, const void *far, int lo, int hi, int z0, int z1, void *st) { return mgk_jacobi2_slab_f32(c, g, gf, k, d, sc, (const float *)b, (const float *)u, (float *)o, (const float *)far, lo, hi, z0, z1, st); }
 W64(rrz)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, const void *b, const void *u, void *bc, void *uc0, double d, double sc, void *st) { return mgk_residual_restrict_jz_f64(c, gf, gc, k, (const double *)b, (const double *)u, (double *)bc, (double *)uc0, d, sc, st); }
 W32(rrz)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, const void *b, const void *u, void *bc, void *uc0, double d, double sc, void *st) { return mgk_residual_restrict_jz_f32(c, gf, gc, k, (const float *)b, (const float *)u, (float *)bc, (float *)uc0, d, sc, st); }
+W64(pjr)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, double d, double sc, const void *b, const void *uc, const void *u, void *o, int z0, int z1, void *st) { return mgk_prolong_jacobi_range_f64(c, gf, gc, k, d, sc, (const double *)b, (const double *)uc, (const double *)u, (double *)o, z0, z1, st); }
+W32(pjr)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, double d, double sc, const void *b, const void *uc, const void *u, void *o, int z0, int z1, void *st) { return mgk_prolong_jacobi_range_f32(c, gf, gc, k, d, sc, (const float *)b, (const float *)uc, (const float *)u, (float *)o, z0, z1, st); }
+W64(rrr)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, const void *b, const void *u, void *bc, int k0, int k1, void *st) { return mgk_residual_restrict_range_f64(c, gf, gc, k, (const double *)b, (const double *)u, (double *)bc, k0, k1, st); }
+W32(rrr)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, const void *b, const void *u, void *bc, int k0, int k1, void *st) { return mgk_residual_restrict_range_f32(c, gf, gc, k, (const float *)b, (const float *)u, (float *)bc, k0, k1, st); }
 static const mg_ops OPS[2] = {
-    {8, jr_64, jz_64, rs_64, rf_64, pa_64, pj_64, rr_64, rg_64, fin_64, rrz_64, j2_64, j2s_64},
-    {4, jr_32, jz_32, rs_32, rf_32, pa_32, pj_32, rr_32, rg_32, fin_32, rrz_32, j2_32, j2s_32},
+    {8, jr_64, jz_64, rs_64, rf_64, pa_64, pj_64, rr_64, rg_64, fin_64, rrz_64, j2_64, j2s_64, pjr_64, rrr_64},
+    {4, jr_32, jz_32, rs_32, rf_32, pa_32, pj_32, rr_32, rg_32, fin_32, rrz_32, j2_32, j2s_32, pjr_32, rrr_32},
 };
 
 struct mg_solver {
@@ -122,6 +129,7 @@ struct mg_solver {
     int started;
     int deferring;          /* mg_solver_cycles: norms are deposited on the device and read once at the end */
     double *d_norms; int d_norms_cap;
+    double *pin; int pin_cap; /* pinned host landing area of the reduced norms */
     int spec_valid;         /* level-0 tmp holds Jacobi(u): made by the sweep+norm kernel that closed the last cycle */
     double solve_seconds;
     int lgraph;             /* levels >= lgraph form the launch-bound coarse part replayed as one HIP graph (0: off) */
@@ -445,6 +453,7 @@ void mg_solver_destroy(mg_solver *s) {
         mgk_sync(s->ctx, NULL);
         for (int q = 0; q < s->ntimers_created; q++) mgk_timer_destroy(s->ctx, s->timers[q]);
         if (s->d_norms) mgk_free(s->ctx, s->d_norms);
+        if (s->pin) mgk_host_free(s->ctx, s->pin);
         for (int p = 0; p < 2; p++) if (s->coarse_graph[p]) mgk_graph_destroy(s->ctx, s->coarse_graph[p]);
         for (int l = 0; l < s->levels; l++) {
             mg_level *L = &s->L[l];
@@ -571,16 +580,27 @@ static int halo(mg_solver *s, int P, mg_level *L, void *field) {
     return 0;
 }
 
+/* start the exchange of u's ghost planes on the comm stream unless they are valid or already travelling: the caller
+ * queues work that needs no ghost plane on the compute stream, then calls ensure_u_ghosts */
+static int begin_u_ghosts(mg_solver *s, int P, mg_level *L) {
+    mg_fset *F = &L->f[P];
+    if (!L->distributed || F->u_ghost_ok || F->u_ghost_pending) return 0;
+    void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
+    CHK(mgk_stream_wait(s->ctx, ms, cs));
+    CHK(s->comm->halo(s->comm, s->ctx, F->u, &F->g, OPS[P].esz, ms));
+    F->u_ghost_pending = 1;
+    return 0;
+}
 /* make the ghost planes of u valid and visible to the compute stream */
 static int ensure_u_ghosts(mg_solver *s, int P, mg_level *L) {
     mg_fset *F = &L->f[P];
     if (!L->distributed) return 0;
+    CHK(begin_u_ghosts(s, P, L));
     if (F->u_ghost_pending) {
         CHK(mgk_stream_wait(s->ctx, mgk_stream_compute(s->ctx), mgk_stream_comm(s->ctx)));
         F->u_ghost_pending = 0;
         F->u_ghost_ok = 1;
     }
-    if (!F->u_ghost_ok) { CHK(halo(s, P, L, F->u)); F->u_ghost_ok = 1; }
     return 0;
 }
 
@@ -696,9 +716,15 @@ static int smooth(mg_solver *s, int P, int l, int maxit) {
                 CHK(mgk_d2d(s->ctx, (char *)F->far + 2 * pb, (char *)F->u + (size_t)(nz - 1) * pb, pb, NULL));   /* my plane nz-2 */
                 /* all exchanges of this pass on the comm stream ... */
                 CHK(mgk_stream_wait(s->ctx, ms, cs));
-                if (!F->u_ghost_pending && !F->u_ghost_ok) CHK(s->comm->halo(s->comm, s->ctx, F->u, &F->g, O->esz, ms));
-                if (!F->b_ghost_ok) CHK(s->comm->halo(s->comm, s->ctx, F->b, &F->g, O->esz, ms));
-                CHK(s->comm->halo(s->comm, s->ctx, F->far, &F->gfar, O->esz, ms));
+                {   /* ONE grouped exchange (one latency): the far planes, u's ghosts unless valid / travelling, b's ghosts once */
+                    void *ff[3];
+                    const mgk_geom *gg[3];
+                    int nf = 0;
+                    if (!F->u_ghost_pending && !F->u_ghost_ok) { ff[nf] = F->u; gg[nf++] = &F->g; }
+                    if (!F->b_ghost_ok) { ff[nf] = F->b; gg[nf++] = &F->g; }
+                    ff[nf] = F->far; gg[nf++] = &F->gfar;
+                    CHK(mg_comm_halo_n(s->comm, s->ctx, nf, ff, gg, O->esz, ms));
+                }
                 /* ... while the planes 2 .. nz-3, which need no ghost data, are already being swept */
                 if (s->cfg.overlap && L->nz_min >= 6) {
                     s->prof_kind = 1;                       /* timed: the interior planes 2 .. nz-3 of the slab */
@@ -770,6 +796,43 @@ static int norm_from_sumsq(mg_solver *s, double ss, double *out) {
     return 0;
 }
 
+/* Sum over ranks of n device doubles that kernels on the compute stream deposited (mgk_defer_result), delivered to the host.
+ * With a device all-reduce hook nothing blocks the compute stream: the comm stream waits for the producers, reduces in
+ * place (RCCL: ncclAllReduce, in the communicator's one total order behind any halo still travelling), copies to pinned
+ * memory, and the host waits for the comm stream alone. */
+static int reduce_slots(mg_solver *s, double *dslots, int n, double *host) {
+    if (n < 1) return 0;
+    if (s->cfg.nranks > 1 && s->comm->allreduce_sum_dev) {
+        void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
+        if (n > s->pin_cap) {
+            if (s->pin) mgk_host_free(s->ctx, s->pin);
+            void *q = NULL;
+            s->pin = NULL; s->pin_cap = 0;
+            CHK(mgk_host_alloc(s->ctx, &q, sizeof(double) * (size_t)n));
+            s->pin = (double *)q; s->pin_cap = n;
+        }
+        CHK(mgk_stream_wait(s->ctx, ms, cs));
+        CHK(s->comm->allreduce_sum_dev(s->comm, s->ctx, dslots, n, ms));
+        CHK(mgk_d2h_async(s->ctx, s->pin, dslots, sizeof(double) * (size_t)n, ms));
+        CHK(mgk_sync(s->ctx, ms));
+        memcpy(host, s->pin, sizeof(double) * (size_t)n);
+        return 0;
+    }
+    CHK(mgk_d2h(s->ctx, host, dslots, sizeof(double) * (size_t)n));                    /* synchronises the compute stream */
+    for (int q = 0; q < n && s->cfg.nranks > 1; q += 64)
+        CHK(s->comm->allreduce_sum(s->comm, s->ctx, host + q, n - q < 64 ? n - q : 64, NULL));
+    return 0;
+}
+static int need_slots(mg_solver *s, int n) {
+    if (n <= s->d_norms_cap) return 0;
+    if (s->d_norms) mgk_free(s->ctx, s->d_norms);
+    void *q = NULL;
+    s->d_norms = NULL; s->d_norms_cap = 0;
+    CHK(mgk_malloc(s->ctx, &q, sizeof(double) * (size_t)n));
+    s->d_norms = (double *)q; s->d_norms_cap = n;
+    return 0;
+}
+
 /* MatMult(res[l-1], r[l-1], b[l]) (src/solver.c:1535) */
 static int restrict_to(mg_solver *s, int P, int l) {
     mg_level *Lf = &s->L[l - 1], *Lc = &s->L[l];
@@ -828,12 +891,25 @@ static int prolong_smooth(mg_solver *s, int P, int l) {
         int c0 = s->zstart[s->cfg.rank], c1 = s->zstart[s->cfg.rank + 1];
         gc.nz = c1 - c0;
         ucoarse = (const char *)Cq->u + (size_t)O->esz * (size_t)c0 * (size_t)Cq->g.plane;
-    } else {
-        CHK(ensure_u_ghosts(s, P, Lc));
+    } else if (Lc->distributed) {
+        CHK(begin_u_ghosts(s, P, Lc));       /* the coarse u's ghost planes start travelling now */
     }
-    CHK(ensure_u_ghosts(s, P, Lf));          /* the neighbours' boundary planes BEFORE the correction */
     /* not counted by the profile: that one times the plain sweep kernel (bench.py roofline leg) */
-    CHK(O->prolong_jacobi(s->ctx, &F->g, &gc, Lf->coef, Lf->dinv, s->cfg.scale, F->b, ucoarse, F->u, F->tmp, NULL));
+    if (Lf->distributed && s->cfg.overlap && Lf->nz_min >= 4 && s->cfg.dim == 3) {
+        /* slab: the output planes 2 .. nz-2 read neither a ghost plane of u (the neighbours' boundary planes BEFORE the
+         * correction) nor one of the coarse u (parents of the fine planes -1, 0 and nz): they are swept while those travel */
+        const int nz = F->g.nz;
+        CHK(begin_u_ghosts(s, P, Lf));
+        CHK(O->prolong_jacobi_range(s->ctx, &F->g, &gc, Lf->coef, Lf->dinv, s->cfg.scale, F->b, ucoarse, F->u, F->tmp, 2, nz - 1, NULL));
+        if (Lc->distributed) CHK(ensure_u_ghosts(s, P, Lc));
+        CHK(ensure_u_ghosts(s, P, Lf));
+        CHK(O->prolong_jacobi_range(s->ctx, &F->g, &gc, Lf->coef, Lf->dinv, s->cfg.scale, F->b, ucoarse, F->u, F->tmp, 0, 2, NULL));
+        CHK(O->prolong_jacobi_range(s->ctx, &F->g, &gc, Lf->coef, Lf->dinv, s->cfg.scale, F->b, ucoarse, F->u, F->tmp, nz - 1, nz, NULL));
+    } else {
+        if (Lf->distributed && Lc->distributed) CHK(ensure_u_ghosts(s, P, Lc));
+        CHK(ensure_u_ghosts(s, P, Lf));          /* the neighbours' boundary planes BEFORE the correction */
+        CHK(O->prolong_jacobi(s->ctx, &F->g, &gc, Lf->coef, Lf->dinv, s->cfg.scale, F->b, ucoarse, F->u, F->tmp, NULL));
+    }
     swap_ptr(&F->u, &F->tmp);
     F->u_ghost_ok = 0; F->u_ghost_pending = 0;
     return smooth(s, P, l, v0 - 1);
@@ -876,11 +952,26 @@ static int descend(mg_solver *s, int P, int l) {
             gc.nz = c1 - c0;
             bc = (char *)Cq->b + (size_t)O->esz * (size_t)c0 * (size_t)Cq->g.plane;
         }
-        CHK(ensure_u_ghosts(s, P, Lf));
-        CHK(O->residual_range(s->ctx, &F->g, Lf->coef, F->b, F->u, F->rv, 0, 1, cs));
-        CHK(mgk_stream_wait(s->ctx, ms, cs));
-        CHK(s->comm->halo(s->comm, s->ctx, F->rv, &F->g, O->esz, ms));
-        CHK(O->residual_restrict(s->ctx, &F->g, &gc, Lf->coef, F->b, F->u, bc, cs));
+        if (s->cfg.overlap && Lf->nz_min >= 8) {
+            /* two dependent exchanges (u's ghost planes, then the residual of plane 0, which needs them) each hidden behind
+             * half of the coarse planes that read no ghost plane; the two boundary coarse planes come last */
+            const int nzc = gc.nz, kmid = nzc / 2;
+            CHK(begin_u_ghosts(s, P, Lf));
+            CHK(O->residual_restrict_range(s->ctx, &F->g, &gc, Lf->coef, F->b, F->u, bc, 1, kmid, cs));
+            CHK(ensure_u_ghosts(s, P, Lf));
+            CHK(O->residual_range(s->ctx, &F->g, Lf->coef, F->b, F->u, F->rv, 0, 1, cs));
+            CHK(mgk_stream_wait(s->ctx, ms, cs));
+            CHK(s->comm->halo(s->comm, s->ctx, F->rv, &F->g, O->esz, ms));
+            CHK(O->residual_restrict_range(s->ctx, &F->g, &gc, Lf->coef, F->b, F->u, bc, kmid, nzc - 1, cs));
+            CHK(O->residual_restrict_range(s->ctx, &F->g, &gc, Lf->coef, F->b, F->u, bc, 0, 1, cs));
+            CHK(O->residual_restrict_range(s->ctx, &F->g, &gc, Lf->coef, F->b, F->u, bc, nzc - 1, nzc, cs));
+        } else {
+            CHK(ensure_u_ghosts(s, P, Lf));
+            CHK(O->residual_range(s->ctx, &F->g, Lf->coef, F->b, F->u, F->rv, 0, 1, cs));
+            CHK(mgk_stream_wait(s->ctx, ms, cs));
+            CHK(s->comm->halo(s->comm, s->ctx, F->rv, &F->g, O->esz, ms));
+            CHK(O->residual_restrict(s->ctx, &F->g, &gc, Lf->coef, F->b, F->u, bc, cs));
+        }
         CHK(mgk_stream_wait(s->ctx, cs, ms));
         if (!last) CHK(O->restrict_finish(s->ctx, &F->g, &gc, F->rv, bc, cs));
         if (!Lc->distributed) {
@@ -967,8 +1058,26 @@ static int vcycle_once(mg_solver *s) {
     } else {
         CHK(cycle_body(s, 0, s->iter == 0));
         /* :1545-1546  r0 = b0 - A0 u0 ; ||r0|| */
+        const int jnorm = (s->cfg.fuse & 8) && (s->cfg.fuse & 1) && s->cfg.ksp_type == MG_KSP_RICHARDSON && s->cfg.v[0] >= 1;
+        if (jnorm && L->distributed && s->cfg.overlap && L->nz_min >= 3 && s->cfg.dim == 3) {
+            /* the same on a slab with the exchange of u's ghost planes hidden: inner planes first, the two boundary planes
+             * once the ghosts have arrived; one reduction over the block partials of the three launches */
+            const int nz = F->g.nz;
+            int n1 = 0, n2 = 0, n3 = 0;
+            CHK(begin_u_ghosts(s, 0, L));
+            CHK(mgk_jacobi_sumsq_range_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u,
+                                           (double *)F->tmp, 1, nz - 1, 0, &n1, NULL));
+            CHK(ensure_u_ghosts(s, 0, L));
+            CHK(mgk_jacobi_sumsq_range_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u,
+                                           (double *)F->tmp, 0, 1, n1, &n2, NULL));
+            CHK(mgk_jacobi_sumsq_range_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u,
+                                           (double *)F->tmp, nz - 1, nz, n1 + n2, &n3, NULL));
+            CHK(mgk_partials_finish(s->ctx, n1 + n2 + n3, &ss, NULL));
+            s->spec_valid = 1;
+            goto norm_done;
+        }
         CHK(ensure_u_ghosts(s, 0, L));
-        if ((s->cfg.fuse & 8) && (s->cfg.fuse & 1) && s->cfg.ksp_type == MG_KSP_RICHARDSON && s->cfg.v[0] >= 1) {
+        if (jnorm) {
             /* ||b - A u|| and, speculatively, the first pre-smoothing sweep of the next cycle in one pass over u and b
              * (both form the same residual).  The sweep lands in tmp and is adopted by smooth() only if another
              * cycle follows; u itself is untouched, so stopping here leaves the solution as the reference has it. */
@@ -981,6 +1090,7 @@ static int vcycle_once(mg_solver *s) {
             CHK(mgk_sumsq_f64(s->ctx, &F->g, (const double *)F->rv, &ss, NULL));
         }
     }
+norm_done:
     if (!s->deferring) CHK(norm_from_sumsq(s, ss, &s->rchk));
     s->iter++;
     if (s->iter < s->rnorm_cap) s->rnorm[s->iter] = s->rchk;            /* :1549 */
@@ -1021,8 +1131,23 @@ int mg_solver_solve(mg_solver *s) {
     CHK(start(s));
     CHK(mgk_sync(s->ctx, NULL));
     double t0 = wall();                                                  /* MPI_Wtime :1526 */
-    while (s->iter < s->cfg.maxiter && 100000000 * s->bnorm > s->rchk && s->rchk > s->cfg.rtol * s->bnorm)   /* :1530 */
-        CHK(vcycle_once(s));
+    const int devnorm = s->cfg.nranks > 1 && s->comm->allreduce_sum_dev != NULL;
+    if (devnorm) CHK(need_slots(s, 1));
+    while (s->iter < s->cfg.maxiter && 100000000 * s->bnorm > s->rchk && s->rchk > s->cfg.rtol * s->bnorm) {   /* :1530 */
+        if (!devnorm) { CHK(vcycle_once(s)); continue; }
+        /* N ranks: the cycle leaves its sum of squares in a device slot; all-reduce + read-back on the comm stream, one
+         * synchronisation (of that stream) per cycle -- the convergence test needs the norm on the host */
+        double ss = 0.0;
+        int rc = mgk_defer_result(s->ctx, s->d_norms);
+        s->deferring = 1;
+        if (!rc) rc = vcycle_once(s);
+        s->deferring = 0;
+        mgk_defer_result(s->ctx, NULL);
+        if (rc) return rc;
+        CHK(reduce_slots(s, s->d_norms, 1, &ss));
+        s->rchk = sqrt(ss);
+        if (s->iter < s->rnorm_cap) s->rnorm[s->iter] = s->rchk;
+    }
     CHK(mgk_sync(s->ctx, NULL));
     s->solve_seconds = wall() - t0;                                      /* :1553 */
     return 0;
@@ -1038,12 +1163,7 @@ int mg_solver_cycles(mg_solver *s, int ncycles) {
     }
     /* a fixed number of cycles needs no norm on the host in between: every cycle deposits its sum of squares in a device
      * slot (no synchronisation, the host runs ahead), one copy and -- on N ranks -- one all-reduce per 64 cycles at the end */
-    if (ncycles > s->d_norms_cap) {
-        if (s->d_norms) mgk_free(s->ctx, s->d_norms);
-        void *q = NULL;
-        CHK(mgk_malloc(s->ctx, &q, sizeof(double) * (size_t)ncycles));
-        s->d_norms = (double *)q; s->d_norms_cap = ncycles;
-    }
+    CHK(need_slots(s, ncycles));
     const int it0 = s->iter;
     s->deferring = 1;
     int rc = 0;
@@ -1056,9 +1176,7 @@ int mg_solver_cycles(mg_solver *s, int ncycles) {
     if (rc) return rc;
     double *ss = (double *)malloc(sizeof(double) * (size_t)(ncycles > 0 ? ncycles : 1));
     if (!ss) return mgfail(MGK_EINVAL, "mg_solver_cycles: out of host memory");
-    rc = ncycles > 0 ? mgk_d2h(s->ctx, ss, s->d_norms, sizeof(double) * (size_t)ncycles) : 0;      /* synchronises */
-    for (int q = 0; q < ncycles && !rc && s->cfg.nranks > 1; q += 64)
-        rc = s->comm->allreduce_sum(s->comm, s->ctx, ss + q, ncycles - q < 64 ? ncycles - q : 64, NULL);
+    rc = reduce_slots(s, s->d_norms, ncycles, ss);
     if (rc) { free(ss); return mgfail(rc, "mg_solver_cycles: reading the deferred norms"); }
     for (int q = 0; q < ncycles; q++) s->rnorm[it0 + 1 + q] = sqrt(ss[q]);
     if (ncycles > 0) s->rchk = s->rnorm[it0 + ncycles];

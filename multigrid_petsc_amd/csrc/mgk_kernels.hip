@@ -125,6 +125,36 @@ extern "C" int mgk_sync(mgk_ctx *c, void *stream) {
     return 0;
 }
 
+// pinned host memory and stream-ordered copies (device-resident reductions read back without a device-wide sync)
+extern "C" int mgk_host_alloc(mgk_ctx *c, void **hptr, size_t bytes) {
+    (void)c;
+    HIPCHK(hipHostMalloc(hptr, bytes ? bytes : 8, hipHostMallocDefault));
+    memset(*hptr, 0, bytes ? bytes : 8);
+    return 0;
+}
+extern "C" int mgk_host_free(mgk_ctx *c, void *hptr) { (void)c; if (hptr) HIPCHK(hipHostFree(hptr)); return 0; }
+extern "C" int mgk_d2h_async(mgk_ctx *c, void *dst_pinned, const void *src, size_t bytes, void *stream) {
+    HIPCHK(hipMemcpyAsync(dst_pinned, src, bytes, hipMemcpyDeviceToHost, S(c, stream)));
+    return 0;
+}
+extern "C" int mgk_h2d_async(mgk_ctx *c, void *dst, const void *src_pinned, size_t bytes, void *stream) {
+    HIPCHK(hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, S(c, stream)));
+    return 0;
+}
+// occupies ONE wavefront for `us` microseconds of wall time (s_memrealtime ticks at 100 MHz): the stand-in for the time a
+// plane spends on an xGMI link when one rank's share of a multi-GPU run is measured on a single GPU (phantom communicator)
+__global__ void __launch_bounds__(64) k_delay(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+extern "C" int mgk_delay_us(mgk_ctx *c, double us, void *stream) {
+    if (!c || us < 0.0 || us > 1.0e6) return fail(MGK_EINVAL, "mgk_delay_us: 0 <= us <= 1e6");
+    if (us == 0.0) return 0;
+    hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, S(c, stream), (unsigned long long)(us * 100.0));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 struct mgk_timer { hipEvent_t a, b; };
 extern "C" int mgk_timer_create(mgk_ctx *c, void **t) {
     (void)c;
@@ -1028,6 +1058,34 @@ extern "C" int mgk_jacobi_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const double 
     int rc = dispatch_st<MODE_JNORM>(c, g, a, S(c, stream), &nblk);
     if (rc) return rc;
     return finish_to_host(c, nblk, 1, S(c, stream), sumsq_host);
+}
+
+// The same on the marching planes [zbeg, zend) only, block partials deposited from slot `part_off` on and NOT reduced:
+// a slab rank sweeps its interior planes while the ghost planes are still travelling, then the two boundary planes, and
+// closes with one mgk_partials_finish over all the slots (fixed order: deterministic).
+extern "C" int mgk_jacobi_sumsq_range_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
+                                          const double *b, const double *u, double *unew, int zbeg, int zend,
+                                          int part_off, int *nparts, void *stream) {
+    if (!c || !g || !coef || !b || !u || !unew || u == unew || !nparts) return fail(MGK_EINVAL, "mgk_jacobi_sumsq_range_f64: bad arguments");
+    const int nm = (g->dim == 3) ? g->nz : g->ny;
+    if (zbeg < 0 || zend > nm || zbeg >= zend || part_off < 0 || part_off >= c->max_partials)
+        return fail(MGK_EINVAL, "mgk_jacobi_sumsq_range_f64: empty or out-of-range plane range / partial offset");
+    StArgs<double> a; memset(&a, 0, sizeof(a));
+    a.u = u + g->org; a.b = b + g->org; a.out = unew + g->org; a.partials = c->partials + part_off;
+    set_coef(a, g, coef); a.dinv = dinv; a.scale = scale;
+    a.zbeg = zbeg; a.zend = zend;
+    // launch_st keeps the block count within max_partials; the offset must leave that much room
+    mgk_ctx lim = *c;
+    lim.max_partials = c->max_partials - part_off;
+    int nblk = 0;
+    int rc = dispatch_st<MODE_JNORM>(&lim, g, a, S(c, stream), &nblk);
+    if (rc) return rc;
+    *nparts = nblk;
+    return 0;
+}
+extern "C" int mgk_partials_finish(mgk_ctx *c, int nparts, double *sumsq_host, void *stream) {
+    if (!c || nparts < 1 || nparts > c->max_partials || !sumsq_host) return fail(MGK_EINVAL, "mgk_partials_finish: bad arguments");
+    return finish_to_host(c, nparts, 1, S(c, stream), sumsq_host);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2211,7 +2269,7 @@ extern "C" int mgk_unpack_f32(mgk_ctx *c, const mgk_geom *g32, const float *padd
 // K4 fused into the first post-smoothing sweep: unew = J(u + P uc)  (src/solver.c:1540-1542)
 template <typename T>
 static int prolong_jacobi(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
-                          const T *b, const T *ucoarse, const T *u, T *unew, void *stream) {
+                          const T *b, const T *ucoarse, const T *u, T *unew, int zbeg, int zend, void *stream) {
     if (!c || !gf || !gc || !coef || !b || !ucoarse || !u || !unew || u == unew || (gf->dim != 3 && sizeof(T) != 8))
         return fail(MGK_EINVAL, "mgk_prolong_jacobi: bad arguments (fp32: 3-D only)");
     XferArgs x;
@@ -2222,15 +2280,30 @@ static int prolong_jacobi(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, co
     a.uc = ucoarse + gc->org; a.crs = gc->pitch; a.cms = (gf->dim == 3) ? gc->plane : gc->pitch;
     a.nxc = gc->nx; a.nyc = gc->ny; a.nzc = gc->nz;
     set_coef(a, gf, coef); a.dinv = (T)dinv; a.scale = (T)scale;
+    const int nm = (gf->dim == 3) ? gf->nz : gf->ny;
+    if (zbeg < 0 || zend > nm || zbeg >= zend) return fail(MGK_EINVAL, "mgk_prolong_jacobi: empty or out-of-range plane range");
+    a.zbeg = zbeg; a.zend = zend;
     return dispatch_st<MODE_PJACOBI>(c, gf, a, S(c, stream), nullptr);
 }
 extern "C" int mgk_prolong_jacobi_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv,
                                       double scale, const double *b, const double *uc, const double *u, double *unew, void *stream) {
-    return prolong_jacobi<double>(c, gf, gc, coef, dinv, scale, b, uc, u, unew, stream);
+    if (!gf) return fail(MGK_EINVAL, "mgk_prolong_jacobi_f64: bad arguments");
+    return prolong_jacobi<double>(c, gf, gc, coef, dinv, scale, b, uc, u, unew, 0, gf->dim == 3 ? gf->nz : gf->ny, stream);
+}
+extern "C" int mgk_prolong_jacobi_range_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv,
+                                            double scale, const double *b, const double *uc, const double *u, double *unew,
+                                            int zbeg, int zend, void *stream) {
+    return prolong_jacobi<double>(c, gf, gc, coef, dinv, scale, b, uc, u, unew, zbeg, zend, stream);
 }
 extern "C" int mgk_prolong_jacobi_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv,
                                       double scale, const float *b, const float *uc, const float *u, float *unew, void *stream) {
-    return prolong_jacobi<float>(c, gf, gc, coef, dinv, scale, b, uc, u, unew, stream);
+    if (!gf) return fail(MGK_EINVAL, "mgk_prolong_jacobi_f32: bad arguments");
+    return prolong_jacobi<float>(c, gf, gc, coef, dinv, scale, b, uc, u, unew, 0, gf->nz, stream);
+}
+extern "C" int mgk_prolong_jacobi_range_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv,
+                                            double scale, const float *b, const float *uc, const float *u, float *unew,
+                                            int zbeg, int zend, void *stream) {
+    return prolong_jacobi<float>(c, gf, gc, coef, dinv, scale, b, uc, u, unew, zbeg, zend, stream);
 }
 
 
@@ -2252,6 +2325,7 @@ struct RRArgs {
     int nxc, nyc, nzc;       // coarse
     long rs, ms, crs, cms;   // fine / coarse row and plane strides
     int kcc, nty;            // coarse planes per chunk, tiles in y
+    int kcbeg, kcend;        // coarse planes [kcbeg, kcend) produced by this launch (whole grid / slab: 0, nzc)
     T a0, a1, a2, a3, a4, a5, a6;
     T *uc0;                  // optional: the coarse level's first sweep from a zero guess, uc0 = scale_c * (bc * dinv_c)
     T dinv_c, scale_c;
@@ -2272,7 +2346,7 @@ __global__ void __launch_bounds__(64 * WX) k_resrestrict(const RRArgs<T> a) {
     const int ty = bid % a.nty, tz = bid / a.nty;
     const int xl = VX * tid, x0 = xl;            // full-row tile: tx = 0
     const int yb = 4 * ty;
-    const int kc0 = tz * a.kcc, kc1 = min(kc0 + a.kcc, a.nzc);
+    const int kc0 = a.kcbeg + tz * a.kcc, kc1 = min(kc0 + a.kcc, a.kcend);
     if (kc0 >= kc1) return;
     const int z0 = 2 * kc0, z1u = 2 * kc1 + 1;   // fine planes z0 .. z1u-1 (= 2*kc1, shared with the next chunk)
     // z-slab of a rank that is not the last one: nz = 2 nzc, the closing plane 2 nzc belongs to the next rank.  The last
@@ -2430,7 +2504,7 @@ __global__ void __launch_bounds__(256) k_restrict_finish(XferArgs a, const T *rg
 
 template <typename T>
 static int residual_restrict(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
-                             const T *b, const T *u, T *bc, T *uc0, double dinv_c, double scale_c, void *stream) {
+                             const T *b, const T *u, T *bc, T *uc0, double dinv_c, double scale_c, int kcbeg, int kcend, void *stream) {
     constexpr int VX = 16 / sizeof(T);
     if (!c || !gf || !gc || !coef || !b || !u || !bc || gf->dim != 3)
         return fail(MGK_EINVAL, "mgk_residual_restrict: bad arguments (3-D only)");
@@ -2449,15 +2523,19 @@ static int residual_restrict(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc,
     a.uc0 = uc0 ? uc0 + gc->org : nullptr; a.dinv_c = (T)dinv_c; a.scale_c = (T)scale_c;
     a.nty = (gf->ny - 1 + 3) / 4;                 // tiles of 5 rows at stride 4; ny = 2 nyc + 1
     if (a.nty < 1) a.nty = 1;
+    if (kcbeg < 0 || kcend > gc->nz || kcbeg >= kcend) return fail(MGK_EINVAL, "mgk_residual_restrict: empty or out-of-range coarse plane range");
+    if (uc0 && (kcbeg != 0 || kcend != gc->nz)) return fail(MGK_EINVAL, "mgk_residual_restrict_jz: whole grids only");
+    a.kcbeg = kcbeg; a.kcend = kcend;
+    const int nkc = kcend - kcbeg;
     const int w = (gf->nx + 1 + 64 * VX - 1) / (64 * VX);       // waves needed for a full row
     // blocks of <= 256 threads (fp32 rows) leave room for two per CU: cut z in two (fp32 at 1023^3: 2.78 -> 1.82 ms)
     long nch = (a.nty >= 256) ? ((w <= 4) ? 2 : 1) : (512 + a.nty - 1) / a.nty;
-    if (g_zchunk > 0) nch = (gc->nz + g_zchunk - 1) / g_zchunk;
-    int kcc = (int)((gc->nz + nch - 1) / nch);
+    if (g_zchunk > 0) nch = (nkc + g_zchunk - 1) / g_zchunk;
+    int kcc = (int)((nkc + nch - 1) / nch);
     if (kcc < 4) kcc = 4;
-    if (kcc > gc->nz) kcc = gc->nz;
+    if (kcc > nkc) kcc = nkc;
     a.kcc = kcc;
-    const long ntz = (gc->nz + kcc - 1) / kcc;
+    const long ntz = (nkc + kcc - 1) / kcc;
     const unsigned nblk = (unsigned)(a.nty * ntz);
     hipStream_t s = S(c, stream);
     if (w <= 1) hipLaunchKernelGGL((k_resrestrict<T, 1>), dim3(nblk), dim3(64), 0, s, a);
@@ -2469,23 +2547,33 @@ static int residual_restrict(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc,
 }
 extern "C" int mgk_residual_restrict_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
                                          const double *b, const double *u, double *bc, void *stream) {
-    return residual_restrict<double>(c, gf, gc, coef, b, u, bc, nullptr, 0.0, 0.0, stream);
+    if (!gc) return fail(MGK_EINVAL, "mgk_residual_restrict_f64: bad arguments");
+    return residual_restrict<double>(c, gf, gc, coef, b, u, bc, nullptr, 0.0, 0.0, 0, gc->nz, stream);
+}
+extern "C" int mgk_residual_restrict_range_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
+                                               const double *b, const double *u, double *bc, int kcbeg, int kcend, void *stream) {
+    return residual_restrict<double>(c, gf, gc, coef, b, u, bc, nullptr, 0.0, 0.0, kcbeg, kcend, stream);
 }
 extern "C" int mgk_residual_restrict_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
                                          const float *b, const float *u, float *bc, void *stream) {
-    return residual_restrict<float>(c, gf, gc, coef, b, u, bc, nullptr, 0.0, 0.0, stream);
+    if (!gc) return fail(MGK_EINVAL, "mgk_residual_restrict_f32: bad arguments");
+    return residual_restrict<float>(c, gf, gc, coef, b, u, bc, nullptr, 0.0, 0.0, 0, gc->nz, stream);
+}
+extern "C" int mgk_residual_restrict_range_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
+                                               const float *b, const float *u, float *bc, int kcbeg, int kcend, void *stream) {
+    return residual_restrict<float>(c, gf, gc, coef, b, u, bc, nullptr, 0.0, 0.0, kcbeg, kcend, stream);
 }
 // the same, also writing the coarse level's first sweep from a zero guess (uc0 = scale_c * (bc * dinv_c), what mgk_jacobi_zero_*
 // would compute from bc): saves that kernel's read of bc
 extern "C" int mgk_residual_restrict_jz_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, const double *b,
                                             const double *u, double *bc, double *uc0, double dinv_c, double scale_c, void *stream) {
-    if (!uc0) return fail(MGK_EINVAL, "mgk_residual_restrict_jz_f64: null uc0");
-    return residual_restrict<double>(c, gf, gc, coef, b, u, bc, uc0, dinv_c, scale_c, stream);
+    if (!uc0 || !gc) return fail(MGK_EINVAL, "mgk_residual_restrict_jz_f64: null uc0");
+    return residual_restrict<double>(c, gf, gc, coef, b, u, bc, uc0, dinv_c, scale_c, 0, gc->nz, stream);
 }
 extern "C" int mgk_residual_restrict_jz_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, const float *b,
                                             const float *u, float *bc, float *uc0, double dinv_c, double scale_c, void *stream) {
-    if (!uc0) return fail(MGK_EINVAL, "mgk_residual_restrict_jz_f32: null uc0");
-    return residual_restrict<float>(c, gf, gc, coef, b, u, bc, uc0, dinv_c, scale_c, stream);
+    if (!uc0 || !gc) return fail(MGK_EINVAL, "mgk_residual_restrict_jz_f32: null uc0");
+    return residual_restrict<float>(c, gf, gc, coef, b, u, bc, uc0, dinv_c, scale_c, 0, gc->nz, stream);
 }
 template <typename T>
 static int restrict_finish(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const T *r, T *bc, void *stream) {

@@ -87,6 +87,17 @@ def _sigs(L):
         "mgk_flat_pointwise_mult": (i, [vp, C.c_long, vp, vp, vp, vp]),
         "mgk_prolong_jacobi_f64": (i, [vp, G, G, c_dp, d, d, vp, vp, vp, vp, vp]),
         "mgk_prolong_jacobi_f32": (i, [vp, G, G, c_dp, d, d, vp, vp, vp, vp, vp]),
+        "mgk_prolong_jacobi_range_f64": (i, [vp, G, G, c_dp, d, d, vp, vp, vp, vp, i, i, vp]),
+        "mgk_prolong_jacobi_range_f32": (i, [vp, G, G, c_dp, d, d, vp, vp, vp, vp, i, i, vp]),
+        "mgk_residual_restrict_range_f64": (i, [vp, G, G, c_dp, vp, vp, vp, i, i, vp]),
+        "mgk_residual_restrict_range_f32": (i, [vp, G, G, c_dp, vp, vp, vp, i, i, vp]),
+        "mgk_jacobi_sumsq_range_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp, i, i, i, C.POINTER(i), vp]),
+        "mgk_partials_finish": (i, [vp, i, C.POINTER(d), vp]),
+        "mgk_host_alloc": (i, [vp, C.POINTER(vp), sz]),
+        "mgk_host_free": (i, [vp, vp]),
+        "mgk_d2h_async": (i, [vp, vp, vp, sz, vp]),
+        "mgk_h2d_async": (i, [vp, vp, vp, sz, vp]),
+        "mgk_delay_us": (i, [vp, d, vp]),
     }
     for name, (res, args) in S.items():
         f = getattr(L, name)

@@ -27,8 +27,15 @@ else:
 try:
     comm = rccl_comm(rank, world, 0, uid=uid)
 except RuntimeError as e:
-    print("RCCL_REFUSED", e)
+    print("RCCL_REFUSED", e, flush=True)
     sys.exit(0)
+print("COMM_UP", rank, flush=True)       # from here on a hang or a mismatch is a FAILURE of the transport, not a refusal
+from multigrid_petsc_amd.comm import selftest       # noqa: E402
+from multigrid_petsc_amd.mgk import Mgk             # noqa: E402
+m = Mgk(0)
+selftest(comm.handle, m.ctx)
+m.close()
+print("SELFTEST_OK", rank, flush=True)
 s = Solver(3, 33, 4, scale=6.0 / 7.0, maxiter=40, rank=rank, nranks=world, comm=comm.handle, dist_min_n=15)
 s.set_rhs_problem()
 it = s.solve()

@@ -360,3 +360,106 @@ def test_fused_residual_restrict_with_coarse_first_sweep(mgk, orc, nf):
     assert np.array_equal(mgk.from_field(gc, duc), orc.jacobi(3, nc, Asc, 0.8, bc, np.zeros(nc ** 3), zero_guess=True))
     for p in (du, db, dbc, duc):
         mgk.free(p)
+
+
+@pytest.mark.parametrize("nf,variant,cuts", [(31, 0, (2, 30)), (63, 2, (2, 62)), (63, 13, (3, 40)), (127, 9, (2, 126)), (255, 9, (2, 254)),
+                                             (63, 6, (5, 6))])
+def test_fused_prolong_jacobi_plane_ranges(mgk, orc, nf, variant, cuts):
+    """mgk_prolong_jacobi_range_f64: the slab solver sweeps the inner planes while the ghost planes travel, then the boundary
+    planes; any cut into plane ranges (even and odd starts) must give the whole-launch result bit for bit"""
+    rng = np.random.default_rng(4400 + nf)
+    nc = (nf - 1) // 2
+    As = _stencil(orc, 3, nf)
+    dinv = 1.0 / As[3]
+    u, b, uc = _rand(rng, nf ** 3), _rand(rng, nf ** 3), _rand(rng, nc ** 3)
+    gf, gc = mgk.geom(3, nf), mgk.geom(3, nc)
+    du, db, duc, dout = mgk.to_field(gf, u), mgk.to_field(gf, b), mgk.to_field(gc, uc), mgk.field(gf)
+    want = orc.jacobi(3, nf, As, 0.8, b, orc.prolong_add(3, nf, uc, u))
+    a, bnd = cuts
+    mgk.L.mgk_set_tuning(variant, -1)
+    for z0, z1 in ((a, bnd), (0, a), (bnd, nf)):          # inner planes first, as the solver does
+        mgk._chk(mgk.L.mgk_prolong_jacobi_range_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), dinv, 0.8, db, duc, du, dout, z0, z1, None))
+    mgk.L.mgk_set_tuning(-1, -1)
+    got = mgk.from_field(gf, dout)
+    assert np.array_equal(got, want), f"max diff {np.abs(got - want).max()}"
+    assert mgk.L.mgk_prolong_jacobi_range_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), dinv, 0.8, db, duc, du, dout, 3, 3, None) != 0
+    for p in (du, db, duc, dout):
+        mgk.free(p)
+
+
+@pytest.mark.parametrize("nf", [15, 31, 63, 127])
+def test_fused_residual_restrict_coarse_plane_ranges(mgk, orc, nf):
+    """mgk_residual_restrict_range_f64 over [1, mid), [mid, nc-1), [0, 1), [nc-1, nc) -- the order of the slab solver -- equals
+    the whole launch and the oracle"""
+    rng = np.random.default_rng(4700 + nf)
+    nc = (nf - 1) // 2
+    As = _stencil(orc, 3, nf)
+    u, b = _rand(rng, nf ** 3), _rand(rng, nf ** 3)
+    gf, gc = mgk.geom(3, nf), mgk.geom(3, nc)
+    du, db, dbc = mgk.to_field(gf, u), mgk.to_field(gf, b), mgk.field(gc)
+    want = orc.restrict(3, nf, orc.residual(3, nf, As, b, u))
+    mid = nc // 2
+    for zc in (-1, 4):
+        mgk.L.mgk_set_tuning(-1, zc)
+        mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dbc, 8 * gc.total, None))
+        for k0, k1 in ((1, mid), (mid, nc - 1), (0, 1), (nc - 1, nc)):
+            mgk._chk(mgk.L.mgk_residual_restrict_range_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), db, du, dbc, k0, k1, None))
+        got = mgk.from_field(gc, dbc)
+        assert np.array_equal(got, want), f"zc={zc} max diff {np.abs(got - want).max()}"
+    mgk.L.mgk_set_tuning(-1, -1)
+    assert mgk.L.mgk_residual_restrict_range_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), db, du, dbc, 2, 2, None) != 0
+    for p in (du, db, dbc):
+        mgk.free(p)
+
+
+@pytest.mark.parametrize("n,variant", [(31, 0), (63, 2), (127, 6), (255, 12)])
+def test_sweep_with_norm_over_plane_ranges(mgk, orc, n, variant):
+    """mgk_jacobi_sumsq_range_f64 x3 + mgk_partials_finish: the sweep equals the plain sweep bit for bit, the sum is that of
+    the whole launch to rounding (block partials of the three launches reduced in slot order)"""
+    rng = np.random.default_rng(4900 + n)
+    As = _stencil(orc, 3, n)
+    dinv = 1.0 / As[3]
+    u, b = _rand(rng, n ** 3), _rand(rng, n ** 3)
+    g = mgk.geom(3, n)
+    du, db, dout = mgk.to_field(g, u), mgk.to_field(g, b), mgk.field(g)
+    mgk.L.mgk_set_tuning(variant, -1)
+    off, np_ = 0, C.c_int()
+    for z0, z1 in ((1, n - 1), (0, 1), (n - 1, n)):
+        mgk._chk(mgk.L.mgk_jacobi_sumsq_range_f64(mgk.ctx, C.byref(g), mgk.coef(As), dinv, 0.8, db, du, dout, z0, z1, off, C.byref(np_), None))
+        off += np_.value
+    ss = C.c_double()
+    mgk._chk(mgk.L.mgk_partials_finish(mgk.ctx, off, C.byref(ss), None))
+    mgk.L.mgk_set_tuning(-1, -1)
+    assert np.array_equal(mgk.from_field(g, dout), orc.jacobi(3, n, As, 0.8, b, u))
+    want = orc.sumsq(orc.residual(3, n, As, b, u))
+    assert abs(ss.value - want) <= 1e-13 * want
+    for p in (du, db, dout):
+        mgk.free(p)
+
+
+def test_pinned_async_copies_and_delay(mgk):
+    """the pieces of the device-resident norm reduction: pinned landing area, stream-ordered copies, and the link-time
+    stand-in of the phantom communicator (holds its stream for about the requested time)"""
+    import time
+    h = C.c_void_p()
+    mgk._chk(mgk.L.mgk_host_alloc(mgk.ctx, C.byref(h), 64))
+    src = (C.c_double * 8)(*[1.5 * q for q in range(8)])
+    d = mgk.alloc(64)
+    ms = mgk.L.mgk_stream_comm(mgk.ctx)
+    C.memmove(h, src, 64)
+    mgk._chk(mgk.L.mgk_h2d_async(mgk.ctx, d, h, 64, ms))
+    C.memset(h, 0, 64)        # safe only after the copy: synchronise first
+    mgk._chk(mgk.L.mgk_sync(mgk.ctx, ms))
+    mgk._chk(mgk.L.mgk_h2d_async(mgk.ctx, d, C.cast(src, C.c_void_p), 64, ms))
+    mgk._chk(mgk.L.mgk_d2h_async(mgk.ctx, h, d, 64, ms))
+    mgk._chk(mgk.L.mgk_sync(mgk.ctx, ms))
+    assert list((C.c_double * 8).from_address(h.value)) == list(src)
+    mgk._chk(mgk.L.mgk_sync(mgk.ctx, None))
+    t0 = time.perf_counter()
+    mgk._chk(mgk.L.mgk_delay_us(mgk.ctx, 20000.0, ms))
+    mgk._chk(mgk.L.mgk_sync(mgk.ctx, ms))
+    dt = time.perf_counter() - t0
+    assert 0.019 <= dt <= 0.2, dt
+    assert mgk.L.mgk_delay_us(mgk.ctx, -1.0, ms) != 0
+    mgk.free(d)
+    mgk._chk(mgk.L.mgk_host_free(mgk.ctx, h))
