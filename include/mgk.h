@@ -172,6 +172,16 @@ int  mgk_residual_restrict_range_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk
                                      const double *b, const double *u, double *bc, int kcbeg, int kcend, void *stream);
 int  mgk_residual_restrict_range_f32(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
                                      const float *b, const float *u, float *bc, int kcbeg, int kcend, void *stream);
+/* z-slab form without the partial plane: `far` (geometry gfar = (nx, ny, 2), as for mgk_jacobi2_slab_*) carries plane 1 of the rank
+ * above in its hi ghost plane, u and b have valid hi ghost planes; an inner slab (has_hi) then evaluates the residual of the
+ * neighbour's first plane itself -- same operands and arithmetic as its owner, same bits -- and completes its last coarse plane:
+ * one exchange before the kernel instead of two dependent ones and a finishing kernel.  has_hi == 0: the last slab / a whole grid */
+int  mgk_residual_restrict_slab_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const mgk_geom *gfar, const double *coef,
+                                    const double *b, const double *u, const double *far, int has_hi, double *bc,
+                                    int kcbeg, int kcend, void *stream);
+int  mgk_residual_restrict_slab_f32(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const mgk_geom *gfar, const double *coef,
+                                    const float *b, const float *u, const float *far, int has_hi, float *bc,
+                                    int kcbeg, int kcend, void *stream);
 /* the same (whole grids), also writing the coarse level's first sweep from a zero guess, uc0 = scale_c * (bc * dinv_c): what
  * mgk_jacobi_zero_* would compute from bc */
 int  mgk_residual_restrict_jz_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef, const double *b,

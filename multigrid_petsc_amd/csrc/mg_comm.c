@@ -396,9 +396,12 @@ static int phantom_allgather_planes(mg_comm *c, mgk_ctx *ctx, void *field, const
     for (int r = 0; r < c->nranks; r++) {
         if (r == me) continue;
         const int cnt = zstart[r + 1] - zstart[r];
-        /* fill the other ranks' planes with copies of mine (as many as fit), so that the gathered level is defined */
-        for (int k = 0; k < cnt && mine > 0; k++)
-            CK(mgk_d2d(ctx, (char *)field + (size_t)(zstart[r] + 1 + k) * pb, (char *)field + (size_t)(zstart[me] + 1 + k % mine) * pb, pb, s));
+        /* fill the other ranks' planes with copies of mine (one contiguous copy per rank, like one message per peer; a rank
+         * that owns more planes than I do gets my run repeated), so that the gathered level is defined */
+        for (int k = 0; k < cnt && mine > 0; k += mine) {
+            const int run = cnt - k < mine ? cnt - k : mine;
+            CK(mgk_d2d(ctx, (char *)field + (size_t)(zstart[r] + 1 + k) * pb, (char *)field + (size_t)(zstart[me] + 1) * pb, (size_t)run * pb, s));
+        }
         if ((double)cnt * (double)pb > most) most = (double)cnt * (double)pb;
     }
     return phantom_hold(c, ctx, most, s);          /* one chunk per link, all links at once */

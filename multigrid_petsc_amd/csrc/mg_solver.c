@@ -78,6 +78,8 @@ typedef struct mg_ops {
     int (*prolong_jacobi_range)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const double *, double, double, const void *, const void *, const void *,
                                 void *, int, int, void *);
     int (*residual_restrict_range)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const double *, const void *, const void *, void *, int, int, void *);
+    int (*residual_restrict_slab)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const mgk_geom *, const double *, const void *, const void *,
+                                  const void *, int, void *, int, int, void *);
 } mg_ops;
 
 #define W64(name) static int name##_64
@@ -110,9 +112,11 @@ W64(pjr)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, do
 W32(pjr)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, double d, double sc, const void *b, const void *uc, const void *u, void *o, int z0, int z1, void *st) { return mgk_prolong_jacobi_range_f32(c, gf, gc, k, d, sc, (const float *)b, (const float *)uc, (const float *)u, (float *)o, z0, z1, st); }
 W64(rrr)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, const void *b, const void *u, void *bc, int k0, int k1, void *st) { return mgk_residual_restrict_range_f64(c, gf, gc, k, (const double *)b, (const double *)u, (double *)bc, k0, k1, st); }
 W32(rrr)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, const void *b, const void *u, void *bc, int k0, int k1, void *st) { return mgk_residual_restrict_range_f32(c, gf, gc, k, (const float *)b, (const float *)u, (float *)bc, k0, k1, st); }
+W64(rrs)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const mgk_geom *gfar, const double *k, const void *b, const void *u, const void *far, int hi, void *bc, int k0, int k1, void *st) { return mgk_residual_restrict_slab_f64(c, gf, gc, gfar, k, (const double *)b, (const double *)u, (const double *)far, hi, (double *)bc, k0, k1, st); }
+W32(rrs)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const mgk_geom *gfar, const double *k, const void *b, const void *u, const void *far, int hi, void *bc, int k0, int k1, void *st) { return mgk_residual_restrict_slab_f32(c, gf, gc, gfar, k, (const float *)b, (const float *)u, (const float *)far, hi, (float *)bc, k0, k1, st); }
 static const mg_ops OPS[2] = {
-    {8, jr_64, jz_64, rs_64, rf_64, pa_64, pj_64, rr_64, rg_64, fin_64, rrz_64, j2_64, j2s_64, pjr_64, rrr_64},
-    {4, jr_32, jz_32, rs_32, rf_32, pa_32, pj_32, rr_32, rg_32, fin_32, rrz_32, j2_32, j2s_32, pjr_32, rrr_32},
+    {8, jr_64, jz_64, rs_64, rf_64, pa_64, pj_64, rr_64, rg_64, fin_64, rrz_64, j2_64, j2s_64, pjr_64, rrr_64, rrs_64},
+    {4, jr_32, jz_32, rs_32, rf_32, pa_32, pj_32, rr_32, rg_32, fin_32, rrz_32, j2_32, j2s_32, pjr_32, rrr_32, rrs_32},
 };
 
 struct mg_solver {
@@ -952,9 +956,38 @@ static int descend(mg_solver *s, int P, int l) {
             gc.nz = c1 - c0;
             bc = (char *)Cq->b + (size_t)O->esz * (size_t)c0 * (size_t)Cq->g.plane;
         }
-        if (s->cfg.overlap && Lf->nz_min >= 8) {
-            /* two dependent exchanges (u's ghost planes, then the residual of plane 0, which needs them) each hidden behind
-             * half of the coarse planes that read no ghost plane; the two boundary coarse planes come last */
+        if (F->far && Lf->nz_min >= 4) {
+            /* ONE exchange: with u's and b's ghost planes and the neighbours' second planes of u (the far field of the two-sweep
+             * passes) every rank evaluates the residual of the plane above its slab itself and completes its last coarse plane.
+             * The exchange travels while the coarse planes that read no ghost plane are restricted. */
+            const size_t pb = (size_t)O->esz * (size_t)F->g.plane;
+            const int nz = F->g.nz, nzc = gc.nz, hi = !last;
+            CHK(mgk_d2d(s->ctx, (char *)F->far + pb, (char *)F->u + 2 * pb, pb, cs));                       /* my plane 1 */
+            CHK(mgk_d2d(s->ctx, (char *)F->far + 2 * pb, (char *)F->u + (size_t)(nz - 1) * pb, pb, cs));   /* my plane nz-2 */
+            CHK(mgk_stream_wait(s->ctx, ms, cs));
+            {
+                void *ff[3];
+                const mgk_geom *gg[3];
+                int nf = 0;
+                if (!F->u_ghost_pending && !F->u_ghost_ok) { ff[nf] = F->u; gg[nf++] = &F->g; }
+                if (!F->b_ghost_ok) { ff[nf] = F->b; gg[nf++] = &F->g; }
+                ff[nf] = F->far; gg[nf++] = &F->gfar;
+                CHK(mg_comm_halo_n(s->comm, s->ctx, nf, ff, gg, O->esz, ms));
+            }
+            const int split = s->cfg.overlap && nzc >= 3 && Lf->nz_min >= 6;
+            if (split) CHK(O->residual_restrict_slab(s->ctx, &F->g, &gc, &F->gfar, Lf->coef, F->b, F->u, F->far, hi, bc, 1, nzc - 1, cs));
+            CHK(mgk_stream_wait(s->ctx, cs, ms));
+            F->u_ghost_pending = 0; F->u_ghost_ok = 1; F->b_ghost_ok = 1;
+            if (split) {
+                CHK(O->residual_restrict_slab(s->ctx, &F->g, &gc, &F->gfar, Lf->coef, F->b, F->u, F->far, hi, bc, 0, 1, cs));
+                CHK(O->residual_restrict_slab(s->ctx, &F->g, &gc, &F->gfar, Lf->coef, F->b, F->u, F->far, hi, bc, nzc - 1, nzc, cs));
+            } else {
+                CHK(O->residual_restrict_slab(s->ctx, &F->g, &gc, &F->gfar, Lf->coef, F->b, F->u, F->far, hi, bc, 0, nzc, cs));
+            }
+            goto gathered;
+        } else if (s->cfg.overlap && Lf->nz_min >= 8) {
+            /* (without the far field: fuse bit 5 off) two dependent exchanges (u's ghost planes, then the residual of plane 0,
+             * which needs them) each hidden behind half of the coarse planes that read no ghost plane */
             const int nzc = gc.nz, kmid = nzc / 2;
             CHK(begin_u_ghosts(s, P, Lf));
             CHK(O->residual_restrict_range(s->ctx, &F->g, &gc, Lf->coef, F->b, F->u, bc, 1, kmid, cs));
@@ -974,6 +1007,7 @@ static int descend(mg_solver *s, int P, int l) {
         }
         CHK(mgk_stream_wait(s->ctx, cs, ms));
         if (!last) CHK(O->restrict_finish(s->ctx, &F->g, &gc, F->rv, bc, cs));
+gathered:
         if (!Lc->distributed) {
             CHK(mgk_stream_wait(s->ctx, ms, cs));
             CHK(s->comm->allgather_planes(s->comm, s->ctx, Cq->b, &Cq->g, s->zstart, O->esz, ms));

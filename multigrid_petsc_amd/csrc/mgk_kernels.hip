@@ -2329,6 +2329,9 @@ struct RRArgs {
     T a0, a1, a2, a3, a4, a5, a6;
     T *uc0;                  // optional: the coarse level's first sweep from a zero guess, uc0 = scale_c * (bc * dinv_c)
     T dinv_c, scale_c;
+    const T *far_hi;         // inner z-slab, optional: plane nz + 1 of u (the rank above's plane 1; interior origin of that plane).
+                             // With it -- and u's and b's hi ghost planes valid -- the residual of plane nz (the neighbour's first
+                             // plane) is evaluated here too, so the last coarse plane is complete: no partial plane, no finish
 };
 
 template <typename T, int WX>
@@ -2352,7 +2355,7 @@ __global__ void __launch_bounds__(64 * WX) k_resrestrict(const RRArgs<T> a) {
     // z-slab of a rank that is not the last one: nz = 2 nzc, the closing plane 2 nzc belongs to the next rank.  The last
     // coarse plane is then left PARTIAL (its dk = 0, 1 terms); k_restrict_finish adds the dk = 2 terms from the
     // neighbour's residual plane in the same order, so the sum is the one of the whole grid.
-    const int z1 = min(z1u, a.nz);
+    const int z1 = a.far_hi ? z1u : min(z1u, a.nz);
     const bool xok = x0 < a.nx;
     const bool lastvec = (x0 + VX > a.nx);
     bool rok[RR];
@@ -2360,6 +2363,8 @@ __global__ void __launch_bounds__(64 * WX) k_resrestrict(const RRArgs<T> a) {
     for (int r = 0; r < RR; r++) rok[r] = xok && (yb + r < a.ny);
     const long rowoff = (long)yb * a.rs;
     const T *up_ = a.u + rowoff + x0, *bp_ = a.b + rowoff + x0;
+    const T *fh_ = a.far_hi ? a.far_hi + rowoff + x0 : nullptr;
+    auto uplane = [&](int p) -> const T * { return (fh_ && p == a.nz + 1) ? fh_ : up_ + (long)p * a.ms; };
     const bool okS = xok, okN = xok && (yb + RR <= a.ny);
     // coarse ownership: lane `tid` -> coarse columns NCJ*tid .. NCJ*tid+NCJ-1, coarse rows 2*ty + {0,1}
     const int jc0 = NCJ * tid;
@@ -2373,7 +2378,7 @@ __global__ void __launch_bounds__(64 * WX) k_resrestrict(const RRArgs<T> a) {
         const long ro = (long)r * a.rs;
         um[r] = ldv(up_ + (long)(z0 - 1) * a.ms + ro, rok[r]);
         uc[r] = ldv(up_ + (long)z0 * a.ms + ro, rok[r]);
-        up[r] = ldv(up_ + (long)(z0 + 1) * a.ms + ro, rok[r]);
+        up[r] = ldv(uplane(z0 + 1) + ro, rok[r]);
         // rows 0 and RR-1 are shared with the neighbouring tiles: cached loads, so the second reader hits L2
         bcur[r] = (r == 0 || r == RR - 1) ? ldv(bp_ + (long)z0 * a.ms + ro, rok[r]) : ldv_stream(bp_ + (long)z0 * a.ms + ro, rok[r]);
         *reinterpret_cast<VT *>(&lds[0][r][xl + VX]) = uc[r];
@@ -2398,7 +2403,7 @@ __global__ void __launch_bounds__(64 * WX) k_resrestrict(const RRArgs<T> a) {
 #pragma unroll
             for (int r = 0; r < RR; r++) {
                 const long ro = (long)r * a.rs;
-                uq[r] = ldv(up_ + (long)(z + 2) * a.ms + ro, rok[r]);
+                uq[r] = ldv(uplane(z + 2) + ro, rok[r]);
                 bn[r] = (r == 0 || r == RR - 1) ? ldv(bp_ + (long)(z + 1) * a.ms + ro, rok[r]) : ldv_stream(bp_ + (long)(z + 1) * a.ms + ro, rok[r]);
             }
             hSn = ldv(up_ + (long)(z + 1) * a.ms - a.rs, okS);
@@ -2504,7 +2509,8 @@ __global__ void __launch_bounds__(256) k_restrict_finish(XferArgs a, const T *rg
 
 template <typename T>
 static int residual_restrict(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
-                             const T *b, const T *u, T *bc, T *uc0, double dinv_c, double scale_c, int kcbeg, int kcend, void *stream) {
+                             const T *b, const T *u, T *bc, T *uc0, double dinv_c, double scale_c, int kcbeg, int kcend, void *stream,
+                             const T *far_hi = nullptr) {
     constexpr int VX = 16 / sizeof(T);
     if (!c || !gf || !gc || !coef || !b || !u || !bc || gf->dim != 3)
         return fail(MGK_EINVAL, "mgk_residual_restrict: bad arguments (3-D only)");
@@ -2521,6 +2527,7 @@ static int residual_restrict(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc,
     a.a0 = (T)coef[0]; a.a1 = (T)coef[1]; a.a2 = (T)coef[2]; a.a3 = (T)coef[3]; a.a4 = (T)coef[4]; a.a5 = (T)coef[5]; a.a6 = (T)coef[6];
     if (uc0 && gf->nz != 2 * gc->nz + 1) return fail(MGK_EINVAL, "mgk_residual_restrict_jz: whole grids only");
     a.uc0 = uc0 ? uc0 + gc->org : nullptr; a.dinv_c = (T)dinv_c; a.scale_c = (T)scale_c;
+    a.far_hi = (gf->nz == 2 * gc->nz) ? far_hi : nullptr;         // only an inner slab has a plane nz + 1 to look at
     a.nty = (gf->ny - 1 + 3) / 4;                 // tiles of 5 rows at stride 4; ny = 2 nyc + 1
     if (a.nty < 1) a.nty = 1;
     if (kcbeg < 0 || kcend > gc->nz || kcbeg >= kcend) return fail(MGK_EINVAL, "mgk_residual_restrict: empty or out-of-range coarse plane range");
@@ -2562,6 +2569,32 @@ extern "C" int mgk_residual_restrict_f32(mgk_ctx *c, const mgk_geom *gf, const m
 extern "C" int mgk_residual_restrict_range_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
                                                const float *b, const float *u, float *bc, int kcbeg, int kcend, void *stream) {
     return residual_restrict<float>(c, gf, gc, coef, b, u, bc, nullptr, 0.0, 0.0, kcbeg, kcend, stream);
+}
+// The same on a z-slab whose `far` field (geometry gfar = (nx, ny, 2), see mgk_jacobi2_slab_*) holds, in its hi ghost plane, plane 1
+// of the rank above, and whose u and b have valid hi ghost planes: an inner slab then evaluates the residual of plane nz itself
+// (same operands, same arithmetic as the owner: same bits) and completes its last coarse plane -- no partial plane to finish.
+template <typename T>
+static int residual_restrict_slab(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const mgk_geom *gfar, const double *coef,
+                                  const T *b, const T *u, const T *far, int has_hi, T *bc, int kcbeg, int kcend, void *stream) {
+    if (!gf || !gc) return fail(MGK_EINVAL, "mgk_residual_restrict_slab: bad arguments");
+    const T *hi = nullptr;
+    if (has_hi) {
+        if (!gfar || !far || gfar->dim != 3 || gfar->nz != 2 || gfar->nx != gf->nx || gfar->ny != gf->ny || gfar->pitch != gf->pitch)
+            return fail(MGK_EINVAL, "mgk_residual_restrict_slab: the far-plane field must have the geometry (nx, ny, 2) of the slab");
+        if (gf->nz != 2 * gc->nz) return fail(MGK_EINVAL, "mgk_residual_restrict_slab: a slab with a rank above has nzf = 2 nzc");
+        hi = far + gfar->org + 2 * gfar->plane;
+    }
+    return residual_restrict<T>(c, gf, gc, coef, b, u, bc, nullptr, 0.0, 0.0, kcbeg, kcend, stream, hi);
+}
+extern "C" int mgk_residual_restrict_slab_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const mgk_geom *gfar, const double *coef,
+                                              const double *b, const double *u, const double *far, int has_hi, double *bc,
+                                              int kcbeg, int kcend, void *stream) {
+    return residual_restrict_slab<double>(c, gf, gc, gfar, coef, b, u, far, has_hi, bc, kcbeg, kcend, stream);
+}
+extern "C" int mgk_residual_restrict_slab_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const mgk_geom *gfar, const double *coef,
+                                              const float *b, const float *u, const float *far, int has_hi, float *bc,
+                                              int kcbeg, int kcend, void *stream) {
+    return residual_restrict_slab<float>(c, gf, gc, gfar, coef, b, u, far, has_hi, bc, kcbeg, kcend, stream);
 }
 // the same, also writing the coarse level's first sweep from a zero guess (uc0 = scale_c * (bc * dinv_c), what mgk_jacobi_zero_*
 // would compute from bc): saves that kernel's read of bc

@@ -463,3 +463,39 @@ def test_pinned_async_copies_and_delay(mgk):
     assert mgk.L.mgk_delay_us(mgk.ctx, -1.0, ms) != 0
     mgk.free(d)
     mgk._chk(mgk.L.mgk_host_free(mgk.ctx, h))
+
+
+@pytest.mark.parametrize("n,cut", [(31, 7), (15, 2), (63, 20), (63, 3)])
+def test_fused_residual_restrict_on_slabs_single_exchange(mgk, orc, n, cut):
+    """mgk_residual_restrict_slab_f64: the inner slab holds the upper slab's planes 0 (u's hi ghost) and 1 (hi ghost of the far
+    field) and b's hi ghost plane, evaluates the residual of the plane above itself and completes its last coarse plane: the
+    two slabs together give the whole-grid restriction bit for bit, with no partial plane and no finishing kernel"""
+    rng = np.random.default_rng(177 + n)
+    nc = (n - 1) // 2
+    As = _stencil(orc, 3, n)
+    u, b = _rand(rng, n ** 3), _rand(rng, n ** 3)
+    want = orc.restrict(3, n, orc.residual(3, n, As, b, u)).reshape(nc, nc, nc)
+    L, coef = mgk.L, mgk.coef(As)
+    w = u.reshape(n, n, n)
+    # inner slab: fine planes [0, 2 cut), coarse planes [0, cut)
+    g0, gc0, gfar = mgk.geom(3, n, n, 2 * cut), mgk.geom(3, nc, nc, cut), mgk.geom(3, n, n, 2)
+    u0, b0, bc0 = _slab_field(mgk, g0, u, n, 0), _slab_field(mgk, g0, b, n, 0), mgk.field(gc0)
+    far = np.zeros(gfar.total)
+    for i in range(n):                      # hi ghost plane of the far field <- plane 1 of the slab above (global plane 2 cut + 1)
+        o = gfar.org + 2 * gfar.plane + i * gfar.pitch
+        far[o:o + n] = w[2 * cut + 1, i]
+    dfar = mgk.upload(far)
+    for k0, k1 in ((1, cut - 1), (0, 1), (cut - 1, cut)) if cut >= 3 else ((0, cut),):
+        mgk._chk(L.mgk_residual_restrict_slab_f64(mgk.ctx, C.byref(g0), C.byref(gc0), C.byref(gfar), coef, b0, u0, dfar, 1, bc0, k0, k1, None))
+    # last slab: fine planes [2 cut, n), no rank above
+    g1, gc1 = mgk.geom(3, n, n, n - 2 * cut), mgk.geom(3, nc, nc, nc - cut)
+    u1, b1, bc1 = _slab_field(mgk, g1, u, n, 2 * cut), _slab_field(mgk, g1, b, n, 2 * cut), mgk.field(gc1)
+    mgk._chk(L.mgk_residual_restrict_slab_f64(mgk.ctx, C.byref(g1), C.byref(gc1), None, coef, b1, u1, None, 0, bc1, 0, nc - cut, None))
+    got0 = mgk.from_field(gc0, bc0).reshape(cut, nc, nc)
+    got1 = mgk.from_field(gc1, bc1).reshape(nc - cut, nc, nc)
+    assert np.array_equal(got0, want[:cut]) and np.array_equal(got1, want[cut:])
+    # a far field of the wrong shape is refused
+    gbad = mgk.geom(3, n, n, 3)
+    assert L.mgk_residual_restrict_slab_f64(mgk.ctx, C.byref(g0), C.byref(gc0), C.byref(gbad), coef, b0, u0, dfar, 1, bc0, 0, cut, None) != 0
+    for p in (u0, b0, bc0, dfar, u1, b1, bc1):
+        mgk.free(p)

@@ -23,10 +23,10 @@ from multigrid_petsc_amd.solver import Solver              # noqa: E402
 MODELS = {"free": (0.0, 0.0), "expected": (20.0, 60.0), "pessimistic": (40.0, 40.0)}
 
 
-def run(rank, nranks, npts, levels, lat, gbs, cycles, warmup, overlap, precision):
+def run(rank, nranks, npts, levels, lat, gbs, cycles, warmup, overlap, precision, **kw):
     c = phantom_comm(rank, nranks, lat, gbs)
     s = Solver(3, npts, levels, scale=6.0 / 7.0, maxiter=cycles + warmup + 1, rank=rank, nranks=nranks, comm=c.handle,
-               overlap=overlap, precision=precision)
+               overlap=overlap, precision=precision, **kw)
     s.set_rhs_problem()
     s.cycles(warmup)
     s.sync()
@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--models", default="free,expected,pessimistic")
     ap.add_argument("--overlap", default="1,0")
+    ap.add_argument("--pair-min-n", type=int, default=0)
+    ap.add_argument("--dist-min-n", type=int, default=0)
     a = ap.parse_args()
     res = {"workload": f"3-D npts={a.npts}, {a.levels} levels, V(3,3), one rank of {a.nranks} z-slabs, phantom neighbours",
            "precision": a.precision, "single_gpu_ms_per_cycle": a.single_ms or None,
@@ -63,7 +65,8 @@ def main():
             key = f"{name}{'' if overlap else '_no_overlap'}"
             res["models"][key] = {"latency_us": lat, "link_GBs": gbs or None, "overlap": bool(overlap), "ranks": {}}
             for r in [int(x) for x in a.ranks.split(",")]:
-                ms, planes = run(r, a.nranks, a.npts, a.levels, lat, gbs, a.cycles, a.warmup, overlap, a.precision)
+                ms, planes = run(r, a.nranks, a.npts, a.levels, lat, gbs, a.cycles, a.warmup, overlap, a.precision,
+                                 pair_min_n=a.pair_min_n, dist_min_n=a.dist_min_n)
                 res["models"][key]["ranks"][str(r)] = {"ms_per_cycle": ms, "local_planes_per_level": planes}
                 print(f"[slab_share] {key:24s} rank {r}: {ms:.3f} ms/cycle", file=sys.stderr, flush=True)
             worst = max(v["ms_per_cycle"] for v in res["models"][key]["ranks"].values())
