@@ -902,7 +902,7 @@ static int dispatch_st(mgk_ctx *c, const mgk_geom *g, StArgs<double> &a, hipStre
     a.nx = g->nx;
     if (g->dim == 3) {
         a.ny = g->ny; a.nm = g->nz; a.rs = g->pitch; a.ms = g->plane;
-        int v = g_variant;
+        int v = g_variant >= 30 ? -1 : g_variant;
         if (v < 0) v = (MODE == MODE_RESNORM && g->nx >= 255) ? 3
                      : (g->nx >= 1023) ? ((MODE == MODE_PJACOBI || MODE == MODE_CRES32) ? 9 : 12)   // on-the-fly corrections: 512-thread blocks (a 1024-thread block is capped at 128 VGPRs and spills)
                      : (g->nx >= 511) ? (MODE == MODE_PJACOBI ? 13 : 6)             // fused prolongation at 511^3: 0.91 -> 0.73 ms
@@ -920,7 +920,7 @@ static int dispatch_st(mgk_ctx *c, const mgk_geom *g, StArgs<double> &a, hipStre
         }
     } else {
         a.ny = 1; a.nm = g->ny; a.rs = 0; a.ms = g->pitch;
-        int v = g_variant;
+        int v = g_variant >= 30 ? -1 : g_variant;
         if (v < 0) v = (g->nx >= 511) ? 2 : (g->nx >= 255 ? 1 : 0);
         switch (v) {
             case 0: return launch_st<double, 2, 1, 1, 1, MODE>(c, a, 1, s, nblocks);
@@ -936,7 +936,7 @@ static int dispatch_st(mgk_ctx *c, const mgk_geom *g, StArgs<float> &a, hipStrea
     a.nx = g->nx;
     if (g->dim != 3) return fail(MGK_EINVAL, "fp32 stencil kernels are built for 3-D only");
     a.ny = g->ny; a.nm = g->nz; a.rs = g->pitch; a.ms = g->plane;
-    int v = g_variant;
+    int v = g_variant >= 30 ? -1 : g_variant;
     if (v < 0) v = (g->nx >= 1023) ? (MODE == MODE_PJACOBI ? 3 : 2) : (g->nx >= 511) ? 1 : 0;
     switch (v) {
         case 0: return launch_st<float, 3, 1, 2, 2, MODE>(c, a, g->ny, s, nblocks);   // 256 x 4, 128 thr
@@ -2266,47 +2266,6 @@ extern "C" int mgk_unpack_f32(mgk_ctx *c, const mgk_geom *g32, const float *padd
     return 0;
 }
 
-// K4 fused into the first post-smoothing sweep: unew = J(u + P uc)  (src/solver.c:1540-1542)
-template <typename T>
-static int prolong_jacobi(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
-                          const T *b, const T *ucoarse, const T *u, T *unew, int zbeg, int zend, void *stream) {
-    if (!c || !gf || !gc || !coef || !b || !ucoarse || !u || !unew || u == unew || (gf->dim != 3 && sizeof(T) != 8))
-        return fail(MGK_EINVAL, "mgk_prolong_jacobi: bad arguments (fp32: 3-D only)");
-    XferArgs x;
-    int rc = xfer_args(gf, gc, x);
-    if (rc) return rc;
-    StArgs<T> a; memset(&a, 0, sizeof(a));
-    a.u = u + gf->org; a.b = b + gf->org; a.out = unew + gf->org;
-    a.uc = ucoarse + gc->org; a.crs = gc->pitch; a.cms = (gf->dim == 3) ? gc->plane : gc->pitch;
-    a.nxc = gc->nx; a.nyc = gc->ny; a.nzc = gc->nz;
-    set_coef(a, gf, coef); a.dinv = (T)dinv; a.scale = (T)scale;
-    const int nm = (gf->dim == 3) ? gf->nz : gf->ny;
-    if (zbeg < 0 || zend > nm || zbeg >= zend) return fail(MGK_EINVAL, "mgk_prolong_jacobi: empty or out-of-range plane range");
-    a.zbeg = zbeg; a.zend = zend;
-    return dispatch_st<MODE_PJACOBI>(c, gf, a, S(c, stream), nullptr);
-}
-extern "C" int mgk_prolong_jacobi_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv,
-                                      double scale, const double *b, const double *uc, const double *u, double *unew, void *stream) {
-    if (!gf) return fail(MGK_EINVAL, "mgk_prolong_jacobi_f64: bad arguments");
-    return prolong_jacobi<double>(c, gf, gc, coef, dinv, scale, b, uc, u, unew, 0, gf->dim == 3 ? gf->nz : gf->ny, stream);
-}
-extern "C" int mgk_prolong_jacobi_range_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv,
-                                            double scale, const double *b, const double *uc, const double *u, double *unew,
-                                            int zbeg, int zend, void *stream) {
-    return prolong_jacobi<double>(c, gf, gc, coef, dinv, scale, b, uc, u, unew, zbeg, zend, stream);
-}
-extern "C" int mgk_prolong_jacobi_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv,
-                                      double scale, const float *b, const float *uc, const float *u, float *unew, void *stream) {
-    if (!gf) return fail(MGK_EINVAL, "mgk_prolong_jacobi_f32: bad arguments");
-    return prolong_jacobi<float>(c, gf, gc, coef, dinv, scale, b, uc, u, unew, 0, gf->nz, stream);
-}
-extern "C" int mgk_prolong_jacobi_range_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv,
-                                            double scale, const float *b, const float *uc, const float *u, float *unew,
-                                            int zbeg, int zend, void *stream) {
-    return prolong_jacobi<float>(c, gf, gc, coef, dinv, scale, b, uc, u, unew, zbeg, zend, stream);
-}
-
-
 // ------------------------------------------------------------------------------------------
 // K2+K3 fused: r = b - A u restricted on the fly, r is never written (src/solver.c:1534-1535).
 // One block owns a full-row tile of RR = 5 fine rows (tile stride 4: the 5th row is recomputed by the next
@@ -2488,6 +2447,448 @@ __global__ void __launch_bounds__(64 * WX) k_resrestrict(const RRArgs<T> a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Register / shuffle forms of the two fused fine-level kernels (round 2).
+//
+// Same tiles, same arithmetic and summation order as k_resrestrict and k_stencil<MODE_PJACOBI> -- results are bit-identical --
+// but shaped like k_jacobi2r: a block is a full-row tile marching along z; lane t owns the column pair (fp32: quad) x = VX t ..
+// of ALL rows of the tile including the two halo rows, so y neighbours are its own registers; x neighbours come by wave
+// shuffle, the two values that cross a wave boundary through a few bytes of LDS; ONE barrier per plane.  No plane tiles in
+// LDS (the old forms held 116-124 KB and were latency bound at one block per CU with one plane of prefetch): the planes live in a
+// ring of NP = PD + 3 register sets indexed statically (the marching loop is unrolled by the ring period: no register
+// rotation), loaded PD planes ahead of their first use.  Row bases are wave-uniform, the lane offset is a 32-bit constant.
+// ------------------------------------------------------------------------------------------
+// lane i <- lane i-1 / lane i+1 of the wavefront.  DPP form: whole-wavefront shifts (wave_shr:1 / wave_shl:1) on the vector ALU
+// instead of ds_bpermute on the LDS pipe; lane 0 / 63 keep their own value (the callers replace it by the wave-edge value).
+template <bool DPP> __device__ __forceinline__ double lane_up(double v) {
+    if (!DPP) return __shfl_up(v, 1, 64);
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <bool DPP> __device__ __forceinline__ double lane_dn(double v) {
+    if (!DPP) return __shfl_down(v, 1, 64);
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <bool DPP> __device__ __forceinline__ float lane_up(float v) {
+    if (!DPP) return __shfl_up(v, 1, 64);
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+template <bool DPP> __device__ __forceinline__ float lane_dn(float v) {
+    if (!DPP) return __shfl_down(v, 1, 64);
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
+// Loads of the row kernels are UNCONDITIONAL: the row / plane index is clamped on the scalar unit to something that exists
+// (rows beyond the ghost row alias the ghost row, planes beyond the chunk alias its last plane), and the shapes are restricted to
+// full rows (nx + 1 a multiple of the wave row) so that no lane lies outside the grid.  No exec masking, no branch per load.
+template <typename T>
+__device__ __forceinline__ V16<T> ldrow(const T *row_uniform, unsigned lane_bytes) {
+    return *reinterpret_cast<const V16<T> *>(reinterpret_cast<const char *>(row_uniform) + lane_bytes);
+}
+__device__ __forceinline__ V16<double> ldrow_stream(const double *row_uniform, unsigned lane_bytes) {
+    return ldv_stream(reinterpret_cast<const double *>(reinterpret_cast<const char *>(row_uniform) + lane_bytes), true);
+}
+__device__ __forceinline__ V16<float> ldrow_stream(const float *row_uniform, unsigned lane_bytes) {
+    return ldv_stream(reinterpret_cast<const float *>(reinterpret_cast<const char *>(row_uniform) + lane_bytes), true);
+}
+
+template <typename T, int WX, int PD, int FORM>
+__global__ void __launch_bounds__(64 * WX) k_rrrow(const RRArgs<T> a) {
+    constexpr bool DPP = (FORM & 2) != 0;
+    constexpr int VX = 16 / sizeof(T), NCJ = VX / 2;
+    constexpr int RR = 5, R1 = RR + 2, NP = PD + 3;
+    __shared__ T eW[2][RR][WX], eE[2][RR][WX], eR[2][RR][WX];
+    using VT = V16<T>;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int ty = bid % a.nty, tz = bid / a.nty;
+    const int x0 = VX * tid, yb = 4 * ty;
+    const int kc0 = a.kcbeg + tz * a.kcc, kc1 = min(kc0 + a.kcc, a.kcend);
+    if (kc0 >= kc1) return;
+    const int z0 = 2 * kc0, z1u = 2 * kc1 + 1;
+    const int z1 = a.far_hi ? z1u : min(z1u, a.nz);          // planes z0 .. z1-1 are processed; plane z1 is the last one read
+    const bool lastlane = (tid == 64 * WX - 1);               // its last element is the right ghost column x = nx: stays 0
+    const unsigned lb = (unsigned)(x0 * (int)sizeof(T));
+    bool rok[RR];                                             // wave-uniform: rows of the tile inside the grid
+#pragma unroll
+    for (int r = 0; r < RR; r++) rok[r] = (yb + r < a.ny);
+    // wave-uniform row bases; rows beyond the ghost row y = ny alias it (zeros: a ghost ROW is always a global boundary)
+    long uro[R1], bro[RR];
+#pragma unroll
+    for (int rr = 0; rr < R1; rr++) uro[rr] = (long)min(yb - 1 + rr, a.ny) * a.rs;
+#pragma unroll
+    for (int r = 0; r < RR; r++) bro[r] = (long)min(yb + r, a.ny) * a.rs;
+    auto uplane = [&](int p) -> const T * {                   // planes beyond z1 alias plane z1 (loaded, never used)
+        const int pp = min(p, z1);
+        return (a.far_hi && pp == a.nz + 1) ? a.far_hi : a.u + (long)pp * a.ms;
+    };
+    const int jc0 = NCJ * tid;
+    const bool crow0 = (2 * ty < a.nyc), crow1 = (2 * ty + 1 < a.nyc);
+    const T w2[3][3] = {{(T)0.0625, (T)0.125, (T)0.0625}, {(T)0.125, (T)0.25, (T)0.125}, {(T)0.0625, (T)0.125, (T)0.0625}};
+
+    VT U[NP][R1], B[NP][RR];
+    // ---- prologue: u planes z0-1 .. z0+PD into slots NP-1, 0 .. PD; b planes z0 .. z0+PD-1 into slots 0 .. PD-1 ----
+#pragma unroll
+    for (int q = -1; q <= PD; q++) {
+        const T *pl = uplane(z0 + q);
+#pragma unroll
+        for (int rr = 0; rr < R1; rr++) U[(q + NP) % NP][rr] = ldrow(pl + uro[rr], lb);
+    }
+#pragma unroll
+    for (int q = 0; q < PD; q++) {
+        const T *pl = a.b + (long)min(z0 + q, z1 - 1) * a.ms;
+#pragma unroll
+        for (int r = 0; r < RR; r++) B[q][r] = (r == 0 || r == RR - 1) ? ldrow(pl + bro[r], lb) : ldrow_stream(pl + bro[r], lb);
+    }
+    if (lane == 0 || lane == 63) {
+#pragma unroll
+        for (int r = 0; r < RR; r++) {
+            if (lane == 0) eW[z0 & 1][r][w] = U[0][r + 1].v[0];
+            else eE[z0 & 1][r][w] = U[0][r + 1].v[VX - 1];
+        }
+    }
+    T acc[2][NCJ], accn[2][NCJ];
+#pragma unroll
+    for (int cl = 0; cl < 2; cl++)
+#pragma unroll
+        for (int q = 0; q < NCJ; q++) { acc[cl][q] = (T)0; accn[cl][q] = (T)0; }
+    __syncthreads();
+
+    for (int zb = z0; zb < z1; zb += NP) {
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const int z = zb + k;
+            if (z < z1) {
+                const int cm = (k + NP - 1) % NP, cc = k, cp = (k + 1) % NP, cl_ = (k + PD + 1) % NP, cb = (k + PD) % NP;
+                // ---- loads first used PD steps from now ----
+                {
+                    const T *pl = uplane(z + PD + 1);
+#pragma unroll
+                    for (int rr = 0; rr < R1; rr++) U[cl_][rr] = ldrow(pl + uro[rr], lb);
+                    const T *pb = a.b + (long)min(z + PD, z1 - 1) * a.ms;
+#pragma unroll
+                    for (int r = 0; r < RR; r++) B[cb][r] = (r == 0 || r == RR - 1) ? ldrow(pb + bro[r], lb) : ldrow_stream(pb + bro[r], lb);
+                }
+                // ---- residual of plane z on the 5 rows of the tile.  The plane z+1 term and b enter the canonical sum LAST:
+                //      everything that needs only planes z-1 and z comes first, so the loads issued one step ago have almost
+                //      two steps to arrive ----
+                VT res[RR];
+#pragma unroll
+                for (int r = 0; r < RR; r++) {
+                    const VT &c = U[cc][r + 1];
+                    T Wv = lane_up<DPP>(c.v[VX - 1]), Ev = lane_dn<DPP>(c.v[0]);
+                    if (lane == 0) Wv = (w > 0) ? eE[z & 1][r][w - 1] : (T)0;
+                    if (lane == 63) Ev = (w < WX - 1) ? eW[z & 1][r][w + 1] : (T)0;
+#pragma unroll
+                    for (int e = 0; e < VX; e++) {
+                        const T wv = (e == 0) ? Wv : c.v[e > 0 ? e - 1 : 0];
+                        const T ev = (e == VX - 1) ? Ev : c.v[e < VX - 1 ? e + 1 : e];
+                        T t = a.a0 * U[cm][r + 1].v[e];
+                        t = t + a.a1 * U[cc][r].v[e];
+                        t = t + a.a2 * wv;
+                        t = t + a.a3 * c.v[e];
+                        t = t + a.a4 * ev;
+                        t = t + a.a5 * U[cc][r + 2].v[e];
+                        res[r].v[e] = t;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < RR; r++) {
+#pragma unroll
+                    for (int e = 0; e < VX; e++) {
+                        const T t = res[r].v[e] + a.a6 * U[cp][r + 1].v[e];
+                        res[r].v[e] = rok[r] ? B[cc][r].v[e] - t : (T)0;
+                    }
+                    if (lastlane) res[r].v[VX - 1] = (T)0;
+                }
+                // ---- wave-edge values of plane z+1 for the next step (other buffer) and of this residual plane ----
+                if (lane == 0 || lane == 63) {
+#pragma unroll
+                    for (int r = 0; r < RR; r++) {
+                        if (lane == 0) { eW[(z + 1) & 1][r][w] = U[cp][r + 1].v[0]; eR[z & 1][r][w] = res[r].v[0]; }
+                        else eE[(z + 1) & 1][r][w] = U[cp][r + 1].v[VX - 1];
+                    }
+                }
+                __syncthreads();      // edges of u(z+1) and of the residual of plane z are visible
+                // ---- full weighting: the running sums of coarse planes z/2-1 (dk = 2) and z/2 (dk = 0) / (z-1)/2 (dk = 1) ----
+                {
+                    const bool even = ((z & 1) == 0);
+                    const T wk = even ? (T)0.25 : (T)0.5;
+                    T nx_[RR];
+#pragma unroll
+                    for (int r = 0; r < RR; r++) {
+                        nx_[r] = lane_dn<DPP>(res[r].v[0]);
+                        if (lane == 63) nx_[r] = (w < WX - 1) ? eR[z & 1][r][w + 1] : (T)0;
+                    }
+#pragma unroll
+                    for (int cl = 0; cl < 2; cl++) {
+                        if (!(cl == 0 ? crow0 : crow1)) continue;
+#pragma unroll
+                        for (int q = 0; q < NCJ; q++) {
+#pragma unroll
+                            for (int di = 0; di < 3; di++) {
+#pragma unroll
+                                for (int dj = 0; dj < 3; dj++) {
+                                    const int e = 2 * q + dj;
+                                    const T val = (e < VX) ? res[2 * cl + di].v[e < VX ? e : 0] : nx_[2 * cl + di];
+                                    const T p = (wk * w2[di][dj]) * val;
+                                    acc[cl][q] += p;
+                                    if (even) accn[cl][q] += p;
+                                }
+                            }
+                        }
+                    }
+                    if (even) {
+                        const int kc = z / 2 - 1;     // completed coarse plane
+#pragma unroll
+                        for (int cl = 0; cl < 2; cl++)
+#pragma unroll
+                            for (int q = 0; q < NCJ; q++) {
+                                if (kc >= kc0 && (cl == 0 ? crow0 : crow1) && jc0 + q < a.nxc) {
+                                    const long oc = (long)kc * a.cms + (long)(2 * ty + cl) * a.crs + jc0 + q;
+                                    a.bc[oc] = acc[cl][q];
+                                    if (a.uc0) { const T zq = acc[cl][q] * a.dinv_c; a.uc0[oc] = a.scale_c * zq; }
+                                }
+                                acc[cl][q] = accn[cl][q]; accn[cl][q] = (T)0;
+                            }
+                    }
+                }
+            }
+        }
+    }
+    if (z1u > z1) {                               // slab without the far plane: partial last coarse plane
+#pragma unroll
+        for (int cl = 0; cl < 2; cl++)
+#pragma unroll
+            for (int q = 0; q < NCJ; q++)
+                if ((cl == 0 ? crow0 : crow1) && jc0 + q < a.nxc)
+                    a.bc[(long)(kc1 - 1) * a.cms + (long)(2 * ty + cl) * a.crs + jc0 + q] = acc[cl][q];
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ V16<T> ldrowp(const T *row_uniform, unsigned lane_bytes, bool ok) {
+    return ok ? *reinterpret_cast<const V16<T> *>(reinterpret_cast<const char *>(row_uniform) + lane_bytes) : v16_zero<T>();
+}
+template <typename T>
+__device__ __forceinline__ V16<T> ldrowp_stream(const T *row_uniform, unsigned lane_bytes, bool ok) {
+    return ldv_stream(reinterpret_cast<const T *>(reinterpret_cast<const char *>(row_uniform) + lane_bytes), ok);
+}
+// fused prolongation + first post-smoothing sweep, register / shuffle form: unew = J(u + P uc)
+template <typename T>
+struct PJArgs {
+    const T *u, *b, *uc;
+    T *out;
+    int nx, ny, nz, nxc, nyc, nzc;
+    long rs, ms, crs, cms;
+    int nty, zc, zbeg, zend;
+    T a0, a1, a2, a3, a4, a5, a6, dinv, scale;
+};
+
+// s += the interpolant of one fine row from the coarse registers: C[j][0 .. NCL-1] = coarse row j at the columns x0/2-1 ..;
+// `two` parent planes (even fine plane: A then Bc, weight 1/2 each) or one (odd: A alone, weight 1); the fine row has one parent
+// row j0 (odd row, weight 1) or two, j0 and j0+1 (even row).  Terms in the order of prolong_vec: ascending (kc, ic, jc).
+template <typename T, int TYC, int NCL>
+__device__ __forceinline__ V16<T> corr_row(const T (&A)[TYC][NCL], const T (&Bc)[TYC][NCL], bool two, int j0, bool tworows) {
+    constexpr int VX = 16 / sizeof(T);
+    const T wk = two ? (T)0.5 : (T)1, wi = tworows ? (T)0.5 : (T)1;
+    const T wh = wk * (wi * (T)0.5), w1 = wk * (wi * (T)1);
+    V16<T> s = v16_zero<T>();
+#pragma unroll
+    for (int qk = 0; qk < 2; qk++) {
+        if (qk == 1 && !two) break;
+#pragma unroll
+        for (int qi = 0; qi < 2; qi++) {
+            if (qi == 1 && !tworows) break;
+            const T c0 = qk == 0 ? A[j0 + qi][0] : Bc[j0 + qi][0];
+            const T c1 = qk == 0 ? A[j0 + qi][1] : Bc[j0 + qi][1];
+            s.v[0] += wh * c0;
+            s.v[0] += wh * c1;
+            s.v[1] += w1 * c1;
+            if (VX == 4) {
+                const T c2 = qk == 0 ? A[j0 + qi][NCL - 1] : Bc[j0 + qi][NCL - 1];
+                s.v[VX - 2] += wh * c1;
+                s.v[VX - 2] += wh * c2;
+                s.v[VX - 1] += w1 * c2;
+            }
+        }
+    }
+    return s;
+}
+
+template <typename T, int WX, int PD, int FORM>
+__global__ void __launch_bounds__(64 * WX) k_pjrow(const PJArgs<T> a) {
+    constexpr bool UNC = (FORM & 1) != 0, DPP = (FORM & 2) != 0;
+    constexpr int VX = 16 / sizeof(T), NCL = VX / 2 + 1;
+    constexpr int TY = 4, R1 = TY + 2, TYC = 4, NP = PD + 3;
+    __shared__ T eW[2][TY][WX], eE[2][TY][WX];
+    using VT = V16<T>;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int ty = bid % a.nty, tz = bid / a.nty;
+    const int x0 = VX * tid, yb = TY * ty;
+    const int z0 = a.zbeg + tz * a.zc, z1 = min(z0 + a.zc, a.zend);
+    if (z0 >= z1) return;
+    const bool xok = x0 < a.nx, lastvec = (x0 + VX > a.nx);
+    const unsigned lb = (unsigned)(x0 * (int)sizeof(T));
+    bool ok[R1];
+#pragma unroll
+    for (int rr = 0; rr < R1; rr++) ok[rr] = xok && (yb - 1 + rr <= a.ny);
+    const T *ub = a.u + (long)(yb - 1) * a.rs, *bb = a.b + (long)yb * a.rs;
+    T *ob = a.out + (long)yb * a.rs;
+    // FORM bit 0: unconditional loads, rows / planes clamped on the scalar unit (full-row shapes: no lane outside the grid)
+    long uro[R1], bro[TY];
+#pragma unroll
+    for (int rr = 0; rr < R1; rr++) uro[rr] = (long)min(yb - 1 + rr, a.ny) * a.rs;
+#pragma unroll
+    for (int j = 0; j < TY; j++) bro[j] = (long)min(yb + j, a.ny) * a.rs;
+    auto LDU = [&](int p, int rr) -> VT {
+        if (UNC) return ldrow(a.u + (long)min(p, z1) * a.ms + uro[rr], lb);
+        return ldrowp(ub + (long)p * a.ms + (long)rr * a.rs, lb, ok[rr] && p <= z1);
+    };
+    auto LDB = [&](int p, int j) -> VT {
+        if (UNC) return ldrow_stream(a.b + (long)min(p, z1 - 1) * a.ms + bro[j], lb);
+        return ldrowp_stream(bb + (long)p * a.ms + (long)j * a.rs, lb, ok[j + 1] && (yb + j < a.ny) && (p < z1));
+    };
+    // coarse rows icb .. icb+3 at the coarse columns x0/2 - 1 + q
+    const int icb = yb / 2 - 1, jcb = x0 / 2 - 1;
+    const T *cb_ = a.uc + (long)icb * a.crs + jcb;
+    long cro[TYC];
+#pragma unroll
+    for (int j = 0; j < TYC; j++) cro[j] = (long)min(icb + j, a.nyc) * a.crs;
+    auto ldc = [&](T (&C_)[TYC][NCL], int kc) {
+        const bool kv = (kc >= -1 && kc <= a.nzc);
+        const T *plc = a.uc + (long)max(-1, min(kc, a.nzc)) * a.cms + jcb;
+#pragma unroll
+        for (int j = 0; j < TYC; j++)
+#pragma unroll
+            for (int q = 0; q < NCL; q++) {
+                if (UNC) C_[j][q] = plc[cro[j] + q];
+                else C_[j][q] = (kv && xok && icb + j <= a.nyc && jcb + q <= a.nxc) ? cb_[(long)kc * a.cms + (long)j * a.crs + q] : (T)0;
+            }
+    };
+    T cLo[TYC][NCL], cHi[TYC][NCL], cSt[TYC][NCL];
+    VT U[NP][R1], B[NP][TY];
+    // u + P uc on the six rows of plane p held in U[slot]: row rr <-> fine row yb-1+rr (yb a multiple of 4: rr even = odd fine row,
+    // one parent row rr/2; rr odd = even fine row, parent rows (rr-1)/2 and (rr+1)/2).  An odd plane p has ONE parent plane,
+    // p >> 1 (passed as A); an even one two, (p >> 1) - 1 and p >> 1 (A, Bc).
+#define PJ_CORRECT(slot, A_, B_, two_)                                                                   \
+    do {                                                                                                 \
+        _Pragma("unroll") for (int rr = 0; rr < R1; rr++)                                                \
+            if (ok[rr]) U[slot][rr] = vadd(U[slot][rr], corr_row<T, TYC, NCL>(A_, B_, two_, rr / 2, (rr & 1) != 0)); \
+    } while (0)
+
+    // ---- prologue ----
+    {
+        const int m = z0 >> 1;                    // floor also for z0 = -... (z0 >= 0 here)
+        ldc(cLo, m - 1); ldc(cHi, m); ldc(cSt, m + 1);
+    }
+#pragma unroll
+    for (int q = -1; q <= PD; q++) {
+        const int p = z0 + q, slot = (q + NP) % NP;
+#pragma unroll
+        for (int rr = 0; rr < R1; rr++) U[slot][rr] = LDU(p, rr);
+    }
+#pragma unroll
+    for (int q = 0; q < PD; q++) {
+#pragma unroll
+        for (int j = 0; j < TY; j++)
+            B[q][j] = LDB(z0 + q, j);
+    }
+    if (z0 & 1) {           // z0 odd: plane z0-1 is even (parents m-1, m), plane z0 odd (parent m)
+        PJ_CORRECT(NP - 1, cLo, cHi, true);
+        PJ_CORRECT(0, cHi, cHi, false);
+    } else {                // z0 even: plane z0-1 is odd (parent m-1), plane z0 even (parents m-1, m)
+        PJ_CORRECT(NP - 1, cLo, cLo, false);
+        PJ_CORRECT(0, cLo, cHi, true);
+    }
+    if (lane == 0 || lane == 63) {
+#pragma unroll
+        for (int j = 0; j < TY; j++) {
+            if (lane == 0) eW[z0 & 1][j][w] = U[0][j + 1].v[0];
+            else eE[z0 & 1][j][w] = U[0][j + 1].v[VX - 1];
+        }
+    }
+    __syncthreads();
+
+    for (int zb = z0; zb < z1; zb += NP) {
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const int z = zb + k;
+            if (z < z1) {
+                const int cm = (k + NP - 1) % NP, cc = k, cp = (k + 1) % NP, cl_ = (k + PD + 1) % NP, cbs = (k + PD) % NP;
+                // ---- loads first used PD steps from now ----
+                {
+#pragma unroll
+                    for (int rr = 0; rr < R1; rr++) U[cl_][rr] = LDU(z + PD + 1, rr);
+#pragma unroll
+                    for (int j = 0; j < TY; j++) B[cbs][j] = LDB(z + PD, j);
+                }
+                // ---- correct plane p = z+1 (first use: the z neighbour of this step's sweep), publish its wave edges ----
+                {
+                    const int p = z + 1;
+                    if ((p & 1) == 0) {           // a new pair of parent planes: (p/2 - 1, p/2); fetch p/2 + 1 for two steps from now
+#pragma unroll
+                        for (int j = 0; j < TYC; j++)
+#pragma unroll
+                            for (int q = 0; q < NCL; q++) { cLo[j][q] = cHi[j][q]; cHi[j][q] = cSt[j][q]; }
+                        ldc(cSt, (p >> 1) + 1);
+                        PJ_CORRECT(cp, cLo, cHi, true);
+                    } else {
+                        PJ_CORRECT(cp, cHi, cHi, false);
+                    }
+                    if (lane == 0 || lane == 63) {
+#pragma unroll
+                        for (int j = 0; j < TY; j++) {
+                            if (lane == 0) eW[p & 1][j][w] = U[cp][j + 1].v[0];
+                            else eE[p & 1][j][w] = U[cp][j + 1].v[VX - 1];
+                        }
+                    }
+                }
+                // ---- sweep of plane z ----
+#pragma unroll
+                for (int j = 0; j < TY; j++) {
+                    const VT &c = U[cc][j + 1];
+                    T Wv = lane_up<DPP>(c.v[VX - 1]), Ev = lane_dn<DPP>(c.v[0]);
+                    if (lane == 0) Wv = (w > 0) ? eE[z & 1][j][w - 1] : (T)0;
+                    if (lane == 63) Ev = (w < WX - 1) ? eW[z & 1][j][w + 1] : (T)0;
+                    VT o;
+#pragma unroll
+                    for (int e = 0; e < VX; e++) {
+                        const T wv = (e == 0) ? Wv : c.v[e > 0 ? e - 1 : 0];
+                        const T ev = (e == VX - 1) ? Ev : c.v[e < VX - 1 ? e + 1 : e];
+                        T t = a.a0 * U[cm][j + 1].v[e];
+                        t = t + a.a1 * U[cc][j].v[e];
+                        t = t + a.a2 * wv;
+                        t = t + a.a3 * c.v[e];
+                        t = t + a.a4 * ev;
+                        t = t + a.a5 * U[cc][j + 2].v[e];
+                        t = t + a.a6 * U[cp][j + 1].v[e];
+                        const T res = B[cc][j].v[e] - t;
+                        const T zz = res * a.dinv;
+                        o.v[e] = c.v[e] + a.scale * zz;
+                        if (lastvec && x0 + e >= a.nx) o.v[e] = (T)0;
+                    }
+                    if (xok && yb + j < a.ny)
+                        stv_stream(reinterpret_cast<T *>(reinterpret_cast<char *>(ob + (long)z * a.ms + (long)j * a.rs) + lb), o);
+                }
+                __syncthreads();      // edges of plane z+1 visible; the buffer of plane z is free for plane z+2
+            }
+        }
+    }
+#undef PJ_CORRECT
+}
+
 // closes the partial last coarse plane of a slab: bc(last) += sum_{di,dj} (1/4 w2[di][dj]) r(ghost plane), ascending (di, dj):
 // the dk = 2 terms of the row of res, appended to the running sum exactly as the whole-grid kernel would.
 template <typename T>
@@ -2507,6 +2908,36 @@ __global__ void __launch_bounds__(256) k_restrict_finish(XferArgs a, const T *rg
     bclast[(long)ic * a.pc + jc] = acc;
 }
 
+// form of the fused kernels when the tuning knob leaves the choice open: the register / shuffle kernels with unconditional loads
+// and DPP lane shifts wherever the shape allows them (measured on MI355X, LDS-tile form -> row form: fp64 fused prolongation sweep
+// 1023^3 5.36 -> 4.45 ms, 511^3 0.77 -> 0.56, 255^3 0.117 -> 0.070; fused residual + restriction 1023^3 3.74-4.04 -> 3.35 ms,
+// 255^3 0.086 -> 0.065; fp32 1023^3 2.88 -> 2.40 / 1.81 -> 1.80 ms, 511^3 0.44 -> 0.30 / 0.36 -> 0.25)
+static int row_form_default(int w, size_t esz) { (void)w; (void)esz; return 34; }
+// the row kernels load unconditionally: full rows (nx + 1 a whole number of wave rows, at most 8) and ny + 1 a multiple of 4
+template <typename T>
+static bool row_shape_ok(const mgk_geom *g) {
+    constexpr int WR = 64 * (16 / (int)sizeof(T));
+    const int w = (g->nx + 1) / WR;
+    return g->dim == 3 && (g->nx + 1) % WR == 0 && (w == 1 || w == 2 || w == 4 || w == 8) && (g->ny + 1) % 4 == 0 && g->ny >= 3;
+}
+// tuning variants: 30 LDS-tile kernels; 31 row kernels; 33 / 34 / 35 experimental forms of the row kernels (see the launchers)
+static int row_form(int w, size_t esz) {
+    return (g_variant >= 31 && g_variant <= 35) ? g_variant : (g_variant == 30) ? 0 : row_form_default(w, esz);
+}
+template <typename T, int PD, int FORM>
+static void launch_rrrow(int w, unsigned nblk, hipStream_t s, const RRArgs<T> &a) {
+    if (w <= 1) hipLaunchKernelGGL((k_rrrow<T, 1, PD, FORM>), dim3(nblk), dim3(64), 0, s, a);
+    else if (w <= 2) hipLaunchKernelGGL((k_rrrow<T, 2, PD, FORM>), dim3(nblk), dim3(128), 0, s, a);
+    else if (w <= 4) hipLaunchKernelGGL((k_rrrow<T, 4, PD, FORM>), dim3(nblk), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_rrrow<T, 8, PD, FORM>), dim3(nblk), dim3(512), 0, s, a);
+}
+template <typename T, int PD, int FORM>
+static void launch_pjrow(int w, unsigned nblk, hipStream_t s, const PJArgs<T> &a) {
+    if (w <= 1) hipLaunchKernelGGL((k_pjrow<T, 1, PD, FORM>), dim3(nblk), dim3(64), 0, s, a);
+    else if (w <= 2) hipLaunchKernelGGL((k_pjrow<T, 2, PD, FORM>), dim3(nblk), dim3(128), 0, s, a);
+    else if (w <= 4) hipLaunchKernelGGL((k_pjrow<T, 4, PD, FORM>), dim3(nblk), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_pjrow<T, 8, PD, FORM>), dim3(nblk), dim3(512), 0, s, a);
+}
 template <typename T>
 static int residual_restrict(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef,
                              const T *b, const T *u, T *bc, T *uc0, double dinv_c, double scale_c, int kcbeg, int kcend, void *stream,
@@ -2545,7 +2976,11 @@ static int residual_restrict(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc,
     const long ntz = (nkc + kcc - 1) / kcc;
     const unsigned nblk = (unsigned)(a.nty * ntz);
     hipStream_t s = S(c, stream);
-    if (w <= 1) hipLaunchKernelGGL((k_resrestrict<T, 1>), dim3(nblk), dim3(64), 0, s, a);
+    // register / shuffle form (k_rrrow): tuning variants 31 / 32 force it with prefetch distance 1 / 2, 30 forces the LDS-tile form
+    const int rowpd = row_shape_ok<T>(gf) ? row_form(w, sizeof(T)) : 0;
+    if (rowpd == 34 || rowpd == 35) launch_rrrow<T, 1, 2>(w, nblk, s, a);      // DPP lane shifts
+    else if (rowpd) launch_rrrow<T, 1, 0>(w, nblk, s, a);
+    else if (w <= 1) hipLaunchKernelGGL((k_resrestrict<T, 1>), dim3(nblk), dim3(64), 0, s, a);
     else if (w <= 2) hipLaunchKernelGGL((k_resrestrict<T, 2>), dim3(nblk), dim3(128), 0, s, a);
     else if (w <= 4) hipLaunchKernelGGL((k_resrestrict<T, 4>), dim3(nblk), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_resrestrict<T, 8>), dim3(nblk), dim3(512), 0, s, a);
@@ -2628,6 +3063,77 @@ extern "C" int mgk_restrict_finish_f64(mgk_ctx *c, const mgk_geom *gf, const mgk
 extern "C" int mgk_restrict_finish_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const float *r, float *bc, void *stream) {
     return restrict_finish<float>(c, gf, gc, r, bc, stream);
 }
+
+// K4 fused into the first post-smoothing sweep: unew = J(u + P uc)  (src/solver.c:1540-1542)
+template <typename T>
+static int prolong_jacobi(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
+                          const T *b, const T *ucoarse, const T *u, T *unew, int zbeg, int zend, void *stream) {
+    if (!c || !gf || !gc || !coef || !b || !ucoarse || !u || !unew || u == unew || (gf->dim != 3 && sizeof(T) != 8))
+        return fail(MGK_EINVAL, "mgk_prolong_jacobi: bad arguments (fp32: 3-D only)");
+    XferArgs x;
+    int rc = xfer_args(gf, gc, x);
+    if (rc) return rc;
+    StArgs<T> a; memset(&a, 0, sizeof(a));
+    a.u = u + gf->org; a.b = b + gf->org; a.out = unew + gf->org;
+    a.uc = ucoarse + gc->org; a.crs = gc->pitch; a.cms = (gf->dim == 3) ? gc->plane : gc->pitch;
+    a.nxc = gc->nx; a.nyc = gc->ny; a.nzc = gc->nz;
+    set_coef(a, gf, coef); a.dinv = (T)dinv; a.scale = (T)scale;
+    const int nm = (gf->dim == 3) ? gf->nz : gf->ny;
+    if (zbeg < 0 || zend > nm || zbeg >= zend) return fail(MGK_EINVAL, "mgk_prolong_jacobi: empty or out-of-range plane range");
+    a.zbeg = zbeg; a.zend = zend;
+    constexpr int VX = 16 / sizeof(T);
+    const int w = (gf->nx + 1 + 64 * VX - 1) / (64 * VX);        // waves per full row
+    const int rowpd = row_shape_ok<T>(gf) ? row_form(w, sizeof(T)) : 0;
+    if (rowpd) {
+        // register / shuffle form (k_pjrow): full-row tiles of 4 rows; one 512-thread block per CU at 1023^3 (256 tiles, one
+        // chunk), smaller blocks two per CU
+        PJArgs<T> q; memset(&q, 0, sizeof(q));
+        q.u = a.u; q.b = a.b; q.uc = a.uc; q.out = a.out;
+        q.nx = gf->nx; q.ny = gf->ny; q.nz = gf->nz; q.nxc = gc->nx; q.nyc = gc->ny; q.nzc = gc->nz;
+        q.rs = gf->pitch; q.ms = gf->plane; q.crs = gc->pitch; q.cms = gc->plane;
+        q.a0 = a.a0; q.a1 = a.a1; q.a2 = a.a2; q.a3 = a.a3; q.a4 = a.a4; q.a5 = a.a5; q.a6 = a.a6; q.dinv = a.dinv; q.scale = a.scale;
+        q.zbeg = zbeg; q.zend = zend;
+        q.nty = (gf->ny + 3) / 4;
+        const int nzr = zend - zbeg;
+        const long target = (w > 4) ? 256 : 512;
+        long nch = (q.nty >= target) ? 1 : (target + q.nty - 1) / q.nty;
+        if (g_zchunk > 0) nch = (nzr + g_zchunk - 1) / g_zchunk;
+        int zc = (int)((nzr + nch - 1) / nch);
+        if (zc < 4) zc = 4;
+        if (zc > nzr) zc = nzr;
+        q.zc = zc;
+        const unsigned nblk = (unsigned)(q.nty * ((nzr + zc - 1) / zc));
+        if (rowpd == 33) launch_pjrow<T, 1, 1>(w, nblk, S(c, stream), q);          // unconditional loads
+        else if (rowpd == 34) launch_pjrow<T, 1, 3>(w, nblk, S(c, stream), q);     // + DPP lane shifts
+        else if (rowpd == 35) launch_pjrow<T, 1, 2>(w, nblk, S(c, stream), q);     // predicated loads, DPP lane shifts
+        else launch_pjrow<T, 1, 0>(w, nblk, S(c, stream), q);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    return dispatch_st<MODE_PJACOBI>(c, gf, a, S(c, stream), nullptr);
+}
+extern "C" int mgk_prolong_jacobi_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv,
+                                      double scale, const double *b, const double *uc, const double *u, double *unew, void *stream) {
+    if (!gf) return fail(MGK_EINVAL, "mgk_prolong_jacobi_f64: bad arguments");
+    return prolong_jacobi<double>(c, gf, gc, coef, dinv, scale, b, uc, u, unew, 0, gf->dim == 3 ? gf->nz : gf->ny, stream);
+}
+extern "C" int mgk_prolong_jacobi_range_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv,
+                                            double scale, const double *b, const double *uc, const double *u, double *unew,
+                                            int zbeg, int zend, void *stream) {
+    return prolong_jacobi<double>(c, gf, gc, coef, dinv, scale, b, uc, u, unew, zbeg, zend, stream);
+}
+extern "C" int mgk_prolong_jacobi_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv,
+                                      double scale, const float *b, const float *uc, const float *u, float *unew, void *stream) {
+    if (!gf) return fail(MGK_EINVAL, "mgk_prolong_jacobi_f32: bad arguments");
+    return prolong_jacobi<float>(c, gf, gc, coef, dinv, scale, b, uc, u, unew, 0, gf->nz, stream);
+}
+extern "C" int mgk_prolong_jacobi_range_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv,
+                                            double scale, const float *b, const float *uc, const float *u, float *unew,
+                                            int zbeg, int zend, void *stream) {
+    return prolong_jacobi<float>(c, gf, gc, coef, dinv, scale, b, uc, u, unew, zbeg, zend, stream);
+}
+
+
 
 // ------------------------------------------------------------------------------------------
 // 2-D operators whose five coefficients depend on the grid row only (the reference's stretched meshes,

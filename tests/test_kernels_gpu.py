@@ -160,7 +160,8 @@ def test_rhs_fill_and_error_sums(mgk, orc, dim, npts):
         mgk.free(p)
 
 
-@pytest.mark.parametrize("nf,variant", [(3, -1), (7, 0), (31, 1), (63, 2), (63, 6), (127, 3), (127, 12), (255, -1), (63, 13), (255, 13), (255, 9)])
+@pytest.mark.parametrize("nf,variant", [(3, -1), (7, 0), (31, 1), (63, 2), (63, 6), (127, 3), (127, 12), (255, -1), (63, 13), (255, 13), (255, 9),
+                                        (3, 31), (7, 31), (15, 34), (31, 31), (63, 31), (63, 33), (127, 31), (127, 34), (255, 31), (255, 35), (511, 31)])
 def test_fused_prolong_jacobi_bit_exact(mgk, orc, nf, variant):
     """unew = Jacobi(u + P uc) in one pass == prolong_add followed by a sweep (src/solver.c:1540-1542)"""
     rng = np.random.default_rng(400 + nf)
@@ -192,14 +193,15 @@ def test_fused_residual_restrict_bit_exact(mgk, orc, nf):
     gf, gc = mgk.geom(3, nf), mgk.geom(3, nc)
     du, db, dbc = mgk.to_field(gf, u), mgk.to_field(gf, b), mgk.field(gc)
     want = orc.restrict(3, nf, orc.residual(3, nf, As, b, u))
-    for zc in (-1, 5):
-        mgk.L.mgk_set_tuning(-1, zc)
-        mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dbc, 8 * gc.total, None))
-        mgk._chk(mgk.L.mgk_residual_restrict_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), db, du, dbc, None))
-        got = mgk.from_field(gc, dbc)
-        assert np.array_equal(got, want), f"zc={zc} max diff {np.abs(got - want).max()}"
-        raw = mgk.raw_field(gc, dbc)
-        assert abs(np.abs(raw).sum() - np.abs(got).sum()) <= 1e-9 * np.abs(got).sum()
+    for variant in (30, 31, 34):            # LDS-tile form, register / shuffle form (ds_bpermute / DPP lane shifts)
+        for zc in (-1, 5):
+            mgk.L.mgk_set_tuning(variant, zc)
+            mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dbc, 8 * gc.total, None))
+            mgk._chk(mgk.L.mgk_residual_restrict_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), db, du, dbc, None))
+            got = mgk.from_field(gc, dbc)
+            assert np.array_equal(got, want), f"variant={variant} zc={zc} max diff {np.abs(got - want).max()}"
+            raw = mgk.raw_field(gc, dbc)
+            assert abs(np.abs(raw).sum() - np.abs(got).sum()) <= 1e-9 * np.abs(got).sum()
     mgk.L.mgk_set_tuning(-1, -1)
     for p in (du, db, dbc):
         mgk.free(p)
@@ -363,7 +365,8 @@ def test_fused_residual_restrict_with_coarse_first_sweep(mgk, orc, nf):
 
 
 @pytest.mark.parametrize("nf,variant,cuts", [(31, 0, (2, 30)), (63, 2, (2, 62)), (63, 13, (3, 40)), (127, 9, (2, 126)), (255, 9, (2, 254)),
-                                             (63, 6, (5, 6))])
+                                             (63, 6, (5, 6)), (31, 31, (2, 30)), (63, 33, (3, 40)), (63, 31, (5, 6)), (127, 31, (2, 126)),
+                                             (255, 34, (2, 254)), (127, 35, (7, 8))])
 def test_fused_prolong_jacobi_plane_ranges(mgk, orc, nf, variant, cuts):
     """mgk_prolong_jacobi_range_f64: the slab solver sweeps the inner planes while the ghost planes travel, then the boundary
     planes; any cut into plane ranges (even and odd starts) must give the whole-launch result bit for bit"""
@@ -399,13 +402,14 @@ def test_fused_residual_restrict_coarse_plane_ranges(mgk, orc, nf):
     du, db, dbc = mgk.to_field(gf, u), mgk.to_field(gf, b), mgk.field(gc)
     want = orc.restrict(3, nf, orc.residual(3, nf, As, b, u))
     mid = nc // 2
-    for zc in (-1, 4):
-        mgk.L.mgk_set_tuning(-1, zc)
-        mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dbc, 8 * gc.total, None))
-        for k0, k1 in ((1, mid), (mid, nc - 1), (0, 1), (nc - 1, nc)):
-            mgk._chk(mgk.L.mgk_residual_restrict_range_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), db, du, dbc, k0, k1, None))
-        got = mgk.from_field(gc, dbc)
-        assert np.array_equal(got, want), f"zc={zc} max diff {np.abs(got - want).max()}"
+    for variant in (30, 31, 34):
+        for zc in (-1, 4):
+            mgk.L.mgk_set_tuning(variant, zc)
+            mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dbc, 8 * gc.total, None))
+            for k0, k1 in ((1, mid), (mid, nc - 1), (0, 1), (nc - 1, nc)):
+                mgk._chk(mgk.L.mgk_residual_restrict_range_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), db, du, dbc, k0, k1, None))
+            got = mgk.from_field(gc, dbc)
+            assert np.array_equal(got, want), f"variant={variant} zc={zc} max diff {np.abs(got - want).max()}"
     mgk.L.mgk_set_tuning(-1, -1)
     assert mgk.L.mgk_residual_restrict_range_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), db, du, dbc, 2, 2, None) != 0
     for p in (du, db, dbc):
@@ -485,12 +489,14 @@ def test_fused_residual_restrict_on_slabs_single_exchange(mgk, orc, n, cut):
         o = gfar.org + 2 * gfar.plane + i * gfar.pitch
         far[o:o + n] = w[2 * cut + 1, i]
     dfar = mgk.upload(far)
+    L.mgk_set_tuning(31 if n % 2 and cut % 2 else 30, -1)       # both forms of the kernel across the parametrisation
     for k0, k1 in ((1, cut - 1), (0, 1), (cut - 1, cut)) if cut >= 3 else ((0, cut),):
         mgk._chk(L.mgk_residual_restrict_slab_f64(mgk.ctx, C.byref(g0), C.byref(gc0), C.byref(gfar), coef, b0, u0, dfar, 1, bc0, k0, k1, None))
     # last slab: fine planes [2 cut, n), no rank above
     g1, gc1 = mgk.geom(3, n, n, n - 2 * cut), mgk.geom(3, nc, nc, nc - cut)
     u1, b1, bc1 = _slab_field(mgk, g1, u, n, 2 * cut), _slab_field(mgk, g1, b, n, 2 * cut), mgk.field(gc1)
     mgk._chk(L.mgk_residual_restrict_slab_f64(mgk.ctx, C.byref(g1), C.byref(gc1), None, coef, b1, u1, None, 0, bc1, 0, nc - cut, None))
+    L.mgk_set_tuning(-1, -1)
     got0 = mgk.from_field(gc0, bc0).reshape(cut, nc, nc)
     got1 = mgk.from_field(gc1, bc1).reshape(nc - cut, nc, nc)
     assert np.array_equal(got0, want[:cut]) and np.array_equal(got1, want[cut:])

@@ -25,13 +25,14 @@ def timeit(fn, reps=4):
         m._chk(L.mgk_timer_elapsed_ms(m.ctx, t, C.byref(ms))); best = min(best, ms.value)
     return best
 N = float(n) ** 3
-for v in (12, 9, 6, 3, 2):
-    for zc in (-1, 256, 128):
+for v in [int(x) for x in os.environ.get("PJ_VARIANTS", "9,31,32").split(",")]:
+    for zc in (-1, 512):
         L.mgk_set_tuning(v, zc)
         pj = timeit(lambda: L.mgk_prolong_jacobi_f64(m.ctx, C.byref(g), C.byref(gc), coef, dinv, 0.85, b, uc, u, out, None))
         print(f"PJ variant {v:2d} zc {zc:4d}: {pj:7.3f} ms  {25 * N / pj / 1e6:7.1f} GB/s", flush=True)
-for zc in (-1, 256, 128, 64):
-    L.mgk_set_tuning(-1, zc)
-    rr = timeit(lambda: L.mgk_residual_restrict_f64(m.ctx, C.byref(g), C.byref(gc), coef, b, u, bc, None))
-    print(f"RR coarse-planes-per-chunk {zc:4d}: {rr:7.3f} ms  {17 * N / rr / 1e6:7.1f} GB/s", flush=True)
+for v in [int(x) for x in os.environ.get("RR_VARIANTS", "30,31,32").split(",")]:
+    for zc in (-1, 256):
+        L.mgk_set_tuning(v, zc)
+        rr = timeit(lambda: L.mgk_residual_restrict_f64(m.ctx, C.byref(g), C.byref(gc), coef, b, u, bc, None))
+        print(f"RR variant {v:2d} coarse-planes-per-chunk {zc:4d}: {rr:7.3f} ms  {17 * N / rr / 1e6:7.1f} GB/s", flush=True)
 m.close()

@@ -20,14 +20,15 @@ def timeit(fn, reps=4):
         m._chk(L.mgk_timer_elapsed_ms(m.ctx, t, C.byref(ms))); best = min(best, ms.value)
     return best
 N = float(n) ** 3
-for v in (2, 3, 1):
-    for zc in (-1, 512, 256):
+for v in [int(x) for x in os.environ.get("PJ_VARIANTS", "-1,34").split(",")]:
+    for zc in (-1,):
         L.mgk_set_tuning(v, zc)
         sw = timeit(lambda: L.mgk_jacobi_f32(m.ctx, C.byref(g), coef, dinv, 0.85, b, u, out, None))
         pj = timeit(lambda: L.mgk_prolong_jacobi_f32(m.ctx, C.byref(g), C.byref(gc), coef, dinv, 0.85, b, uc, u, out, None))
         print(f"variant {v} zc {zc:4d}: sweep {sw:6.3f} ms {12 * N / sw / 1e6:7.1f} GB/s | PJ {pj:6.3f} ms {12.5 * N / pj / 1e6:7.1f} GB/s", flush=True)
-for zc in (-1, 256, 128, 64):
-    L.mgk_set_tuning(-1, zc)
-    rr = timeit(lambda: L.mgk_residual_restrict_f32(m.ctx, C.byref(g), C.byref(gc), coef, b, u, bc, None))
-    print(f"RR32 coarse-planes-per-chunk {zc:4d}: {rr:6.3f} ms  {8.5 * N / rr / 1e6:7.1f} GB/s", flush=True)
+for v in [int(x) for x in os.environ.get("RR_VARIANTS", "-1,34").split(",")]:
+    for zc in (-1,):
+        L.mgk_set_tuning(v, zc)
+        rr = timeit(lambda: L.mgk_residual_restrict_f32(m.ctx, C.byref(g), C.byref(gc), coef, b, u, bc, None))
+        print(f"RR32 variant {v:2d} coarse-planes-per-chunk {zc:4d}: {rr:6.3f} ms  {8.5 * N / rr / 1e6:7.1f} GB/s", flush=True)
 m.close()
