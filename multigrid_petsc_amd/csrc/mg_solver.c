@@ -356,7 +356,8 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
         s->cfg.dist_min_n = n0 < 255 ? n0 : 255;
     }
     if (s->cfg.fuse < 0) s->cfg.fuse = 63 | 256;
-    if (s->cfg.pair_min_n <= 0) s->cfg.pair_min_n = (cfg->dim == 3) ? 511 : 2047;   /* where a two-sweep pass beats two sweeps */
+    if (s->cfg.pair_min_n <= 0) s->cfg.pair_min_n = (cfg->dim == 3) ? 255 : 2047;   /* where a two-sweep pass beats two sweeps
+                                                                                      * (255^3: 0.107 ms against 2 x 0.063) */
     if (s->cfg.mesh) s->cfg.fuse = 0;           /* row-dependent coefficients: the kernel-per-operation cycle on the row-table kernels */
     if (s->cfg.overlap < 0) s->cfg.overlap = 1;
     if (s->cfg.graph < 0) s->cfg.graph = 1;

@@ -1102,6 +1102,31 @@ extern "C" int mgk_partials_finish(mgk_ctx *c, int nparts, double *sumsq_host, v
 // one Jacobi update of a lane vector: o = c + scale * ((b - A.(dn, s, w, c, e, n, up)) * dinv), terms in the canonical order.
 // The float overload works on the 4-wide vector type so that the compiler issues packed fp32 instructions (v_pk_mul_f32 /
 // v_pk_add_f32: two lanes of the lane vector per instruction); every lane sees the same IEEE operations in the same order.
+// lane i <- lane i-1 / lane i+1 of the wavefront.  DPP form: whole-wavefront shifts (wave_shr:1 / wave_shl:1) on the vector ALU
+// instead of ds_bpermute on the LDS pipe; lane 0 / 63 keep their own value (the callers replace it by the wave-edge value).
+template <bool DPP> __device__ __forceinline__ double lane_up(double v) {
+    if (!DPP) return __shfl_up(v, 1, 64);
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <bool DPP> __device__ __forceinline__ double lane_dn(double v) {
+    if (!DPP) return __shfl_down(v, 1, 64);
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <bool DPP> __device__ __forceinline__ float lane_up(float v) {
+    if (!DPP) return __shfl_up(v, 1, 64);
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+template <bool DPP> __device__ __forceinline__ float lane_dn(float v) {
+    if (!DPP) return __shfl_down(v, 1, 64);
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
 template <typename T>
 __device__ __forceinline__ V16<T> jac7(T a0, T a1, T a2, T a3, T a4, T a5, T a6, T dinv, T scale, const V16<T> &dn, const V16<T> &sv,
                                        const V16<T> &c, const V16<T> &nv, const V16<T> &upv, T Wv, T Ev, const V16<T> &b) {
@@ -1161,8 +1186,9 @@ struct J2Args {
     int zbeg, zend;          // output planes of this launch (whole grid / slab: 0, nz)
 };
 
-template <typename T, int WX>
+template <typename T, int WX, int FORM>
 __global__ void __launch_bounds__(64 * WX) k_jacobi2(const J2Args<T> a) {
+    constexpr bool UNC = (FORM & 1) != 0, DPP = (FORM & 2) != 0;      // as in k_jacobi2r
     constexpr int VX = 16 / sizeof(T), TY = 4, R1 = TY + 4, R2 = TY + 2, TX = 64 * VX * WX, LW = TX + 2 * VX;
     __shared__ __attribute__((aligned(16))) T ring[3][R2][LW];
     __shared__ T edgeW[2][R2][WX], edgeE[2][R2][WX];          // first / last element of every wave's row segment
@@ -1194,21 +1220,46 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2(const J2Args<T> a) {
 
     // zero the ring (u'(-1) and the padding columns are 0) -- one pass, strided over the block
     for (int i = tid; i < 3 * R2 * LW; i += 64 * WX) (&ring[0][0][0])[i] = (T)0;
+    const unsigned lb = (unsigned)(x0 * (int)sizeof(T));
+    long uro[R1], bro[R2];
+#pragma unroll
+    for (int rr = 0; rr < R1; rr++) uro[rr] = (long)max(-1, min(yb - 2 + rr, a.ny)) * a.rs;
+#pragma unroll
+    for (int q = 0; q < R2; q++) bro[q] = (long)max(0, min(yb - 1 + q, a.ny)) * a.rs;
+    auto LDU = [&](int p, int rr, bool pv) -> VT {
+        if (UNC) {
+            const int pp = max(pmin, min(p, pmax));
+            const T *pl = (pp == -2) ? a.far_lo : (pp == a.nz + 1) ? a.far_hi : a.u + (long)pp * a.ms;
+            return *reinterpret_cast<const VT *>(reinterpret_cast<const char *>(pl + uro[rr]) + lb);
+        }
+        return ldv(uplane(p) + (long)rr * a.rs, uok[rr] && pv);
+    };
+    auto LDB = [&](int p, int q, bool pv, bool stream) -> VT {
+        if (UNC) {
+            const T *pl = a.b + (long)max(smin, min(p, smax)) * a.ms + bro[q];
+            const T *ad = reinterpret_cast<const T *>(reinterpret_cast<const char *>(pl) + lb);
+            return stream ? ldv_stream(ad, true) : ldv(ad, true);
+        }
+        const T *bp = bp_ + (long)p * a.ms + (long)q * a.rs;
+        const bool ok = xok && s1ok[q] && pv;
+        return stream ? ldv_stream(bp, ok) : ldv(bp, ok);
+    };
 
     VT ua[R1], ub[R1], uc[R1], ud[R1], b1[R2], bn[R2], b0[TY];
     const int t0 = z0 - 2;                                    // first step: stage 1 of plane z0 - 1
 #pragma unroll
     for (int rr = 0; rr < R1; rr++) {
         const long ro = (long)rr * a.rs;
-        ua[rr] = ldv(uplane(t0) + ro, uok[rr] && t0 >= pmin);
-        ub[rr] = ldv(uplane(t0 + 1) + ro, uok[rr] && t0 + 1 >= pmin);
-        uc[rr] = ldv(uplane(t0 + 2) + ro, uok[rr]);
+        (void)ro;
+        ua[rr] = LDU(t0, rr, t0 >= pmin);
+        ub[rr] = LDU(t0 + 1, rr, t0 + 1 >= pmin);
+        uc[rr] = LDU(t0 + 2, rr, true);
         ud[rr] = v16_zero<T>();
     }
 #pragma unroll
     for (int q = 0; q < R2; q++) {
         const int p = t0 + 1;
-        b1[q] = ldv(bp_ + (long)p * a.ms + (long)q * a.rs, xok && s1ok[q] && p >= smin && p <= smax);
+        b1[q] = LDB(p, q, p >= smin && p <= smax, false);
         bn[q] = v16_zero<T>();
     }
 #pragma unroll
@@ -1228,15 +1279,10 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2(const J2Args<T> a) {
         // ---- loads consumed in the next step ----
         {
             const bool pu = (t + 3 <= pmax), pb = (t + 2 <= smax) && (t + 1 < z1);
-            const T *un = uplane(t + 3);
 #pragma unroll
-            for (int rr = 0; rr < R1; rr++) ud[rr] = ldv(un + (long)rr * a.rs, uok[rr] && pu);
+            for (int rr = 0; rr < R1; rr++) ud[rr] = LDU(t + 3, rr, pu);
 #pragma unroll
-            for (int q = 0; q < R2; q++) {
-                const T *bp = bp_ + (long)(t + 2) * a.ms + (long)q * a.rs;
-                const bool ok = xok && s1ok[q] && pb;
-                bn[q] = (q >= 2 && q < R2 - 2) ? ldv_stream(bp, ok) : ldv(bp, ok);     // rows shared with neighbours: cached
-            }
+            for (int q = 0; q < R2; q++) bn[q] = LDB(t + 2, q, pb, q >= 2 && q < R2 - 2);     // rows shared with neighbours: cached
         }
         // ---- stage 1: u'(p) on rows yb-1 .. yb+TY ----
         {
@@ -1245,7 +1291,7 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2(const J2Args<T> a) {
 #pragma unroll
             for (int q = 0; q < R2; q++) {
                 const int rr = q + 1;
-                T Wv = __shfl_up(ub[rr].v[VX - 1], 1, 64), Ev = __shfl_down(ub[rr].v[0], 1, 64);
+                T Wv = lane_up<DPP>(ub[rr].v[VX - 1]), Ev = lane_dn<DPP>(ub[rr].v[0]);
                 if (lane == 0) Wv = (w > 0) ? edgeE[eb][q][w - 1] : (T)0;
                 if (lane == 63) Ev = (w < WX - 1) ? edgeW[eb][q][w + 1] : (T)0;
                 VT o = jac7(a.a0, a.a1, a.a2, a.a3, a.a4, a.a5, a.a6, a.dinv, a.scale, ua[rr], ub[rr - 1], ub[rr], ub[rr + 1], uc[rr], Wv, Ev, b1[q]);
@@ -1300,8 +1346,11 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2(const J2Args<T> a) {
 // neighbours of the second sweep are read from, double buffered (written in step t-1, read in step t while u'(t+1) goes
 // to the other buffer).  The plane of u brought in for the next step is loaded straight into the registers of the plane
 // the first sweep has just finished with.
-template <typename T, int WX>
+template <typename T, int WX, int FORM>
 __global__ void __launch_bounds__(64 * WX) k_jacobi2r(const J2Args<T> a) {
+    // FORM bit 0: unconditional loads with rows / planes clamped on the scalar unit (full-row shapes only: no lane outside the
+    // grid; whatever a clamped load brings in only reaches first-sweep values that are forced to 0 anyway); bit 1: DPP lane shifts
+    constexpr bool UNC = (FORM & 1) != 0, DPP = (FORM & 2) != 0;
     constexpr int VX = 16 / sizeof(T), TY = 4, R1 = TY + 4, R2 = TY + 2, TX = 64 * VX * WX, LW = TX + 2 * VX;
     __shared__ __attribute__((aligned(16))) T cen[2][R2][LW];
     __shared__ T edgeW[2][R2][WX], edgeE[2][R2][WX];
@@ -1331,20 +1380,45 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2r(const J2Args<T> a) {
         return (p == -2 ? a.far_lo : p == a.nz + 1 ? a.far_hi : a.u + (long)p * a.ms) + uoff;
     };
     for (int i = tid; i < 2 * R2 * LW; i += 64 * WX) (&cen[0][0][0])[i] = (T)0;
+    const unsigned lb = (unsigned)(x0 * (int)sizeof(T));
+    long uro[R1], bro[R2];
+#pragma unroll
+    for (int rr = 0; rr < R1; rr++) uro[rr] = (long)max(-1, min(yb - 2 + rr, a.ny)) * a.rs;
+#pragma unroll
+    for (int q = 0; q < R2; q++) bro[q] = (long)max(0, min(yb - 1 + q, a.ny)) * a.rs;
+    auto LDU = [&](int p, int rr, bool pv) -> VT {
+        if (UNC) {
+            const int pp = max(pmin, min(p, pmax));
+            const T *pl = (pp == -2) ? a.far_lo : (pp == a.nz + 1) ? a.far_hi : a.u + (long)pp * a.ms;
+            return *reinterpret_cast<const VT *>(reinterpret_cast<const char *>(pl + uro[rr]) + lb);
+        }
+        return ldv(uplane(p) + (long)rr * a.rs, uok[rr] && pv);
+    };
+    auto LDB = [&](int p, int q, bool pv, bool stream) -> VT {
+        if (UNC) {
+            const T *pl = a.b + (long)max(smin, min(p, smax)) * a.ms + bro[q];
+            const T *ad = reinterpret_cast<const T *>(reinterpret_cast<const char *>(pl) + lb);
+            return stream ? ldv_stream(ad, true) : ldv(ad, true);
+        }
+        const T *bp = bp_ + (long)p * a.ms + (long)q * a.rs;
+        const bool ok = xok && s1ok[q] && pv;
+        return stream ? ldv_stream(bp, ok) : ldv(bp, ok);
+    };
 
     VT ua[R1], ub[R1], uc[R1], b1[R2], bn[R2], b0[TY], wm[TY], wc[TY], wp[TY];
     const int t0 = z0 - 2;
 #pragma unroll
     for (int rr = 0; rr < R1; rr++) {
         const long ro = (long)rr * a.rs;
-        ua[rr] = ldv(uplane(t0) + ro, uok[rr] && t0 >= pmin);
-        ub[rr] = ldv(uplane(t0 + 1) + ro, uok[rr] && t0 + 1 >= pmin);
-        uc[rr] = ldv(uplane(t0 + 2) + ro, uok[rr]);
+        (void)ro;
+        ua[rr] = LDU(t0, rr, t0 >= pmin);
+        ub[rr] = LDU(t0 + 1, rr, t0 + 1 >= pmin);
+        uc[rr] = LDU(t0 + 2, rr, true);
     }
 #pragma unroll
     for (int q = 0; q < R2; q++) {
         const int p = t0 + 1;
-        b1[q] = ldv(bp_ + (long)p * a.ms + (long)q * a.rs, xok && s1ok[q] && p >= smin && p <= smax);
+        b1[q] = LDB(p, q, p >= smin && p <= smax, false);
         bn[q] = v16_zero<T>();
     }
 #pragma unroll
@@ -1363,11 +1437,7 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2r(const J2Args<T> a) {
         {   // b of the next step (u of the next step is issued after the first sweep, into the registers it frees)
             const bool pb = (t + 2 <= smax) && (t + 1 < z1);
 #pragma unroll
-            for (int q = 0; q < R2; q++) {
-                const T *bp = bp_ + (long)(t + 2) * a.ms + (long)q * a.rs;
-                const bool ok = xok && s1ok[q] && pb;
-                bn[q] = (q >= 2 && q < R2 - 2) ? ldv_stream(bp, ok) : ldv(bp, ok);
-            }
+            for (int q = 0; q < R2; q++) bn[q] = LDB(t + 2, q, pb, q >= 2 && q < R2 - 2);
         }
         // ---- second sweep of plane t: neighbours in x / y from cen[t & 1] (written in step t-1), z neighbours wm / wp ... ----
         // (wp = u'(t+1) is produced by the first sweep below, so the first sweep goes first)
@@ -1377,7 +1447,7 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2r(const J2Args<T> a) {
 #pragma unroll
             for (int q = 0; q < R2; q++) {
                 const int rr = q + 1;
-                T Wv = __shfl_up(ub[rr].v[VX - 1], 1, 64), Ev = __shfl_down(ub[rr].v[0], 1, 64);
+                T Wv = lane_up<DPP>(ub[rr].v[VX - 1]), Ev = lane_dn<DPP>(ub[rr].v[0]);
                 if (lane == 0) Wv = (w > 0) ? edgeE[eb][q][w - 1] : (T)0;
                 if (lane == 63) Ev = (w < WX - 1) ? edgeW[eb][q][w + 1] : (T)0;
                 VT o;
@@ -1411,9 +1481,8 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2r(const J2Args<T> a) {
         // plane t+3 of u into the registers of plane t (the first sweep is done with them)
         {
             const bool pu = (t + 3 <= pmax);
-            const T *un = uplane(t + 3);
 #pragma unroll
-            for (int rr = 0; rr < R1; rr++) ua[rr] = ldv(un + (long)rr * a.rs, uok[rr] && pu);
+            for (int rr = 0; rr < R1; rr++) ua[rr] = LDU(t + 3, rr, pu);
         }
         if (t >= z0) {
             const int cb = t & 1;
@@ -1488,17 +1557,34 @@ static int jacobi2(mgk_ctx *c, const mgk_geom *g, const double *coef, double din
     // one 512-thread block per CU (fp64, 1023^3): the one-barrier variant (4.51 vs 5.15 ms per pass); smaller blocks run two
     // per CU and hide the second barrier, and prefer the ring variant's full-step prefetch distance (fp64 511^3: 0.66 vs
     // 0.72 ms; fp32 1023^3: 3.98 vs 7.29 ms, the register variant is at the 256-VGPR limit there)
-    const bool ring = (g_variant == 1) || (g_variant != 2 && !(sizeof(T) == 8 && w > 4));
+    const bool ring = (g_variant == 1) || (g_variant == 37) || (g_variant != 2 && g_variant != 36 && !(sizeof(T) == 8 && w > 4));
+    // full-row shapes: unconditional loads + DPP lane shifts (tuning variants 36 / 37 keep the predicated / ds_bpermute form)
+    constexpr int WR = 64 * VX;
+    const bool full = (g->nx + 1) % WR == 0 && (g->ny + 1) % 4 == 0 && g_variant != 36 && g_variant != 37;
     if (ring) {
-        if (w <= 1) hipLaunchKernelGGL((k_jacobi2<T, 1>), dim3(nblk), dim3(64), 0, s, a);
-        else if (w <= 2) hipLaunchKernelGGL((k_jacobi2<T, 2>), dim3(nblk), dim3(128), 0, s, a);
-        else if (w <= 4) hipLaunchKernelGGL((k_jacobi2<T, 4>), dim3(nblk), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((k_jacobi2<T, 8>), dim3(nblk), dim3(512), 0, s, a);
+        if (full) {
+            if (w <= 1) hipLaunchKernelGGL((k_jacobi2<T, 1, 3>), dim3(nblk), dim3(64), 0, s, a);
+            else if (w <= 2) hipLaunchKernelGGL((k_jacobi2<T, 2, 3>), dim3(nblk), dim3(128), 0, s, a);
+            else if (w <= 4) hipLaunchKernelGGL((k_jacobi2<T, 4, 3>), dim3(nblk), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_jacobi2<T, 8, 3>), dim3(nblk), dim3(512), 0, s, a);
+        } else {
+            if (w <= 1) hipLaunchKernelGGL((k_jacobi2<T, 1, 0>), dim3(nblk), dim3(64), 0, s, a);
+            else if (w <= 2) hipLaunchKernelGGL((k_jacobi2<T, 2, 0>), dim3(nblk), dim3(128), 0, s, a);
+            else if (w <= 4) hipLaunchKernelGGL((k_jacobi2<T, 4, 0>), dim3(nblk), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_jacobi2<T, 8, 0>), dim3(nblk), dim3(512), 0, s, a);
+        }
     } else {
-        if (w <= 1) hipLaunchKernelGGL((k_jacobi2r<T, 1>), dim3(nblk), dim3(64), 0, s, a);
-        else if (w <= 2) hipLaunchKernelGGL((k_jacobi2r<T, 2>), dim3(nblk), dim3(128), 0, s, a);
-        else if (w <= 4) hipLaunchKernelGGL((k_jacobi2r<T, 4>), dim3(nblk), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((k_jacobi2r<T, 8>), dim3(nblk), dim3(512), 0, s, a);
+        if (full) {
+            if (w <= 1) hipLaunchKernelGGL((k_jacobi2r<T, 1, 3>), dim3(nblk), dim3(64), 0, s, a);
+            else if (w <= 2) hipLaunchKernelGGL((k_jacobi2r<T, 2, 3>), dim3(nblk), dim3(128), 0, s, a);
+            else if (w <= 4) hipLaunchKernelGGL((k_jacobi2r<T, 4, 3>), dim3(nblk), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_jacobi2r<T, 8, 3>), dim3(nblk), dim3(512), 0, s, a);
+        } else {
+            if (w <= 1) hipLaunchKernelGGL((k_jacobi2r<T, 1, 0>), dim3(nblk), dim3(64), 0, s, a);
+            else if (w <= 2) hipLaunchKernelGGL((k_jacobi2r<T, 2, 0>), dim3(nblk), dim3(128), 0, s, a);
+            else if (w <= 4) hipLaunchKernelGGL((k_jacobi2r<T, 4, 0>), dim3(nblk), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_jacobi2r<T, 8, 0>), dim3(nblk), dim3(512), 0, s, a);
+        }
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -2459,31 +2545,6 @@ __global__ void __launch_bounds__(64 * WX) k_resrestrict(const RRArgs<T> a) {
 // ring of NP = PD + 3 register sets indexed statically (the marching loop is unrolled by the ring period: no register
 // rotation), loaded PD planes ahead of their first use.  Row bases are wave-uniform, the lane offset is a 32-bit constant.
 // ------------------------------------------------------------------------------------------
-// lane i <- lane i-1 / lane i+1 of the wavefront.  DPP form: whole-wavefront shifts (wave_shr:1 / wave_shl:1) on the vector ALU
-// instead of ds_bpermute on the LDS pipe; lane 0 / 63 keep their own value (the callers replace it by the wave-edge value).
-template <bool DPP> __device__ __forceinline__ double lane_up(double v) {
-    if (!DPP) return __shfl_up(v, 1, 64);
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-template <bool DPP> __device__ __forceinline__ double lane_dn(double v) {
-    if (!DPP) return __shfl_down(v, 1, 64);
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-template <bool DPP> __device__ __forceinline__ float lane_up(float v) {
-    if (!DPP) return __shfl_up(v, 1, 64);
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
-}
-template <bool DPP> __device__ __forceinline__ float lane_dn(float v) {
-    if (!DPP) return __shfl_down(v, 1, 64);
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xf, 0xf, false));
-}
-
 // Loads of the row kernels are UNCONDITIONAL: the row / plane index is clamped on the scalar unit to something that exists
 // (rows beyond the ghost row alias the ghost row, planes beyond the chunk alias its last plane), and the shapes are restricted to
 // full rows (nx + 1 a multiple of the wave row) so that no lane lies outside the grid.  No exec masking, no branch per load.

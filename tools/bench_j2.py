@@ -24,8 +24,8 @@ def timeit(fn, reps=5):
 N = float(n) ** 3
 one = timeit(lambda: L.mgk_jacobi_f64(m.ctx, C.byref(g), coef, dinv, 0.85, b, u, out, None))
 print(f"n={n} plain sweep: {one:.3f} ms ({24 * N / one / 1e6:.0f} GB/s) -> two sweeps {2 * one:.3f} ms", flush=True)
-for var, zc in [(v, z) for v in (-1, 1) for z in zcs]:
+for var, zc in [(v, z) for v in (2, 36, 1, 37) for z in zcs]:
     L.mgk_set_tuning(var, zc)
     two = timeit(lambda: L.mgk_jacobi2_f64(m.ctx, C.byref(g), coef, dinv, 0.85, b, u, out, None))
-    print(f"n={n} variant={'one-barrier' if var < 0 else 'ring'} zc={zc}: two-in-one {two:.3f} ms  ({24 * N / two / 1e6:.0f} GB/s of the 24 B/unknown minimum; {two / (2 * one):.2f} x the two plain sweeps)", flush=True)
+    print(f"n={n} variant={ {2: 'one-barrier', 36: 'one-barrier, predicated loads + ds_bpermute', 1: 'ring', 37: 'ring, predicated loads + ds_bpermute'}[var]} zc={zc}: two-in-one {two:.3f} ms  ({24 * N / two / 1e6:.0f} GB/s of the 24 B/unknown minimum; {two / (2 * one):.2f} x the two plain sweeps)", flush=True)
 m.close()
