@@ -117,6 +117,99 @@ def plain_sweep_probe(device, n):
             "algorithmic_bytes_per_launch": JACOBI_BYTES_PER_DOF * float(n) ** 3}
 
 
+# ---------------------------------------------------------------------------------------------
+# whole-cycle roofline: the bytes ONE V(3,3) cycle of this implementation cannot avoid moving,
+# per unknown of the level where a pass runs, times the level sizes
+# ---------------------------------------------------------------------------------------------
+def cycle_compulsory_bytes(dim, npts, levels, precision):
+    """3-D fp64, fine level: sweep+norm 24 + two sweeps in one pass 24 + fused residual/restriction 16+8/8 + fused
+    prolongation sweep 24+8/8 + two sweeps in one pass 24 = 114 B/unknown; coarser levels have no norm pass and get their
+    first (zero-guess) sweep from the restriction kernel (+8 written): 24 + 17 + 8/8 + 25 + 24 = 91.  2-D (no fused
+    residual/restriction, pairs on levels >= 2047^2 only): fine 24 + 24 + 24 (residual) + 10 (restriction) + 26 + 24 = 132,
+    coarser levels 16 + 48 + 34 + 26 + 48 = 172 (one sweep per pass), capped at what the per-operation count of SURVEY 8(d3)
+    gives.  Mixed precision: the fp32 inner cycle moves half of the 3-D figures (no norm pass: 45 / 45.5) plus the fp64 outer
+    correction+residual pass, 32 B per fine unknown.  The coarsest level makes v1 = 3 plain sweeps (16 + 24 + 24)."""
+    tot = 0.0
+    for l in range(levels):
+        n = (npts - 1) // (2 ** l) - 1
+        N = float(n) ** dim
+        if l == levels - 1 and levels > 1:
+            per = 64.0
+        elif dim == 3:
+            per = 114.0 if l == 0 else 91.0
+        else:
+            per = 132.0 if (l == 0 and n >= 2047) else 172.0
+        if precision == "mixed":
+            per = (91.0 / 2 if l else 91.0 / 2 + 32.0) if not (l == levels - 1 and levels > 1) else 32.0
+        tot += per * N
+    return tot
+
+
+def golden_history(key):
+    """normalised residual histories rnorm[i]/rnorm[0] of the bench configurations (tests/golden/bench_history.json, made by
+    tools/make_bench_golden.py on an MI355X with the kernel-per-operation cycle, fuse=0); None when the file has no entry"""
+    path = os.path.join(ROOT, "tests", "golden", "bench_history.json")
+    try:
+        return json.load(open(path)).get(key)
+    except Exception:
+        return None
+
+
+def check_history(key, rn):
+    """every entry of the history this run produced against the committed one, while it is above the rounding floor"""
+    gold = golden_history(key)
+    if not gold:
+        return None
+    worst, ncmp = 0.0, 0
+    for i in range(1, min(len(rn), len(gold))):
+        g = gold[i]
+        if g < 1e-9:
+            break
+        worst = max(worst, abs(rn[i] / rn[0] / g - 1.0))
+        ncmp += 1
+    return {"entries_compared": ncmp, "max_rel_dev": worst, "ok": bool(ncmp > 0 and worst <= 1e-9)}
+
+
+def run_config(dim, npts, precision, steps, warmup, device):
+    """one more BASELINE configuration on this GPU (single rank): ms per cycle, DOF-updates/s, the HIP-event timed dominant
+    fine-level smoother launch, the whole-cycle roofline, and the residual history against the committed one"""
+    from multigrid_petsc_amd.solver import Solver
+    levels = 0
+    while (npts - 1) % (2 ** levels) == 0 and (npts - 1) // (2 ** levels) - 1 >= 1:
+        levels += 1
+    scale = 6.0 / 7.0 if dim == 3 else 0.8
+    s = Solver(dim, npts, levels, v=(3, 3), maxiter=steps + warmup + 1, scale=scale, device=device, precision=precision)
+    s.set_rhs_problem()
+    s.cycles(warmup)
+    s.sync()
+    s.profile(True)
+    t0 = time.perf_counter()
+    s.cycles(steps)
+    s.sync()
+    el = time.perf_counter() - t0
+    pair_ms, pair_n = s.profile_read(1)
+    one_ms, one_n = s.profile_read(0)
+    n0 = npts - 2
+    N0 = float(n0) ** dim
+    esz = 8.0 if precision == "fp64" else 4.0
+    out = {"workload": f"{dim}-D npts={npts} ({n0}^{dim}), {levels} levels, V(3,3), {precision}",
+           "ms_per_cycle": 1e3 * el / steps, "dof_updates_per_s": s.dof_updates_per_cycle * steps / el, "steps": steps, "warmup": warmup}
+    if pair_n:
+        t = pair_ms / pair_n
+        out["dominant_kernel"] = {"kernel": "two fine-level sweeps in one pass", "avg_launch_ms": t, "launches": pair_n,
+                                  "achieved_GBs": 3 * esz * N0 / (t * 1e-3) / 1e9, "frac": 3 * esz * N0 / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    elif one_n:
+        t = one_ms / one_n
+        out["dominant_kernel"] = {"kernel": "one fine-level sweep", "avg_launch_ms": t, "launches": one_n,
+                                  "achieved_GBs": 3 * esz * N0 / (t * 1e-3) / 1e9, "frac": 3 * esz * N0 / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    cb = cycle_compulsory_bytes(dim, npts, levels, precision)
+    gbs = cb / (el / steps) / 1e9
+    out["cycle_roofline"] = {"compulsory_bytes": cb, "GB/s": gbs, "frac": gbs / HBM_PEAK_GBS}
+    out["history"] = check_history(f"{dim}d_{npts}_{precision}", s.rnorm)
+    s.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,6 +221,7 @@ def main():
     ap.add_argument("--precision", choices=["fp64", "mixed"], default="fp64",
                     help="mixed = BASELINE config 5: fp32 smoother sweeps, fp64 residual/correction (1 GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations (2-D 4097^2, 3-D 513^3, mixed 1025^3)")
     ap.add_argument("--cpu-npts", type=int, default=257)
     ap.add_argument("--cpu-levels", type=int, default=8)
     ap.add_argument("--cpu-cycles", type=int, default=120)
@@ -296,6 +390,14 @@ def main():
             "residual_reduction_per_cycle": float((rn[-1] / rn[-1 - args.steps]) ** (1.0 / args.steps)) if len(rn) > args.steps else None,
             "roofline": roof,
         }
+        if world == 1:
+            cb = cycle_compulsory_bytes(args.dim, args.npts, levels, args.precision)
+            gbs = cb / (elapsed / args.steps) / 1e9
+            # the whole cycle against the bytes it cannot avoid (per-operation count of SURVEY 8(d3) beside it)
+            out["cycle_roofline"] = {"compulsory_bytes": cb, "GB/s": gbs, "frac": gbs / HBM_PEAK_GBS,
+                                     "bytes_per_fine_unknown": cb / float(n0) ** args.dim,
+                                     "model": "bytes one cycle of THIS implementation must move (fused passes; DESIGN.md section 4)"}
+            out["history"] = check_history(f"{args.dim}d_{args.npts}_{args.precision}", rn)
     s.close()
     if rank == 0:
         if world == 1 and pair_n and args.dim == 3 and args.precision == "fp64":
@@ -313,6 +415,17 @@ def main():
                 out["roofline"]["measured_ceiling"] = tri
             except Exception as e:   # reporting only
                 out["roofline"]["measured_ceiling"] = {"error": str(e)}
+        default_headline = (world == 1 and args.dim == 3 and args.npts == 1025 and args.precision == "fp64")
+        if default_headline and not args.no_configs:
+            # the other single-GPU BASELINE configurations ride in the same line (configs 2, 3, 5); config 4 is the N > 1 run
+            out["configs"] = []
+            for name, (d_, np_, pr_) in (("config2", (2, 4097, "fp64")), ("config3", (3, 513, "fp64")), ("config5", (3, 1025, "mixed"))):
+                try:
+                    c_ = run_config(d_, np_, pr_, 10, 2, local_rank)
+                except Exception as e:   # reporting only
+                    c_ = {"error": str(e)}
+                c_["baseline_config"] = name
+                out["configs"].append(c_)
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args)

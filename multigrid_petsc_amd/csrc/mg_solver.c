@@ -747,8 +747,12 @@ static int smooth(mg_solver *s, int P, int l, int maxit) {
                     CHK(O->jacobi2_slab(s->ctx, &F->g, &F->gfar, L->coef, L->dinv, s->cfg.scale, F->b, F->u, F->tmp, F->far, lo, hi, 0, nz, cs));
                 }
             } else if (s->cfg.dim == 2) {
+                s->prof_kind = 1;
+                void *t = prof_begin(s, l);
+                s->prof_kind = 0;
                 CHK(mgk_jacobi2_2d_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u,
                                        (double *)F->tmp, NULL));
+                prof_end(s, t);
             } else {
                 s->prof_kind = 1;
                 void *t = prof_begin(s, l);

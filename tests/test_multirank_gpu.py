@@ -290,3 +290,39 @@ def test_phantom_rank_runs_the_slab_cycle(rank):
     assert np.all(np.isfinite(s.rnorm)) and s.iterations == 3
     s.close()
     c.close()
+
+
+@pytest.mark.timeout(900)
+def test_full_size_eight_slabs_equal_the_single_rank_cycle():
+    """BASELINE config 4 at its own size: 1023^3 cut into the 8 z-slabs of the 8-GPU job (loopback ranks share this one GPU;
+    every kernel, stream, event and exchange of the slab path runs, only the wire differs) for 3 V-cycles, against the
+    single-rank run: residual history to rounding, and the field through the three GetError sums (max |e| identical --
+    it is one element of the field -- the two sums to summation order)."""
+    from multigrid_petsc_amd.solver import Solver
+    from multigrid_petsc_amd.comm import LoopbackWorld
+    s = Solver(3, 1025, 10, scale=6.0 / 7.0, maxiter=8)
+    s.set_rhs_problem()
+    s.cycles(3)
+    s.sync()
+    rn1, e1 = s.rnorm.copy(), s.error_norms()
+    s.close()
+    world = LoopbackWorld(8)
+
+    def fn(rank, comm):
+        r = Solver(3, 1025, 10, scale=6.0 / 7.0, maxiter=8, rank=rank, nranks=8, comm=comm)
+        r.set_rhs_problem()
+        r.cycles(3)
+        r.sync()
+        out = (r.rnorm.copy(), r.error_norms(), [r.level_planes(l) for l in range(10)])
+        r.close()
+        return out
+
+    try:
+        res = world.run(fn)
+    finally:
+        world.close()
+    assert sum(r[2][0][1] for r in res) == 1023 and all(r[2][3][1] == 127 for r in res)      # levels 0-2 cut, 127^3 replicated
+    for rn, e, _ in res:
+        assert np.abs(rn / rn1 - 1).max() <= 1e-12
+        assert e[0] == e1[0]
+        assert abs(e[1] - e1[1]) <= 1e-12 * e1[1] and abs(e[2] - e1[2]) <= 1e-12 * e1[2]
