@@ -78,6 +78,14 @@ int main(int argc, char **argv) {
     if ((v = get("-pc_type")) && strcmp(v, "jacobi")) { fprintf(stderr, "mgpoisson: only -pc_type jacobi is built\n"); return 2; }
     if ((v = get("-cycle")) && atoi(v) != 0) { fprintf(stderr, "mgpoisson: only -cycle 0 (V-cycle) is built\n"); return 2; }
     if ((v = get("-mesh"))) c.mesh = atoi(v);
+    /* the V-cycle has one grid per level (src/poisson.c:61-71 guards the other combinations): -grids, when given, must agree */
+    if ((v = get("-grids")) && atoi(v) != c.levels) {
+        fprintf(stderr, "mgpoisson: -grids %d differs from -levels %d: only one grid per level (the V-cycle case) is built\n", atoi(v), c.levels);
+        return 2;
+    }
+    int map = 2;                                       /* poisson.in:11 */
+    if ((v = get("-map"))) map = atoi(v);
+    if (map < 0 || map > 2) { fprintf(stderr, "mgpoisson: -map must be 0, 1 or 2 (src/poisson.c:190-192)\n"); return 2; }
 
     mg_solver *s = NULL;
     if (mg_solver_create(&s, &c, NULL)) { fprintf(stderr, "mgpoisson: %s\n", mg_last_error()); return 1; }
@@ -102,6 +110,7 @@ int main(int argc, char **argv) {
         double *u = (double *)malloc(N * sizeof(double)), *x = (double *)malloc((size_t)c.npts * sizeof(double));
         if (!u || !x || mg_solver_get_solution(s, u)) { fprintf(stderr, "mgpoisson: cannot fetch the solution: %s\n", mg_last_error()); return 1; }
         double *y = (double *)malloc((size_t)c.npts * sizeof(double));
+        if (!y) { fprintf(stderr, "mgpoisson: out of memory\n"); return 1; }
         x[0] = 0.0;                                       /* Coords, uniform branch: repeated addition (src/mesh.c:150-152) */
         for (int q = 1; q < c.npts - 1; q++) x[q] = x[q - 1] + 1.0 / (c.npts - 1);
         x[c.npts - 1] = 1.0;
@@ -138,7 +147,8 @@ int main(int argc, char **argv) {
     for (int l = 0; l < c.levels; l++) printf("1\t");
     printf("\nNumber of unknowns per level:\t");
     for (int l = 0; l < c.levels; l++) { double n = mg_solver_level_n(s, l); printf("%.0f\t", c.dim == 3 ? n * n * n : n * n); }
-    printf("\nMapping style :\t\t\tLocal grid after grid\n");     /* one grid per level: all three styles coincide */
+    /* one grid per level: the three styles give the same (lexicographic) map; the line names the one that was asked for */
+    printf("\nMapping style :\t\t\t%s\n", map == 0 ? "Grid after grid" : map == 1 ? "Through the grids" : "Local grid after grid");
     printf("Cycle :\t\t\t\tV-Cycle\n");
     printf("Number of smoothing steps :\t%d(fine) %d(coarsest)\n", c.v[0], c.v[1]);
     printf("Number of processes:\t\t1\n");

@@ -496,6 +496,7 @@ static int sin_tables(mg_solver *s, double **cx, double **sx, double **sy, doubl
     int npts = s->cfg.npts, n = L->n;
     double *c = (double *)malloc(sizeof(double) * npts);
     double *t = (double *)malloc(sizeof(double) * n), *tc = (double *)malloc(sizeof(double) * n);
+    if (!c || !t || !tc) { free(c); free(t); free(tc); return mgfail(MGK_EINVAL, "sin_tables: out of host memory"); }
     coords_uniform(npts, c);
     for (int j = 0; j < n; j++) {
         t[j] = sin(MG_PI * c[j + 1]);

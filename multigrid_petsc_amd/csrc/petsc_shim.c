@@ -867,11 +867,24 @@ PetscErrorCode PCMGSetR(PC pc, PetscInt l, Vec c) { pcmg *mg = need_mg(pc, "PCMG
 PetscErrorCode PCMGSetRhs(PC pc, PetscInt l, Vec c) { pcmg *mg = need_mg(pc, "PCMGSetRhs"); mg->b[mg_level(mg, l, "PCMGSetRhs")] = c; return 0; }
 PetscErrorCode PCMGSetX(PC pc, PetscInt l, Vec c) { pcmg *mg = need_mg(pc, "PCMGSetX"); mg->x[mg_level(mg, l, "PCMGSetX")] = c; return 0; }
 
+/* No -pc_type: PETSc would use ILU(0) (block Jacobi + ILU(0) on several ranks), which this drop-in does not provide.
+ * MGPETSC_DEFAULT_PC=jacobi opts in to the substitution silently; MGPETSC_DEFAULT_PC=refuse makes the run stop instead of
+ * producing numbers that differ from a PETSc run while looking like one; otherwise Jacobi is substituted and the run says so
+ * on stderr AND in its stdout report (and in KSPView), once. */
 static int ksp_pc(KSP k) {
     if (k->pc == P_DEFAULT) {
         if (!g_notice_pc) {
-            fprintf(stderr, "[mgpetsc] note: PETSc's default preconditioner (ILU(0)) is not provided; "
-                            "using -pc_type jacobi (pass it explicitly to silence this note)\n");
+            const char *e = getenv("MGPETSC_DEFAULT_PC");
+            if (e && !strcmp(e, "refuse")) {
+                fprintf(stderr, "[mgpetsc] no -pc_type given: PETSc's default preconditioner (ILU(0)) is not provided and "
+                                "MGPETSC_DEFAULT_PC=refuse is set; pass -pc_type jacobi\n");
+                exit(2);
+            }
+            if (!(e && !strcmp(e, "jacobi"))) {
+                fprintf(stderr, "[mgpetsc] note: PETSc's default preconditioner (ILU(0)) is not provided; "
+                                "using -pc_type jacobi (pass it explicitly to silence this note)\n");
+                printf("[mgpetsc] -pc_type not given: Jacobi substituted for PETSc's default ILU(0); iteration counts differ from a PETSc run\n");
+            }
             g_notice_pc = 1;
         }
         return P_JACOBI;

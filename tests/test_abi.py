@@ -127,3 +127,69 @@ def test_implicit_maps_equal_the_reference_maps_bit_exactly(npts, levels, style)
                 L.mg_global_to_grid(2, n, idx, C.byref(k), C.byref(i), C.byref(j))
                 assert (i.value, j.value, l) == tuple(glob[3 * idx:3 * idx + 3])
             assert np.array_equal(S.get_ranges(tot, procs), ranges)
+
+
+def _petsc_surface():
+    """every function include/petscksp.h declares (prototypes only: `type name(args);` at the start of a line)"""
+    txt = open(os.path.join(ROOT, "include", "petscksp.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = "\n".join(l for l in txt.splitlines() if not l.lstrip().startswith("#"))
+    names = re.findall(r"^\s*(?:PetscErrorCode|PetscViewer|int|double)\s+([A-Za-z_][A-Za-z0-9_]*)\s*\(", txt, flags=re.M)
+    return sorted(set(names))
+
+
+def test_libmgpetsc_exports_the_whole_petsc_surface():
+    """the drop-in must export every PETSc / MPI entry point its header promises the reference driver"""
+    from multigrid_petsc_amd._lib import load_mgpetsc
+    L = load_mgpetsc()
+    names = _petsc_surface()
+    assert len(names) >= 80 and "KSPSolve" in names and "MPI_Wtime" in names and "PCMGSetX" in names
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, f"libmgpetsc.so does not export {missing}"
+
+
+def test_reference_objects_need_nothing_the_drop_in_lacks(tmp_path):
+    """In the build container (the reference is present): compile the reference's six UNMODIFIED sources against
+    include/petscksp.h and require every undefined symbol of the objects to be exported by libmgpetsc.so / libmgk.so or to
+    come from libc / libm -- the link of build/refdriver/poisson cannot fail on a missing PETSc entry point."""
+    import subprocess
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "src")):
+        pytest.skip("the reference tree is not on this machine")
+    from multigrid_petsc_amd._lib import load_mgpetsc, load_mgk
+    Lp, Lk = load_mgpetsc(), load_mgk()
+    libc = C.CDLL(None)
+    libm = C.CDLL("libm.so.6")
+    undefined = set()
+    for f in ("array", "matbuild", "mesh", "problem", "solver", "poisson"):
+        o = str(tmp_path / (f + ".o"))
+        subprocess.run(["gcc", "-std=c99", "-O1", "-w", "-I" + os.path.join(ref, "include"), "-I" + os.path.join(ROOT, "include"),
+                        "-c", os.path.join(ref, "src", f + ".c"), "-o", o], check=True)
+        out = subprocess.run(["nm", "-u", o], check=True, stdout=subprocess.PIPE, text=True).stdout
+        undefined |= {l.split()[-1] for l in out.splitlines() if l.strip()}
+    defined = set()
+    for f in ("array", "matbuild", "mesh", "problem", "solver", "poisson"):
+        out = subprocess.run(["nm", "--defined-only", str(tmp_path / (f + ".o"))], check=True, stdout=subprocess.PIPE, text=True).stdout
+        defined |= {l.split()[-1] for l in out.splitlines() if l.strip()}
+    need = sorted(undefined - defined - {"_GLOBAL_OFFSET_TABLE_"})
+    surface = set(_petsc_surface())
+    missing = [n for n in need if not (hasattr(Lp, n) or hasattr(Lk, n) or hasattr(libc, n) or hasattr(libm, n))]
+    assert not missing, f"undefined in the reference objects and provided by nobody: {missing}"
+    petsc_like = [n for n in need if re.match(r"(Petsc|Vec|Mat|KSP|PC|IS|MPI_|PETSC_)", n)]
+    assert len(petsc_like) >= 60
+    not_declared = [n for n in petsc_like if n not in surface]
+    assert not not_declared, f"used by the reference but not declared in include/petscksp.h: {not_declared}"
+
+
+def test_own_driver_refuses_option_combinations_it_does_not_build(tmp_path):
+    """mgpoisson checks its options before it touches the GPU: -grids != -levels (several grids per level), -map outside 0..2,
+    another -pc_type or -cycle stop with exit code 2 and a message (the reference guards its own combinations the same way,
+    src/poisson.c:61-71)"""
+    import subprocess
+    exe = os.path.join(ROOT, "multigrid_petsc_amd", "mgpoisson")
+    if not os.path.exists(exe):
+        pytest.skip("mgpoisson is not built")
+    for args, msg in ((["-levels", "2", "-grids", "3"], "-grids 3 differs from -levels 2"), (["-map", "5"], "-map must be"),
+                      (["-pc_type", "ilu"], "only -pc_type jacobi"), (["-cycle", "3"], "only -cycle 0")):
+        p = subprocess.run([exe] + args, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
+        assert p.returncode == 2 and msg in p.stdout, (args, p.returncode, p.stdout)

@@ -228,8 +228,26 @@ def test_reference_driver_default_options_file(orc, tmp_path):
     it, rdat, u, e, out = _run_reference_driver(tmp_path, opts)
     ref = orc.vcycle(2, 17, 2, 3, 3, maxiter=100000, scale=1.0, use_csr=0)
     assert it == ref["iters"] == 99
-    assert "default preconditioner (ILU(0)) is not provided" in out
+    assert "default preconditioner (ILU(0)) is not provided" in out                    # stderr note
+    assert "Jacobi substituted for PETSc's default ILU(0)" in out                      # and in the stdout report
     assert np.array_equal(u, ref["u"])
+    # MGPETSC_DEFAULT_PC=jacobi opts in silently; =refuse stops the run instead of printing PETSc-looking numbers
+    it2, _, u2, _, out2 = _run_reference_driver(tmp_path, opts, {"MGPETSC_DEFAULT_PC": "jacobi"})
+    assert it2 == 99 and np.array_equal(u2, u) and "ILU(0)" not in out2.split("KSP Object")[0]
+    env = dict(os.environ, MGPETSC_DEFAULT_PC="refuse")
+    p = subprocess.run([REFDRV], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 2 and "MGPETSC_DEFAULT_PC=refuse" in p.stdout
+
+
+def test_own_driver_names_the_mapping_style_it_was_given(tmp_path):
+    """src/poisson.c:190-192: the PrintInfo block names the -map style (with one grid per level all three give the same map)"""
+    for m, name in ((0, "Grid after grid"), (1, "Through the grids"), (2, "Local grid after grid")):
+        p = subprocess.run([MGPOISSON, "-dim", "2", "-npts", "17", "-levels", "2", "-grids", "2", "-pc_type", "jacobi",
+                            "-ksp_richardson_scale", "0.8", "-map", str(m)], cwd=tmp_path, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout
+        line = [l for l in p.stdout.splitlines() if l.startswith("Mapping style")][0]
+        assert line.split(":")[1].strip() == name
 
 
 @pytest.mark.skipif(not os.path.exists(REFDRV), reason="build/refdriver/poisson absent")
