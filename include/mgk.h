@@ -213,6 +213,19 @@ int  mgk_prolong_jacobi_range_f32(mgk_ctx *ctx, const mgk_geom *gf, const mgk_ge
                                   double scale, const float *b, const float *uc, const float *u, float *unew,
                                   int zbeg, int zend, void *stream);
 
+/* ---- the tail of the hierarchy in one kernel (src/solver.c:1533-1544 restricted to the levels t .. L-1) ----
+ * One 1024-lane workgroup keeps u, its ping-pong partner and b of the `nlev` coarsest levels in LDS (n[0] <= mgk_tail_max_n(dim):
+ * 15 in 3-D, 63 in 2-D; n[l-1] = 2 n[l] + 1) and runs: v0 sweeps from a zero guess on the first level (v1 on the last one),
+ * residual + full weighting + sweeps down to the last level, then prolongation + v0 sweeps back up; Richardson + Jacobi with
+ * the level's 7 (2-D: 5 used; layout of mgk_jacobi_f64's coef, 7 doubles per level) coefficients and 1/diag.  Every operation
+ * evaluates the expressions of the kernel it replaces, so the result is bit-identical to the kernel-per-operation loop.
+ * b: right-hand side of the first tail level (padded field of geometry g0), u: its solution after the post-smoothing. */
+int  mgk_tail_cycle_f64(mgk_ctx *ctx, const mgk_geom *g0, int nlev, const int *n, const double *coef7, const double *dinv,
+                        double scale, int v0, int v1, const double *b, double *u, void *stream);
+int  mgk_tail_cycle_f32(mgk_ctx *ctx, const mgk_geom *g0, int nlev, const int *n, const double *coef7, const double *dinv,
+                        double scale, int v0, int v1, const float *b, float *u, void *stream);
+int  mgk_tail_max_n(int dim);
+
 /* ---- K6: VecNorm(NORM_2) (src/solver.c:1512,1518,1546): returns sum of squares of the interior ---- */
 int  mgk_sumsq_f64(mgk_ctx *ctx, const mgk_geom *g, const double *x, double *sumsq_host, void *stream);
 

@@ -80,6 +80,7 @@ typedef struct mg_ops {
     int (*residual_restrict_range)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const double *, const void *, const void *, void *, int, int, void *);
     int (*residual_restrict_slab)(mgk_ctx *, const mgk_geom *, const mgk_geom *, const mgk_geom *, const double *, const void *, const void *,
                                   const void *, int, void *, int, int, void *);
+    int (*tail_cycle)(mgk_ctx *, const mgk_geom *, int, const int *, const double *, const double *, double, int, int, const void *, void *, void *);
 } mg_ops;
 
 #define W64(name) static int name##_64
@@ -114,9 +115,11 @@ W64(rrr)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, co
 W32(rrr)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, const void *b, const void *u, void *bc, int k0, int k1, void *st) { return mgk_residual_restrict_range_f32(c, gf, gc, k, (const float *)b, (const float *)u, (float *)bc, k0, k1, st); }
 W64(rrs)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const mgk_geom *gfar, const double *k, const void *b, const void *u, const void *far, int hi, void *bc, int k0, int k1, void *st) { return mgk_residual_restrict_slab_f64(c, gf, gc, gfar, k, (const double *)b, (const double *)u, (const double *)far, hi, (double *)bc, k0, k1, st); }
 W32(rrs)(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const mgk_geom *gfar, const double *k, const void *b, const void *u, const void *far, int hi, void *bc, int k0, int k1, void *st) { return mgk_residual_restrict_slab_f32(c, gf, gc, gfar, k, (const float *)b, (const float *)u, (const float *)far, hi, (float *)bc, k0, k1, st); }
+W64(tc)(mgk_ctx *c, const mgk_geom *g0, int nl, const int *n, const double *k7, const double *di, double sc, int v0, int v1, const void *b, void *u, void *st) { return mgk_tail_cycle_f64(c, g0, nl, n, k7, di, sc, v0, v1, (const double *)b, (double *)u, st); }
+W32(tc)(mgk_ctx *c, const mgk_geom *g0, int nl, const int *n, const double *k7, const double *di, double sc, int v0, int v1, const void *b, void *u, void *st) { return mgk_tail_cycle_f32(c, g0, nl, n, k7, di, sc, v0, v1, (const float *)b, (float *)u, st); }
 static const mg_ops OPS[2] = {
-    {8, jr_64, jz_64, rs_64, rf_64, pa_64, pj_64, rr_64, rg_64, fin_64, rrz_64, j2_64, j2s_64, pjr_64, rrr_64, rrs_64},
-    {4, jr_32, jz_32, rs_32, rf_32, pa_32, pj_32, rr_32, rg_32, fin_32, rrz_32, j2_32, j2s_32, pjr_32, rrr_32, rrs_32},
+    {8, jr_64, jz_64, rs_64, rf_64, pa_64, pj_64, rr_64, rg_64, fin_64, rrz_64, j2_64, j2s_64, pjr_64, rrr_64, rrs_64, tc_64},
+    {4, jr_32, jz_32, rs_32, rf_32, pa_32, pj_32, rr_32, rg_32, fin_32, rrz_32, j2_32, j2s_32, pjr_32, rrr_32, rrs_32, tc_32},
 };
 
 struct mg_solver {
@@ -137,6 +140,7 @@ struct mg_solver {
     int spec_valid;         /* level-0 tmp holds Jacobi(u): made by the sweep+norm kernel that closed the last cycle */
     double solve_seconds;
     int lgraph;             /* levels >= lgraph form the launch-bound coarse part replayed as one HIP graph (0: off) */
+    int ltail;              /* levels >= ltail (n <= 15 in 3-D, <= 63 in 2-D) run as ONE kernel with their fields in LDS (0: off) */
     void *coarse_graph[2];  /* one recording per precision */
     /* profiling */
     int prof_on, prof_n;
@@ -355,7 +359,7 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
         const int n0 = mg_grid_n(cfg->npts, 0);
         s->cfg.dist_min_n = n0 < 255 ? n0 : 255;
     }
-    if (s->cfg.fuse < 0) s->cfg.fuse = 63 | 256;
+    if (s->cfg.fuse < 0) s->cfg.fuse = 63 | 256 | 512;
     if (s->cfg.pair_min_n <= 0) s->cfg.pair_min_n = (cfg->dim == 3) ? 255 : 2047;   /* where a two-sweep pass beats two sweeps
                                                                                       * (255^3: 0.107 ms against 2 x 0.063) */
     if (s->cfg.mesh) s->cfg.fuse = 0;           /* row-dependent coefficients: the kernel-per-operation cycle on the row-table kernels */
@@ -445,6 +449,14 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
             if (N <= 2097152.0) { s->lgraph = l; break; }
         }
         if (s->lgraph && s->levels - s->lgraph < 2) s->lgraph = 0;      /* not worth a graph */
+    }
+    /* the tail: the first level l >= 1 that is whole on this rank, fed by a whole level... any level qualifies as long as it
+     * and everything below it fit in LDS (n <= mgk_tail_max_n) -- and at least two levels are left, else a tail is no gain */
+    s->ltail = 0;
+    if ((s->cfg.fuse & 512) && s->cfg.ksp_type == MG_KSP_RICHARDSON && !s->cfg.mesh && s->cfg.v[0] >= 1) {
+        for (int l = (s->ldist > 0 ? s->ldist : 1); l < s->levels; l++)
+            if (s->L[l].n <= mgk_tail_max_n(cfg->dim)) { s->ltail = l; break; }
+        if (s->ltail && (s->levels - s->ltail < 2 || s->levels - s->ltail > 8)) s->ltail = 0;
     }
     s->rnorm_cap = (cfg->maxiter > 0 ? cfg->maxiter : 0) + 1;
     s->rnorm = (double *)calloc((size_t)s->rnorm_cap, sizeof(double));
@@ -925,8 +937,39 @@ static int prolong_smooth(mg_solver *s, int P, int l) {
     return smooth(s, P, l, v0 - 1);
 }
 
+static int descend_restrict(mg_solver *s, int P, int l, int no_jz);
+/* the levels ltail .. L-1 of one cycle in ONE kernel (their fields live in LDS): b of level ltail is there, u of level ltail
+ * comes back post-smoothed (src/solver.c:1536-1543 for those levels) */
+static int tail(mg_solver *s, int P) {
+    const int lt = s->ltail, nl = s->levels - lt;
+    int n[8];
+    double k7[8 * 7], di[8];
+    for (int q = 0; q < nl; q++) {
+        const mg_level *L = &s->L[lt + q];
+        n[q] = L->n; di[q] = L->dinv;
+        for (int e = 0; e < 7; e++) k7[7 * q + e] = L->coef[e];
+    }
+    mg_fset *F = &s->L[lt].f[P];
+    CHK(OPS[P].tail_cycle(s->ctx, &F->g, nl, n, k7, di, s->cfg.scale, s->cfg.v[0], s->cfg.v[1], F->b, F->u, NULL));
+    F->jz_ready = 0;
+    return 0;
+}
+
 /* one step of the descent: b_l = R(b_{l-1} - A u_{l-1}); smooth level l from a zero guess (src/solver.c:1534-1537) */
 static int descend(mg_solver *s, int P, int l) {
+    const int levels = s->levels, *v = s->cfg.v;
+    if (s->ltail && l == s->ltail) {              /* the restriction feeds the tail kernel, which smooths this level and all below */
+        CHK(descend_restrict(s, P, l, 1));
+        return tail(s, P);
+    }
+    CHK(descend_restrict(s, P, l, 0));
+    CHK(smooth(s, P, l, l == levels - 1 ? v[1] : v[0]));                /* :1536 */
+    if (l != levels - 1) s->L[l].f[P].guess_nonzero = 1;                /* :1537 */
+    return 0;
+}
+
+/* b_l = R(b_{l-1} - A u_{l-1})  (src/solver.c:1534-1535) */
+static int descend_restrict(mg_solver *s, int P, int l, int no_jz) {
     const int levels = s->levels, *v = s->cfg.v;
     mg_level *Lf = &s->L[l - 1];
     const mg_ops *O = &OPS[P];
@@ -936,7 +979,7 @@ static int descend(mg_solver *s, int P, int l) {
         /* :1534-1535 in one pass: b_l = R (b - A u), the fine residual is never written */
         mg_fset *Cq = &s->L[l].f[P];
         const int sweeps = (l == levels - 1) ? v[1] : v[0];
-        if ((s->cfg.fuse & 256) && s->cfg.ksp_type == MG_KSP_RICHARDSON && sweeps >= 1 && !Cq->guess_nonzero) {
+        if ((s->cfg.fuse & 256) && !no_jz && s->cfg.ksp_type == MG_KSP_RICHARDSON && sweeps >= 1 && !Cq->guess_nonzero) {
             /* ... and the coarse level's first sweep from its zero guess comes out of the same kernel (saves re-reading b_l) */
             CHK(O->residual_restrict_jz(s->ctx, &Lf->f[P].g, &Cq->g, Lf->coef, Lf->f[P].b, Lf->f[P].u, Cq->b, Cq->tmp, s->L[l].dinv,
                                         s->cfg.scale, NULL));
@@ -1023,8 +1066,6 @@ gathered:
         CHK(residual(s, P, l - 1));                                     /* :1534 */
         CHK(restrict_to(s, P, l));                                      /* :1535 */
     }
-    CHK(smooth(s, P, l, l == levels - 1 ? v[1] : v[0]));                /* :1536 */
-    if (l != levels - 1) s->L[l].f[P].guess_nonzero = 1;                /* :1537 */
     return 0;
 }
 
@@ -1032,14 +1073,14 @@ gathered:
  * (each level swaps u/tmp an even number of times per cycle; the coarsest is copied back when v1 is odd), so the
  * recorded kernels stay valid. */
 static int coarse_part(mg_solver *s, int P, int lg) {
-    const int levels = s->levels;
-    for (int l = lg; l < levels; l++) CHK(descend(s, P, l));
-    if (s->cfg.v[1] & 1) {                                              /* restore the coarsest level's buffer identity */
+    const int levels = s->levels, lend = s->ltail ? s->ltail : levels - 1;     /* last level the loops below handle themselves */
+    for (int l = lg; l <= lend; l++) CHK(descend(s, P, l));
+    if (!s->ltail && (s->cfg.v[1] & 1)) {                               /* restore the coarsest level's buffer identity */
         mg_fset *Cz = &s->L[levels - 1].f[P];
         CHK(mgk_d2d(s->ctx, Cz->tmp, Cz->u, (size_t)OPS[P].esz * (size_t)Cz->g.total, NULL));
         swap_ptr(&Cz->u, &Cz->tmp);
     }
-    for (int l = levels - 2; l >= lg; l--) {
+    for (int l = lend - 1; l >= lg; l--) {
         CHK(prolong_smooth(s, P, l));                                   /* :1540-1542 */
         s->L[l].f[P].guess_nonzero = 0;                                 /* :1543 (l != 0 here) */
     }
@@ -1053,8 +1094,9 @@ static int cycle_body(mg_solver *s, int P, int first) {
     const int lg = s->lgraph ? s->lgraph : levels;                      /* levels >= lg run as one HIP graph */
     CHK(smooth(s, P, 0, v[0]));                                         /* :1531 */
     if (first) s->L[0].f[P].guess_nonzero = 1;                          /* :1532 */
-    for (int l = 1; l < lg; l++) CHK(descend(s, P, l));
-    if (lg < levels) {
+    const int lend = s->ltail ? s->ltail : levels - 1;
+    for (int l = 1; l < lg && l <= lend; l++) CHK(descend(s, P, l));
+    if (lg < levels && lg <= lend) {
         if (!s->coarse_graph[P]) {                                      /* record once ... */
             CHK(mgk_capture_begin(s->ctx));
             int rc = coarse_part(s, P, lg);
@@ -1065,7 +1107,7 @@ static int cycle_body(mg_solver *s, int P, int first) {
         }
         CHK(mgk_graph_launch(s->ctx, s->coarse_graph[P]));              /* ... replay every cycle */
     }
-    for (int l = (lg < levels ? lg - 1 : levels - 2); l >= 0; l--) {
+    for (int l = ((lg < levels && lg <= lend) ? lg - 1 : lend - 1); l >= 0; l--) {
         CHK(prolong_smooth(s, P, l));                                   /* :1540-1542 */
         if (l != 0) s->L[l].f[P].guess_nonzero = 0;                     /* :1543 */
     }

@@ -3196,6 +3196,211 @@ extern "C" int mgk_prolong_jacobi_range_f32(mgk_ctx *c, const mgk_geom *gf, cons
 
 
 
+
+// ------------------------------------------------------------------------------------------
+// The tail of the hierarchy in ONE kernel: the levels with n <= 15 (3-D) / n <= 63 (2-D) hold at most a few thousand
+// unknowns each; their part of a V-cycle is ~50 launches of ~4.5 us of which the arithmetic is a rounding error.  One
+// 1024-lane workgroup keeps u, its ping-pong partner and b of EVERY tail level in LDS (ghost rings included: 139 KB in 3-D,
+// 137 KB in 2-D) and walks the reference's loop (src/solver.c:1533-1544) over them with a workgroup barrier between
+// operations.  Each operation evaluates exactly the expressions of the kernels it replaces (k_stencil / k_jacobi_zero /
+// k_restrict / k_prolong_add: same terms, same order, no FMA), so the cycle stays bit-identical.
+// In: b of the first tail level (global, padded layout; produced by the restriction from the level above).
+// Out: u of that level after its post-smoothing (global), ready for the prolongation to the level above.
+// ------------------------------------------------------------------------------------------
+#define MGK_TAIL_MAXLEV 8
+#define MGK_TAIL_LDS_BYTES 143360          /* 140 KiB of the 160 KiB */
+template <typename T>
+struct TailArgs {
+    int dim, nlev, v0, v1;
+    int n[MGK_TAIL_MAXLEV];
+    int off[MGK_TAIL_MAXLEV];              // offset (elements) of the level's three arrays in LDS: A0, A1 (u ping-pong), B; each (n+2)^dim
+    T coef[MGK_TAIL_MAXLEV][7], dinv[MGK_TAIL_MAXLEV];
+    T scale;
+    const T *b_in;
+    T *u_out;                              // both at the interior origin of the first tail level's padded field
+    long rs, ms;                           // its row / plane strides
+    int total;                             // elements of LDS in use
+};
+
+template <typename T, int DIM>
+__device__ __forceinline__ int tail_idx(int m, int k, int i, int j) {      // (k,i,j) interior coordinates -> index in an (n+2)^DIM array
+    return (DIM == 3) ? ((k + 1) * m + (i + 1)) * m + (j + 1) : (i + 1) * m + (j + 1);
+}
+// mode 0: out = u + scale*((b - A u)*dinv); mode 1: out = b - A u; mode 2 (zero guess): out = scale*(b*dinv)
+template <typename T, int DIM>
+__device__ void tail_stencil(int mode, int n, const T *cf, T dinv, T scale, const T *u, const T *b, T *out) {
+    const int m = n + 2, N = (DIM == 3) ? n * n * n : n * n, sk = m * m;
+    for (int p = threadIdx.x; p < N; p += blockDim.x) {
+        const int j = p % n, i = (p / n) % n, k = (DIM == 3) ? p / (n * n) : 0;
+        const int q = tail_idx<T, DIM>(m, k, i, j);
+        if (mode == 2) { const T zx = b[q] * dinv; out[q] = scale * zx; continue; }
+        T t;
+        if (DIM == 3) {
+            t = cf[0] * u[q - sk];
+            t = t + cf[1] * u[q - m];
+            t = t + cf[2] * u[q - 1];
+            t = t + cf[3] * u[q];
+            t = t + cf[4] * u[q + 1];
+            t = t + cf[5] * u[q + m];
+            t = t + cf[6] * u[q + sk];
+        } else {
+            t = cf[0] * u[q - m];
+            t = t + cf[1] * u[q - 1];
+            t = t + cf[2] * u[q];
+            t = t + cf[3] * u[q + 1];
+            t = t + cf[4] * u[q + m];
+        }
+        const T res = b[q] - t;
+        if (mode == 1) { out[q] = res; continue; }
+        const T zz = res * dinv;
+        out[q] = u[q] + scale * zz;
+    }
+}
+// bc = R r (k_restrict: ascending fine index (dk, di, dj), weights w1[dk]*w2[di][dj])
+template <typename T, int DIM>
+__device__ void tail_restrict(int nf, int nc, const T *r, T *bc) {
+    const int mf = nf + 2, mc = nc + 2, N = (DIM == 3) ? nc * nc * nc : nc * nc;
+    const T w2[3][3] = {{(T)0.0625, (T)0.125, (T)0.0625}, {(T)0.125, (T)0.25, (T)0.125}, {(T)0.0625, (T)0.125, (T)0.0625}};
+    const T w1[3] = {(T)0.25, (T)0.5, (T)0.25};
+    for (int p = threadIdx.x; p < N; p += blockDim.x) {
+        const int jc = p % nc, ic = (p / nc) % nc, kc = (DIM == 3) ? p / (nc * nc) : 0;
+        T sum = (T)0;
+        if (DIM == 3) {
+#pragma unroll
+            for (int dk = 0; dk < 3; dk++)
+#pragma unroll
+                for (int di = 0; di < 3; di++) {
+                    const T *row = r + tail_idx<T, DIM>(mf, 2 * kc + dk, 2 * ic + di, 2 * jc);
+                    sum += (w1[dk] * w2[di][0]) * row[0];
+                    sum += (w1[dk] * w2[di][1]) * row[1];
+                    sum += (w1[dk] * w2[di][2]) * row[2];
+                }
+        } else {
+#pragma unroll
+            for (int di = 0; di < 3; di++) {
+                const T *row = r + tail_idx<T, DIM>(mf, 0, 2 * ic + di, 2 * jc);
+                sum += w2[di][0] * row[0];
+                sum += w2[di][1] * row[1];
+                sum += w2[di][2] * row[2];
+            }
+        }
+        bc[tail_idx<T, DIM>(mc, kc, ic, jc)] = sum;
+    }
+}
+// uf += P uc (k_prolong_add / prolong_one: parents in ascending coarse index, weight wk*(wi*wj) each)
+template <typename T, int DIM>
+__device__ void tail_prolong_add(int nf, int nc, const T *uc, T *uf) {
+    const int mf = nf + 2, mc = nc + 2, N = (DIM == 3) ? nf * nf * nf : nf * nf;
+    for (int p = threadIdx.x; p < N; p += blockDim.x) {
+        const int x = p % nf, i = (p / nf) % nf, k = (DIM == 3) ? p / (nf * nf) : 1;
+        const int iodd = i & 1, kodd = k & 1, xodd = x & 1;
+        const int ic0 = iodd ? (i - 1) / 2 : i / 2 - 1, nic = iodd ? 1 : 2;
+        const int kc0 = (DIM == 3) ? (kodd ? (k - 1) / 2 : k / 2 - 1) : 0, nkc = (DIM == 3) ? (kodd ? 1 : 2) : 1;
+        const int jc0 = xodd ? (x - 1) / 2 : x / 2 - 1, njc = xodd ? 1 : 2;
+        const T wi = iodd ? (T)1 : (T)0.5, wk = (DIM == 3) ? (kodd ? (T)1 : (T)0.5) : (T)1, wj = xodd ? (T)1 : (T)0.5;
+        const T w = (DIM == 3) ? wk * (wi * wj) : wi * wj;
+        T s = (T)0;
+        for (int qk = 0; qk < nkc; qk++)
+            for (int qi = 0; qi < nic; qi++)
+                for (int qj = 0; qj < njc; qj++) s += w * uc[tail_idx<T, DIM>(mc, kc0 + qk, ic0 + qi, jc0 + qj)];
+        const int q = tail_idx<T, DIM>(mf, (DIM == 3) ? k : 0, i, x);
+        uf[q] = uf[q] + s;
+    }
+}
+
+template <typename T, int DIM>
+__global__ void __launch_bounds__(1024) k_tail(const TailArgs<T> a) {
+    __shared__ __attribute__((aligned(16))) unsigned char raw[MGK_TAIL_LDS_BYTES];
+    T *lds = reinterpret_cast<T *>(raw);
+    for (int q = threadIdx.x; q < a.total; q += blockDim.x) lds[q] = (T)0;        // ghost rings stay 0 (homogeneous Dirichlet)
+    __syncthreads();
+    int cur[MGK_TAIL_MAXLEV];                     // which of A0 / A1 holds u of the level
+    auto A = [&](int l, int which) -> T * { const int m = a.n[l] + 2; const int sz = (DIM == 3) ? m * m * m : m * m; return lds + a.off[l] + which * sz; };
+    auto Bv = [&](int l) -> T * { return A(l, 2); };
+    {   // b of the first tail level from global memory
+        const int n = a.n[0], m = n + 2, N = (DIM == 3) ? n * n * n : n * n;
+        T *b0 = Bv(0);
+        for (int p = threadIdx.x; p < N; p += blockDim.x) {
+            const int j = p % n, i = (p / n) % n, k = (DIM == 3) ? p / (n * n) : 0;
+            b0[tail_idx<T, DIM>(m, k, i, j)] = a.b_in[(long)k * a.ms + (long)i * a.rs + j];
+        }
+    }
+    __syncthreads();
+    // KSPSolve from a zero guess, `sweeps` Richardson+Jacobi sweeps (src/solver.c:1536): the first is scale*(b*dinv)
+    auto smooth0 = [&](int l, int sweeps) {
+        cur[l] = 0;
+        if (sweeps < 1) return;                   // KSPSolve zero-fills: A0 is still all zeros
+        tail_stencil<T, DIM>(2, a.n[l], a.coef[l], a.dinv[l], a.scale, A(l, 0), Bv(l), A(l, 0));
+        __syncthreads();
+        for (int it = 1; it < sweeps; it++) {
+            tail_stencil<T, DIM>(0, a.n[l], a.coef[l], a.dinv[l], a.scale, A(l, cur[l]), Bv(l), A(l, cur[l] ^ 1));
+            __syncthreads();
+            cur[l] ^= 1;
+        }
+    };
+    smooth0(0, a.nlev == 1 ? a.v1 : a.v0);
+    for (int l = 1; l < a.nlev; l++) {            // :1534-1537
+        tail_stencil<T, DIM>(1, a.n[l - 1], a.coef[l - 1], a.dinv[l - 1], a.scale, A(l - 1, cur[l - 1]), Bv(l - 1), A(l - 1, cur[l - 1] ^ 1));
+        __syncthreads();
+        tail_restrict<T, DIM>(a.n[l - 1], a.n[l], A(l - 1, cur[l - 1] ^ 1), Bv(l));
+        __syncthreads();
+        // the zero-guess sweep writes A0 of level l, which is all zeros only in the first cycle... it is overwritten in full
+        smooth0(l, l == a.nlev - 1 ? a.v1 : a.v0);
+    }
+    for (int l = a.nlev - 2; l >= 0; l--) {       // :1540-1542
+        tail_prolong_add<T, DIM>(a.n[l], a.n[l + 1], A(l + 1, cur[l + 1]), A(l, cur[l]));
+        __syncthreads();
+        for (int it = 0; it < a.v0; it++) {
+            tail_stencil<T, DIM>(0, a.n[l], a.coef[l], a.dinv[l], a.scale, A(l, cur[l]), Bv(l), A(l, cur[l] ^ 1));
+            __syncthreads();
+            cur[l] ^= 1;
+        }
+    }
+    {
+        const int n = a.n[0], m = n + 2, N = (DIM == 3) ? n * n * n : n * n;
+        const T *u0 = A(0, cur[0]);
+        for (int p = threadIdx.x; p < N; p += blockDim.x) {
+            const int j = p % n, i = (p / n) % n, k = (DIM == 3) ? p / (n * n) : 0;
+            a.u_out[(long)k * a.ms + (long)i * a.rs + j] = u0[tail_idx<T, DIM>(m, k, i, j)];
+        }
+    }
+}
+
+template <typename T>
+static int tail_cycle(mgk_ctx *c, const mgk_geom *g0, int nlev, const int *n, const double *coef7, const double *dinv, double scale,
+                      int v0, int v1, const T *b, T *u, void *stream) {
+    if (!c || !g0 || !n || !coef7 || !dinv || !b || !u || nlev < 1 || nlev > MGK_TAIL_MAXLEV || v0 < 0 || v1 < 0)
+        return fail(MGK_EINVAL, "mgk_tail_cycle: bad arguments");
+    if (n[0] != g0->nx || g0->ny != g0->nx || (g0->dim == 3 && g0->nz != g0->nx))
+        return fail(MGK_EINVAL, "mgk_tail_cycle: the first tail level must be a whole cube / square of n[0] unknowns per side");
+    TailArgs<T> a; memset(&a, 0, sizeof(a));
+    a.dim = g0->dim; a.nlev = nlev; a.v0 = v0; a.v1 = v1; a.scale = (T)scale;
+    long off = 0;
+    for (int l = 0; l < nlev; l++) {
+        if (n[l] < 1 || (l > 0 && n[l - 1] != 2 * n[l] + 1)) return fail(MGK_EINVAL, "mgk_tail_cycle: need n[l-1] = 2 n[l] + 1");
+        const long m = n[l] + 2, sz = (g0->dim == 3) ? m * m * m : m * m;
+        a.n[l] = n[l]; a.off[l] = (int)off; off += 3 * sz;
+        for (int q = 0; q < 7; q++) a.coef[l][q] = (T)coef7[7 * l + q];
+        a.dinv[l] = (T)dinv[l];
+    }
+    if (off * (long)sizeof(T) > MGK_TAIL_LDS_BYTES) return fail(MGK_EINVAL, "mgk_tail_cycle: the levels do not fit in LDS");
+    a.total = (int)off;
+    a.b_in = b + g0->org; a.u_out = u + g0->org; a.rs = g0->pitch; a.ms = g0->plane;
+    if (g0->dim == 3) hipLaunchKernelGGL((k_tail<T, 3>), dim3(1), dim3(1024), 0, S(c, stream), a);
+    else hipLaunchKernelGGL((k_tail<T, 2>), dim3(1), dim3(1024), 0, S(c, stream), a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int mgk_tail_cycle_f64(mgk_ctx *c, const mgk_geom *g0, int nlev, const int *n, const double *coef7, const double *dinv,
+                                  double scale, int v0, int v1, const double *b, double *u, void *stream) {
+    return tail_cycle<double>(c, g0, nlev, n, coef7, dinv, scale, v0, v1, b, u, stream);
+}
+extern "C" int mgk_tail_cycle_f32(mgk_ctx *c, const mgk_geom *g0, int nlev, const int *n, const double *coef7, const double *dinv,
+                                  double scale, int v0, int v1, const float *b, float *u, void *stream) {
+    return tail_cycle<float>(c, g0, nlev, n, coef7, dinv, scale, v0, v1, b, u, stream);
+}
+extern "C" int mgk_tail_max_n(int dim) { return dim == 3 ? 15 : 63; }
+
 // ------------------------------------------------------------------------------------------
 // 2-D operators whose five coefficients depend on the grid row only (the reference's stretched meshes,
 // -mesh 1/2: metrics are functions of y, src/mesh.c:45-107, src/problem.c:3-22).  Same marching kernel; the

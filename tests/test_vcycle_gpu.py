@@ -270,3 +270,39 @@ def test_own_driver_on_stretched_meshes(orc, mesh, npts, levels):
     e, eref = s.error_norms(), orc.error_norms_mesh(npts, mesh, ref["u"])
     assert e[0] == eref[0] and abs(e[1] - eref[1]) <= RTOL * eref[1] and abs(e[2] - eref[2]) <= RTOL * eref[2]
     s.close()
+
+
+@pytest.mark.parametrize("dim,npts,levels,precision", [
+    (3, 33, 5, "fp64"), (3, 65, 6, "fp64"), (3, 65, 4, "fp64"), (3, 17, 4, "fp64"), (3, 129, 7, "fp64"),
+    (2, 129, 7, "fp64"), (2, 65, 6, "fp64"), (2, 513, 9, "fp64"), (2, 129, 3, "fp64"), (3, 65, 6, "mixed"), (3, 129, 7, "mixed"),
+])
+def test_lds_tail_kernel_equals_the_per_operation_levels(dim, npts, levels, precision):
+    """fuse bit 9: the levels with n <= 15 (3-D) / <= 63 (2-D) as ONE kernel with their fields in LDS (mgk_tail_cycle_*) against
+    the same cycle with one launch per operation on those levels: iteration count, residual history and solution identical"""
+    from multigrid_petsc_amd.solver import Solver
+    scale = 6.0 / 7.0 if dim == 3 else 0.8
+    res = []
+    for fuse in (63 | 256, 63 | 256 | 512):
+        s = Solver(dim, npts, levels, scale=scale, maxiter=60, precision=precision, fuse=fuse)
+        s.set_rhs_problem()
+        it = s.solve()
+        res.append((it, s.rnorm.copy(), s.solution()))
+        s.close()
+    assert res[0][0] == res[1][0]
+    assert np.array_equal(res[0][1], res[1][1])
+    assert np.array_equal(res[0][2], res[1][2])
+
+
+def test_lds_tail_kernel_refuses_what_does_not_fit(mgk):
+    import ctypes as C
+    g = mgk.geom(3, 31)
+    n = (C.c_int * 2)(31, 15)
+    k7 = (C.c_double * 14)(*([1.0] * 14))
+    di = (C.c_double * 2)(1.0, 1.0)
+    f = mgk.field(g)
+    assert mgk.L.mgk_tail_max_n(3) == 15 and mgk.L.mgk_tail_max_n(2) == 63
+    assert mgk.L.mgk_tail_cycle_f64(mgk.ctx, C.byref(g), 2, n, k7, di, 1.0, 3, 3, f, f, None) != 0        # 31^3 does not fit in LDS
+    g2 = mgk.geom(3, 15)
+    n2 = (C.c_int * 2)(15, 6)
+    assert mgk.L.mgk_tail_cycle_f64(mgk.ctx, C.byref(g2), 2, n2, k7, di, 1.0, 3, 3, f, f, None) != 0      # not a 2n+1 hierarchy
+    mgk.free(f)
