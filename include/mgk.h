@@ -189,6 +189,11 @@ int  mgk_residual_restrict_jz_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_ge
 int  mgk_residual_restrict_jz_f32(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef, const float *b,
                                   const float *u, float *bc, float *uc0, double dinv_c, double scale_c, void *stream);
 
+/* 2-D form of K2+K3 (constant coefficients): b_coarse = R (b - A u) in one pass, optionally also the coarse level's first sweep from
+ * a zero guess (uc0 = scale_c * (bc * dinv_c); NULL: not written).  Bit-identical to mgk_residual_f64 + mgk_restrict_fw_f64. */
+int  mgk_residual_restrict_2d_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef, const double *b,
+                                  const double *u, double *bc, double *uc0, double dinv_c, double scale_c, void *stream);
+
 /* ---- K3: MatMult(res[l], r, b[l+1]) full weighting (src/solver.c:1535, matrix :1071-1092) ----
  * coarse (kc,ic,jc) gathers fine (2kc+dk, 2ic+di, 2jc+dj), d in {0,1,2}.  gc->nz coarse planes are
  * produced from fine planes 0..2*gc->nz (plane gf->nz is the fine ghost plane in the slab case). */

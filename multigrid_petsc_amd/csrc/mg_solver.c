@@ -701,9 +701,11 @@ static int smooth(mg_solver *s, int P, int l, int maxit) {
         s->spec_valid = 0;
         it0 = 1;
     }
-    /* two sweeps per pass (temporal blocking) where it pays: whole 3-D grids of 511^3 and more.  Not on the level whose
-     * buffers the coarse-level HIP graph refers to (a pass swaps u/tmp once, not twice: see coarse_part) */
-    const int pair_ok = (s->cfg.fuse & 32) && L->n >= s->cfg.pair_min_n && (s->lgraph == 0 || l < s->lgraph - 1) &&
+    /* two sweeps per pass (temporal blocking) where it pays (3-D from 255^3, 2-D from 2047^2).  Also on the level whose buffers
+     * the coarse-level HIP graph refers to: pre- and post-smoothing group their v0 sweeps in the same way (one launch for the
+     * first sweep -- zero guess / fused prolongation / adopted speculative sweep -- then pairs), so a level swaps u/tmp the
+     * same number of times on the way down and on the way up: an even count per cycle, the pointers the graph recorded stay valid */
+    const int pair_ok = (s->cfg.fuse & 32) && L->n >= s->cfg.pair_min_n &&
                         ((s->cfg.dim == 3 && L->n + 1 <= 1024 && (!L->distributed || (F->far && L->nz_min >= 4))) ||
                          (s->cfg.dim == 2 && P == 0));
     if (maxit < 1 || F->guess_nonzero) F->jz_ready = 0;
@@ -1062,6 +1064,15 @@ gathered:
             CHK(s->comm->allgather_planes(s->comm, s->ctx, Cq->b, &Cq->g, s->zstart, O->esz, ms));
             CHK(mgk_stream_wait(s->ctx, cs, ms));
         }
+    } else if ((s->cfg.fuse & 4) && s->cfg.dim == 2 && P == 0 && !s->cfg.mesh && Lf->n >= 127) {
+        /* 2-D: the same fusion, one independent wave per tile (mgk_residual_restrict_2d_f64), with the coarse level's first
+         * zero-guess sweep when that level is smoothed by its own launches */
+        mg_fset *Cq = &s->L[l].f[P];
+        const int sweeps = (l == levels - 1) ? v[1] : v[0];
+        const int jz = (s->cfg.fuse & 256) && !no_jz && s->cfg.ksp_type == MG_KSP_RICHARDSON && sweeps >= 1 && !Cq->guess_nonzero;
+        CHK(mgk_residual_restrict_2d_f64(s->ctx, &Lf->f[P].g, &Cq->g, Lf->coef, (const double *)Lf->f[P].b, (const double *)Lf->f[P].u,
+                                         (double *)Cq->b, jz ? (double *)Cq->tmp : NULL, s->L[l].dinv, s->cfg.scale, NULL));
+        if (jz) Cq->jz_ready = 1;
     } else {
         CHK(residual(s, P, l - 1));                                     /* :1534 */
         CHK(restrict_to(s, P, l));                                      /* :1535 */

@@ -3401,6 +3401,125 @@ extern "C" int mgk_tail_cycle_f32(mgk_ctx *c, const mgk_geom *g0, int nlev, cons
 }
 extern "C" int mgk_tail_max_n(int dim) { return dim == 3 ? 15 : 63; }
 
+
+// ------------------------------------------------------------------------------------------
+// 2-D fused residual + full weighting: b_c = R (b - A u), the fine residual is never written (src/solver.c:1534-1535).
+// Every WAVE is independent (no LDS, no barrier): it owns 64 adjacent column pairs of the fine grid -- lanes 1 .. 62 produce the
+// coarse columns centred on their pairs, lane 0 only supplies the west neighbour of lane 1 and lane 63 the residual east of lane
+// 62 (tiles overlap by two lanes) -- and marches along y over a chunk of coarse rows with the rows y-1, y, y+1 of u in a register
+// ring loaded PD rows ahead; x neighbours by DPP lane shifts.  The running sums follow the row of res exactly: (di, dj)
+// ascending, an even fine row being di = 2 of the coarse row below and di = 0 of the one above (equal weights: one product).
+// Traffic: 16 B per fine unknown read + 2 B written instead of 24 + 10.
+// ------------------------------------------------------------------------------------------
+struct RR2dArgs {
+    const double *u, *b;
+    double *bc, *uc0;
+    int nx, ny, nxc, nyc;
+    long rs, crs;
+    int ntx, ycc;
+    double a0, a2, a3, a4, a6, dinv_c, scale_c;
+};
+template <int PD>
+__global__ void __launch_bounds__(256) k_rr2d(const RR2dArgs a) {
+    constexpr int NP = PD + 3;
+    using VT = V16<double>;
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tx = wid % a.ntx, cy = wid / a.ntx;
+    const int ic0 = cy * a.ycc, ic1 = min(ic0 + a.ycc, a.nyc);
+    if (ic0 >= ic1) return;                                   // whole wave
+    const int p = tx * 62 + lane - 1;                         // pair index = coarse column of this lane
+    const int x0 = 2 * p;
+    const bool xok = (x0 >= 0 && x0 < a.nx);
+    const bool store = (lane >= 1 && lane <= 62 && p < a.nxc);
+    const int xc = min(max(x0, 0), a.nx - 1);                 // clamped: every lane loads from inside the row, invalid lanes are zeroed
+    const double *up_ = a.u + xc, *bp_ = a.b + xc;
+    const int y0 = 2 * ic0, y1 = 2 * ic1 + 1;                 // fine rows y0 .. y1-1 are processed, row y1 is the last one read
+    auto ldu = [&](int y) -> VT {
+        VT v = *reinterpret_cast<const VT *>(up_ + (long)min(y, y1) * a.rs);
+        if (!xok) { v.v[0] = 0.0; v.v[1] = 0.0; }
+        return v;
+    };
+    auto ldb = [&](int y) -> VT {
+        VT v = ldv_stream(bp_ + (long)min(y, y1 - 1) * a.rs, true);
+        if (!xok) { v.v[0] = 0.0; v.v[1] = 0.0; }
+        return v;
+    };
+    const double w2[3][3] = {{0.0625, 0.125, 0.0625}, {0.125, 0.25, 0.125}, {0.0625, 0.125, 0.0625}};
+    VT U[NP], B[NP];
+#pragma unroll
+    for (int q = -1; q <= PD; q++) U[(q + NP) % NP] = ldu(y0 + q);
+#pragma unroll
+    for (int q = 0; q < PD; q++) B[q] = ldb(y0 + q);
+    double acc = 0.0, accn = 0.0;
+    for (int yb = y0; yb < y1; yb += NP) {
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const int y = yb + k;
+            if (y < y1) {
+                const int cm = (k + NP - 1) % NP, cc = k, cp = (k + 1) % NP;
+                U[(k + PD + 1) % NP] = ldu(y + PD + 1);
+                B[(k + PD) % NP] = ldb(y + PD);
+                const VT &c = U[cc];
+                const double Wv = lane_up<true>(c.v[1]), Ev = lane_dn<true>(c.v[0]);
+                VT r;
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const double wv = (e == 0) ? Wv : c.v[0];
+                    const double ev = (e == 1) ? Ev : c.v[1];
+                    double t = a.a0 * U[cm].v[e];
+                    t = t + a.a2 * wv;
+                    t = t + a.a3 * c.v[e];
+                    t = t + a.a4 * ev;
+                    t = t + a.a6 * U[cp].v[e];
+                    r.v[e] = B[cc].v[e] - t;
+                    if (!xok || x0 + e >= a.nx) r.v[e] = 0.0;
+                }
+                const double rn = lane_dn<true>(r.v[0]);
+                const bool even = ((y & 1) == 0);
+                const int di = even ? 0 : 1;
+                double pr = w2[di][0] * r.v[0];
+                acc += pr; if (even) accn += pr;
+                pr = w2[di][1] * r.v[1];
+                acc += pr; if (even) accn += pr;
+                pr = w2[di][2] * rn;
+                acc += pr; if (even) accn += pr;
+                if (even) {
+                    const int ic = y / 2 - 1;                 // completed coarse row
+                    if (ic >= ic0 && store) {
+                        const long oc = (long)ic * a.crs + p;
+                        a.bc[oc] = acc;
+                        if (a.uc0) { const double zq = acc * a.dinv_c; a.uc0[oc] = a.scale_c * zq; }
+                    }
+                    acc = accn; accn = 0.0;
+                }
+            }
+        }
+    }
+}
+extern "C" int mgk_residual_restrict_2d_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, const double *b,
+                                            const double *u, double *bc, double *uc0, double dinv_c, double scale_c, void *stream) {
+    if (!c || !gf || !gc || !coef || !b || !u || !bc || gf->dim != 2 || gc->dim != 2)
+        return fail(MGK_EINVAL, "mgk_residual_restrict_2d_f64: bad arguments (2-D)");
+    if (gf->nx != 2 * gc->nx + 1 || gf->ny != 2 * gc->ny + 1) return fail(MGK_EINVAL, "mgk_residual_restrict_2d_f64: need nf = 2 nc + 1");
+    RR2dArgs a; memset(&a, 0, sizeof(a));
+    a.u = u + gf->org; a.b = b + gf->org; a.bc = bc + gc->org; a.uc0 = uc0 ? uc0 + gc->org : nullptr;
+    a.nx = gf->nx; a.ny = gf->ny; a.nxc = gc->nx; a.nyc = gc->ny; a.rs = gf->pitch; a.crs = gc->pitch;
+    a.a0 = coef[0]; a.a2 = coef[1]; a.a3 = coef[2]; a.a4 = coef[3]; a.a6 = coef[4];
+    a.dinv_c = dinv_c; a.scale_c = scale_c;
+    a.ntx = (gc->nx + 61) / 62;
+    long nch = (4096 + a.ntx - 1) / a.ntx;                    // ~4096 waves (16 per CU); every chunk re-reads two fine rows
+    if (g_zchunk > 0) nch = (gc->ny + g_zchunk - 1) / g_zchunk;
+    int ycc = (int)((gc->ny + nch - 1) / nch);
+    if (ycc < 4) ycc = 4;
+    if (ycc > gc->ny) ycc = gc->ny;
+    a.ycc = ycc;
+    const long waves = (long)a.ntx * ((gc->ny + ycc - 1) / ycc);
+    hipLaunchKernelGGL((k_rr2d<2>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, S(c, stream), a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // 2-D operators whose five coefficients depend on the grid row only (the reference's stretched meshes,
 // -mesh 1/2: metrics are functions of y, src/mesh.c:45-107, src/problem.c:3-22).  Same marching kernel; the

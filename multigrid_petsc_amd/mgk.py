@@ -93,6 +93,7 @@ def _sigs(L):
         "mgk_residual_restrict_range_f32": (i, [vp, G, G, c_dp, vp, vp, vp, i, i, vp]),
         "mgk_residual_restrict_slab_f64": (i, [vp, G, G, G, c_dp, vp, vp, vp, i, vp, i, i, vp]),
         "mgk_residual_restrict_slab_f32": (i, [vp, G, G, G, c_dp, vp, vp, vp, i, vp, i, i, vp]),
+        "mgk_residual_restrict_2d_f64": (i, [vp, G, G, c_dp, vp, vp, vp, vp, d, d, vp]),
         "mgk_tail_cycle_f64": (i, [vp, G, i, C.POINTER(i), c_dp, c_dp, d, i, i, vp, vp, vp]),
         "mgk_tail_cycle_f32": (i, [vp, G, i, C.POINTER(i), c_dp, c_dp, d, i, i, vp, vp, vp]),
         "mgk_tail_max_n": (i, [i]),

@@ -505,3 +505,30 @@ def test_fused_residual_restrict_on_slabs_single_exchange(mgk, orc, n, cut):
     assert L.mgk_residual_restrict_slab_f64(mgk.ctx, C.byref(g0), C.byref(gc0), C.byref(gbad), coef, b0, u0, dfar, 1, bc0, 0, cut, None) != 0
     for p in (u0, b0, bc0, dfar, u1, b1, bc1):
         mgk.free(p)
+
+
+@pytest.mark.parametrize("nf", [3, 7, 63, 127, 255, 1023, 2047])
+def test_fused_residual_restrict_2d_bit_exact(mgk, orc, nf):
+    """mgk_residual_restrict_2d_f64 == residual followed by full weighting (src/solver.c:1534-1535), and its optional second
+    output == the zero-guess sweep of the coarse level, bit for bit; several y chunkings"""
+    rng = np.random.default_rng(7100 + nf)
+    nc = (nf - 1) // 2
+    As = _stencil(orc, 2, nf)
+    Ac = _stencil(orc, 2, nc)
+    u, b = _rand(rng, nf ** 2), _rand(rng, nf ** 2)
+    gf, gc = mgk.geom(2, nf), mgk.geom(2, nc)
+    du, db, dbc, duc0 = mgk.to_field(gf, u), mgk.to_field(gf, b), mgk.field(gc), mgk.field(gc)
+    want = orc.restrict(2, nf, orc.residual(2, nf, As, b, u))
+    dinv_c = 1.0 / Ac[2]
+    for zc in (-1, 5, 64):
+        mgk.L.mgk_set_tuning(-1, zc)
+        mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dbc, 8 * gc.total, None))
+        mgk._chk(mgk.L.mgk_residual_restrict_2d_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), db, du, dbc, duc0, dinv_c, 0.8, None))
+        got = mgk.from_field(gc, dbc)
+        assert np.array_equal(got, want), f"zc={zc} max diff {np.abs(got - want).max()}"
+        assert np.array_equal(mgk.from_field(gc, duc0), 0.8 * (want * dinv_c))
+        raw = mgk.raw_field(gc, dbc)
+        assert abs(np.abs(raw).sum() - np.abs(got).sum()) <= 1e-9 * max(np.abs(got).sum(), 1e-300)
+    mgk.L.mgk_set_tuning(-1, -1)
+    for p in (du, db, dbc, duc0):
+        mgk.free(p)
