@@ -25,6 +25,7 @@ for _ in range(3):
     m._chk(L.mgk_residual_f64(m.ctx, C.byref(g), coef, b, u, out, None))
     m._chk(L.mgk_residual_sumsq_f64(m.ctx, C.byref(g), coef, b, u, C.byref(ss), None))
     m._chk(L.mgk_jacobi2_f64(m.ctx, C.byref(g), coef, dinv, 6.0 / 7.0, b, u, out, None))
+    m._chk(L.mgk_jacobi_sumsq_f64(m.ctx, C.byref(g), coef, dinv, 6.0 / 7.0, b, u, out, C.byref(ss), None))
 m.sync()
 gc = m.geom(3, (n - 1) // 2)
 uc, bc = m.field(gc), m.field(gc)
