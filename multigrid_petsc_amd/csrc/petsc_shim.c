@@ -573,7 +573,10 @@ static void mat_device_csr(Mat A) {
     }
     DEV(mgk_h2d(G, A->d_val, A->val, sizeof(double) * (size_t)A->nz));
     /* PCJACOBI: 1/diag in the layout of the row vectors */
-    const long dlen = A->grow_ok ? A->grow.total : A->m;
+    /* (length = nalloc of a row vector, see vec_new: the flat BLAS-1 kernels run over whole allocations; sized A->m the
+     *  pointwise multiply of KSPSolve read up to 15 doubles past the end -- found by the sanitized CPU build) */
+    long dlen = A->grow_ok ? A->grow.total : ((long)A->m + 15) / 16 * 16;
+    if (dlen < 16) dlen = 16;
     if (!A->d_dinv_len) { void *pp; DEV(mgk_malloc(G, &pp, sizeof(double) * (size_t)(dlen ? dlen : 1))); mgk_free(G, A->d_dinv); A->d_dinv = (double *)pp; A->d_dinv_len = dlen; }
     double *dinv = (double *)calloc((size_t)(dlen ? dlen : 1), sizeof(double));
     for (long r = 0; r < A->m; r++) {

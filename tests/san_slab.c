@@ -1,0 +1,79 @@
+/* tests/san_slab.c -- TEST INFRASTRUCTURE: the slab (multi-rank) host logic of csrc/mg_solver.c + csrc/mg_comm.c under
+ * AddressSanitizer / UBSan on the CPU, over tests/mock_mgk.cpp.  P loopback ranks (threads) solve the 3-D problem; the
+ * concatenated solution must equal the single-rank one bit for bit; the transport self-test runs on every rank, and the
+ * phantom communicator drives one rank of 8 through a few cycles.  usage: san_slab P npts levels dist_min_n [mixed] */
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "mgsolve.h"
+#include "mg_comm.h"
+
+typedef struct { int rank, P, npts, levels, dmin, mixed, rc; void *shared; double *u; long n; int it; } job;
+
+static void cfg(mg_config *c, const job *j, int rank, int P) {
+    mg_config_default(c);
+    c->dim = 3; c->npts = j->npts; c->levels = j->levels; c->scale = 6.0 / 7.0; c->maxiter = 60;
+    c->rank = rank; c->nranks = P; c->dist_min_n = j->dmin; c->precision = j->mixed ? MG_PREC_MIXED : MG_PREC_FP64;
+    c->pair_min_n = 7;                /* two-sweep passes on the small test levels too */
+}
+static void *work(void *p) {
+    job *j = (job *)p;
+    mg_comm *cm = j->P > 1 ? mg_comm_loopback_create(j->shared, j->rank) : NULL;
+    mg_config c; cfg(&c, j, j->rank, j->P);
+    mg_solver *s = NULL;
+    j->rc = 1;
+    if (j->P > 1) {
+        mgk_ctx *ctx = NULL;
+        if (mgk_ctx_create(&ctx, 0) || mg_comm_selftest(cm, ctx)) { fprintf(stderr, "selftest: %s\n", mg_comm_last_error()); return NULL; }
+        mgk_ctx_destroy(ctx);
+    }
+    if (mg_solver_create(&s, &c, cm)) { fprintf(stderr, "create: %s\n", mg_last_error()); return NULL; }
+    if (mg_solver_set_rhs_problem(s) || mg_solver_solve(s)) { fprintf(stderr, "solve: %s\n", mg_last_error()); return NULL; }
+    j->n = mg_solver_local_unknowns(s);
+    j->u = (double *)malloc(sizeof(double) * (size_t)j->n);
+    j->it = mg_solver_iterations(s);
+    double e[3];
+    if (mg_solver_get_solution(s, j->u) || mg_solver_error_norms(s, e)) { fprintf(stderr, "fetch: %s\n", mg_last_error()); return NULL; }
+    /* fixed-count cycling with deferred norms as bench.py does it */
+    if (mg_solver_reset(s) || mg_solver_cycles(s, 3) || mg_solver_sync(s)) { fprintf(stderr, "cycles: %s\n", mg_last_error()); return NULL; }
+    mg_solver_destroy(s);
+    if (cm) mg_comm_destroy(cm);
+    j->rc = 0;
+    return NULL;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 5) { fprintf(stderr, "usage: san_slab P npts levels dist_min_n [mixed]\n"); return 2; }
+    const int P = atoi(argv[1]);
+    job base; memset(&base, 0, sizeof(base));
+    base.npts = atoi(argv[2]); base.levels = atoi(argv[3]); base.dmin = atoi(argv[4]); base.mixed = argc > 5 && !strcmp(argv[5], "mixed");
+    job one = base; one.P = 1;
+    work(&one);
+    if (one.rc) return 1;
+    job *js = (job *)calloc((size_t)P, sizeof(job));
+    pthread_t *th = (pthread_t *)calloc((size_t)P, sizeof(pthread_t));
+    void *shared = mg_comm_loopback_shared_create(P);
+    for (int r = 0; r < P; r++) { js[r] = base; js[r].rank = r; js[r].P = P; js[r].shared = shared; pthread_create(&th[r], NULL, work, &js[r]); }
+    long off = 0; int bad = 0;
+    for (int r = 0; r < P; r++) {
+        pthread_join(th[r], NULL);
+        if (js[r].rc || js[r].it != one.it) { fprintf(stderr, "rank %d failed (rc %d, %d vs %d cycles)\n", r, js[r].rc, js[r].it, one.it); bad = 1; continue; }
+        if (off + js[r].n > one.n || memcmp(js[r].u, one.u + off, sizeof(double) * (size_t)js[r].n)) { fprintf(stderr, "rank %d: solution differs from the single-rank one\n", r); bad = 1; }
+        off += js[r].n;
+        free(js[r].u);
+    }
+    if (off != one.n) { fprintf(stderr, "slabs do not add up\n"); bad = 1; }
+    mg_comm_loopback_shared_destroy(shared);
+    /* one rank of 8 on the phantom communicator (timing aid): the code path only */
+    mg_comm *ph = mg_comm_phantom_create(3, 8, 1.0, 50.0);
+    mg_config c; job pj = base; pj.dmin = base.dmin; cfg(&c, &pj, 3, 8);
+    mg_solver *s = NULL;
+    if (!ph || mg_solver_create(&s, &c, ph) || mg_solver_set_rhs_problem(s) || mg_solver_cycles(s, 2) || mg_solver_sync(s)) { fprintf(stderr, "phantom: %s\n", mg_last_error()); bad = 1; }
+    if (s) mg_solver_destroy(s);
+    if (ph) mg_comm_destroy(ph);
+    free(one.u); free(js); free(th);
+    printf("SAN_SLAB_%s P=%d cycles=%d\n", bad ? "FAILED" : "OK", P, one.it);
+    return bad;
+}
