@@ -956,6 +956,11 @@ static void set_coef(StArgs<T> &a, const mgk_geom *g, const double *coef) {
     }
 }
 
+// register / shuffle form of the plain sweeps (k_jrow, defined with the other row kernels further down)
+template <typename T> static bool jrow_ok(const mgk_geom *g);
+template <typename T, bool NORM>
+static int launch_jrow(mgk_ctx *c, const mgk_geom *g, const StArgs<T> &a, int zbeg, int zend, hipStream_t s, double *partials, int max_partials, int *nparts);
+
 extern "C" int mgk_jacobi_range_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
                                     const double *b, const double *u, double *unew, int zbeg, int zend, void *stream) {
     if (!c || !g || !coef || !b || !u || !unew || u == unew) return fail(MGK_EINVAL, "mgk_jacobi_f64: bad arguments");
@@ -965,6 +970,7 @@ extern "C" int mgk_jacobi_range_f64(mgk_ctx *c, const mgk_geom *g, const double 
     a.u = u + g->org; a.b = b + g->org; a.out = unew + g->org;
     set_coef(a, g, coef); a.dinv = dinv; a.scale = scale;
     a.zbeg = zbeg; a.zend = zend;
+    if (jrow_ok<double>(g)) return launch_jrow<double, false>(c, g, a, zbeg, zend, S(c, stream), nullptr, 0, nullptr);
     return dispatch_st<MODE_JACOBI>(c, g, a, S(c, stream), nullptr);
 }
 extern "C" int mgk_jacobi_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
@@ -1055,7 +1061,8 @@ extern "C" int mgk_jacobi_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const double 
     a.u = u + g->org; a.b = b + g->org; a.out = unew + g->org; a.partials = c->partials;
     set_coef(a, g, coef); a.dinv = dinv; a.scale = scale;
     int nblk = 0;
-    int rc = dispatch_st<MODE_JNORM>(c, g, a, S(c, stream), &nblk);
+    int rc = jrow_ok<double>(g) ? launch_jrow<double, true>(c, g, a, 0, g->nz, S(c, stream), c->partials, c->max_partials, &nblk)
+                                : dispatch_st<MODE_JNORM>(c, g, a, S(c, stream), &nblk);
     if (rc) return rc;
     return finish_to_host(c, nblk, 1, S(c, stream), sumsq_host);
 }
@@ -1078,7 +1085,8 @@ extern "C" int mgk_jacobi_sumsq_range_f64(mgk_ctx *c, const mgk_geom *g, const d
     mgk_ctx lim = *c;
     lim.max_partials = c->max_partials - part_off;
     int nblk = 0;
-    int rc = dispatch_st<MODE_JNORM>(&lim, g, a, S(c, stream), &nblk);
+    int rc = jrow_ok<double>(g) ? launch_jrow<double, true>(c, g, a, zbeg, zend, S(c, stream), c->partials + part_off, lim.max_partials, &nblk)
+                                : dispatch_st<MODE_JNORM>(&lim, g, a, S(c, stream), &nblk);
     if (rc) return rc;
     *nparts = nblk;
     return 0;
@@ -2198,6 +2206,7 @@ extern "C" int mgk_jacobi_range_f32(mgk_ctx *c, const mgk_geom *g, const double 
     a.u = u + g->org; a.b = b + g->org; a.out = unew + g->org;
     set_coef(a, g, coef); a.dinv = (float)dinv; a.scale = (float)scale;
     a.zbeg = zbeg; a.zend = zend;
+    if (jrow_ok<float>(g)) return launch_jrow<float, false>(c, g, a, zbeg, zend, S(c, stream), nullptr, 0, nullptr);
     return dispatch_st<MODE_JACOBI>(c, g, a, S(c, stream), nullptr);
 }
 extern "C" int mgk_jacobi_f32(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
@@ -2950,6 +2959,163 @@ __global__ void __launch_bounds__(64 * WX) k_pjrow(const PJArgs<T> a) {
 #undef PJ_CORRECT
 }
 
+
+// ------------------------------------------------------------------------------------------
+// One Richardson + Jacobi sweep in the register / shuffle shape of k_pjrow (no correction): full-row tile of 4 rows, lane = column
+// pair of all 6 rows, DPP lane shifts, unconditional clamped loads, static ring of PD + 3 planes (without the coarse parents
+// there is room for two planes of prefetch), one barrier per plane.  NORM: also the sum of squares of the residual of the
+// INPUT field (the norm that closes a cycle fused with the first sweep of the next one, mgk_jacobi_sumsq_*).
+// Same expressions, same order as k_stencil<MODE_JACOBI / MODE_JNORM>: bit-identical output.
+// ------------------------------------------------------------------------------------------
+template <typename T, int WX, int PD, bool NORM>
+__global__ void __launch_bounds__(64 * WX) k_jrow(const PJArgs<T> a, double *partials) {
+    constexpr int VX = 16 / sizeof(T);
+    constexpr int TY = 4, R1 = TY + 2, NP = PD + 3;
+    __shared__ T eW[2][TY][WX], eE[2][TY][WX];
+    using VT = V16<T>;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int ty = bid % a.nty, tz = bid / a.nty;
+    const int x0 = VX * tid, yb = TY * ty;
+    const int z0 = a.zbeg + tz * a.zc, z1 = min(z0 + a.zc, a.zend);
+    double acc = 0.0;
+    if (z0 < z1) {
+        const bool lastlane = (tid == 64 * WX - 1);
+        const unsigned lb = (unsigned)(x0 * (int)sizeof(T));
+        long uro[R1], bro[TY];
+#pragma unroll
+        for (int rr = 0; rr < R1; rr++) uro[rr] = (long)min(yb - 1 + rr, a.ny) * a.rs;
+#pragma unroll
+        for (int j = 0; j < TY; j++) bro[j] = (long)min(yb + j, a.ny) * a.rs;
+        VT U[NP][R1], B[NP][TY];
+#pragma unroll
+        for (int q = -1; q <= PD; q++) {
+            const T *pl = a.u + (long)min(z0 + q, z1) * a.ms;
+#pragma unroll
+            for (int rr = 0; rr < R1; rr++) U[(q + NP) % NP][rr] = ldrow(pl + uro[rr], lb);
+        }
+#pragma unroll
+        for (int q = 0; q < PD; q++) {
+            const T *pl = a.b + (long)min(z0 + q, z1 - 1) * a.ms;
+#pragma unroll
+            for (int j = 0; j < TY; j++) B[q][j] = ldrow_stream(pl + bro[j], lb);
+        }
+        if (lane == 0 || lane == 63) {
+#pragma unroll
+            for (int j = 0; j < TY; j++) {
+                if (lane == 0) eW[z0 & 1][j][w] = U[0][j + 1].v[0];
+                else eE[z0 & 1][j][w] = U[0][j + 1].v[VX - 1];
+            }
+        }
+        __syncthreads();
+        for (int zb = z0; zb < z1; zb += NP) {
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+                const int z = zb + k;
+                if (z < z1) {
+                    const int cm = (k + NP - 1) % NP, cc = k, cp = (k + 1) % NP;
+                    {
+                        const T *pl = a.u + (long)min(z + PD + 1, z1) * a.ms;
+#pragma unroll
+                        for (int rr = 0; rr < R1; rr++) U[(k + PD + 1) % NP][rr] = ldrow(pl + uro[rr], lb);
+                        const T *pb = a.b + (long)min(z + PD, z1 - 1) * a.ms;
+#pragma unroll
+                        for (int j = 0; j < TY; j++) B[(k + PD) % NP][j] = ldrow_stream(pb + bro[j], lb);
+                    }
+                    VT part[TY];
+#pragma unroll
+                    for (int j = 0; j < TY; j++) {
+                        const VT &c = U[cc][j + 1];
+                        T Wv = lane_up<true>(c.v[VX - 1]), Ev = lane_dn<true>(c.v[0]);
+                        if (lane == 0) Wv = (w > 0) ? eE[z & 1][j][w - 1] : (T)0;
+                        if (lane == 63) Ev = (w < WX - 1) ? eW[z & 1][j][w + 1] : (T)0;
+#pragma unroll
+                        for (int e = 0; e < VX; e++) {
+                            const T wv = (e == 0) ? Wv : c.v[e > 0 ? e - 1 : 0];
+                            const T ev = (e == VX - 1) ? Ev : c.v[e < VX - 1 ? e + 1 : e];
+                            T t = a.a0 * U[cm][j + 1].v[e];
+                            t = t + a.a1 * U[cc][j].v[e];
+                            t = t + a.a2 * wv;
+                            t = t + a.a3 * c.v[e];
+                            t = t + a.a4 * ev;
+                            t = t + a.a5 * U[cc][j + 2].v[e];
+                            part[j].v[e] = t;
+                        }
+                    }
+                    if (lane == 0 || lane == 63) {            // wave edges of plane z+1 for the next step (first touch of that plane)
+#pragma unroll
+                        for (int j = 0; j < TY; j++) {
+                            if (lane == 0) eW[(z + 1) & 1][j][w] = U[cp][j + 1].v[0];
+                            else eE[(z + 1) & 1][j][w] = U[cp][j + 1].v[VX - 1];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < TY; j++) {
+                        VT o;
+                        const bool rowin = (yb + j < a.ny);
+#pragma unroll
+                        for (int e = 0; e < VX; e++) {
+                            const T t = part[j].v[e] + a.a6 * U[cp][j + 1].v[e];
+                            const T res = B[cc][j].v[e] - t;
+                            const T zz = res * a.dinv;
+                            o.v[e] = U[cc][j + 1].v[e] + a.scale * zz;
+                            if (NORM && rowin && !(lastlane && e == VX - 1)) acc += (double)res * (double)res;
+                        }
+                        if (lastlane) o.v[VX - 1] = (T)0;
+                        if (rowin)
+                            stv_stream(reinterpret_cast<T *>(reinterpret_cast<char *>(a.out + (long)z * a.ms + (long)(yb + j) * a.rs) + lb), o);
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+    }
+    if (NORM) {
+        __shared__ double red[16];
+        const double s = block_sum(acc, red);
+        if (threadIdx.x == 0) partials[blockIdx.x] = s;
+    }
+}
+template <typename T, bool NORM>
+static int launch_jrow(mgk_ctx *c, const mgk_geom *g, const StArgs<T> &a, int zbeg, int zend, hipStream_t s, double *partials, int max_partials, int *nparts) {
+    constexpr int VX = 16 / sizeof(T);
+    const int w = (g->nx + 1) / (64 * VX);
+    PJArgs<T> q; memset(&q, 0, sizeof(q));
+    q.u = a.u; q.b = a.b; q.out = a.out;
+    q.nx = g->nx; q.ny = g->ny; q.nz = g->nz; q.rs = g->pitch; q.ms = g->plane;
+    q.a0 = a.a0; q.a1 = a.a1; q.a2 = a.a2; q.a3 = a.a3; q.a4 = a.a4; q.a5 = a.a5; q.a6 = a.a6; q.dinv = a.dinv; q.scale = a.scale;
+    q.zbeg = zbeg; q.zend = zend;
+    q.nty = (g->ny + 3) / 4;
+    const int nzr = zend - zbeg;
+    // 512-thread blocks: one per CU (256 tiles at 1023^3, one chunk); smaller blocks several per CU.  Small levels: short chunks
+    const long target = (w > 4) ? 256 : (w > 2 ? 512 : 1024);
+    long nch = (q.nty >= target) ? 1 : (target + q.nty - 1) / q.nty;
+    if (g_zchunk > 0) nch = (nzr + g_zchunk - 1) / g_zchunk;
+    int zc = (int)((nzr + nch - 1) / nch);
+    if (zc < 4) zc = 4;
+    if (zc > nzr) zc = nzr;
+    long nblk = (long)q.nty * ((nzr + zc - 1) / zc);
+    if (NORM && nblk > max_partials) {
+        const long ntz = max_partials / q.nty;
+        if (ntz < 1) return fail(MGK_EINVAL, "row sweep: partial buffer too small");
+        zc = (int)((nzr + ntz - 1) / ntz);
+        nblk = (long)q.nty * ((nzr + zc - 1) / zc);
+    }
+    q.zc = zc;
+    if (nparts) *nparts = (int)nblk;
+    (void)c;
+#define JROW_LAUNCH(WXV) hipLaunchKernelGGL((k_jrow<T, WXV, (sizeof(T) == 8 ? 2 : 1), NORM>), dim3((unsigned)nblk), dim3(64 * WXV), 0, s, q, partials)
+    if (w <= 1) JROW_LAUNCH(1);
+    else if (w <= 2) JROW_LAUNCH(2);
+    else if (w <= 4) JROW_LAUNCH(4);
+    else JROW_LAUNCH(8);
+#undef JROW_LAUNCH
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // closes the partial last coarse plane of a slab: bc(last) += sum_{di,dj} (1/4 w2[di][dj]) r(ghost plane), ascending (di, dj):
 // the dk = 2 terms of the row of res, appended to the running sum exactly as the whole-grid kernel would.
 template <typename T>
@@ -2984,6 +3150,12 @@ static bool row_shape_ok(const mgk_geom *g) {
 // tuning variants: 30 LDS-tile kernels; 31 row kernels; 33 / 34 / 35 experimental forms of the row kernels (see the launchers)
 static int row_form(int w, size_t esz) {
     return (g_variant >= 31 && g_variant <= 35) ? g_variant : (g_variant == 30) ? 0 : row_form_default(w, esz);
+}
+// (measured on one box, LDS-tile kernel -> row form: fp64 1023^3 sweep 4.48 -> 4.30 ms, sweep+norm 4.48 -> 4.36; 511^3 0.534 -> 0.543,
+//  255^3 0.064 -> 0.066; fp32 1023^3 2.1 -> 2.3: the row form is the default for fp64 rows of 1024 only, tuning variant 34 forces it)
+template <typename T> static bool jrow_ok(const mgk_geom *g) {
+    if (!row_shape_ok<T>(g) || g->nx < 127) return false;
+    return g_variant == 34 || (g_variant < 0 && sizeof(T) == 8 && g->nx + 1 >= 1024);
 }
 template <typename T, int PD, int FORM>
 static void launch_rrrow(int w, unsigned nblk, hipStream_t s, const RRArgs<T> &a) {

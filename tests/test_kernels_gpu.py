@@ -27,7 +27,7 @@ def _stencil(orc, dim, n):
     return orc.level_stencil(dim, n + 2, 0)[0]
 
 
-CASES_3D = [(3, n, v) for n in (1, 3, 7, 31) for v in (0, 2)] + \
+CASES_3D = [(3, n, v) for n in (1, 3, 7, 31) for v in (0, 2)] + [(3, 127, 34), (3, 255, 34), (3, 255, -1), (3, 63, 34)] + \
            [(3, 63, v) for v in (0, 1, 2, 3, 6, 9, 12, 13)] + [(3, 127, v) for v in (1, 2, 3, 6, 9, 12, 13)]
 CASES_2D = [(2, n, v) for n in (1, 3, 15, 127) for v in (0, 1)] + [(2, 255, v) for v in (0, 1, 2)] + \
            [(2, 1023, 2), (2, 2047, 2)]
@@ -207,7 +207,8 @@ def test_fused_residual_restrict_bit_exact(mgk, orc, nf):
         mgk.free(p)
 
 
-@pytest.mark.parametrize("dim,n,variant", [(3, 7, 0), (3, 31, 2), (3, 127, 1), (3, 255, 6), (2, 127, 0), (2, 1023, 2)])
+@pytest.mark.parametrize("dim,n,variant", [(3, 7, 0), (3, 31, 2), (3, 127, 1), (3, 255, 6), (2, 127, 0), (2, 1023, 2),
+                                            (3, 127, 34), (3, 255, -1), (3, 255, 34), (3, 63, 34)])
 def test_sweep_with_input_residual_norm_bit_exact(mgk, orc, dim, n, variant):
     """mgk_jacobi_sumsq_f64: the sweep is the plain Jacobi sweep, the sum is ||b - A u||^2 of the INPUT field"""
     rng = np.random.default_rng(4000 + n)
@@ -416,7 +417,7 @@ def test_fused_residual_restrict_coarse_plane_ranges(mgk, orc, nf):
         mgk.free(p)
 
 
-@pytest.mark.parametrize("n,variant", [(31, 0), (63, 2), (127, 6), (255, 12)])
+@pytest.mark.parametrize("n,variant", [(31, 0), (63, 2), (127, 6), (255, 12), (127, 34), (255, 34)])
 def test_sweep_with_norm_over_plane_ranges(mgk, orc, n, variant):
     """mgk_jacobi_sumsq_range_f64 x3 + mgk_partials_finish: the sweep equals the plain sweep bit for bit, the sum is that of
     the whole launch to rounding (block partials of the three launches reduced in slot order)"""
