@@ -326,3 +326,29 @@ def test_full_size_eight_slabs_equal_the_single_rank_cycle():
         assert np.abs(rn / rn1 - 1).max() <= 1e-12
         assert e[0] == e1[0]
         assert abs(e[1] - e1[1]) <= 1e-12 * e1[1] and abs(e[2] - e1[2]) <= 1e-12 * e1[2]
+
+
+@pytest.mark.timeout(900)
+def test_bench_never_falls_back_silently(tmp_path):
+    """bench.py with N = 2 and the default (RCCL) transport on ONE GPU: RCCL cannot give two ranks one device, so either the
+    communicator or the first-run gate fails on every rank.  The run must then (a) end with exit code 3 when fallbacks are
+    forbidden, (b) otherwise finish on the host-staged transport AND say so at the top level of its JSON line.  If RCCL does
+    run two ranks on this device the line must say transport rccl with no fallback."""
+    import json
+    env = dict(os.environ, MG_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    bench = os.path.join(ROOT, "bench.py")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", bench, "--gpus", "2", "--steps", "3", "--warmup", "1", "--npts", "65", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2
+    if j["transport_fallback"]:
+        assert j["transport"] == "host" and "RCCL transport unusable" in p.stderr
+        cmd[cmd.index("29541")] = "29543"
+        q = subprocess.run(cmd, env=dict(env, MG_BENCH_ALLOW_FALLBACK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert q.returncode != 0 and not [l for l in q.stdout.strip().splitlines() if l.startswith("{")]
+    else:
+        assert j["transport"] == "rccl"
