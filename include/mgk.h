@@ -59,6 +59,10 @@ int  mgk_set_device(int device);                                  /* hipSetDevic
 int  mgk_ctx_create(mgk_ctx **ctx, int device);
 void mgk_ctx_destroy(mgk_ctx *ctx);
 const char *mgk_last_error(void);
+/* > 0: the 3-D marching kernels launched on this context cut z into chunks of about `planes` planes instead of the long streams
+ * a single GPU prefers -- a slab rank sets it so that the workgroups of an exchange (RCCL send/recv kernels on the high-priority
+ * comm stream) are dispatched within one short block's time instead of behind a chip-filling kernel; 0: built-in choice */
+int  mgk_ctx_set_chunk_planes(mgk_ctx *ctx, int planes);
 void *mgk_stream_compute(mgk_ctx *ctx);
 void *mgk_stream_comm(mgk_ctx *ctx);
 int  mgk_malloc(mgk_ctx *ctx, void **dptr, size_t bytes);          /* zero-filled */
@@ -76,6 +80,9 @@ int  mgk_h2d_async(mgk_ctx *ctx, void *dst, const void *src_pinned, size_t bytes
 /* one wavefront busy-waits `us` microseconds on `stream` (nothing else is touched): stands for the time a halo plane spends
  * on a link when one rank's share of an N-GPU run is timed on one GPU (mg_comm phantom back end); never on the product path */
 int  mgk_delay_us(mgk_ctx *ctx, double us, void *stream);
+/* copies `bytes` (multiple of 16) with `blocks` small workgroups that then stay resident until `us` microseconds have passed: the
+ * footprint of a send/recv kernel that moves a plane at link speed; phantom back end only */
+int  mgk_paced_copy(mgk_ctx *ctx, void *dst, const void *src, size_t bytes, double us, int blocks, void *stream);
 /* stream-ordered event timing for bench.py's roofline leg */
 int  mgk_timer_create(mgk_ctx *ctx, void **timer);
 int  mgk_timer_start(mgk_ctx *ctx, void *timer, void *stream);

@@ -50,6 +50,8 @@ typedef struct mg_config {
     int overlap;        /* nranks > 1: halo of sweep k on the comm stream while sweep k's interior runs; default on (-1) */
     int graph;          /* replay the launch-bound coarse levels as one captured HIP graph; default on (-1) */
     int pair_min_n;     /* levels with n >= pair_min_n run their sweeps two per pass (fuse bit 5); <=0: default 255 (3-D), 2047 (2-D) */
+    int slab_chunk;     /* nranks > 1: planes per workgroup of the marching kernels (short blocks let the exchange kernels in beside the
+                         * interior launches); <0: default 32, 0: the long streams of a single GPU */
     int mesh;           /* -mesh: 0 uniform; 1 / 2: the reference's meshes stretched in y (src/mesh.c:45-107,165-169), 2-D, one GPU,
                          * Richardson + Jacobi: the operator rows then depend on the grid row (per-row coefficient tables) */
 } mg_config;

@@ -367,20 +367,24 @@ static int phantom_hold(mg_comm *c, mgk_ctx *ctx, double bytes_per_direction, vo
     double us = im->lat_us + (im->gbs > 0.0 ? bytes_per_direction / (im->gbs * 1.0e3) : 0.0);   /* GB/s = 1e3 B/us */
     return mgk_delay_us(ctx, us, s);
 }
+/* an exchange = ONE wavefront that holds the stream for latency + bytes per direction / link bandwidth (lo and hi planes travel
+ * over different links at the same time), i.e. what a send/recv kernel's residency looks like to the rest of the chip; then the
+ * ghost planes are filled from the rank's own boundary planes (mirror: same bytes written, defined values) by 32 small workgroups
+ * -- not by a chip-wide copy kernel, which would queue behind the marching kernel it is supposed to overlap with */
 static int phantom_halo_n(mg_comm *c, mgk_ctx *ctx, int nf, void *const *fields, const mgk_geom *const *geoms, int esz, void *stream) {
     if (c->nranks == 1 || nf < 1) return 0;
     void *s = stream_of(ctx, stream);
     double bytes = 0.0;
+    for (int q = 0; q < nf; q++) bytes += (double)esz * (double)geoms[q]->plane;
+    CK(phantom_hold(c, ctx, bytes, s));
     for (int q = 0; q < nf; q++) {
         const mgk_geom *g = geoms[q];
         const size_t pb = (size_t)esz * (size_t)g->plane;
         char *f = (char *)fields[q];
-        /* the neighbours' planes are stood in for by my own boundary planes (mirror): same bytes written, defined values */
-        if (c->rank > 0) CK(mgk_d2d(ctx, f, f + pb, pb, s));
-        if (c->rank < c->nranks - 1) CK(mgk_d2d(ctx, f + (size_t)(g->nz + 1) * pb, f + (size_t)g->nz * pb, pb, s));
-        bytes += (double)pb;                       /* the two directions use two links at once */
+        if (c->rank > 0) CK(mgk_paced_copy(ctx, f, f + pb, pb, 0.0, 32, s));
+        if (c->rank < c->nranks - 1) CK(mgk_paced_copy(ctx, f + (size_t)(g->nz + 1) * pb, f + (size_t)g->nz * pb, pb, 0.0, 32, s));
     }
-    return phantom_hold(c, ctx, bytes, s);
+    return 0;
 }
 static int phantom_halo(mg_comm *c, mgk_ctx *ctx, void *field, const mgk_geom *g, int esz, void *stream) {
     void *const f[1] = {field};

@@ -302,6 +302,7 @@ void mg_config_default(mg_config *c) {
     c->overlap = -1;
     c->graph = -1;
     c->pair_min_n = 0;
+    c->slab_chunk = -1;
 }
 
 static int alloc_fset(mg_solver *s, mg_fset *F, int esz, int all4) {
@@ -370,6 +371,11 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
     s->levels = cfg->levels;
     int rc = mgk_ctx_create(&s->ctx, cfg->device);
     if (rc) { free(s); return mgfail(rc, "mg_solver_create: mgk_ctx_create"); }
+    if (s->cfg.slab_chunk < 0) {                /* default 32 planes; MG_SLAB_CHUNK overrides (0: the long streams of a single GPU) */
+        const char *e = getenv("MG_SLAB_CHUNK");
+        s->cfg.slab_chunk = (e && *e && atoi(e) >= 0) ? atoi(e) : 32;
+    }
+    if (s->cfg.nranks > 1 && s->cfg.dim == 3) mgk_ctx_set_chunk_planes(s->ctx, s->cfg.slab_chunk);
 
     /* which levels are distributed */
     s->ldist = 0;

@@ -42,6 +42,8 @@ struct mgk_ctx {
     hipEvent_t ev[32];     // ring of dependency events for mgk_stream_wait (no create/destroy on the hot path)
     int ev_next;
     double *defer_slot;    // non-null: the next single-value reductions deposit here (device) instead of syncing to the host
+    int chunk_planes;      // > 0: the 3-D marching kernels launched on this context cut z into chunks of about this many planes
+                           // (slab ranks: short blocks, so that the exchange kernels of the comm stream find CUs beside them)
 };
 
 extern "C" const char *mgk_last_error(void) { return g_err; }
@@ -65,7 +67,14 @@ extern "C" int mgk_ctx_create(mgk_ctx **out, int device) {
     mgk_ctx *c = new mgk_ctx();
     c->device = device;
     HIPCHK(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c->comm, hipStreamNonBlocking));
+    {   // the comm stream gets the highest priority the device offers: when CUs free up, the (few) workgroups of an exchange are
+        // dispatched before the next workgroups of the marching kernel that fills the chip
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; hi = 0; }
+        if (hipStreamCreateWithPriority(&c->comm, hipStreamNonBlocking, hi) != hipSuccess)
+            HIPCHK(hipStreamCreateWithFlags(&c->comm, hipStreamNonBlocking));
+    }
+    c->chunk_planes = 0;
     c->max_partials = 16384;
     HIPCHK(hipMalloc(&c->partials, sizeof(double) * 3 * c->max_partials));
     HIPCHK(hipMalloc(&c->result_dev, sizeof(double) * 8));
@@ -89,6 +98,11 @@ extern "C" void mgk_ctx_destroy(mgk_ctx *c) {
     delete c;
 }
 
+extern "C" int mgk_ctx_set_chunk_planes(mgk_ctx *c, int planes) {
+    if (!c || planes < 0) return fail(MGK_EINVAL, "mgk_ctx_set_chunk_planes: planes >= 0");
+    c->chunk_planes = planes;
+    return 0;
+}
 extern "C" void *mgk_stream_compute(mgk_ctx *c) { return (void *)c->compute; }
 extern "C" void *mgk_stream_comm(mgk_ctx *c) { return (void *)c->comm; }
 static inline hipStream_t S(mgk_ctx *c, void *s) { return s ? (hipStream_t)s : c->compute; }
@@ -146,6 +160,20 @@ extern "C" int mgk_h2d_async(mgk_ctx *c, void *dst, const void *src_pinned, size
 __global__ void __launch_bounds__(64) k_delay(unsigned long long ticks) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+// `bytes` (a multiple of 16) from src to dst by a handful of small workgroups that then stay resident until `us` microseconds have
+// passed since they started: the footprint of a send/recv kernel that moves a plane at link speed (phantom communicator)
+__global__ void __launch_bounds__(256) k_paced_copy(const uint4 *src, uint4 *dst, long n16, unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n16; q += (long)gridDim.x * blockDim.x) dst[q] = src[q];
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+extern "C" int mgk_paced_copy(mgk_ctx *c, void *dst, const void *src, size_t bytes, double us, int blocks, void *stream) {
+    if (!c || !dst || !src || (bytes & 15) || us < 0.0 || us > 1.0e6 || blocks < 1 || blocks > 64) return fail(MGK_EINVAL, "mgk_paced_copy: bad arguments");
+    hipLaunchKernelGGL(k_paced_copy, dim3((unsigned)blocks), dim3(256), 0, S(c, stream), (const uint4 *)src, (uint4 *)dst, (long)(bytes / 16),
+                       (unsigned long long)(us * 100.0));
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 extern "C" int mgk_delay_us(mgk_ctx *c, double us, void *stream) {
     if (!c || us < 0.0 || us > 1.0e6) return fail(MGK_EINVAL, "mgk_delay_us: 0 <= us <= 1e6");
@@ -875,6 +903,7 @@ static int launch_st(mgk_ctx *c, StArgs<T> &a, int nrows, hipStream_t s, int *nb
         // (3-D likewise: 2-plane chunks on the cache-resident coarse levels, 255^3 cycle 1.09 -> 0.94 ms)
         const int zmin = (MODE == MODE_RESNORM && DIM == 3) ? 16 : 2;
         if (zc < zmin) zc = zmin;
+        if (DIM == 3 && c->chunk_planes > 0 && zc > c->chunk_planes) zc = c->chunk_planes;     // slab ranks: never longer than the hint
     }
     if (zc > nmr) zc = nmr;
     a.zc = zc;
@@ -1555,6 +1584,7 @@ static int jacobi2(mgk_ctx *c, const mgk_geom *g, const double *coef, double din
     const long target = (w > 4) ? 256 : (sizeof(T) == 4 ? 1024 : 512);      // fp32 1023^3: 1024 blocks 2.72 ms, 512 blocks 2.84 ms
     long nch = (a.nty >= target) ? 1 : (target + a.nty - 1) / a.nty;
     if (g_zchunk > 0) nch = (nzr + g_zchunk - 1) / g_zchunk;
+    else if (c->chunk_planes > 0 && nch < (nzr + c->chunk_planes - 1) / c->chunk_planes) nch = (nzr + c->chunk_planes - 1) / c->chunk_planes;
     int zc = (int)((nzr + nch - 1) / nch);
     if (zc < 8) zc = 8;
     if (zc > nzr) zc = nzr;
@@ -3093,6 +3123,7 @@ static int launch_jrow(mgk_ctx *c, const mgk_geom *g, const StArgs<T> &a, int zb
     const long target = (w > 4) ? 256 : (w > 2 ? 512 : 1024);
     long nch = (q.nty >= target) ? 1 : (target + q.nty - 1) / q.nty;
     if (g_zchunk > 0) nch = (nzr + g_zchunk - 1) / g_zchunk;
+    else if (c->chunk_planes > 0 && nch < (nzr + c->chunk_planes - 1) / c->chunk_planes) nch = (nzr + c->chunk_planes - 1) / c->chunk_planes;
     int zc = (int)((nzr + nch - 1) / nch);
     if (zc < 4) zc = 4;
     if (zc > nzr) zc = nzr;
@@ -3105,7 +3136,6 @@ static int launch_jrow(mgk_ctx *c, const mgk_geom *g, const StArgs<T> &a, int zb
     }
     q.zc = zc;
     if (nparts) *nparts = (int)nblk;
-    (void)c;
 #define JROW_LAUNCH(WXV) hipLaunchKernelGGL((k_jrow<T, WXV, (sizeof(T) == 8 ? 2 : 1), NORM>), dim3((unsigned)nblk), dim3(64 * WXV), 0, s, q, partials)
     if (w <= 1) JROW_LAUNCH(1);
     else if (w <= 2) JROW_LAUNCH(2);
@@ -3202,6 +3232,7 @@ static int residual_restrict(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc,
     // blocks of <= 256 threads (fp32 rows) leave room for two per CU: cut z in two (fp32 at 1023^3: 2.78 -> 1.82 ms)
     long nch = (a.nty >= 256) ? ((w <= 4) ? 2 : 1) : (512 + a.nty - 1) / a.nty;
     if (g_zchunk > 0) nch = (nkc + g_zchunk - 1) / g_zchunk;
+    else if (c->chunk_planes > 1 && nch < (nkc + c->chunk_planes / 2 - 1) / (c->chunk_planes / 2)) nch = (nkc + c->chunk_planes / 2 - 1) / (c->chunk_planes / 2);
     int kcc = (int)((nkc + nch - 1) / nch);
     if (kcc < 4) kcc = 4;
     if (kcc > nkc) kcc = nkc;
@@ -3331,6 +3362,7 @@ static int prolong_jacobi(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, co
         const long target = (w > 4) ? 256 : 512;
         long nch = (q.nty >= target) ? 1 : (target + q.nty - 1) / q.nty;
         if (g_zchunk > 0) nch = (nzr + g_zchunk - 1) / g_zchunk;
+        else if (c->chunk_planes > 0 && nch < (nzr + c->chunk_planes - 1) / c->chunk_planes) nch = (nzr + c->chunk_planes - 1) / c->chunk_planes;
         int zc = (int)((nzr + nch - 1) / nch);
         if (zc < 4) zc = 4;
         if (zc > nzr) zc = nzr;

@@ -94,6 +94,7 @@ def _sigs(L):
         "mgk_residual_restrict_slab_f64": (i, [vp, G, G, G, c_dp, vp, vp, vp, i, vp, i, i, vp]),
         "mgk_residual_restrict_slab_f32": (i, [vp, G, G, G, c_dp, vp, vp, vp, i, vp, i, i, vp]),
         "mgk_residual_restrict_2d_f64": (i, [vp, G, G, c_dp, vp, vp, vp, vp, d, d, vp]),
+        "mgk_ctx_set_chunk_planes": (i, [vp, i]),
         "mgk_tail_cycle_f64": (i, [vp, G, i, C.POINTER(i), c_dp, c_dp, d, i, i, vp, vp, vp]),
         "mgk_tail_cycle_f32": (i, [vp, G, i, C.POINTER(i), c_dp, c_dp, d, i, i, vp, vp, vp]),
         "mgk_tail_max_n": (i, [i]),
@@ -104,6 +105,7 @@ def _sigs(L):
         "mgk_d2h_async": (i, [vp, vp, vp, sz, vp]),
         "mgk_h2d_async": (i, [vp, vp, vp, sz, vp]),
         "mgk_delay_us": (i, [vp, d, vp]),
+        "mgk_paced_copy": (i, [vp, vp, vp, sz, d, i, vp]),
     }
     for name, (res, args) in S.items():
         f = getattr(L, name)

@@ -16,7 +16,7 @@ class MgConfig(C.Structure):
                 ("emin", C.c_double), ("emax", C.c_double), ("rtol", C.c_double),
                 ("device", C.c_int), ("precision", C.c_int), ("rank", C.c_int), ("nranks", C.c_int),
                 ("dist_min_n", C.c_int), ("fuse", C.c_int), ("overlap", C.c_int), ("graph", C.c_int),
-                ("pair_min_n", C.c_int), ("mesh", C.c_int)]
+                ("pair_min_n", C.c_int), ("slab_chunk", C.c_int), ("mesh", C.c_int)]
 
 
 class MgError(RuntimeError):
@@ -102,7 +102,7 @@ class Solver:
 
     def __init__(self, dim, npts, levels, v=(3, 3), maxiter=100000, ksp_type="richardson", scale=1.0,
                  eigenvalues=(0.0, 0.0), rtol=1.0e-7, device=0, rank=0, nranks=1, comm=None,
-                 dist_min_n=0, fuse=-1, overlap=-1, precision="fp64", graph=-1, pair_min_n=0, mesh=0):
+                 dist_min_n=0, fuse=-1, overlap=-1, precision="fp64", graph=-1, pair_min_n=0, mesh=0, slab_chunk=-1):
         self.L = _lib()
         cfg = MgConfig()
         self.L.mg_config_default(C.byref(cfg))
@@ -117,6 +117,7 @@ class Solver:
         cfg.precision = {"fp64": 0, "mixed": 1}[precision]
         cfg.dist_min_n, cfg.fuse, cfg.overlap, cfg.graph = dist_min_n, fuse, overlap, graph
         cfg.pair_min_n = pair_min_n
+        cfg.slab_chunk = slab_chunk
         cfg.mesh = mesh
         self.cfg = cfg
         self.h = C.c_void_p()

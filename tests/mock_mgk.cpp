@@ -58,6 +58,7 @@ int mgk_ctx_create(mgk_ctx **out, int device) {
     return 0;
 }
 void mgk_ctx_destroy(mgk_ctx *c) { delete c; }
+int mgk_ctx_set_chunk_planes(mgk_ctx *c, int planes) { return (c && planes >= 0) ? 0 : fail(MGK_EINVAL, "mgk_ctx_set_chunk_planes"); }
 void *mgk_stream_compute(mgk_ctx *c) { return &c->cs; }
 void *mgk_stream_comm(mgk_ctx *c) { return &c->ms; }
 int mgk_malloc(mgk_ctx *, void **p, size_t bytes) { *p = calloc(1, bytes ? bytes : 8); return *p ? 0 : fail(MGK_EINVAL, "mgk_malloc"); }
@@ -71,6 +72,10 @@ int mgk_d2h_async(mgk_ctx *, void *d, const void *s, size_t n, void *) { memcpy(
 int mgk_h2d_async(mgk_ctx *, void *d, const void *s, size_t n, void *) { memcpy(d, s, n); return 0; }
 int mgk_d2d(mgk_ctx *c, void *d, const void *s, size_t n, void *) { return run(c, [=] { memmove(d, s, n); }); }
 int mgk_sync(mgk_ctx *, void *) { return 0; }
+int mgk_paced_copy(mgk_ctx *c, void *d, const void *s, size_t n, double us, int blocks, void *) {
+    if (!c || !d || !s || (n & 15) || us < 0 || blocks < 1) return fail(MGK_EINVAL, "mgk_paced_copy");
+    return run(c, [=] { memmove(d, s, n); });
+}
 int mgk_delay_us(mgk_ctx *, double us, void *) { return us < 0 ? fail(MGK_EINVAL, "mgk_delay_us") : 0; }
 int mgk_timer_create(mgk_ctx *, void **t) { *t = malloc(8); return 0; }
 int mgk_timer_start(mgk_ctx *, void *, void *) { return 0; }

@@ -55,18 +55,21 @@ def main():
     ap.add_argument("--overlap", default="1,0")
     ap.add_argument("--pair-min-n", type=int, default=0)
     ap.add_argument("--dist-min-n", type=int, default=0)
+    ap.add_argument("--slab-chunks", default="-1", help="comma list of mg_config.slab_chunk values (-1: default 32, 0: long streams)")
     a = ap.parse_args()
     res = {"workload": f"3-D npts={a.npts}, {a.levels} levels, V(3,3), one rank of {a.nranks} z-slabs, phantom neighbours",
            "precision": a.precision, "single_gpu_ms_per_cycle": a.single_ms or None,
            "ideal_share_ms": (a.single_ms / a.nranks) if a.single_ms else None, "models": {}}
-    for name in a.models.split(","):
+    for name, overlap, chunk in [(n_, o_, c_) for n_ in a.models.split(",") for o_ in [int(x) for x in a.overlap.split(",")]
+                                 for c_ in [int(x) for x in a.slab_chunks.split(",")]]:
         lat, gbs = MODELS[name]
-        for overlap in [int(x) for x in a.overlap.split(",")]:
-            key = f"{name}{'' if overlap else '_no_overlap'}"
-            res["models"][key] = {"latency_us": lat, "link_GBs": gbs or None, "overlap": bool(overlap), "ranks": {}}
+        if True:
+            key = f"{name}{'' if overlap else '_no_overlap'}{'' if chunk < 0 else '_chunk%d' % chunk}"
+            res["models"][key] = {"latency_us": lat, "link_GBs": gbs or None, "overlap": bool(overlap),
+                                  "slab_chunk_planes": 32 if chunk < 0 else chunk, "ranks": {}}
             for r in [int(x) for x in a.ranks.split(",")]:
                 ms, planes = run(r, a.nranks, a.npts, a.levels, lat, gbs, a.cycles, a.warmup, overlap, a.precision,
-                                 pair_min_n=a.pair_min_n, dist_min_n=a.dist_min_n)
+                                 pair_min_n=a.pair_min_n, dist_min_n=a.dist_min_n, slab_chunk=chunk)
                 res["models"][key]["ranks"][str(r)] = {"ms_per_cycle": ms, "local_planes_per_level": planes}
                 print(f"[slab_share] {key:24s} rank {r}: {ms:.3f} ms/cycle", file=sys.stderr, flush=True)
             worst = max(v["ms_per_cycle"] for v in res["models"][key]["ranks"].values())
