@@ -22,6 +22,8 @@ import os
 import sys
 import time
 
+# one process per GPU: the host driver of this pool supports dmabuf IPC only; RCCL's peer mapping fails without it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -249,6 +251,19 @@ def main():
     comm = None
     transport = "none"
     transport_fallback = False
+    if world > 1:
+        # watchdog: a transport that hangs (a collective some rank never enters) must end the job with a message instead of
+        # sitting in the launcher until the driver's limit; the whole N-GPU run takes seconds
+        import threading
+        limit = float(os.environ.get("MG_BENCH_WATCHDOG_S", "420"))
+
+        def _watchdog():
+            print(f"[bench rank {rank}] no result after {limit:.0f} s -- a collective is stuck (transport "
+                  f"{os.environ.get('MG_BENCH_TRANSPORT', 'rccl')}); aborting", file=sys.stderr, flush=True)
+            os._exit(4)
+        wd = threading.Timer(limit, _watchdog)
+        wd.daemon = True
+        wd.start()
     if world > 1:
         import torch.distributed as dist   # control plane only (id broadcast, barrier, max-reduce)
         import torch
