@@ -934,7 +934,7 @@ static int dispatch_st(mgk_ctx *c, const mgk_geom *g, StArgs<double> &a, hipStre
         a.ny = g->ny; a.nm = g->nz; a.rs = g->pitch; a.ms = g->plane;
         int v = g_variant >= 30 ? -1 : g_variant;
         if (v < 0) v = (MODE == MODE_RESNORM && g->nx >= 255) ? 3
-                     : (g->nx >= 1023) ? ((MODE == MODE_PJACOBI || MODE == MODE_CRES32) ? 9 : 12)   // on-the-fly corrections: 512-thread blocks (a 1024-thread block is capped at 128 VGPRs and spills)
+                     : (g->nx >= 1023) ? ((MODE == MODE_PJACOBI || MODE == MODE_CRES32 || MODE == MODE_CHEBY) ? 9 : 12)   // on-the-fly corrections and the Chebyshev step's third operand: 512-thread blocks (a 1024-thread block is capped at 128 VGPRs and spills: Chebyshev step 9.88 -> 5.96 ms)
                      : (g->nx >= 511) ? (MODE == MODE_PJACOBI ? 13 : 6)             // fused prolongation at 511^3: 0.91 -> 0.73 ms
                      : (g->nx >= 255) ? 2 : (g->nx >= 127 ? 1 : 0);
         switch (v) {
