@@ -308,6 +308,14 @@ int  mgk_correct_residual_f64_f32(mgk_ctx *ctx, const mgk_geom *g, const mgk_geo
                                   const double *b, const double *u, const float *e32, double *unew, float *r32,
                                   double *sumsq_host, void *stream);
 int  mgk_correct_f64_from_f32(mgk_ctx *ctx, const mgk_geom *g, const mgk_geom *g32, const float *e32, double *u, void *stream);
+/* the two bridges above, also writing e0 = scale * (r32 * dinv) in fp32: the first sweep of the fp32 correction cycle from its zero
+ * guess (the arithmetic of mgk_jacobi_zero_f32 on the value just stored): one launch and one read of r32 less per outer step */
+int  mgk_residual_f64_to_f32_jz(mgk_ctx *ctx, const mgk_geom *g, const mgk_geom *g32, const double *coef,
+                                const double *b, const double *u, float *r32, float *e0, double dinv, double scale,
+                                double *sumsq_host, void *stream);
+int  mgk_correct_residual_f64_f32_jz(mgk_ctx *ctx, const mgk_geom *g, const mgk_geom *g32, const double *coef,
+                                     const double *b, const double *u, const float *e32, double *unew, float *r32,
+                                     float *e0, double dinv, double scale, double *sumsq_host, void *stream);
 int  mgk_pack_f32(mgk_ctx *ctx, const mgk_geom *g32, const double *compact_dev, float *padded_dev, void *stream);
 int  mgk_unpack_f32(mgk_ctx *ctx, const mgk_geom *g32, const float *padded_dev, double *compact_dev, void *stream);
 

@@ -1141,18 +1141,27 @@ static int vcycle_once(mg_solver *s) {
         mg_fset *E = &L->f[1];
         E->guess_nonzero = 0;
         CHK(cycle_body(s, 1, 1));
+        /* the fp32 cycle that follows starts from e = 0: its first sweep, scale * (r32 * dinv), comes out of the same pass that
+         * produces r32 (fuse bit 8): one launch and one read of r32 less per outer step */
+        const int jz = (s->cfg.fuse & 256) && s->cfg.v[0] >= 1 && s->levels > 1;
         if ((s->cfg.fuse & 16) && F->tmp && !L->distributed) {
             /* u += (double) e and r32 = (float)(b - A u) in one pass (32 B/unknown instead of 20 + 20) */
-            CHK(mgk_correct_residual_f64_f32(s->ctx, &F->g, &E->g, L->coef, (const double *)F->b, (const double *)F->u,
-                                             (const float *)E->u, (double *)F->tmp, (float *)E->b, &ss, NULL));
+            if (jz) CHK(mgk_correct_residual_f64_f32_jz(s->ctx, &F->g, &E->g, L->coef, (const double *)F->b, (const double *)F->u,
+                                                        (const float *)E->u, (double *)F->tmp, (float *)E->b, (float *)E->tmp, L->dinv,
+                                                        s->cfg.scale, &ss, NULL));
+            else CHK(mgk_correct_residual_f64_f32(s->ctx, &F->g, &E->g, L->coef, (const double *)F->b, (const double *)F->u,
+                                                  (const float *)E->u, (double *)F->tmp, (float *)E->b, &ss, NULL));
             swap_ptr(&F->u, &F->tmp);
             F->u_ghost_ok = 0; F->u_ghost_pending = 0;
         } else {
             CHK(mgk_correct_f64_from_f32(s->ctx, &F->g, &E->g, (const float *)E->u, (double *)F->u, NULL));
             F->u_ghost_ok = 0; F->u_ghost_pending = 0;
             CHK(ensure_u_ghosts(s, 0, L));
-            CHK(mgk_residual_f64_to_f32(s->ctx, &F->g, &E->g, L->coef, (const double *)F->b, (const double *)F->u, (float *)E->b, &ss, NULL));
+            if (jz) CHK(mgk_residual_f64_to_f32_jz(s->ctx, &F->g, &E->g, L->coef, (const double *)F->b, (const double *)F->u, (float *)E->b,
+                                                   (float *)E->tmp, L->dinv, s->cfg.scale, &ss, NULL));
+            else CHK(mgk_residual_f64_to_f32(s->ctx, &F->g, &E->g, L->coef, (const double *)F->b, (const double *)F->u, (float *)E->b, &ss, NULL));
         }
+        E->jz_ready = jz;
         E->b_ghost_ok = 0;
     } else {
         CHK(cycle_body(s, 0, s->iter == 0));

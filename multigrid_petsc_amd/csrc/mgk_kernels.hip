@@ -389,6 +389,8 @@ struct StArgs {
     int nxc, nyc, nzc;
     T *out;
     float *out32;          // MODE_RES32 / MODE_CRES32: float copy of the fp64 residual (own strides below)
+    float *jz32;           // optional: the fp32 cycle's first sweep from its zero guess, scale32 * (r32 * dinv32), same strides
+    float dinv32, scale32;
     const float *e32;      // MODE_CRES32: fp32 correction added to u on the fly (same fp32 geometry as out32)
     double *partials;
     int nx, ny, nm;       // nm: number of marching planes (nz in 3-D, ny in 2-D)
@@ -797,6 +799,13 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
                 if (MODE == MODE_RES32 || MODE == MODE_CRES32) {
                     float2 f; f.x = (float)o.v[0]; f.y = (float)o.v[VX - 1];     // T == double here (VX == 2)
                     *reinterpret_cast<float2 *>(a.out32 + (DIM == 3 ? (long)yb * a.ors : 0) + x0 + (long)z * a.oms + (long)r * a.ors) = f;
+                    if (a.jz32) {                                               // k_jacobi_zero<float>'s arithmetic on the value just stored
+                        float2 zq;
+                        const float zx = f.x * a.dinv32, zy = f.y * a.dinv32;
+                        zq.x = a.scale32 * zx; zq.y = a.scale32 * zy;
+                        if (x0 + 1 == a.nx) zq.y = 0.f;
+                        *reinterpret_cast<float2 *>(a.jz32 + (DIM == 3 ? (long)yb * a.ors : 0) + x0 + (long)z * a.oms + (long)r * a.ors) = zq;
+                    }
                     if (MODE == MODE_CRES32) stv_stream(a.out + rowoff + x0 + (long)z * a.ms + (long)r * a.rs, uc[r]);   // the corrected u
                 } else if (MODE != MODE_RESNORM) {
                     stv_stream(a.out + rowoff + x0 + (long)z * a.ms + (long)r * a.rs, o);
@@ -2336,6 +2345,25 @@ extern "C" int mgk_residual_f64_to_f32(mgk_ctx *c, const mgk_geom *g, const mgk_
     return finish_to_host(c, nblk, 1, S(c, stream), sumsq_host);
 }
 
+// the same, also writing e0 = scale32 * (r32 * dinv32): the first sweep of the fp32 correction cycle from its zero guess (what
+// mgk_jacobi_zero_f32 would compute from r32: one launch and one read of r32 less)
+extern "C" int mgk_residual_f64_to_f32_jz(mgk_ctx *c, const mgk_geom *g, const mgk_geom *g32, const double *coef,
+                                          const double *b, const double *u, float *r32, float *e0, double dinv, double scale,
+                                          double *sumsq_host, void *stream) {
+    if (!c || !g || !g32 || !coef || !b || !u || !r32 || !e0 || e0 == r32 || !sumsq_host || g->dim != 3 ||
+        g->nx != g32->nx || g->ny != g32->ny || g->nz != g32->nz)
+        return fail(MGK_EINVAL, "mgk_residual_f64_to_f32_jz: bad arguments");
+    StArgs<double> a; memset(&a, 0, sizeof(a));
+    a.u = u + g->org; a.b = b + g->org; a.out32 = r32 + g32->org; a.ors = g32->pitch; a.oms = g32->plane;
+    a.jz32 = e0 + g32->org; a.dinv32 = (float)dinv; a.scale32 = (float)scale;
+    a.partials = c->partials;
+    set_coef(a, g, coef);
+    int nblk = 0;
+    int rc = dispatch_st<MODE_RES32>(c, g, a, S(c, stream), &nblk);
+    if (rc) return rc;
+    return finish_to_host(c, nblk, 1, S(c, stream), sumsq_host);
+}
+
 // The whole outer step of the mixed-precision iteration in one pass: unew = u + (double) e32 (written), r32 = (float)(b - A unew),
 // sum r^2.  Every u value the block touches is corrected on the fly, like the fused prolongation sweep does with the
 // coarse interpolant: 8 (u) + 4 (e32) + 8 (b) read, 8 (unew) + 4 (r32) written = 32 B instead of 20 + 20.
@@ -2348,6 +2376,24 @@ extern "C" int mgk_correct_residual_f64_f32(mgk_ctx *c, const mgk_geom *g, const
     StArgs<double> a; memset(&a, 0, sizeof(a));
     a.u = u + g->org; a.b = b + g->org; a.out = unew + g->org;
     a.out32 = r32 + g32->org; a.e32 = e32 + g32->org; a.ors = g32->pitch; a.oms = g32->plane;
+    a.partials = c->partials;
+    set_coef(a, g, coef);
+    int nblk = 0;
+    int rc = dispatch_st<MODE_CRES32>(c, g, a, S(c, stream), &nblk);
+    if (rc) return rc;
+    return finish_to_host(c, nblk, 1, S(c, stream), sumsq_host);
+}
+
+extern "C" int mgk_correct_residual_f64_f32_jz(mgk_ctx *c, const mgk_geom *g, const mgk_geom *g32, const double *coef,
+                                               const double *b, const double *u, const float *e32, double *unew, float *r32,
+                                               float *e0, double dinv, double scale, double *sumsq_host, void *stream) {
+    if (!c || !g || !g32 || !coef || !b || !u || !e32 || !unew || !r32 || !e0 || e0 == r32 || (const float *)e0 == e32 || !sumsq_host ||
+        u == unew || (const float *)r32 == e32 || g->dim != 3 || g->nx != g32->nx || g->ny != g32->ny || g->nz != g32->nz)
+        return fail(MGK_EINVAL, "mgk_correct_residual_f64_f32_jz: bad arguments");
+    StArgs<double> a; memset(&a, 0, sizeof(a));
+    a.u = u + g->org; a.b = b + g->org; a.out = unew + g->org;
+    a.out32 = r32 + g32->org; a.e32 = e32 + g32->org; a.ors = g32->pitch; a.oms = g32->plane;
+    a.jz32 = e0 + g32->org; a.dinv32 = (float)dinv; a.scale32 = (float)scale;
     a.partials = c->partials;
     set_coef(a, g, coef);
     int nblk = 0;

@@ -95,6 +95,8 @@ def _sigs(L):
         "mgk_residual_restrict_slab_f32": (i, [vp, G, G, G, c_dp, vp, vp, vp, i, vp, i, i, vp]),
         "mgk_residual_restrict_2d_f64": (i, [vp, G, G, c_dp, vp, vp, vp, vp, d, d, vp]),
         "mgk_ctx_set_chunk_planes": (i, [vp, i]),
+        "mgk_residual_f64_to_f32_jz": (i, [vp, G, G, c_dp, vp, vp, vp, vp, d, d, C.POINTER(d), vp]),
+        "mgk_correct_residual_f64_f32_jz": (i, [vp, G, G, c_dp, vp, vp, vp, vp, vp, vp, d, d, C.POINTER(d), vp]),
         "mgk_tail_cycle_f64": (i, [vp, G, i, C.POINTER(i), c_dp, c_dp, d, i, i, vp, vp, vp]),
         "mgk_tail_cycle_f32": (i, [vp, G, i, C.POINTER(i), c_dp, c_dp, d, i, i, vp, vp, vp]),
         "mgk_tail_max_n": (i, [i]),

@@ -536,6 +536,16 @@ int mgk_residual_f64_to_f32(mgk_ctx *c, const mgk_geom *g, const mgk_geom *g32, 
     deliver(c, sumsq_field<double>(*g, r.data(), 0, g->nz), out);
     return 0;
 }
+static void jz32(const mgk_geom &H, const float *r32, float *e0, double dinv, double scale) {
+    for (int k = 0; k < H.nz; k++) for (int i = 0; i < H.ny; i++) for (int j = 0; j < H.nx; j++) { const float zx = at(r32, H, k, i, j) * (float)dinv; at(e0, H, k, i, j) = (float)scale * zx; }
+}
+int mgk_residual_f64_to_f32_jz(mgk_ctx *c, const mgk_geom *g, const mgk_geom *g32, const double *coef, const double *b, const double *u, float *r32, float *e0,
+                               double dinv, double scale, double *out, void *s) {
+    if (!e0 || e0 == r32) return fail(MGK_EINVAL, "mgk_residual_f64_to_f32_jz");
+    int rc = mgk_residual_f64_to_f32(c, g, g32, coef, b, u, r32, out, s);
+    if (!rc) jz32(*g32, r32, e0, dinv, scale);
+    return rc;
+}
 int mgk_correct_f64_from_f32(mgk_ctx *c, const mgk_geom *g, const mgk_geom *g32, const float *e, double *u, void *) {
     if (!c || !g || !g32 || !e || !u || g->nx != g32->nx || g->ny != g32->ny || g->nz != g32->nz) return fail(MGK_EINVAL, "mgk_correct_f64_from_f32");
     const mgk_geom G = *g, H = *g32;
@@ -546,5 +556,12 @@ int mgk_correct_residual_f64_f32(mgk_ctx *c, const mgk_geom *g, const mgk_geom *
     memcpy(unew, u, sizeof(double) * (size_t)g->total);
     int rc = mgk_correct_f64_from_f32(c, g, g32, e, unew, s);
     return rc ? rc : mgk_residual_f64_to_f32(c, g, g32, coef, b, unew, r32, out, s);
+}
+int mgk_correct_residual_f64_f32_jz(mgk_ctx *c, const mgk_geom *g, const mgk_geom *g32, const double *coef, const double *b, const double *u, const float *e, double *unew,
+                                    float *r32, float *e0, double dinv, double scale, double *out, void *s) {
+    if (!e0 || e0 == r32 || (const float *)e0 == e) return fail(MGK_EINVAL, "mgk_correct_residual_f64_f32_jz");
+    int rc = mgk_correct_residual_f64_f32(c, g, g32, coef, b, u, e, unew, r32, out, s);
+    if (!rc) jz32(*g32, r32, e0, dinv, scale);
+    return rc;
 }
 }   // extern "C"
