@@ -261,6 +261,23 @@ int  mgk_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *g, int mode, const double *ct
                      const double *b, const double *u, double *out, void *stream);
 int  mgk_jacobi_zero_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *g, const double *dtab, double scale,
                                  const double *b, double *unew, void *stream);
+/* the fused forms of the cycle on a row-table operator (the constant-coefficient entry points of the same names with the
+ * tables in place of coef / dinv; same arithmetic per point, so a stretched-mesh cycle stays bit-identical to the
+ * kernel-per-operation one): */
+int  mgk_jacobi2_2d_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *g, const double *ctab, const double *dtab, double scale,
+                                const double *b, const double *u, double *unew, void *stream);          /* mgk_jacobi2_2d_f64 */
+int  mgk_jacobi_sumsq_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *g, const double *ctab, const double *dtab, double scale,
+                                  const double *b, const double *u, double *unew, double *sumsq_host, void *stream);   /* mgk_jacobi_sumsq_f64 */
+int  mgk_residual_sumsq_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *g, const double *ctab, const double *b, const double *u,
+                                    double *sumsq_host, void *stream);                                  /* mgk_residual_sumsq_f64 */
+int  mgk_prolong_jacobi_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *ctab, const double *dtab,
+                                    double scale, const double *b, const double *uc, const double *u, double *unew, void *stream);   /* mgk_prolong_jacobi_f64 */
+/* ctab_f: table of the FINE level; dtab_c: 1/diag table of the COARSE level (needed only with uc0) */
+int  mgk_residual_restrict_2d_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *ctab_f, const double *b,
+                                          const double *u, double *bc, double *uc0, const double *dtab_c, double scale_c, void *stream);
+/* ctab[l] / dtab[l]: the device tables of tail level l (n[l] x 5 and n[l] doubles) */
+int  mgk_tail_cycle_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *g0, int nlev, const int *n, const double *const *ctab,
+                                const double *const *dtab, double scale, int v0, int v1, const double *b, double *u, void *stream);
 
 /* ---- flat BLAS-1 / AIJ kernels behind the PETSc-surface shim (include/petscksp.h) ----
  * n counts doubles of a whole allocation (padded fields: ghosts are 0 and stay 0). */

@@ -53,7 +53,8 @@ typedef struct mg_config {
     int slab_chunk;     /* nranks > 1: planes per workgroup of the marching kernels (short blocks let the exchange kernels in beside the
                          * interior launches); <0: default 32, 0: the long streams of a single GPU */
     int mesh;           /* -mesh: 0 uniform; 1 / 2: the reference's meshes stretched in y (src/mesh.c:45-107,165-169), 2-D, one GPU,
-                         * Richardson + Jacobi: the operator rows then depend on the grid row (per-row coefficient tables) */
+                         * Richardson + Jacobi: the operator rows then depend on the grid row (per-row coefficient tables); the same
+                         * fused cycle on the row-table forms of its kernels (mgk_*_rowcoef_f64) */
 } mg_config;
 
 void mg_config_default(mg_config *cfg);     /* poisson.in defaults + -pc_type jacobi -ksp_richardson_scale 1 */

@@ -363,7 +363,7 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
     if (s->cfg.fuse < 0) s->cfg.fuse = 63 | 256 | 512;
     if (s->cfg.pair_min_n <= 0) s->cfg.pair_min_n = (cfg->dim == 3) ? 255 : 2047;   /* where a two-sweep pass beats two sweeps
                                                                                       * (255^3: 0.107 ms against 2 x 0.063) */
-    if (s->cfg.mesh) s->cfg.fuse = 0;           /* row-dependent coefficients: the kernel-per-operation cycle on the row-table kernels */
+    if (s->cfg.mesh) s->cfg.fuse &= ~(16 | 128);   /* row-dependent coefficients (2-D, fp64): the same fused cycle on the row-table forms of the kernels */
     if (s->cfg.overlap < 0) s->cfg.overlap = 1;
     if (s->cfg.graph < 0) s->cfg.graph = 1;
     if (s->cfg.nranks < 1) s->cfg.nranks = 1;
@@ -459,7 +459,7 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
     /* the tail: the first level l >= 1 that is whole on this rank, fed by a whole level... any level qualifies as long as it
      * and everything below it fit in LDS (n <= mgk_tail_max_n) -- and at least two levels are left, else a tail is no gain */
     s->ltail = 0;
-    if ((s->cfg.fuse & 512) && s->cfg.ksp_type == MG_KSP_RICHARDSON && !s->cfg.mesh && s->cfg.v[0] >= 1) {
+    if ((s->cfg.fuse & 512) && s->cfg.ksp_type == MG_KSP_RICHARDSON && s->cfg.v[0] >= 1) {
         for (int l = (s->ldist > 0 ? s->ldist : 1); l < s->levels; l++)
             if (s->L[l].n <= mgk_tail_max_n(cfg->dim)) { s->ltail = l; break; }
         if (s->ltail && (s->levels - s->ltail < 2 || s->levels - s->ltail > 8)) s->ltail = 0;
@@ -715,21 +715,14 @@ static int smooth(mg_solver *s, int P, int l, int maxit) {
                         ((s->cfg.dim == 3 && L->n + 1 <= 1024 && (!L->distributed || (F->far && L->nz_min >= 4))) ||
                          (s->cfg.dim == 2 && P == 0));
     if (maxit < 1 || F->guess_nonzero) F->jz_ready = 0;
-    if (s->cfg.mesh) {                                   /* -mesh 1/2: row-table kernels, one sweep per launch */
-        for (int it = 0; it < maxit; it++) {
-            if (it == 0 && !F->guess_nonzero)
-                CHK(mgk_jacobi_zero_rowcoef_f64(s->ctx, &F->g, L->dtab, s->cfg.scale, (const double *)F->b, (double *)F->tmp, NULL));
-            else
-                CHK(mgk_rowcoef_f64(s->ctx, &F->g, 0, L->ctab, L->dtab, s->cfg.scale, (const double *)F->b, (const double *)F->u,
-                                    (double *)F->tmp, NULL));
-            swap_ptr(&F->u, &F->tmp);
-        }
-        return 0;
-    }
+    const int mesh = s->cfg.mesh != 0;                   /* -mesh 1/2 (2-D, fp64, one GPU): the row-table forms of the same kernels */
     for (int it = it0; it < maxit; it++) {
         if (it == 0 && !F->guess_nonzero) {
             /* r = b, x = 0 + scale*(B b): u is not read (already in tmp when the fused residual+restriction wrote it) */
-            if (!F->jz_ready) CHK(O->jacobi_zero(s->ctx, &F->g, L->dinv, s->cfg.scale, F->b, F->tmp, NULL));
+            if (!F->jz_ready) {
+                if (mesh) CHK(mgk_jacobi_zero_rowcoef_f64(s->ctx, &F->g, L->dtab, s->cfg.scale, (const double *)F->b, (double *)F->tmp, NULL));
+                else CHK(O->jacobi_zero(s->ctx, &F->g, L->dinv, s->cfg.scale, F->b, F->tmp, NULL));
+            }
             F->jz_ready = 0;
         } else if (pair_ok && maxit - it >= 2) {
             if (L->distributed) {
@@ -771,8 +764,10 @@ static int smooth(mg_solver *s, int P, int l, int maxit) {
                 s->prof_kind = 1;
                 void *t = prof_begin(s, l);
                 s->prof_kind = 0;
-                CHK(mgk_jacobi2_2d_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u,
-                                       (double *)F->tmp, NULL));
+                if (mesh) CHK(mgk_jacobi2_2d_rowcoef_f64(s->ctx, &F->g, L->ctab, L->dtab, s->cfg.scale, (const double *)F->b,
+                                                         (const double *)F->u, (double *)F->tmp, NULL));
+                else CHK(mgk_jacobi2_2d_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u,
+                                            (double *)F->tmp, NULL));
                 prof_end(s, t);
             } else {
                 s->prof_kind = 1;
@@ -800,8 +795,10 @@ static int smooth(mg_solver *s, int P, int l, int maxit) {
         } else {
             CHK(ensure_u_ghosts(s, P, L));
             void *t = prof_begin(s, l);
-            CHK(O->jacobi_range(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, F->b, F->u, F->tmp, 0,
-                                F->g.dim == 3 ? F->g.nz : F->g.ny, NULL));
+            if (mesh) CHK(mgk_rowcoef_f64(s->ctx, &F->g, 0, L->ctab, L->dtab, s->cfg.scale, (const double *)F->b, (const double *)F->u,
+                                          (double *)F->tmp, NULL));
+            else CHK(O->jacobi_range(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, F->b, F->u, F->tmp, 0,
+                                     F->g.dim == 3 ? F->g.nz : F->g.ny, NULL));
             prof_end(s, t);
         }
         F->u_ghost_ok = 0; F->u_ghost_pending = 0;
@@ -938,7 +935,9 @@ static int prolong_smooth(mg_solver *s, int P, int l) {
     } else {
         if (Lf->distributed && Lc->distributed) CHK(ensure_u_ghosts(s, P, Lc));
         CHK(ensure_u_ghosts(s, P, Lf));          /* the neighbours' boundary planes BEFORE the correction */
-        CHK(O->prolong_jacobi(s->ctx, &F->g, &gc, Lf->coef, Lf->dinv, s->cfg.scale, F->b, ucoarse, F->u, F->tmp, NULL));
+        if (s->cfg.mesh) CHK(mgk_prolong_jacobi_rowcoef_f64(s->ctx, &F->g, &gc, Lf->ctab, Lf->dtab, s->cfg.scale, (const double *)F->b,
+                                                            (const double *)ucoarse, (const double *)F->u, (double *)F->tmp, NULL));
+        else CHK(O->prolong_jacobi(s->ctx, &F->g, &gc, Lf->coef, Lf->dinv, s->cfg.scale, F->b, ucoarse, F->u, F->tmp, NULL));
     }
     swap_ptr(&F->u, &F->tmp);
     F->u_ghost_ok = 0; F->u_ghost_pending = 0;
@@ -958,6 +957,12 @@ static int tail(mg_solver *s, int P) {
         for (int e = 0; e < 7; e++) k7[7 * q + e] = L->coef[e];
     }
     mg_fset *F = &s->L[lt].f[P];
+    if (s->cfg.mesh) {
+        const double *ct[8], *dt[8];
+        for (int q = 0; q < nl; q++) { ct[q] = s->L[lt + q].ctab; dt[q] = s->L[lt + q].dtab; }
+        CHK(mgk_tail_cycle_rowcoef_f64(s->ctx, &F->g, nl, n, ct, dt, s->cfg.scale, s->cfg.v[0], s->cfg.v[1], (const double *)F->b,
+                                       (double *)F->u, NULL));
+    } else
     CHK(OPS[P].tail_cycle(s->ctx, &F->g, nl, n, k7, di, s->cfg.scale, s->cfg.v[0], s->cfg.v[1], F->b, F->u, NULL));
     F->jz_ready = 0;
     return 0;
@@ -1070,14 +1075,17 @@ gathered:
             CHK(s->comm->allgather_planes(s->comm, s->ctx, Cq->b, &Cq->g, s->zstart, O->esz, ms));
             CHK(mgk_stream_wait(s->ctx, cs, ms));
         }
-    } else if ((s->cfg.fuse & 4) && s->cfg.dim == 2 && P == 0 && !s->cfg.mesh && Lf->n >= 127) {
+    } else if ((s->cfg.fuse & 4) && s->cfg.dim == 2 && P == 0 && Lf->n >= 127) {
         /* 2-D: the same fusion, one independent wave per tile (mgk_residual_restrict_2d_f64), with the coarse level's first
          * zero-guess sweep when that level is smoothed by its own launches */
         mg_fset *Cq = &s->L[l].f[P];
         const int sweeps = (l == levels - 1) ? v[1] : v[0];
         const int jz = (s->cfg.fuse & 256) && !no_jz && s->cfg.ksp_type == MG_KSP_RICHARDSON && sweeps >= 1 && !Cq->guess_nonzero;
-        CHK(mgk_residual_restrict_2d_f64(s->ctx, &Lf->f[P].g, &Cq->g, Lf->coef, (const double *)Lf->f[P].b, (const double *)Lf->f[P].u,
-                                         (double *)Cq->b, jz ? (double *)Cq->tmp : NULL, s->L[l].dinv, s->cfg.scale, NULL));
+        if (s->cfg.mesh) CHK(mgk_residual_restrict_2d_rowcoef_f64(s->ctx, &Lf->f[P].g, &Cq->g, Lf->ctab, (const double *)Lf->f[P].b,
+                                                                  (const double *)Lf->f[P].u, (double *)Cq->b, jz ? (double *)Cq->tmp : NULL,
+                                                                  s->L[l].dtab, s->cfg.scale, NULL));
+        else CHK(mgk_residual_restrict_2d_f64(s->ctx, &Lf->f[P].g, &Cq->g, Lf->coef, (const double *)Lf->f[P].b, (const double *)Lf->f[P].u,
+                                              (double *)Cq->b, jz ? (double *)Cq->tmp : NULL, s->L[l].dinv, s->cfg.scale, NULL));
         if (jz) Cq->jz_ready = 1;
     } else {
         CHK(residual(s, P, l - 1));                                     /* :1534 */
@@ -1189,10 +1197,14 @@ static int vcycle_once(mg_solver *s) {
             /* ||b - A u|| and, speculatively, the first pre-smoothing sweep of the next cycle in one pass over u and b
              * (both form the same residual).  The sweep lands in tmp and is adopted by smooth() only if another
              * cycle follows; u itself is untouched, so stopping here leaves the solution as the reference has it. */
-            CHK(mgk_jacobi_sumsq_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u,
-                                     (double *)F->tmp, &ss, NULL));
+            if (s->cfg.mesh) CHK(mgk_jacobi_sumsq_rowcoef_f64(s->ctx, &F->g, L->ctab, L->dtab, s->cfg.scale, (const double *)F->b,
+                                                              (const double *)F->u, (double *)F->tmp, &ss, NULL));
+            else CHK(mgk_jacobi_sumsq_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u,
+                                          (double *)F->tmp, &ss, NULL));
             s->spec_valid = 1;
-        } else if (s->cfg.fuse & 1) CHK(mgk_residual_sumsq_f64(s->ctx, &F->g, L->coef, (const double *)F->b, (const double *)F->u, &ss, NULL));
+        } else if ((s->cfg.fuse & 1) && s->cfg.mesh)
+            CHK(mgk_residual_sumsq_rowcoef_f64(s->ctx, &F->g, L->ctab, (const double *)F->b, (const double *)F->u, &ss, NULL));
+        else if (s->cfg.fuse & 1) CHK(mgk_residual_sumsq_f64(s->ctx, &F->g, L->coef, (const double *)F->b, (const double *)F->u, &ss, NULL));
         else {
             CHK(residual(s, 0, 0));
             CHK(mgk_sumsq_f64(s->ctx, &F->g, (const double *)F->rv, &ss, NULL));

@@ -1682,6 +1682,7 @@ struct J2dArgs {
     long rs;
     int ntx, yc;
     double a0, a2, a3, a4, a6, dinv, scale;
+    const double *ctab, *dtab;      // optional (stretched meshes): 5 coefficients {(i-1), W, C, E, (i+1)} and 1/diag per grid row
 };
 template <int WX>
 __global__ void __launch_bounds__(64 * WX) k_jacobi2_2d(const J2dArgs a) {
@@ -1711,6 +1712,13 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2_2d(const J2dArgs a) {
         const int p = t + 1;
         ud = ldu(t + 3);
         bn = (t + 1 < y1) ? ldb(t + 2) : v16_zero<double>();
+        // coefficients of the two rows worked on in this step: launch constants, or the table rows p (first sweep) and t (second)
+        double p0 = a.a0, p2 = a.a2, p3 = a.a3, p4 = a.a4, p6 = a.a6, pd = a.dinv, q0 = a.a0, q2 = a.a2, q3 = a.a3, q4 = a.a4, q6 = a.a6, qd = a.dinv;
+        if (a.ctab) {
+            const double *cp = a.ctab + 5 * (long)min(max(p, 0), a.ny - 1), *cq = a.ctab + 5 * (long)min(max(t, 0), a.ny - 1);
+            p0 = cp[0]; p2 = cp[1]; p3 = cp[2]; p4 = cp[3]; p6 = cp[4]; pd = a.dtab[min(max(p, 0), a.ny - 1)];
+            q0 = cq[0]; q2 = cq[1]; q3 = cq[2]; q4 = cq[3]; q6 = cq[4]; qd = a.dtab[min(max(t, 0), a.ny - 1)];
+        }
         // ---- first sweep of row p ----
         {
             double Wv = __shfl_up(ub.v[VX - 1], 1, 64), Ev = __shfl_down(ub.v[0], 1, 64);
@@ -1721,13 +1729,13 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2_2d(const J2dArgs a) {
             for (int e = 0; e < VX; e++) {
                 const double wv = (e == 0) ? Wv : ub.v[0];
                 const double ev = (e == VX - 1) ? Ev : ub.v[VX - 1];
-                double s = a.a0 * ua.v[e];
-                s = s + a.a2 * wv;
-                s = s + a.a3 * ub.v[e];
-                s = s + a.a4 * ev;
-                s = s + a.a6 * uc.v[e];
+                double s = p0 * ua.v[e];
+                s = s + p2 * wv;
+                s = s + p3 * ub.v[e];
+                s = s + p4 * ev;
+                s = s + p6 * uc.v[e];
                 const double res = b1.v[e] - s;
-                const double zz = res * a.dinv;
+                const double zz = res * pd;
                 wp.v[e] = ub.v[e] + a.scale * zz;
                 if (!pin || !xin || (lastvec && x0 + e >= a.nx)) wp.v[e] = 0.0;
             }
@@ -1742,13 +1750,13 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2_2d(const J2dArgs a) {
             for (int e = 0; e < VX; e++) {
                 const double wv = (e == 0) ? Wv : wc.v[0];
                 const double ev = (e == VX - 1) ? Ev : wc.v[VX - 1];
-                double s = a.a0 * wm.v[e];
-                s = s + a.a2 * wv;
-                s = s + a.a3 * wc.v[e];
-                s = s + a.a4 * ev;
-                s = s + a.a6 * wp.v[e];
+                double s = q0 * wm.v[e];
+                s = s + q2 * wv;
+                s = s + q3 * wc.v[e];
+                s = s + q4 * ev;
+                s = s + q6 * wp.v[e];
                 const double res = b0.v[e] - s;
-                const double zz = res * a.dinv;
+                const double zz = res * qd;
                 o.v[e] = wc.v[e] + a.scale * zz;
                 if (lastvec && x0 + e >= a.nx) o.v[e] = 0.0;
             }
@@ -1761,14 +1769,14 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2_2d(const J2dArgs a) {
         b0 = b1; b1 = bn; wm = wc; wc = wp; ua = ub; ub = uc; uc = ud;
     }
 }
-extern "C" int mgk_jacobi2_2d_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
-                                  const double *b, const double *u, double *unew, void *stream) {
-    if (!c || !g || !coef || !b || !u || !unew || u == unew || g->dim != 2) return fail(MGK_EINVAL, "mgk_jacobi2_2d_f64: bad arguments (2-D)");
+static int jacobi2_2d(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale, const double *ctab, const double *dtab,
+                      const double *b, const double *u, double *unew, void *stream) {
+    if (!c || !g || (!coef && !ctab) || (ctab && !dtab) || !b || !u || !unew || u == unew || g->dim != 2) return fail(MGK_EINVAL, "mgk_jacobi2_2d: bad arguments (2-D)");
     J2dArgs a; memset(&a, 0, sizeof(a));
     a.u = u + g->org; a.b = b + g->org; a.out = unew + g->org;
     a.nx = g->nx; a.ny = g->ny; a.rs = g->pitch;
-    a.a0 = coef[0]; a.a2 = coef[1]; a.a3 = coef[2]; a.a4 = coef[3]; a.a6 = coef[4];
-    a.dinv = dinv; a.scale = scale;
+    if (coef) { a.a0 = coef[0]; a.a2 = coef[1]; a.a3 = coef[2]; a.a4 = coef[3]; a.a6 = coef[4]; }
+    a.dinv = dinv; a.scale = scale; a.ctab = ctab; a.dtab = dtab;
     constexpr int WX = 4, TXE = 2 * (64 * WX - 2);
     a.ntx = (g->nx + TXE - 1) / TXE;
     long nch = (2048 + a.ntx - 1) / a.ntx;
@@ -1781,6 +1789,15 @@ extern "C" int mgk_jacobi2_2d_f64(mgk_ctx *c, const mgk_geom *g, const double *c
     hipLaunchKernelGGL((k_jacobi2_2d<WX>), dim3((unsigned)(a.ntx * nty)), dim3(64 * WX), 0, S(c, stream), a);
     HIPCHK(hipGetLastError());
     return 0;
+}
+extern "C" int mgk_jacobi2_2d_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
+                                  const double *b, const double *u, double *unew, void *stream) {
+    return jacobi2_2d(c, g, coef, dinv, scale, nullptr, nullptr, b, u, unew, stream);
+}
+extern "C" int mgk_jacobi2_2d_rowcoef_f64(mgk_ctx *c, const mgk_geom *g, const double *ctab, const double *dtab, double scale,
+                                          const double *b, const double *u, double *unew, void *stream) {
+    if (!ctab) return fail(MGK_EINVAL, "mgk_jacobi2_2d_rowcoef_f64: null table");
+    return jacobi2_2d(c, g, nullptr, 1.0, scale, ctab, dtab, b, u, unew, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3492,6 +3509,7 @@ struct TailArgs {
     T *u_out;                              // both at the interior origin of the first tail level's padded field
     long rs, ms;                           // its row / plane strides
     int total;                             // elements of LDS in use
+    const T *ctab[MGK_TAIL_MAXLEV], *dtab[MGK_TAIL_MAXLEV];   // optional (2-D stretched meshes): per-row coefficients / 1/diag of every tail level
 };
 
 template <typename T, int DIM>
@@ -3500,11 +3518,13 @@ __device__ __forceinline__ int tail_idx(int m, int k, int i, int j) {      // (k
 }
 // mode 0: out = u + scale*((b - A u)*dinv); mode 1: out = b - A u; mode 2 (zero guess): out = scale*(b*dinv)
 template <typename T, int DIM>
-__device__ void tail_stencil(int mode, int n, const T *cf, T dinv, T scale, const T *u, const T *b, T *out) {
+__device__ void tail_stencil(int mode, int n, const T *cf_, T dinv_, T scale, const T *u, const T *b, T *out, const T *ctab = nullptr, const T *dtab = nullptr) {
     const int m = n + 2, N = (DIM == 3) ? n * n * n : n * n, sk = m * m;
     for (int p = threadIdx.x; p < N; p += blockDim.x) {
         const int j = p % n, i = (p / n) % n, k = (DIM == 3) ? p / (n * n) : 0;
         const int q = tail_idx<T, DIM>(m, k, i, j);
+        const T *cf = (DIM == 2 && ctab) ? ctab + 5 * i : cf_;
+        const T dinv = (DIM == 2 && dtab) ? dtab[i] : dinv_;
         if (mode == 2) { const T zx = b[q] * dinv; out[q] = scale * zx; continue; }
         T t;
         if (DIM == 3) {
@@ -3602,17 +3622,17 @@ __global__ void __launch_bounds__(1024) k_tail(const TailArgs<T> a) {
     auto smooth0 = [&](int l, int sweeps) {
         cur[l] = 0;
         if (sweeps < 1) return;                   // KSPSolve zero-fills: A0 is still all zeros
-        tail_stencil<T, DIM>(2, a.n[l], a.coef[l], a.dinv[l], a.scale, A(l, 0), Bv(l), A(l, 0));
+        tail_stencil<T, DIM>(2, a.n[l], a.coef[l], a.dinv[l], a.scale, A(l, 0), Bv(l), A(l, 0), a.ctab[l], a.dtab[l]);
         __syncthreads();
         for (int it = 1; it < sweeps; it++) {
-            tail_stencil<T, DIM>(0, a.n[l], a.coef[l], a.dinv[l], a.scale, A(l, cur[l]), Bv(l), A(l, cur[l] ^ 1));
+            tail_stencil<T, DIM>(0, a.n[l], a.coef[l], a.dinv[l], a.scale, A(l, cur[l]), Bv(l), A(l, cur[l] ^ 1), a.ctab[l], a.dtab[l]);
             __syncthreads();
             cur[l] ^= 1;
         }
     };
     smooth0(0, a.nlev == 1 ? a.v1 : a.v0);
     for (int l = 1; l < a.nlev; l++) {            // :1534-1537
-        tail_stencil<T, DIM>(1, a.n[l - 1], a.coef[l - 1], a.dinv[l - 1], a.scale, A(l - 1, cur[l - 1]), Bv(l - 1), A(l - 1, cur[l - 1] ^ 1));
+        tail_stencil<T, DIM>(1, a.n[l - 1], a.coef[l - 1], a.dinv[l - 1], a.scale, A(l - 1, cur[l - 1]), Bv(l - 1), A(l - 1, cur[l - 1] ^ 1), a.ctab[l - 1], a.dtab[l - 1]);
         __syncthreads();
         tail_restrict<T, DIM>(a.n[l - 1], a.n[l], A(l - 1, cur[l - 1] ^ 1), Bv(l));
         __syncthreads();
@@ -3623,7 +3643,7 @@ __global__ void __launch_bounds__(1024) k_tail(const TailArgs<T> a) {
         tail_prolong_add<T, DIM>(a.n[l], a.n[l + 1], A(l + 1, cur[l + 1]), A(l, cur[l]));
         __syncthreads();
         for (int it = 0; it < a.v0; it++) {
-            tail_stencil<T, DIM>(0, a.n[l], a.coef[l], a.dinv[l], a.scale, A(l, cur[l]), Bv(l), A(l, cur[l] ^ 1));
+            tail_stencil<T, DIM>(0, a.n[l], a.coef[l], a.dinv[l], a.scale, A(l, cur[l]), Bv(l), A(l, cur[l] ^ 1), a.ctab[l], a.dtab[l]);
             __syncthreads();
             cur[l] ^= 1;
         }
@@ -3640,8 +3660,9 @@ __global__ void __launch_bounds__(1024) k_tail(const TailArgs<T> a) {
 
 template <typename T>
 static int tail_cycle(mgk_ctx *c, const mgk_geom *g0, int nlev, const int *n, const double *coef7, const double *dinv, double scale,
-                      int v0, int v1, const T *b, T *u, void *stream) {
-    if (!c || !g0 || !n || !coef7 || !dinv || !b || !u || nlev < 1 || nlev > MGK_TAIL_MAXLEV || v0 < 0 || v1 < 0)
+                      int v0, int v1, const T *b, T *u, void *stream, const T *const *ctab = nullptr, const T *const *dtab = nullptr) {
+    if (!c || !g0 || !n || (!coef7 && !ctab) || (!dinv && !dtab) || !b || !u || nlev < 1 || nlev > MGK_TAIL_MAXLEV || v0 < 0 || v1 < 0 ||
+        (ctab && (!dtab || g0->dim != 2)))
         return fail(MGK_EINVAL, "mgk_tail_cycle: bad arguments");
     if (n[0] != g0->nx || g0->ny != g0->nx || (g0->dim == 3 && g0->nz != g0->nx))
         return fail(MGK_EINVAL, "mgk_tail_cycle: the first tail level must be a whole cube / square of n[0] unknowns per side");
@@ -3652,8 +3673,10 @@ static int tail_cycle(mgk_ctx *c, const mgk_geom *g0, int nlev, const int *n, co
         if (n[l] < 1 || (l > 0 && n[l - 1] != 2 * n[l] + 1)) return fail(MGK_EINVAL, "mgk_tail_cycle: need n[l-1] = 2 n[l] + 1");
         const long m = n[l] + 2, sz = (g0->dim == 3) ? m * m * m : m * m;
         a.n[l] = n[l]; a.off[l] = (int)off; off += 3 * sz;
-        for (int q = 0; q < 7; q++) a.coef[l][q] = (T)coef7[7 * l + q];
-        a.dinv[l] = (T)dinv[l];
+        for (int q = 0; q < 7; q++) a.coef[l][q] = coef7 ? (T)coef7[7 * l + q] : (T)0;
+        a.dinv[l] = dinv ? (T)dinv[l] : (T)1;
+        a.ctab[l] = ctab ? ctab[l] : nullptr; a.dtab[l] = dtab ? dtab[l] : nullptr;
+        if (ctab && (!ctab[l] || !dtab[l])) return fail(MGK_EINVAL, "mgk_tail_cycle: null coefficient table");
     }
     if (off * (long)sizeof(T) > MGK_TAIL_LDS_BYTES) return fail(MGK_EINVAL, "mgk_tail_cycle: the levels do not fit in LDS");
     a.total = (int)off;
@@ -3670,6 +3693,12 @@ extern "C" int mgk_tail_cycle_f64(mgk_ctx *c, const mgk_geom *g0, int nlev, cons
 extern "C" int mgk_tail_cycle_f32(mgk_ctx *c, const mgk_geom *g0, int nlev, const int *n, const double *coef7, const double *dinv,
                                   double scale, int v0, int v1, const float *b, float *u, void *stream) {
     return tail_cycle<float>(c, g0, nlev, n, coef7, dinv, scale, v0, v1, b, u, stream);
+}
+// 2-D stretched meshes: ctab[l] / dtab[l] are the device tables (n[l] x 5 and n[l] doubles) of tail level l
+extern "C" int mgk_tail_cycle_rowcoef_f64(mgk_ctx *c, const mgk_geom *g0, int nlev, const int *n, const double *const *ctab, const double *const *dtab,
+                                          double scale, int v0, int v1, const double *b, double *u, void *stream) {
+    if (!ctab || !dtab) return fail(MGK_EINVAL, "mgk_tail_cycle_rowcoef_f64: null tables");
+    return tail_cycle<double>(c, g0, nlev, n, nullptr, nullptr, scale, v0, v1, b, u, stream, ctab, dtab);
 }
 extern "C" int mgk_tail_max_n(int dim) { return dim == 3 ? 15 : 63; }
 
@@ -3690,6 +3719,7 @@ struct RR2dArgs {
     long rs, crs;
     int ntx, ycc;
     double a0, a2, a3, a4, a6, dinv_c, scale_c;
+    const double *ctab, *dtab_c;    // optional (stretched meshes): coefficients per FINE grid row, 1/diag per COARSE grid row
 };
 template <int PD>
 __global__ void __launch_bounds__(256) k_rr2d(const RR2dArgs a) {
@@ -3734,16 +3764,18 @@ __global__ void __launch_bounds__(256) k_rr2d(const RR2dArgs a) {
                 B[(k + PD) % NP] = ldb(y + PD);
                 const VT &c = U[cc];
                 const double Wv = lane_up<true>(c.v[1]), Ev = lane_dn<true>(c.v[0]);
+                double k0 = a.a0, k2 = a.a2, k3 = a.a3, k4 = a.a4, k6 = a.a6;
+                if (a.ctab) { const double *cr = a.ctab + 5 * (long)y; k0 = cr[0]; k2 = cr[1]; k3 = cr[2]; k4 = cr[3]; k6 = cr[4]; }
                 VT r;
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
                     const double wv = (e == 0) ? Wv : c.v[0];
                     const double ev = (e == 1) ? Ev : c.v[1];
-                    double t = a.a0 * U[cm].v[e];
-                    t = t + a.a2 * wv;
-                    t = t + a.a3 * c.v[e];
-                    t = t + a.a4 * ev;
-                    t = t + a.a6 * U[cp].v[e];
+                    double t = k0 * U[cm].v[e];
+                    t = t + k2 * wv;
+                    t = t + k3 * c.v[e];
+                    t = t + k4 * ev;
+                    t = t + k6 * U[cp].v[e];
                     r.v[e] = B[cc].v[e] - t;
                     if (!xok || x0 + e >= a.nx) r.v[e] = 0.0;
                 }
@@ -3761,7 +3793,7 @@ __global__ void __launch_bounds__(256) k_rr2d(const RR2dArgs a) {
                     if (ic >= ic0 && store) {
                         const long oc = (long)ic * a.crs + p;
                         a.bc[oc] = acc;
-                        if (a.uc0) { const double zq = acc * a.dinv_c; a.uc0[oc] = a.scale_c * zq; }
+                        if (a.uc0) { const double zq = acc * (a.dtab_c ? a.dtab_c[ic] : a.dinv_c); a.uc0[oc] = a.scale_c * zq; }
                     }
                     acc = accn; accn = 0.0;
                 }
@@ -3769,16 +3801,16 @@ __global__ void __launch_bounds__(256) k_rr2d(const RR2dArgs a) {
         }
     }
 }
-extern "C" int mgk_residual_restrict_2d_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, const double *b,
-                                            const double *u, double *bc, double *uc0, double dinv_c, double scale_c, void *stream) {
-    if (!c || !gf || !gc || !coef || !b || !u || !bc || gf->dim != 2 || gc->dim != 2)
+static int residual_restrict_2d(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, const double *ctab, const double *dtab_c,
+                                const double *b, const double *u, double *bc, double *uc0, double dinv_c, double scale_c, void *stream) {
+    if (!c || !gf || !gc || (!coef && !ctab) || !b || !u || !bc || gf->dim != 2 || gc->dim != 2 || (uc0 && ctab && !dtab_c))
         return fail(MGK_EINVAL, "mgk_residual_restrict_2d_f64: bad arguments (2-D)");
     if (gf->nx != 2 * gc->nx + 1 || gf->ny != 2 * gc->ny + 1) return fail(MGK_EINVAL, "mgk_residual_restrict_2d_f64: need nf = 2 nc + 1");
     RR2dArgs a; memset(&a, 0, sizeof(a));
     a.u = u + gf->org; a.b = b + gf->org; a.bc = bc + gc->org; a.uc0 = uc0 ? uc0 + gc->org : nullptr;
     a.nx = gf->nx; a.ny = gf->ny; a.nxc = gc->nx; a.nyc = gc->ny; a.rs = gf->pitch; a.crs = gc->pitch;
-    a.a0 = coef[0]; a.a2 = coef[1]; a.a3 = coef[2]; a.a4 = coef[3]; a.a6 = coef[4];
-    a.dinv_c = dinv_c; a.scale_c = scale_c;
+    if (coef) { a.a0 = coef[0]; a.a2 = coef[1]; a.a3 = coef[2]; a.a4 = coef[3]; a.a6 = coef[4]; }
+    a.dinv_c = dinv_c; a.scale_c = scale_c; a.ctab = ctab; a.dtab_c = dtab_c;
     a.ntx = (gc->nx + 61) / 62;
     long nch = (4096 + a.ntx - 1) / a.ntx;                    // ~4096 waves (16 per CU); every chunk re-reads two fine rows
     if (g_zchunk > 0) nch = (gc->ny + g_zchunk - 1) / g_zchunk;
@@ -3790,6 +3822,15 @@ extern "C" int mgk_residual_restrict_2d_f64(mgk_ctx *c, const mgk_geom *gf, cons
     hipLaunchKernelGGL((k_rr2d<2>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, S(c, stream), a);
     HIPCHK(hipGetLastError());
     return 0;
+}
+extern "C" int mgk_residual_restrict_2d_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, const double *b,
+                                            const double *u, double *bc, double *uc0, double dinv_c, double scale_c, void *stream) {
+    return residual_restrict_2d(c, gf, gc, coef, nullptr, nullptr, b, u, bc, uc0, dinv_c, scale_c, stream);
+}
+extern "C" int mgk_residual_restrict_2d_rowcoef_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *ctab_f, const double *b,
+                                                    const double *u, double *bc, double *uc0, const double *dtab_c, double scale_c, void *stream) {
+    if (!ctab_f) return fail(MGK_EINVAL, "mgk_residual_restrict_2d_rowcoef_f64: null table");
+    return residual_restrict_2d(c, gf, gc, nullptr, ctab_f, dtab_c, b, u, bc, uc0, 1.0, scale_c, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3811,6 +3852,44 @@ extern "C" int mgk_rowcoef_f64(mgk_ctx *c, const mgk_geom *g, int mode, const do
     if (mode == MODE_RESIDUAL) return dispatch_st<MODE_RESIDUAL>(c, g, a, s, nullptr);
     if (mode == MODE_APPLY) return dispatch_st<MODE_APPLY>(c, g, a, s, nullptr);
     return fail(MGK_EINVAL, "mgk_rowcoef_f64: unknown mode");
+}
+// stretched meshes (2-D): the fused forms of the cycle on the row-table operator -- k_stencil reads its coefficients per marching
+// step in every mode, so these are the constant-coefficient entry points with the tables in place of the constants
+extern "C" int mgk_jacobi_sumsq_rowcoef_f64(mgk_ctx *c, const mgk_geom *g, const double *ctab, const double *dtab, double scale,
+                                            const double *b, const double *u, double *unew, double *sumsq_host, void *stream) {
+    if (!c || !g || g->dim != 2 || !ctab || !dtab || !b || !u || !unew || u == unew || !sumsq_host) return fail(MGK_EINVAL, "mgk_jacobi_sumsq_rowcoef_f64: bad arguments (2-D)");
+    StArgs<double> a; memset(&a, 0, sizeof(a));
+    a.u = u + g->org; a.b = b + g->org; a.out = unew + g->org; a.partials = c->partials;
+    a.ctab = ctab; a.dtab = dtab; a.scale = scale; a.dinv = 1.0;
+    int nblk = 0;
+    int rc = dispatch_st<MODE_JNORM>(c, g, a, S(c, stream), &nblk);
+    if (rc) return rc;
+    return finish_to_host(c, nblk, 1, S(c, stream), sumsq_host);
+}
+extern "C" int mgk_residual_sumsq_rowcoef_f64(mgk_ctx *c, const mgk_geom *g, const double *ctab, const double *b, const double *u,
+                                              double *sumsq_host, void *stream) {
+    if (!c || !g || g->dim != 2 || !ctab || !b || !u || !sumsq_host) return fail(MGK_EINVAL, "mgk_residual_sumsq_rowcoef_f64: bad arguments (2-D)");
+    StArgs<double> a; memset(&a, 0, sizeof(a));
+    a.u = u + g->org; a.b = b + g->org; a.partials = c->partials;
+    a.ctab = ctab; a.dinv = 1.0;
+    int nblk = 0;
+    int rc = dispatch_st<MODE_RESNORM>(c, g, a, S(c, stream), &nblk);
+    if (rc) return rc;
+    return finish_to_host(c, nblk, 1, S(c, stream), sumsq_host);
+}
+extern "C" int mgk_prolong_jacobi_rowcoef_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *ctab, const double *dtab, double scale,
+                                              const double *b, const double *uc, const double *u, double *unew, void *stream) {
+    if (!c || !gf || !gc || gf->dim != 2 || !ctab || !dtab || !b || !uc || !u || !unew || u == unew) return fail(MGK_EINVAL, "mgk_prolong_jacobi_rowcoef_f64: bad arguments (2-D)");
+    XferArgs x;
+    int rc = xfer_args(gf, gc, x);
+    if (rc) return rc;
+    StArgs<double> a; memset(&a, 0, sizeof(a));
+    a.u = u + gf->org; a.b = b + gf->org; a.out = unew + gf->org;
+    a.uc = uc + gc->org; a.crs = gc->pitch; a.cms = gc->pitch;
+    a.nxc = gc->nx; a.nyc = gc->ny; a.nzc = gc->nz;
+    a.ctab = ctab; a.dtab = dtab; a.scale = scale; a.dinv = 1.0;
+    a.zbeg = 0; a.zend = gf->ny;
+    return dispatch_st<MODE_PJACOBI>(c, gf, a, S(c, stream), nullptr);
 }
 extern "C" int mgk_jacobi_zero_rowcoef_f64(mgk_ctx *c, const mgk_geom *g, const double *dtab, double scale,
                                            const double *b, double *unew, void *stream) {

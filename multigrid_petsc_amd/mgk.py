@@ -50,6 +50,12 @@ def _sigs(L):
         "mgk_jacobi2_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp, vp]),
         "mgk_jacobi2_f32": (i, [vp, G, c_dp, d, d, vp, vp, vp, vp]),
         "mgk_jacobi2_2d_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp, vp]),
+        "mgk_jacobi2_2d_rowcoef_f64": (i, [vp, G, vp, vp, d, vp, vp, vp, vp]),
+        "mgk_jacobi_sumsq_rowcoef_f64": (i, [vp, G, vp, vp, d, vp, vp, vp, C.POINTER(d), vp]),
+        "mgk_residual_sumsq_rowcoef_f64": (i, [vp, G, vp, vp, vp, C.POINTER(d), vp]),
+        "mgk_prolong_jacobi_rowcoef_f64": (i, [vp, G, G, vp, vp, d, vp, vp, vp, vp, vp]),
+        "mgk_residual_restrict_2d_rowcoef_f64": (i, [vp, G, G, vp, vp, vp, vp, vp, vp, d, vp]),
+        "mgk_tail_cycle_rowcoef_f64": (i, [vp, G, i, C.POINTER(i), C.POINTER(vp), C.POINTER(vp), d, i, i, vp, vp, vp]),
         "mgk_jacobi_sumsq_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp, C.POINTER(d), vp]),
         "mgk_restrict_fw_f64": (i, [vp, G, G, vp, vp, vp]),
         "mgk_prolong_add_f64": (i, [vp, G, G, vp, vp, vp]),

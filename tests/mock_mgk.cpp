@@ -422,10 +422,17 @@ int mgk_residual_restrict_2d_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom 
     });
 }
 }   // extern "C"
-template <class T> static int tail_api(mgk_ctx *c, const mgk_geom *g0, int nlev, const int *n, const double *coef7, const double *dinv, double scale, int v0, int v1, const T *b, T *u) {
-    if (!c || !g0 || !n || !coef7 || !dinv || !b || !u || nlev < 1 || nlev > 8 || n[0] != g0->nx || n[0] > mgk_tail_max_n(g0->dim)) return fail(MGK_EINVAL, "mgk_tail_cycle");
+template <class T> static int tail_api(mgk_ctx *c, const mgk_geom *g0, int nlev, const int *n, const double *coef7, const double *dinv, double scale, int v0, int v1, const T *b, T *u,
+                                       const double *const *ctab = nullptr, const double *const *dtab = nullptr) {
+    if (!c || !g0 || !n || (!coef7 && !ctab) || (!dinv && !dtab) || !b || !u || nlev < 1 || nlev > 8 || n[0] != g0->nx || n[0] > mgk_tail_max_n(g0->dim)) return fail(MGK_EINVAL, "mgk_tail_cycle");
+    if (ctab && (!dtab || g0->dim != 2 || sizeof(T) != 8)) return fail(MGK_EINVAL, "mgk_tail_cycle: tables are 2-D fp64");
     for (int l = 1; l < nlev; l++) if (n[l - 1] != 2 * n[l] + 1) return fail(MGK_EINVAL, "mgk_tail_cycle: hierarchy");
-    const mgk_geom G0 = *g0; std::vector<int> nn(n, n + nlev); std::vector<double> k7(coef7, coef7 + 7 * nlev), di(dinv, dinv + nlev);
+    const mgk_geom G0 = *g0; std::vector<int> nn(n, n + nlev);
+    std::vector<double> k7(7 * nlev, 0.0), di(nlev, 1.0);
+    if (coef7) k7.assign(coef7, coef7 + 7 * nlev);
+    if (dinv) di.assign(dinv, dinv + nlev);
+    std::vector<const double *> ct(nlev, nullptr), dt(nlev, nullptr);
+    for (int l = 0; l < nlev && ctab; l++) { ct[l] = ctab[l]; dt[l] = dtab[l]; if (!ct[l] || !dt[l]) return fail(MGK_EINVAL, "mgk_tail_cycle: null table"); }
     return run(c, [=] {
         std::vector<mgk_geom> G(nlev);
         std::vector<std::vector<T>> U(nlev), W(nlev), B(nlev);
@@ -437,14 +444,14 @@ template <class T> static int tail_api(mgk_ctx *c, const mgk_geom *g0, int nlev,
         auto smooth = [&](int l, int sweeps, bool zero) {
             for (int it = 0; it < sweeps; it++) {
                 if (it == 0 && zero) { for (long q = 0; q < G[l].total; q++) W[l][q] = (T)0;
-                    for (int k = 0; k < G[l].nz; k++) for (int i = 0; i < G[l].ny; i++) for (int j = 0; j < G[l].nx; j++) { const T zx = at(B[l].data(), G[l], k, i, j) * (T)di[l]; at(W[l].data(), G[l], k, i, j) = (T)scale * zx; } }
-                else st_op<T>(M_JACOBI, G[l], &k7[7 * l], di[l], scale, 0, 0, 0, B[l].data(), U[l].data(), (const T *)nullptr, W[l].data(), 0, NMARCH(&G[l]));
+                    for (int k = 0; k < G[l].nz; k++) for (int i = 0; i < G[l].ny; i++) for (int j = 0; j < G[l].nx; j++) { const T zx = at(B[l].data(), G[l], k, i, j) * (T)(dt[l] ? dt[l][i] : di[l]); at(W[l].data(), G[l], k, i, j) = (T)scale * zx; } }
+                else st_op<T>(M_JACOBI, G[l], &k7[7 * l], di[l], scale, 0, 0, 0, B[l].data(), U[l].data(), (const T *)nullptr, W[l].data(), 0, NMARCH(&G[l]), ct[l], dt[l]);
                 U[l].swap(W[l]);
             }
         };
         smooth(0, nlev == 1 ? v1 : v0, true);
         for (int l = 1; l < nlev; l++) {
-            st_op<T>(M_RESIDUAL, G[l - 1], &k7[7 * (l - 1)], 1, 1, 0, 0, 0, B[l - 1].data(), U[l - 1].data(), (const T *)nullptr, W[l - 1].data(), 0, NMARCH(&G[l - 1]));
+            st_op<T>(M_RESIDUAL, G[l - 1], &k7[7 * (l - 1)], 1, 1, 0, 0, 0, B[l - 1].data(), U[l - 1].data(), (const T *)nullptr, W[l - 1].data(), 0, NMARCH(&G[l - 1]), ct[l - 1], dt[l - 1]);
             restrict_fw<T>(G[l - 1], G[l], W[l - 1].data(), B[l].data(), 0, G[l].dim == 3 ? G[l].nz : 1);
             std::fill(U[l].begin(), U[l].end(), (T)0);
             smooth(l, l == nlev - 1 ? v1 : v0, true);
@@ -460,6 +467,53 @@ template <class T> static int tail_api(mgk_ctx *c, const mgk_geom *g0, int nlev,
 extern "C" {
 int mgk_tail_cycle_f64(mgk_ctx *c, const mgk_geom *g0, int nl, const int *n, const double *k7, const double *di, double s, int v0, int v1, const double *b, double *u, void *) { return tail_api<double>(c, g0, nl, n, k7, di, s, v0, v1, b, u); }
 int mgk_tail_cycle_f32(mgk_ctx *c, const mgk_geom *g0, int nl, const int *n, const double *k7, const double *di, double s, int v0, int v1, const float *b, float *u, void *) { return tail_api<float>(c, g0, nl, n, k7, di, s, v0, v1, b, u); }
+
+// the fused forms on a row-table operator (2-D stretched meshes)
+int mgk_tail_cycle_rowcoef_f64(mgk_ctx *c, const mgk_geom *g0, int nl, const int *n, const double *const *ctab, const double *const *dtab, double s, int v0, int v1, const double *b, double *u, void *) {
+    if (!ctab || !dtab) return fail(MGK_EINVAL, "mgk_tail_cycle_rowcoef_f64");
+    return tail_api<double>(c, g0, nl, n, nullptr, nullptr, s, v0, v1, b, u, ctab, dtab);
+}
+int mgk_jacobi2_2d_rowcoef_f64(mgk_ctx *c, const mgk_geom *g, const double *ctab, const double *dtab, double scale, const double *b, const double *u, double *o, void *) {
+    if (!c || !g || g->dim != 2 || !ctab || !dtab || !b || !u || !o || u == o) return fail(MGK_EINVAL, "mgk_jacobi2_2d_rowcoef_f64");
+    const mgk_geom G = *g;
+    return run(c, [=] {
+        std::vector<double> w(G.total, 0.0);
+        st_op<double>(M_JACOBI, G, nullptr, 1.0, scale, 0, 0, 0, b, u, (const double *)nullptr, w.data(), 0, G.ny, ctab, dtab);
+        st_op<double>(M_JACOBI, G, nullptr, 1.0, scale, 0, 0, 0, b, w.data(), (const double *)nullptr, o, 0, G.ny, ctab, dtab);
+    });
+}
+int mgk_residual_sumsq_rowcoef_f64(mgk_ctx *c, const mgk_geom *g, const double *ctab, const double *b, const double *u, double *out, void *) {
+    if (!c || !g || g->dim != 2 || !ctab || !b || !u || !out) return fail(MGK_EINVAL, "mgk_residual_sumsq_rowcoef_f64");
+    if (c->capturing) return fail(MGK_EINVAL, "reduction to the host inside a capture");
+    std::vector<double> r(g->total, 0.0);
+    st_op<double>(M_RESIDUAL, *g, nullptr, 1, 1, 0, 0, 0, b, u, (const double *)nullptr, r.data(), 0, g->ny, ctab, (const double *)nullptr);
+    deliver(c, sumsq_field<double>(*g, r.data(), 0, g->ny), out);
+    return 0;
+}
+int mgk_jacobi_sumsq_rowcoef_f64(mgk_ctx *c, const mgk_geom *g, const double *ctab, const double *dtab, double scale, const double *b, const double *u, double *o, double *out, void *) {
+    if (!c || !g || g->dim != 2 || !ctab || !dtab || !b || !u || !o || u == o || !out) return fail(MGK_EINVAL, "mgk_jacobi_sumsq_rowcoef_f64");
+    if (c->capturing) return fail(MGK_EINVAL, "reduction to the host inside a capture");
+    std::vector<double> r(g->total, 0.0);
+    st_op<double>(M_RESIDUAL, *g, nullptr, 1, 1, 0, 0, 0, b, u, (const double *)nullptr, r.data(), 0, g->ny, ctab, dtab);
+    st_op<double>(M_JACOBI, *g, nullptr, 1.0, scale, 0, 0, 0, b, u, (const double *)nullptr, o, 0, g->ny, ctab, dtab);
+    deliver(c, sumsq_field<double>(*g, r.data(), 0, g->ny), out);
+    return 0;
+}
+int mgk_prolong_jacobi_rowcoef_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *ctab, const double *dtab, double scale, const double *b, const double *uc, const double *u, double *o, void *) {
+    if (!c || !ctab || !dtab || !b || !uc || !u || !o || u == o || !xfer_ok(gf, gc) || gf->dim != 2) return fail(MGK_EINVAL, "mgk_prolong_jacobi_rowcoef_f64");
+    const mgk_geom F = *gf, Cg = *gc;
+    return run(c, [=] { std::vector<double> t = corrected<double>(F, Cg, uc, u); st_op<double>(M_JACOBI, F, nullptr, 1.0, scale, 0, 0, 0, b, t.data(), (const double *)nullptr, o, 0, F.ny, ctab, dtab); });
+}
+int mgk_residual_restrict_2d_rowcoef_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *ctab, const double *b, const double *u, double *bc, double *uc0, const double *dtab_c, double scale_c, void *) {
+    if (!c || !ctab || !b || !u || !bc || !xfer_ok(gf, gc) || gf->dim != 2 || (uc0 && !dtab_c)) return fail(MGK_EINVAL, "mgk_residual_restrict_2d_rowcoef_f64");
+    const mgk_geom F = *gf, Cg = *gc;
+    return run(c, [=] {
+        std::vector<double> r(F.total, 0.0);
+        st_op<double>(M_RESIDUAL, F, nullptr, 1, 1, 0, 0, 0, b, u, (const double *)nullptr, r.data(), 0, F.ny, ctab, (const double *)nullptr);
+        restrict_fw<double>(F, Cg, r.data(), bc, 0, 1);
+        if (uc0) for (int i = 0; i < Cg.ny; i++) for (int j = 0; j < Cg.nx; j++) { const double zq = at(bc, Cg, 0, i, j) * dtab_c[i]; at(uc0, Cg, 0, i, j) = scale_c * zq; }
+    });
+}
 
 int mgk_pack_f64(mgk_ctx *c, const mgk_geom *g, const double *compact, double *padded, void *) {
     if (!c || !g || !compact || !padded) return fail(MGK_EINVAL, "mgk_pack_f64");

@@ -533,3 +533,129 @@ def test_fused_residual_restrict_2d_bit_exact(mgk, orc, nf):
     mgk.L.mgk_set_tuning(-1, -1)
     for p in (du, db, dbc, duc0):
         mgk.free(p)
+
+
+# ---- the fused kernels on row-table operators (2-D stretched meshes) against numpy in the canonical term order ----
+def _rt_apply(ct, u):
+    """A u for the row-table operator: per grid row i the five coefficients {(i-1), W, C, E, (i+1)}, terms summed in that order"""
+    n = u.shape[0]
+    p = np.zeros((n + 2, n + 2))
+    p[1:-1, 1:-1] = u
+    t = ct[:, 0:1] * p[:-2, 1:-1]
+    t = t + ct[:, 1:2] * p[1:-1, :-2]
+    t = t + ct[:, 2:3] * p[1:-1, 1:-1]
+    t = t + ct[:, 3:4] * p[1:-1, 2:]
+    t = t + ct[:, 4:5] * p[2:, 1:-1]
+    return t
+
+
+def _rt_jacobi(ct, b, u, scale):
+    res = b - _rt_apply(ct, u)
+    return u + scale * (res * (1.0 / ct[:, 2:3]))
+
+
+def _rt_tables(rng, n):
+    q = float((n + 1) ** 2)
+    ct = np.empty((n, 5))
+    ct[:, 0] = q * rng.uniform(0.5, 1.5, n)
+    ct[:, 1] = q * rng.uniform(0.5, 1.5, n)
+    ct[:, 3] = ct[:, 1]
+    ct[:, 4] = q * rng.uniform(0.5, 1.5, n)
+    ct[:, 2] = -(ct[:, 0] + ct[:, 1] + ct[:, 3] + ct[:, 4])
+    return ct, 1.0 / ct[:, 2]
+
+
+@pytest.mark.parametrize("n", [3, 7, 63, 255, 509, 1023, 2047])
+def test_row_table_forms_of_the_fused_2d_kernels(mgk, orc, n):
+    """mgk_jacobi2_2d_rowcoef / mgk_jacobi_sumsq_rowcoef / mgk_residual_sumsq_rowcoef / mgk_prolong_jacobi_rowcoef /
+    mgk_residual_restrict_2d_rowcoef: each equals the kernel-per-operation sequence on the same row tables, bit for bit"""
+    rng = np.random.default_rng(8800 + n)
+    nc = (n - 1) // 2
+    ct, dt = _rt_tables(rng, n)
+    has_c = nc >= 1 and nc % 2 == 1                 # 509: a sweep-only shape (no vertex-centred coarse grid below it)
+    ctc, dtc = _rt_tables(rng, max(nc, 1))
+    u, b, uc = _rand(rng, n * n).reshape(n, n), _rand(rng, n * n).reshape(n, n), _rand(rng, nc * nc)
+    g, gc = mgk.geom(2, n), mgk.geom(2, nc if has_c else 1)
+    du, db, dout = mgk.to_field(g, u.ravel()), mgk.to_field(g, b.ravel()), mgk.field(g)
+    dct, ddt, ddtc = mgk.upload(ct.ravel()), mgk.upload(dt), mgk.upload(dtc)
+    ss = C.c_double(0.0)
+    for zc in (-1, 7):
+        mgk.L.mgk_set_tuning(-1, zc)
+        # two sweeps in one pass
+        mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dout, 8 * g.total, None))
+        mgk._chk(mgk.L.mgk_jacobi2_2d_rowcoef_f64(mgk.ctx, C.byref(g), dct, ddt, 0.8, db, du, dout, None))
+        want = _rt_jacobi(ct, b, _rt_jacobi(ct, b, u, 0.8), 0.8)
+        got = mgk.from_field(g, dout).reshape(n, n)
+        assert np.array_equal(got, want), f"jacobi2 zc={zc}: {np.abs(got - want).max()}"
+        raw = mgk.raw_field(g, dout)
+        assert abs(np.abs(raw).sum() - np.abs(got).sum()) <= 1e-9 * np.abs(got).sum()
+        # sweep + norm of the residual it forms, and the norm alone
+        mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dout, 8 * g.total, None))
+        mgk._chk(mgk.L.mgk_jacobi_sumsq_rowcoef_f64(mgk.ctx, C.byref(g), dct, ddt, 0.8, db, du, dout, C.byref(ss), None))
+        res = b - _rt_apply(ct, u)
+        assert np.array_equal(mgk.from_field(g, dout).reshape(n, n), _rt_jacobi(ct, b, u, 0.8))
+        assert abs(ss.value - float((res * res).sum())) <= 1e-12 * float((res * res).sum())
+        mgk._chk(mgk.L.mgk_residual_sumsq_rowcoef_f64(mgk.ctx, C.byref(g), dct, db, du, C.byref(ss), None))
+        assert abs(ss.value - float((res * res).sum())) <= 1e-12 * float((res * res).sum())
+        if has_c:
+            # prolongation fused into the sweep
+            duc = mgk.to_field(gc, uc)
+            corrected = orc.prolong_add(2, n, uc, u.ravel()).reshape(n, n)
+            mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dout, 8 * g.total, None))
+            mgk._chk(mgk.L.mgk_prolong_jacobi_rowcoef_f64(mgk.ctx, C.byref(g), C.byref(gc), dct, ddt, 0.8, db, duc, du, dout, None))
+            got = mgk.from_field(g, dout).reshape(n, n)
+            want = _rt_jacobi(ct, b, corrected, 0.8)
+            assert np.array_equal(got, want), f"prolong_jacobi zc={zc}: {np.abs(got - want).max()}"
+            # residual + restriction (+ the coarse level's zero-guess sweep with ITS 1/diag table)
+            dbc, duc0 = mgk.field(gc), mgk.field(gc)
+            mgk._chk(mgk.L.mgk_residual_restrict_2d_rowcoef_f64(mgk.ctx, C.byref(g), C.byref(gc), dct, db, du, dbc, duc0, ddtc, 0.8, None))
+            wantc = orc.restrict(2, n, res.ravel())
+            assert np.array_equal(mgk.from_field(gc, dbc), wantc)
+            assert np.array_equal(mgk.from_field(gc, duc0).reshape(nc, nc), 0.8 * (wantc.reshape(nc, nc) * dtc[:, None]))
+            for p in (duc, dbc, duc0):
+                mgk.free(p)
+    mgk.L.mgk_set_tuning(-1, -1)
+    for p in (du, db, dout, dct, ddt, ddtc):
+        mgk.free(p)
+
+
+@pytest.mark.parametrize("n0,nlev", [(63, 5), (31, 3), (15, 4), (7, 2)])
+def test_lds_tail_kernel_on_row_tables(mgk, orc, n0, nlev):
+    """mgk_tail_cycle_rowcoef_f64 against the same levels stepped with numpy in the canonical order (zero-guess sweep, sweeps,
+    residual + full weighting, prolongation + sweeps)"""
+    rng = np.random.default_rng(8900 + n0)
+    ns = [n0]
+    for _ in range(nlev - 1):
+        ns.append((ns[-1] - 1) // 2)
+    tabs = [_rt_tables(rng, n) for n in ns]
+    b0 = _rand(rng, n0 * n0).reshape(n0, n0)
+    v0, v1, scale = 3, 3, 0.8
+
+    def smooth(l, b, u, sweeps, zero):
+        ct, dt = tabs[l]
+        for it in range(sweeps):
+            if it == 0 and zero:
+                u = scale * (b * dt[:, None])
+            else:
+                u = _rt_jacobi(ct, b, u, scale)
+        return u
+    B, U = [b0], []
+    for l in range(nlev):
+        U.append(smooth(l, B[l], np.zeros_like(B[l]), v1 if l == nlev - 1 else v0, True))
+        if l < nlev - 1:
+            r = B[l] - _rt_apply(tabs[l][0], U[l])
+            B.append(orc.restrict(2, ns[l], r.ravel()).reshape(ns[l + 1], ns[l + 1]))
+    for l in range(nlev - 2, -1, -1):
+        U[l] = orc.prolong_add(2, ns[l], U[l + 1].ravel(), U[l].ravel()).reshape(ns[l], ns[l])
+        U[l] = smooth(l, B[l], U[l], v0, False)
+    g = mgk.geom(2, n0)
+    db, du = mgk.to_field(g, b0.ravel()), mgk.field(g)
+    dts = [(mgk.upload(ct.ravel()), mgk.upload(dt)) for ct, dt in tabs]
+    cta = (C.c_void_p * nlev)(*[C.cast(a, C.c_void_p).value for a, _ in dts])
+    dta = (C.c_void_p * nlev)(*[C.cast(d, C.c_void_p).value for _, d in dts])
+    nn = (C.c_int * nlev)(*ns)
+    mgk._chk(mgk.L.mgk_tail_cycle_rowcoef_f64(mgk.ctx, C.byref(g), nlev, nn, cta, dta, scale, v0, v1, db, du, None))
+    got = mgk.from_field(g, du).reshape(n0, n0)
+    assert np.array_equal(got, U[0]), f"max diff {np.abs(got - U[0]).max()}"
+    for p in [db, du] + [x for t in dts for x in t]:
+        mgk.free(p)

@@ -255,12 +255,18 @@ def test_fused_residual_restriction_on_small_levels(orc, npts, levels, precision
     s.close()
 
 
-@pytest.mark.parametrize("mesh,npts,levels", [(1, 33, 4), (2, 33, 4), (1, 129, 6), (2, 257, 7), (1, 513, 8)])
-def test_own_driver_on_stretched_meshes(orc, mesh, npts, levels):
-    """SURVEY 8(f) N1 in the own driver: -mesh 1/2 (src/mesh.c:45-107,165-169) -- per-row coefficient tables on every level,
-    the row-table kernels, the kernel-per-operation cycle.  Bit-identical to the oracle's assembled stretched-mesh leg."""
+@pytest.mark.parametrize("mesh,npts,levels,kw", [
+    (1, 33, 4, {}), (2, 33, 4, {}), (1, 129, 6, {}), (2, 257, 7, {}), (1, 513, 8, {}), (2, 513, 9, {}),
+    (1, 513, 8, {"pair_min_n": 63}), (2, 1025, 8, {"pair_min_n": 255}), (1, 257, 7, {"fuse": 0}), (2, 513, 9, {"graph": 0}),
+    (1, 2049, 11, {}),
+])
+def test_own_driver_on_stretched_meshes(orc, mesh, npts, levels, kw):
+    """SURVEY 8(f) N1 in the own driver: -mesh 1/2 (src/mesh.c:45-107,165-169) -- per-row coefficient tables on every level and
+    the SAME fused cycle as on the uniform mesh on the row-table forms of its kernels (fused prolongation+sweep, residual+
+    restriction+zero-guess sweep, norm+speculative sweep, two-sweep passes, the LDS tail, the coarse-level graph); fuse=0 is the
+    kernel-per-operation cycle.  Bit-identical to the oracle's assembled stretched-mesh leg."""
     from multigrid_petsc_amd.solver import Solver
-    s = Solver(2, npts, levels, v=(3, 3), maxiter=1000, scale=0.8, mesh=mesh)
+    s = Solver(2, npts, levels, v=(3, 3), maxiter=1000, scale=0.8, mesh=mesh, **kw)
     s.set_rhs_problem()
     it = s.solve()
     ref = orc.vcycle(2, npts, levels, 3, 3, maxiter=1000, scale=0.8, use_csr=1, mesh=mesh)
