@@ -124,8 +124,9 @@ def plain_sweep_probe(device, n):
 # per unknown of the level where a pass runs, times the level sizes
 # ---------------------------------------------------------------------------------------------
 def cycle_compulsory_bytes(dim, npts, levels, precision):
-    """3-D fp64, fine level: sweep+norm 24 + two sweeps in one pass 24 + fused residual/restriction 16+8/8 + fused
-    prolongation sweep 24+8/8 + two sweeps in one pass 24 = 114 B/unknown; coarser levels have no norm pass and get their
+    """3-D fp64, fine level: norm + two sweeps in one pass 24 + last pre-smoothing sweep fused with residual/restriction 24+2*8/8 +
+    fused prolongation sweep 24+8/8 + two sweeps in one pass 24 = 99 B/unknown on the full-row shapes those two kernels are built
+    for (n = 255, 511, 1023; otherwise sweep+norm 24 + pair 24 + residual/restriction 17: 114); coarser levels have no norm pass and get their
     first (zero-guess) sweep from the restriction kernel (+8 written): 24 + 17 + 8/8 + 25 + 24 = 91.  2-D (no fused
     residual/restriction, pairs on levels >= 2047^2 only): fine 24 + 24 + 24 (residual) + 10 (restriction) + 26 + 24 = 132,
     coarser levels 16 + 48 + 34 + 26 + 48 = 172 (one sweep per pass), capped at what the per-operation count of SURVEY 8(d3)
@@ -138,7 +139,7 @@ def cycle_compulsory_bytes(dim, npts, levels, precision):
         if l == levels - 1 and levels > 1:
             per = 64.0
         elif dim == 3:
-            per = 114.0 if l == 0 else 91.0
+            per = (99.0 if (n + 1) in (256, 512, 1024) and precision != "mixed" else 114.0) if l == 0 else 91.0
         else:
             per = 132.0 if (l == 0 and n >= 2047) else 172.0
         if precision == "mixed":

@@ -279,6 +279,21 @@ int  mgk_residual_restrict_2d_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *gf, cons
 int  mgk_tail_cycle_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *g0, int nlev, const int *n, const double *const *ctab,
                                 const double *const *dtab, double scale, int v0, int v1, const double *b, double *u, void *stream);
 
+/* two sweeps in one pass AND sumsq = || b - A u ||^2 of the INPUT field (the first sweep forms that residual anyway): the norm
+ * that closes cycle k (src/solver.c:1545-1546) out of the pass that makes the first two pre-smoothing sweeps of cycle k+1
+ * (:1531).  fp64, full-row 3-D shapes (n = 127, 255, 511, 1023), whole grid; mgk_jacobi2_sumsq_ok_f64 tells (1 / 0). */
+int  mgk_jacobi2_sumsq_ok_f64(const mgk_geom *g);
+int  mgk_jacobi2_sumsq_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale,
+                           const double *b, const double *u, double *unew, double *sumsq_host, void *stream);
+/* The LAST pre-smoothing sweep fused with the residual and its full weighting (src/solver.c:1531, last Richardson iteration,
+ * + :1534-1535): unew = J(u); bc = R (b - A unew); uc0 (optional) = scale_c * (bc * dinv_c) -- 26 B per fine unknown instead of
+ * 24 + 18 B for the sweep and the fused residual+restriction as two passes.  Built for full-row 3-D shapes (n = 127, 255, 511,
+ * 1023), whole grid; mgk_sweep_residual_restrict_ok_f64 tells (1 / 0). */
+int  mgk_sweep_residual_restrict_ok_f64(const mgk_geom *gf, const mgk_geom *gc);
+int  mgk_sweep_residual_restrict_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
+                                     const double *b, const double *u, double *unew, double *bc, double *uc0,
+                                     double dinv_c, double scale_c, void *stream);
+
 /* ---- flat BLAS-1 / AIJ kernels behind the PETSc-surface shim (include/petscksp.h) ----
  * n counts doubles of a whole allocation (padded fields: ghosts are 0 and stay 0). */
 int  mgk_flat_axpy(mgk_ctx *ctx, long n, double a, const double *x, double *y, void *stream);       /* VecAXPY  y += a x (src/solver.c:1517,1541) */

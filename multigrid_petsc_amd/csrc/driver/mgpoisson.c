@@ -75,6 +75,9 @@ int main(int argc, char **argv) {
     if ((v = get("-ksp_chebyshev_eigenvalues"))) sscanf(v, "%lf,%lf", &c.emin, &c.emax);
     if ((v = get("-precision"))) c.precision = !strcmp(v, "mixed") ? MG_PREC_MIXED : MG_PREC_FP64;
     if ((v = get("-device"))) c.device = atoi(v);
+    if ((v = get("-mg_fuse"))) c.fuse = atoi(v);                    /* tuning / testing: mg_config.fuse, .pair_min_n, .graph */
+    if ((v = get("-mg_pair_min_n"))) c.pair_min_n = atoi(v);
+    if ((v = get("-mg_graph"))) c.graph = atoi(v);
     if ((v = get("-pc_type")) && strcmp(v, "jacobi")) { fprintf(stderr, "mgpoisson: only -pc_type jacobi is built\n"); return 2; }
     if ((v = get("-cycle")) && atoi(v) != 0) { fprintf(stderr, "mgpoisson: only -cycle 0 (V-cycle) is built\n"); return 2; }
     if ((v = get("-mesh"))) c.mesh = atoi(v);

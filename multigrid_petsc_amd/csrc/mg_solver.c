@@ -41,6 +41,7 @@ typedef struct mg_fset {
     int u_ghost_ok;         /* z ghost planes of `u` hold the neighbours' current boundary planes */
     int u_ghost_pending;    /* ... but the exchange is still in flight on the comm stream */
     int jz_ready;           /* tmp already holds the first sweep from a zero guess (written by the fused residual+restriction) */
+    int last_sweep_pending; /* pre-smoothing stopped one sweep short: the restriction that follows makes it (mgk_sweep_residual_restrict_f64) */
     int b_ghost_ok;         /* z ghost planes of `b` hold the neighbours' boundary planes (two-sweep passes on slabs) */
     void *far;              /* distributed levels: field of geometry gfar = (nx, ny, 2) for the neighbours' SECOND planes of u */
     mgk_geom gfar;
@@ -137,7 +138,7 @@ struct mg_solver {
     int deferring;          /* mg_solver_cycles: norms are deposited on the device and read once at the end */
     double *d_norms; int d_norms_cap;
     double *pin; int pin_cap; /* pinned host landing area of the reduced norms */
-    int spec_valid;         /* level-0 tmp holds Jacobi(u): made by the sweep+norm kernel that closed the last cycle */
+    int spec_valid;         /* > 0: level-0 tmp holds that many sweeps of u, made by the sweep(s)+norm kernel that closed the last cycle */
     double solve_seconds;
     int lgraph;             /* levels >= lgraph form the launch-bound coarse part replayed as one HIP graph (0: off) */
     int ltail;              /* levels >= ltail (n <= 15 in 3-D, <= 63 in 2-D) run as ONE kernel with their fields in LDS (0: off) */
@@ -360,10 +361,10 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
         const int n0 = mg_grid_n(cfg->npts, 0);
         s->cfg.dist_min_n = n0 < 255 ? n0 : 255;
     }
-    if (s->cfg.fuse < 0) s->cfg.fuse = 63 | 256 | 512;
+    if (s->cfg.fuse < 0) s->cfg.fuse = 63 | 256 | 512 | 1024;
     if (s->cfg.pair_min_n <= 0) s->cfg.pair_min_n = (cfg->dim == 3) ? 255 : 2047;   /* where a two-sweep pass beats two sweeps
                                                                                       * (255^3: 0.107 ms against 2 x 0.063) */
-    if (s->cfg.mesh) s->cfg.fuse &= ~(16 | 128);   /* row-dependent coefficients (2-D, fp64): the same fused cycle on the row-table forms of the kernels */
+    if (s->cfg.mesh) s->cfg.fuse &= ~(16 | 128 | 1024);   /* row-dependent coefficients (2-D, fp64): the same fused cycle on the row-table forms of the kernels */
     if (s->cfg.overlap < 0) s->cfg.overlap = 1;
     if (s->cfg.graph < 0) s->cfg.graph = 1;
     if (s->cfg.nranks < 1) s->cfg.nranks = 1;
@@ -690,7 +691,17 @@ static int smooth_chebyshev(mg_solver *s, int l, int maxit) {
 }
 
 /* KSPSolve(ksp[l], b[l], u[l]) with KSP_NORM_NONE and max_it = maxit (src/solver.c:1465-1509) */
-static int smooth(mg_solver *s, int P, int l, int maxit) {
+/* the last pre-smoothing sweep of level l can be left to the restriction that follows (one pass for sweep + residual + full weighting,
+ * fuse bit 10): fp64, whole 3-D grids of full-row shape.  Not when that restriction is the first kernel of the coarse-level graph while
+ * this level's sweeps run outside it (the replayed kernel would keep the buffers of the recording cycle; the swap is made on the host) */
+static int srr_ok(const mg_solver *s, int P, int l) {
+    if (!(s->cfg.fuse & 1024) || P != 0 || s->cfg.dim != 3 || s->cfg.mesh || s->cfg.ksp_type != MG_KSP_RICHARDSON) return 0;
+    if (l + 1 >= s->levels || s->L[l].distributed || (s->lgraph && l + 1 == s->lgraph)) return 0;
+    return mgk_sweep_residual_restrict_ok_f64(&s->L[l].f[0].g, &s->L[l + 1].f[0].g);
+}
+
+/* pre: pre-smoothing, a restriction from this level follows (src/solver.c:1531 / :1536 before :1534 of the next level) */
+static int smooth(mg_solver *s, int P, int l, int maxit, int pre) {
     if (s->cfg.ksp_type == MG_KSP_CHEBYSHEV) return smooth_chebyshev(s, l, maxit);
     mg_level *L = &s->L[l];
     mg_fset *F = &L->f[P];
@@ -700,13 +711,15 @@ static int smooth(mg_solver *s, int P, int l, int maxit) {
         F->u_ghost_ok = 0; F->u_ghost_pending = 0;
     }
     int it0 = 0;
-    if (l == 0 && P == 0 && s->spec_valid && maxit >= 1 && F->guess_nonzero) {
-        /* the first sweep was already made by the kernel that evaluated the previous cycle's residual norm */
+    F->last_sweep_pending = 0;
+    if (l == 0 && P == 0 && s->spec_valid && maxit >= s->spec_valid && F->guess_nonzero) {
+        /* the first sweep(s) were already made by the kernel that evaluated the previous cycle's residual norm */
         swap_ptr(&F->u, &F->tmp);
         F->u_ghost_ok = 0; F->u_ghost_pending = 0;
+        it0 = s->spec_valid;
         s->spec_valid = 0;
-        it0 = 1;
     }
+    const int defer_last = pre && srr_ok(s, P, l);
     /* two sweeps per pass (temporal blocking) where it pays (3-D from 255^3, 2-D from 2047^2).  Also on the level whose buffers
      * the coarse-level HIP graph refers to: pre- and post-smoothing group their v0 sweeps in the same way (one launch for the
      * first sweep -- zero guess / fused prolongation / adopted speculative sweep -- then pairs), so a level swaps u/tmp the
@@ -724,6 +737,9 @@ static int smooth(mg_solver *s, int P, int l, int maxit) {
                 else CHK(O->jacobi_zero(s->ctx, &F->g, L->dinv, s->cfg.scale, F->b, F->tmp, NULL));
             }
             F->jz_ready = 0;
+        } else if (defer_last && it == maxit - 1) {
+            F->last_sweep_pending = 1;                      /* made by the restriction's kernel (descend_restrict) */
+            break;
         } else if (pair_ok && maxit - it >= 2) {
             if (L->distributed) {
                 /* slab: the second sweep of my first / last plane needs the first sweep of the neighbour's last / first plane,
@@ -910,7 +926,7 @@ static int prolong_smooth(mg_solver *s, int P, int l) {
     const int v0 = s->cfg.v[0];
     if (!(s->cfg.fuse & 2) || s->cfg.ksp_type != MG_KSP_RICHARDSON || v0 < 1) {
         CHK(prolong_from(s, P, l));
-        return smooth(s, P, l, v0);
+        return smooth(s, P, l, v0, 0);
     }
     mgk_geom gc = Cq->g;
     const void *ucoarse = Cq->u;
@@ -941,7 +957,7 @@ static int prolong_smooth(mg_solver *s, int P, int l) {
     }
     swap_ptr(&F->u, &F->tmp);
     F->u_ghost_ok = 0; F->u_ghost_pending = 0;
-    return smooth(s, P, l, v0 - 1);
+    return smooth(s, P, l, v0 - 1, 0);
 }
 
 static int descend_restrict(mg_solver *s, int P, int l, int no_jz);
@@ -976,7 +992,7 @@ static int descend(mg_solver *s, int P, int l) {
         return tail(s, P);
     }
     CHK(descend_restrict(s, P, l, 0));
-    CHK(smooth(s, P, l, l == levels - 1 ? v[1] : v[0]));                /* :1536 */
+    CHK(smooth(s, P, l, l == levels - 1 ? v[1] : v[0], l != levels - 1));   /* :1536 */
     if (l != levels - 1) s->L[l].f[P].guess_nonzero = 1;                /* :1537 */
     return 0;
 }
@@ -986,6 +1002,19 @@ static int descend_restrict(mg_solver *s, int P, int l, int no_jz) {
     const int levels = s->levels, *v = s->cfg.v;
     mg_level *Lf = &s->L[l - 1];
     const mg_ops *O = &OPS[P];
+    if (Lf->f[P].last_sweep_pending) {
+        /* the last pre-smoothing sweep, the residual and its restriction in one pass (:1531 / :1536 last iteration, :1534-1535) */
+        mg_fset *F = &Lf->f[P], *Cq = &s->L[l].f[P];
+        const int sweeps = (l == levels - 1) ? v[1] : v[0];
+        const int jz = (s->cfg.fuse & 256) && !no_jz && sweeps >= 1 && !Cq->guess_nonzero;
+        CHK(mgk_sweep_residual_restrict_f64(s->ctx, &F->g, &Cq->g, Lf->coef, Lf->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u,
+                                            (double *)F->tmp, (double *)Cq->b, jz ? (double *)Cq->tmp : NULL, s->L[l].dinv, s->cfg.scale, NULL));
+        swap_ptr(&F->u, &F->tmp);
+        F->u_ghost_ok = 0; F->u_ghost_pending = 0; F->last_sweep_pending = 0;
+        Cq->b_ghost_ok = 0;
+        if (jz) Cq->jz_ready = 1;
+        return 0;
+    }
     /* (below 255^3 the marching fused kernel is latency bound: residual + restriction as two short kernels are quicker) */
     if ((s->cfg.fuse & 4) && O->residual_restrict && s->cfg.dim == 3 && !Lf->distributed && Lf->n + 1 <= 1024 &&
         (Lf->n >= 255 || (s->cfg.fuse & 128))) {
@@ -1117,7 +1146,7 @@ static int coarse_part(mg_solver *s, int P, int lg) {
 static int cycle_body(mg_solver *s, int P, int first) {
     const int levels = s->levels, *v = s->cfg.v;
     const int lg = s->lgraph ? s->lgraph : levels;                      /* levels >= lg run as one HIP graph */
-    CHK(smooth(s, P, 0, v[0]));                                         /* :1531 */
+    CHK(smooth(s, P, 0, v[0], levels > 1));                             /* :1531 */
     if (first) s->L[0].f[P].guess_nonzero = 1;                          /* :1532 */
     const int lend = s->ltail ? s->ltail : levels - 1;
     for (int l = 1; l < lg && l <= lend; l++) CHK(descend(s, P, l));
@@ -1197,11 +1226,17 @@ static int vcycle_once(mg_solver *s) {
             /* ||b - A u|| and, speculatively, the first pre-smoothing sweep of the next cycle in one pass over u and b
              * (both form the same residual).  The sweep lands in tmp and is adopted by smooth() only if another
              * cycle follows; u itself is untouched, so stopping here leaves the solution as the reference has it. */
+            /* (not when level 0 feeds the coarse-level graph: adopting two sweeps at once changes how often level 0 swaps u / tmp in
+             * a cycle from the recording cycle's count, and the recorded restriction reads level 0's buffers) */
+            const int two = (s->cfg.fuse & 1024) && (s->cfg.fuse & 32) && !s->cfg.mesh && !L->distributed && s->cfg.dim == 3 &&
+                            s->cfg.v[0] >= 2 && L->n >= s->cfg.pair_min_n && s->lgraph != 1 && mgk_jacobi2_sumsq_ok_f64(&F->g);
             if (s->cfg.mesh) CHK(mgk_jacobi_sumsq_rowcoef_f64(s->ctx, &F->g, L->ctab, L->dtab, s->cfg.scale, (const double *)F->b,
                                                               (const double *)F->u, (double *)F->tmp, &ss, NULL));
+            else if (two) CHK(mgk_jacobi2_sumsq_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u,
+                                                    (double *)F->tmp, &ss, NULL));      /* ... and the second one: two sweeps in the pass */
             else CHK(mgk_jacobi_sumsq_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u,
                                           (double *)F->tmp, &ss, NULL));
-            s->spec_valid = 1;
+            s->spec_valid = two ? 2 : 1;
         } else if ((s->cfg.fuse & 1) && s->cfg.mesh)
             CHK(mgk_residual_sumsq_rowcoef_f64(s->ctx, &F->g, L->ctab, (const double *)F->b, (const double *)F->u, &ss, NULL));
         else if (s->cfg.fuse & 1) CHK(mgk_residual_sumsq_f64(s->ctx, &F->g, L->coef, (const double *)F->b, (const double *)F->u, &ss, NULL));
@@ -1225,7 +1260,7 @@ static int start(mg_solver *s) {
     CHK(mgk_sumsq_f64(s->ctx, &F->g, (const double *)F->b, &ss, NULL)); /* VecNorm(b[0]) :1512 */
     CHK(norm_from_sumsq(s, ss, &s->bnorm));
     for (int l = 0; l < s->levels; l++)
-        for (int p = 0; p < 2; p++) { s->L[l].f[p].guess_nonzero = 0; s->L[l].f[p].u_ghost_ok = 0; s->L[l].f[p].u_ghost_pending = 0; s->L[l].f[p].b_ghost_ok = 0; s->L[l].f[p].jz_ready = 0; }
+        for (int p = 0; p < 2; p++) { s->L[l].f[p].guess_nonzero = 0; s->L[l].f[p].u_ghost_ok = 0; s->L[l].f[p].u_ghost_pending = 0; s->L[l].f[p].b_ghost_ok = 0; s->L[l].f[p].jz_ready = 0; s->L[l].f[p].last_sweep_pending = 0; }
     CHK(mgk_memset0(s->ctx, F->u, sizeof(double) * (size_t)F->g.total, NULL));   /* VecSet(u[0],0) :1514 */
     /* rv = A u - b with u = 0 (:1516-1517); ||A u - b|| = ||b - A u||, evaluated by the same residual kernel */
     if (s->cfg.precision == MG_PREC_MIXED)

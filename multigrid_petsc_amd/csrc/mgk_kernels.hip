@@ -1217,6 +1217,18 @@ __device__ __forceinline__ V16<float> jac7(float a0, float a1, float a2, float a
     return o;
 }
 
+// row loads of the register / shuffle kernels: wave-uniform row base + a 32-bit lane offset, unconditional
+template <typename T>
+__device__ __forceinline__ V16<T> ldrow(const T *row_uniform, unsigned lane_bytes) {
+    return *reinterpret_cast<const V16<T> *>(reinterpret_cast<const char *>(row_uniform) + lane_bytes);
+}
+__device__ __forceinline__ V16<double> ldrow_stream(const double *row_uniform, unsigned lane_bytes) {
+    return ldv_stream(reinterpret_cast<const double *>(reinterpret_cast<const char *>(row_uniform) + lane_bytes), true);
+}
+__device__ __forceinline__ V16<float> ldrow_stream(const float *row_uniform, unsigned lane_bytes) {
+    return ldv_stream(reinterpret_cast<const float *>(reinterpret_cast<const char *>(row_uniform) + lane_bytes), true);
+}
+
 template <typename T>
 struct J2Args {
     const T *u, *b;
@@ -1231,6 +1243,7 @@ struct J2Args {
     const T *far_lo, *far_hi;
     int has_lo, has_hi;
     int zbeg, zend;          // output planes of this launch (whole grid / slab: 0, nz)
+    double *partials;        // k_jacobi2r<.., NORM = true>: one partial sum of squares per block (|| b - A u ||^2 of the INPUT field)
 };
 
 template <typename T, int WX, int FORM>
@@ -1393,7 +1406,10 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2(const J2Args<T> a) {
 // neighbours of the second sweep are read from, double buffered (written in step t-1, read in step t while u'(t+1) goes
 // to the other buffer).  The plane of u brought in for the next step is loaded straight into the registers of the plane
 // the first sweep has just finished with.
-template <typename T, int WX, int FORM>
+// NORM: the first sweep forms b - A u of the input field on the way; its sum of squares over the points this block owns goes to
+// partials[blockIdx.x] -- the residual norm that closes cycle k (src/solver.c:1545-1546) out of the pass that makes the first TWO
+// pre-smoothing sweeps of cycle k+1 (:1531).
+template <typename T, int WX, int FORM, bool NORM = false>
 __global__ void __launch_bounds__(64 * WX) k_jacobi2r(const J2Args<T> a) {
     // FORM bit 0: unconditional loads with rows / planes clamped on the scalar unit (full-row shapes only: no lane outside the
     // grid; whatever a clamped load brings in only reaches first-sweep values that are forced to 0 anyway); bit 1: DPP lane shifts
@@ -1409,7 +1425,7 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2r(const J2Args<T> a) {
     const int ty = bid % a.nty, tz = bid / a.nty;
     const int yb = TY * ty;
     const int z0 = a.zbeg + tz * a.zc, z1 = min(z0 + a.zc, a.zend);
-    if (z0 >= z1) return;
+    if (z0 >= z1) { if (NORM && tid == 0) a.partials[blockIdx.x] = 0.0; return; }
     const int xl = VX * tid, x0 = xl;
     const bool xok = x0 < a.nx;
     const bool lastvec = (x0 + VX > a.nx);
@@ -1453,6 +1469,7 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2r(const J2Args<T> a) {
     };
 
     VT ua[R1], ub[R1], uc[R1], b1[R2], bn[R2], b0[TY], wm[TY], wc[TY], wp[TY];
+    double nacc = 0.0;
     const int t0 = z0 - 2;
 #pragma unroll
     for (int rr = 0; rr < R1; rr++) {
@@ -1513,6 +1530,10 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2r(const J2Args<T> a) {
                     const T zz = res * a.dinv;
                     o.v[e] = ub[rr].v[e] + a.scale * zz;
                     if (!pin || !s1ok[q] || !xok || (lastvec && x0 + e >= a.nx)) o.v[e] = (T)0;
+                    if (NORM && q >= 1 && q <= TY) {              // rows this tile owns, planes this chunk owns, inside the grid
+                        const bool own = (p >= z0 && p < z1) && s1ok[q] && xok && !(lastvec && x0 + e >= a.nx);
+                        nacc += own ? (double)res * (double)res : 0.0;
+                    }
                 }
                 *reinterpret_cast<VT *>(&cen[cb][q][xl + VX]) = o;
                 if (q >= 1 && q <= TY) wp[q - 1] = o;
@@ -1567,13 +1588,22 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2r(const J2Args<T> a) {
 #pragma unroll
         for (int rr = 0; rr < R1; rr++) { VT tmpv = ua[rr]; ua[rr] = ub[rr]; ub[rr] = uc[rr]; uc[rr] = tmpv; }
     }
+    if (NORM) {
+        double *red = reinterpret_cast<double *>(&cen[0][0][0]);           // free after the last barrier of the loop
+        __syncthreads();
+        const double sblk = block_sum(nacc, red);
+        if (tid == 0) a.partials[blockIdx.x] = sblk;
+    }
 }
 
 
 
+template <typename T> struct j2norm { static constexpr bool built = false; };
+template <> struct j2norm<double> { static constexpr bool built = true; };
 template <typename T>
 static int jacobi2(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
-                   const T *b, const T *u, T *unew, const T *far_lo, const T *far_hi, int zbeg, int zend, void *stream) {
+                   const T *b, const T *u, T *unew, const T *far_lo, const T *far_hi, int zbeg, int zend, void *stream,
+                   int *norm_parts = nullptr) {
     constexpr int VX = 16 / sizeof(T);
     if (!c || !g || !coef || !b || !u || !unew || u == unew || g->dim != 3) return fail(MGK_EINVAL, "mgk_jacobi2: bad arguments (3-D)");
     if (g->nx + 1 > 1024) return fail(MGK_EINVAL, "mgk_jacobi2: nx + 1 > 1024 is not built");
@@ -1602,6 +1632,22 @@ static int jacobi2(mgk_ctx *c, const mgk_geom *g, const double *coef, double din
     const long ntz = (nzr + zc - 1) / zc;
     const unsigned nblk = (unsigned)(a.nty * ntz);
     hipStream_t s = S(c, stream);
+    if (norm_parts) {
+        // with the residual norm of the input field: the register form on full-row shapes only
+        constexpr int WRn = 64 * VX;
+        if (!j2norm<T>::built || (g->nx + 1) % WRn != 0 || (g->ny + 1) % 4 != 0 || (long)nblk > c->max_partials)
+            return fail(MGK_EINVAL, "mgk_jacobi2_sumsq: built for fp64 full-row shapes (n = 127, 255, 511, 1023)");
+        a.partials = c->partials;
+        if constexpr (j2norm<T>::built) {
+            if (w <= 1) hipLaunchKernelGGL((k_jacobi2r<T, 1, 3, true>), dim3(nblk), dim3(64), 0, s, a);
+            else if (w <= 2) hipLaunchKernelGGL((k_jacobi2r<T, 2, 3, true>), dim3(nblk), dim3(128), 0, s, a);
+            else if (w <= 4) hipLaunchKernelGGL((k_jacobi2r<T, 4, 3, true>), dim3(nblk), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_jacobi2r<T, 8, 3, true>), dim3(nblk), dim3(512), 0, s, a);
+        }
+        HIPCHK(hipGetLastError());
+        *norm_parts = (int)nblk;
+        return 0;
+    }
     // one 512-thread block per CU (fp64, 1023^3): the one-barrier variant (4.51 vs 5.15 ms per pass); smaller blocks run two
     // per CU and hide the second barrier, and prefer the ring variant's full-step prefetch distance (fp64 511^3: 0.66 vs
     // 0.72 ms; fp32 1023^3: 3.98 vs 7.29 ms, the register variant is at the 256-VGPR limit there)
@@ -1647,6 +1693,19 @@ extern "C" int mgk_jacobi2_f32(mgk_ctx *c, const mgk_geom *g, const double *coef
     if (!g) return fail(MGK_EINVAL, "mgk_jacobi2_f32: bad arguments");
     return jacobi2<float>(c, g, coef, dinv, scale, b, u, unew, nullptr, nullptr, 0, g->nz, stream);
 }
+// Two sweeps AND || b - A u ||^2 of the input field (formed by the first sweep anyway): closes cycle k (src/solver.c:1545-1546)
+// and makes the first two pre-smoothing sweeps of cycle k+1 (:1531) in one pass.  unew is only adopted if another cycle runs.
+extern "C" int mgk_jacobi2_sumsq_ok_f64(const mgk_geom *g) {
+    return (g && g->dim == 3 && (g->nx + 1) % 128 == 0 && (g->ny + 1) % 4 == 0 && g->nx + 1 <= 1024) ? 1 : 0;
+}
+extern "C" int mgk_jacobi2_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
+                                     const double *b, const double *u, double *unew, double *sumsq_host, void *stream) {
+    if (!g || !sumsq_host) return fail(MGK_EINVAL, "mgk_jacobi2_sumsq_f64: bad arguments");
+    int nparts = 0;
+    int rc = jacobi2<double>(c, g, coef, dinv, scale, b, u, unew, nullptr, nullptr, 0, g->nz, stream, &nparts);
+    if (rc) return rc;
+    return finish_to_host(c, nparts, 1, S(c, stream), sumsq_host);
+}
 // The same on a z-slab.  `far` is a field of geometry (nx, ny, nz = 2) whose ghost planes hold the neighbours' second plane
 // (lo ghost: plane nz-2 of the rank below, hi ghost: plane 1 of the rank above; mgk_geom of it in gfar); u's own ghost
 // planes hold their last / first plane and b's ghost planes their b.  has_lo / has_hi: a neighbour exists on that side.
@@ -1669,6 +1728,274 @@ extern "C" int mgk_jacobi2_slab_f32(mgk_ctx *c, const mgk_geom *g, const mgk_geo
                                     const float *b, const float *u, float *unew, const float *far, int has_lo, int has_hi,
                                     int zbeg, int zend, void *stream) {
     return jacobi2_slab<float>(c, g, gfar, coef, dinv, scale, b, u, unew, far, has_lo, has_hi, zbeg, zend, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// The LAST pre-smoothing sweep fused with the residual and its full weighting (src/solver.c:1531 last iteration + :1534-1535):
+//     out = J(u);   b_c = R (b - A out)   [; uc0 = scale_c * (b_c * dinv_c)]
+// in one pass -- 8 B (u) + 8 B (b) read, 8 B (out) + 1 B (b_c) [+ 1 B] written per fine unknown instead of 24 + 18 B for the
+// sweep and the fused residual+restriction as two passes.  Structure of k_jacobi2r (full-row tile marching along z, the lane
+// owns a column pair of all rows, the swept centre plane in LDS, one barrier per plane) with the second stage replaced by
+// k_rrrow's residual + running full-weighting sums.  A tile of TY fine rows owns TY/2 coarse rows, which read the residual on
+// TY+1 rows, hence the sweep on TY+3 rows and u on TY+5 rows (the tile's neighbours recompute the shared rows; they come from L2).
+// Same per-point expressions and summation order as the kernels it replaces: bit-identical.
+// Shapes: full rows (nx + 1 == 64 * VX * WX), ny + 1 a multiple of 4, whole grid (no z-slab).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct SRRArgs {
+    const T *u, *b;
+    T *out, *bc, *uc0;
+    int nx, ny, nz, nxc, nyc, nzc;
+    long rs, ms, crs, cms;
+    int nty, kcc;            // tiles in y, coarse planes per chunk
+    T a0, a1, a2, a3, a4, a5, a6, dinv, scale, dinv_c, scale_c;
+};
+template <typename T, int WX, int TY>
+__global__ void __launch_bounds__(64 * WX) k_srr(const SRRArgs<T> a) {
+    constexpr int VX = 16 / sizeof(T), NCJ = VX / 2, NCR = TY / 2, RS = TY + 1, R2 = TY + 3, R1 = TY + 5;
+    constexpr int TX = 64 * VX * WX, LW = TX + 2 * VX;
+    __shared__ __attribute__((aligned(16))) T cen[2][R2][LW];
+    __shared__ T edgeW[2][R2][WX], edgeE[2][R2][WX], eR[2][RS][WX];
+    using VT = V16<T>;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int ty = bid % a.nty, tz = bid / a.nty;
+    const int yb = TY * ty;
+    const int kc0 = tz * a.kcc, kc1 = min(kc0 + a.kcc, a.nzc);
+    if (kc0 >= kc1) return;
+    const int z0 = 2 * kc0, z1 = min(2 * kc1 + 1, a.nz);          // planes whose residual this chunk forms: [z0, z1)
+    const int zs1 = (kc1 == a.nzc) ? a.nz : 2 * kc1;              // planes of the swept field this chunk stores: [z0, zs1)
+    const int xl = VX * tid, x0 = xl;
+    const bool lastlane = (tid == 64 * WX - 1);                   // its last element is the ghost column x = nx: stays 0
+    const unsigned lb = (unsigned)(x0 * (int)sizeof(T));
+    bool s1ok[R2], rok[RS];
+#pragma unroll
+    for (int q = 0; q < R2; q++) { const int y = yb - 1 + q; s1ok[q] = y >= 0 && y < a.ny; }
+#pragma unroll
+    for (int j = 0; j < RS; j++) rok[j] = (yb + j < a.ny);
+    bool crow[NCR];
+#pragma unroll
+    for (int cl = 0; cl < NCR; cl++) crow[cl] = (NCR * ty + cl < a.nyc);
+    long uro[R1], bro[R2];
+#pragma unroll
+    for (int rr = 0; rr < R1; rr++) uro[rr] = (long)max(-1, min(yb - 2 + rr, a.ny)) * a.rs;
+#pragma unroll
+    for (int q = 0; q < R2; q++) bro[q] = (long)max(0, min(yb - 1 + q, a.ny)) * a.rs;
+    // unconditional loads, rows / planes clamped on the scalar unit: whatever a clamped load brings in only reaches first-sweep
+    // values that are forced to 0
+    auto LDU = [&](int p, int rr) -> VT { return ldrow(a.u + (long)max(-1, min(p, a.nz)) * a.ms + uro[rr], lb); };
+    auto LDB = [&](int p, int q, bool stream) -> VT {
+        const T *pl = a.b + (long)max(0, min(p, a.nz - 1)) * a.ms + bro[q];
+        return stream ? ldrow_stream(pl, lb) : ldrow(pl, lb);
+    };
+    for (int i = tid; i < 2 * R2 * LW; i += 64 * WX) (&cen[0][0][0])[i] = (T)0;
+    const int jc0 = NCJ * tid;
+    const T w2[3][3] = {{(T)0.0625, (T)0.125, (T)0.0625}, {(T)0.125, (T)0.25, (T)0.125}, {(T)0.0625, (T)0.125, (T)0.0625}};
+
+    VT ua[R1], ub[R1], uc[R1], b1[R2], bn[R2], b0[RS], wm[RS], wc[RS], wp[RS];
+    const int t0 = z0 - 2;                                        // first step: the sweep of plane z0 - 1
+#pragma unroll
+    for (int rr = 0; rr < R1; rr++) { ua[rr] = LDU(t0, rr); ub[rr] = LDU(t0 + 1, rr); uc[rr] = LDU(t0 + 2, rr); }
+#pragma unroll
+    for (int q = 0; q < R2; q++) { b1[q] = LDB(t0 + 1, q, false); bn[q] = v16_zero<T>(); }
+#pragma unroll
+    for (int j = 0; j < RS; j++) { b0[j] = v16_zero<T>(); wm[j] = b0[j]; wc[j] = b0[j]; wp[j] = b0[j]; }
+    if (lane == 0 || lane == 63) {
+#pragma unroll
+        for (int q = 0; q < R2; q++) {
+            if (lane == 0) edgeW[(t0 + 1) & 1][q][w] = ub[q + 1].v[0];
+            else edgeE[(t0 + 1) & 1][q][w] = ub[q + 1].v[VX - 1];
+        }
+    }
+    T acc[NCR][NCJ], accn[NCR][NCJ];
+#pragma unroll
+    for (int cl = 0; cl < NCR; cl++)
+#pragma unroll
+        for (int q = 0; q < NCJ; q++) { acc[cl][q] = (T)0; accn[cl][q] = (T)0; }
+    __syncthreads();
+
+    for (int t = t0; t < z1; t++) {
+        const int p = t + 1;                                      // plane the sweep produces in this step
+#pragma unroll
+        for (int q = 0; q < R2; q++) bn[q] = LDB(t + 2, q, q >= 2 && q < R2 - 2);      // b of the next step; rows shared with neighbours: cached
+        // ---- the sweep of plane p on rows yb-1 .. yb+TY+1 ----
+        {
+            const bool pin = (p >= 0 && p < a.nz);
+            const bool pst = (p >= z0 && p < zs1);
+            const int eb = p & 1, cb = p & 1;
+#pragma unroll
+            for (int q = 0; q < R2; q++) {
+                const int rr = q + 1;
+                T Wv = lane_up<true>(ub[rr].v[VX - 1]), Ev = lane_dn<true>(ub[rr].v[0]);
+                if (lane == 0) Wv = (w > 0) ? edgeE[eb][q][w - 1] : (T)0;
+                if (lane == 63) Ev = (w < WX - 1) ? edgeW[eb][q][w + 1] : (T)0;
+                VT o;
+#pragma unroll
+                for (int e = 0; e < VX; e++) {
+                    const T wv = (e == 0) ? Wv : ub[rr].v[e - 1 < 0 ? 0 : e - 1];
+                    const T ev = (e == VX - 1) ? Ev : ub[rr].v[e + 1 > VX - 1 ? VX - 1 : e + 1];
+                    T s = a.a0 * ua[rr].v[e];
+                    s = s + a.a1 * ub[rr - 1].v[e];
+                    s = s + a.a2 * wv;
+                    s = s + a.a3 * ub[rr].v[e];
+                    s = s + a.a4 * ev;
+                    s = s + a.a5 * ub[rr + 1].v[e];
+                    s = s + a.a6 * uc[rr].v[e];
+                    const T res = b1[q].v[e] - s;
+                    const T zz = res * a.dinv;
+                    o.v[e] = ub[rr].v[e] + a.scale * zz;
+                    if (!pin || !s1ok[q] || (lastlane && e == VX - 1)) o.v[e] = (T)0;
+                }
+                *reinterpret_cast<VT *>(&cen[cb][q][xl + VX]) = o;
+                if (q >= 1 && q <= RS) wp[q - 1] = o;
+                if (q >= 1 && q <= TY) { if (pst && s1ok[q]) stv_stream(a.out + (long)p * a.ms + (long)(yb + q - 1) * a.rs + x0, o); }
+            }
+            if (lane == 0 || lane == 63) {
+#pragma unroll
+                for (int q = 0; q < R2; q++) {
+                    if (lane == 0) edgeW[eb ^ 1][q][w] = uc[q + 1].v[0];
+                    else edgeE[eb ^ 1][q][w] = uc[q + 1].v[VX - 1];
+                }
+            }
+        }
+        // plane t+3 of u into the registers of plane t (the sweep is done with them)
+#pragma unroll
+        for (int rr = 0; rr < R1; rr++) ua[rr] = LDU(t + 3, rr);
+        // ---- residual of the swept plane t on rows yb .. yb+TY: x / y neighbours from cen[t & 1] (written in step t-1) ----
+        VT res[RS];
+        if (t >= z0) {
+            const int cb = t & 1;
+#pragma unroll
+            for (int j = 0; j < RS; j++) {
+                const int q = j + 1;
+                const VT sv = *reinterpret_cast<const VT *>(&cen[cb][q - 1][xl + VX]);
+                const VT nv = *reinterpret_cast<const VT *>(&cen[cb][q + 1][xl + VX]);
+                const T Wv = cen[cb][q][xl + VX - 1], Ev = cen[cb][q][xl + 2 * VX];
+#pragma unroll
+                for (int e = 0; e < VX; e++) {
+                    const T wv = (e == 0) ? Wv : wc[j].v[e - 1 < 0 ? 0 : e - 1];
+                    const T ev = (e == VX - 1) ? Ev : wc[j].v[e + 1 > VX - 1 ? VX - 1 : e + 1];
+                    T s = a.a0 * wm[j].v[e];
+                    s = s + a.a1 * sv.v[e];
+                    s = s + a.a2 * wv;
+                    s = s + a.a3 * wc[j].v[e];
+                    s = s + a.a4 * ev;
+                    s = s + a.a5 * nv.v[e];
+                    s = s + a.a6 * wp[j].v[e];
+                    res[j].v[e] = rok[j] ? b0[j].v[e] - s : (T)0;
+                }
+                if (lastlane) res[j].v[VX - 1] = (T)0;
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < RS; j++) eR[cb][j][w] = res[j].v[0];
+            }
+        }
+        __syncthreads();            // cen[(t+1)&1] = the swept plane t+1 complete; wave-edge values of this residual plane visible
+        // ---- full weighting: running sums of the coarse planes t/2-1 (dk = 2) and t/2 (dk = 0) / (t-1)/2 (dk = 1) ----
+        if (t >= z0) {
+            const bool even = ((t & 1) == 0);
+            const T wk = even ? (T)0.25 : (T)0.5;
+            T nx_[RS];
+#pragma unroll
+            for (int j = 0; j < RS; j++) {
+                nx_[j] = lane_dn<true>(res[j].v[0]);
+                if (lane == 63) nx_[j] = (w < WX - 1) ? eR[t & 1][j][w + 1] : (T)0;
+            }
+#pragma unroll
+            for (int cl = 0; cl < NCR; cl++) {
+                if (!crow[cl]) continue;
+#pragma unroll
+                for (int q = 0; q < NCJ; q++) {
+#pragma unroll
+                    for (int di = 0; di < 3; di++) {
+#pragma unroll
+                        for (int dj = 0; dj < 3; dj++) {
+                            const int e = 2 * q + dj;
+                            const T val = (e < VX) ? res[2 * cl + di].v[e < VX ? e : 0] : nx_[2 * cl + di];
+                            const T pr = (wk * w2[di][dj]) * val;
+                            acc[cl][q] += pr;
+                            if (even) accn[cl][q] += pr;
+                        }
+                    }
+                }
+            }
+            if (even) {
+                const int kc = t / 2 - 1;     // completed coarse plane
+#pragma unroll
+                for (int cl = 0; cl < NCR; cl++)
+#pragma unroll
+                    for (int q = 0; q < NCJ; q++) {
+                        if (kc >= kc0 && crow[cl] && jc0 + q < a.nxc) {
+                            const long oc = (long)kc * a.cms + (long)(NCR * ty + cl) * a.crs + jc0 + q;
+                            a.bc[oc] = acc[cl][q];
+                            if (a.uc0) { const T zq = acc[cl][q] * a.dinv_c; a.uc0[oc] = a.scale_c * zq; }
+                        }
+                        acc[cl][q] = accn[cl][q]; accn[cl][q] = (T)0;
+                    }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RS; j++) { b0[j] = b1[j + 1]; wm[j] = wc[j]; wc[j] = wp[j]; }
+#pragma unroll
+        for (int q = 0; q < R2; q++) b1[q] = bn[q];
+#pragma unroll
+        for (int rr = 0; rr < R1; rr++) { VT tmpv = ua[rr]; ua[rr] = ub[rr]; ub[rr] = uc[rr]; uc[rr] = tmpv; }
+    }
+}
+
+// shapes the fused sweep + residual + restriction is built for: full rows of 1 / 2 / 4 / 8 waves, whole 3-D grid
+template <typename T>
+static bool srr_shape_ok(const mgk_geom *gf, const mgk_geom *gc) {
+    constexpr int VX = 16 / sizeof(T);
+    if (!gf || !gc || gf->dim != 3 || gc->dim != 3) return false;
+    if (gf->nx != 2 * gc->nx + 1 || gf->ny != 2 * gc->ny + 1 || gf->nz != 2 * gc->nz + 1) return false;
+    const int wr = 64 * VX;
+    if ((gf->nx + 1) % wr != 0 || (gf->ny + 1) % 4 != 0) return false;
+    const int w = (gf->nx + 1) / wr;
+    return w == 1 || w == 2 || w == 4 || w == 8;
+}
+extern "C" int mgk_sweep_residual_restrict_ok_f64(const mgk_geom *gf, const mgk_geom *gc) { return srr_shape_ok<double>(gf, gc) ? 1 : 0; }
+
+template <typename T, int TY>
+static void launch_srr(int w, unsigned nblk, hipStream_t s, const SRRArgs<T> &a) {
+    if (w <= 1) hipLaunchKernelGGL((k_srr<T, 1, TY>), dim3(nblk), dim3(64), 0, s, a);
+    else if (w <= 2) hipLaunchKernelGGL((k_srr<T, 2, TY>), dim3(nblk), dim3(128), 0, s, a);
+    else if (w <= 4) hipLaunchKernelGGL((k_srr<T, 4, TY>), dim3(nblk), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_srr<T, 8, TY>), dim3(nblk), dim3(512), 0, s, a);
+}
+// out = J(u); bc = R (b - A out); uc0 (optional) = scale_c * (bc * dinv_c)
+extern "C" int mgk_sweep_residual_restrict_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
+                                               const double *b, const double *u, double *unew, double *bc, double *uc0,
+                                               double dinv_c, double scale_c, void *stream) {
+    typedef double T;
+    if (!c || !gf || !gc || !coef || !b || !u || !unew || u == unew || !bc) return fail(MGK_EINVAL, "mgk_sweep_residual_restrict_f64: bad arguments");
+    if (!srr_shape_ok<T>(gf, gc)) return fail(MGK_EINVAL, "mgk_sweep_residual_restrict_f64: built for full-row 3-D shapes (n = 127, 255, 511, 1023), whole grid");
+    SRRArgs<T> a; memset(&a, 0, sizeof(a));
+    a.u = u + gf->org; a.b = b + gf->org; a.out = unew + gf->org; a.bc = bc + gc->org; a.uc0 = uc0 ? uc0 + gc->org : nullptr;
+    a.nx = gf->nx; a.ny = gf->ny; a.nz = gf->nz; a.nxc = gc->nx; a.nyc = gc->ny; a.nzc = gc->nz;
+    a.rs = gf->pitch; a.ms = gf->plane; a.crs = gc->pitch; a.cms = gc->plane;
+    a.a0 = coef[0]; a.a1 = coef[1]; a.a2 = coef[2]; a.a3 = coef[3]; a.a4 = coef[4]; a.a5 = coef[5]; a.a6 = coef[6];
+    a.dinv = dinv; a.scale = scale; a.dinv_c = dinv_c; a.scale_c = scale_c;
+    constexpr int VX = 16 / sizeof(T);
+    const int w = (gf->nx + 1) / (64 * VX);
+    const int TYsel = (g_variant == 41) ? 4 : 2;                     // tuning variant 41: tiles of 4 rows
+    a.nty = (gf->ny + TYsel - 1) / TYsel;
+    // blocks: a multiple of what the chip holds at once (512-thread blocks: one per CU); every chunk recomputes three planes
+    const long target = (w > 4) ? 512 : 1024;
+    long nch = (a.nty >= target) ? 1 : (target + a.nty - 1) / a.nty;
+    if (g_zchunk > 0) nch = (gc->nz + g_zchunk - 1) / g_zchunk;
+    int kcc = (int)((gc->nz + nch - 1) / nch);
+    if (kcc < 4) kcc = 4;
+    if (kcc > gc->nz) kcc = gc->nz;
+    a.kcc = kcc;
+    const unsigned nblk = (unsigned)(a.nty * ((gc->nz + kcc - 1) / kcc));
+    if (TYsel == 4) launch_srr<T, 4>(w, nblk, S(c, stream), a);
+    else launch_srr<T, 2>(w, nblk, S(c, stream), a);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 // 2-D version of the two-sweep pass: blocks of 64*WX lanes march along y over an x tile of 128*WX columns; a lane owns one
@@ -2672,16 +2999,6 @@ __global__ void __launch_bounds__(64 * WX) k_resrestrict(const RRArgs<T> a) {
 // Loads of the row kernels are UNCONDITIONAL: the row / plane index is clamped on the scalar unit to something that exists
 // (rows beyond the ghost row alias the ghost row, planes beyond the chunk alias its last plane), and the shapes are restricted to
 // full rows (nx + 1 a multiple of the wave row) so that no lane lies outside the grid.  No exec masking, no branch per load.
-template <typename T>
-__device__ __forceinline__ V16<T> ldrow(const T *row_uniform, unsigned lane_bytes) {
-    return *reinterpret_cast<const V16<T> *>(reinterpret_cast<const char *>(row_uniform) + lane_bytes);
-}
-__device__ __forceinline__ V16<double> ldrow_stream(const double *row_uniform, unsigned lane_bytes) {
-    return ldv_stream(reinterpret_cast<const double *>(reinterpret_cast<const char *>(row_uniform) + lane_bytes), true);
-}
-__device__ __forceinline__ V16<float> ldrow_stream(const float *row_uniform, unsigned lane_bytes) {
-    return ldv_stream(reinterpret_cast<const float *>(reinterpret_cast<const char *>(row_uniform) + lane_bytes), true);
-}
 
 template <typename T, int WX, int PD, int FORM>
 __global__ void __launch_bounds__(64 * WX) k_rrrow(const RRArgs<T> a) {

@@ -468,6 +468,34 @@ extern "C" {
 int mgk_tail_cycle_f64(mgk_ctx *c, const mgk_geom *g0, int nl, const int *n, const double *k7, const double *di, double s, int v0, int v1, const double *b, double *u, void *) { return tail_api<double>(c, g0, nl, n, k7, di, s, v0, v1, b, u); }
 int mgk_tail_cycle_f32(mgk_ctx *c, const mgk_geom *g0, int nl, const int *n, const double *k7, const double *di, double s, int v0, int v1, const float *b, float *u, void *) { return tail_api<float>(c, g0, nl, n, k7, di, s, v0, v1, b, u); }
 
+// two sweeps + the norm of the input field's residual; the last pre-smoothing sweep fused with residual + restriction
+int mgk_jacobi2_sumsq_ok_f64(const mgk_geom *g) { return (g && g->dim == 3 && g->nx >= 7) ? 1 : 0; }     // (the mock takes any 3-D shape: host logic only)
+int mgk_jacobi2_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale, const double *b, const double *u, double *o, double *out, void *) {
+    if (!c || !g || g->dim != 3 || !coef || !b || !u || !o || u == o || !out) return fail(MGK_EINVAL, "mgk_jacobi2_sumsq_f64");
+    if (c->capturing) return fail(MGK_EINVAL, "reduction to the host inside a capture");
+    std::vector<double> r(g->total, 0.0), w(g->total, 0.0);
+    st_op<double>(M_RESIDUAL, *g, coef, 1, 1, 0, 0, 0, b, u, (const double *)nullptr, r.data(), 0, g->nz);
+    st_op<double>(M_JACOBI, *g, coef, dinv, scale, 0, 0, 0, b, u, (const double *)nullptr, w.data(), 0, g->nz);
+    st_op<double>(M_JACOBI, *g, coef, dinv, scale, 0, 0, 0, b, w.data(), (const double *)nullptr, o, 0, g->nz);
+    deliver(c, sumsq_field<double>(*g, r.data(), 0, g->nz), out);
+    return 0;
+}
+int mgk_sweep_residual_restrict_ok_f64(const mgk_geom *gf, const mgk_geom *gc) { return (xfer_ok(gf, gc) && gf->dim == 3 && gf->nz == 2 * gc->nz + 1 && gf->nx >= 7) ? 1 : 0; }
+int mgk_sweep_residual_restrict_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale, const double *b, const double *u, double *o,
+                                    double *bc, double *uc0, double dinv_c, double scale_c, void *) {
+    if (!c || !coef || !b || !u || !o || u == o || !bc || !mgk_sweep_residual_restrict_ok_f64(gf, gc)) return fail(MGK_EINVAL, "mgk_sweep_residual_restrict_f64");
+    const mgk_geom F = *gf, Cg = *gc; std::vector<double> k(coef, coef + 7);
+    return run(c, [=] {
+        st_op<double>(M_JACOBI, F, k.data(), dinv, scale, 0, 0, 0, b, u, (const double *)nullptr, o, 0, F.nz);
+        std::vector<double> r(F.total, 0.0);
+        st_op<double>(M_RESIDUAL, F, k.data(), 1, 1, 0, 0, 0, b, o, (const double *)nullptr, r.data(), 0, F.nz);
+        restrict_fw<double>(F, Cg, r.data(), bc, 0, Cg.nz);
+        if (uc0) for (int kc = 0; kc < Cg.nz; kc++) for (int i = 0; i < Cg.ny; i++) for (int j = 0; j < Cg.nx; j++) {
+            const double zq = at(bc, Cg, kc, i, j) * dinv_c; at(uc0, Cg, kc, i, j) = scale_c * zq;
+        }
+    });
+}
+
 // the fused forms on a row-table operator (2-D stretched meshes)
 int mgk_tail_cycle_rowcoef_f64(mgk_ctx *c, const mgk_geom *g0, int nl, const int *n, const double *const *ctab, const double *const *dtab, double s, int v0, int v1, const double *b, double *u, void *) {
     if (!ctab || !dtab) return fail(MGK_EINVAL, "mgk_tail_cycle_rowcoef_f64");

@@ -70,6 +70,10 @@ def _run(exe, args, cwd, env=None, ok_codes=(0,)):
     (["-dim", "2", "-npts", "129", "-levels", "7", "-ksp_richardson_scale", "0.8", "-map", "0"], 2, 129, 7, 0.8),
     (["-dim", "3", "-npts", "33", "-levels", "5", "-ksp_richardson_scale", "0.857142857142857095"], 3, 33, 5, 6.0 / 7.0),
     (["-dim", "3", "-npts", "17", "-levels", "2", "-ksp_richardson_scale", "0.857142857142857095"], 3, 17, 2, 6.0 / 7.0),
+    # pairs of sweeps on every level: the norm pass makes two sweeps, the last pre-smoothing sweep runs in the restriction's pass
+    (["-dim", "3", "-npts", "33", "-levels", "4", "-ksp_richardson_scale", "0.857142857142857095", "-mg_pair_min_n", "7"], 3, 33, 4, 6.0 / 7.0),
+    (["-dim", "3", "-npts", "33", "-levels", "3", "-ksp_richardson_scale", "0.857142857142857095", "-mg_pair_min_n", "7", "-mg_graph", "0"], 3, 33, 3, 6.0 / 7.0),
+    (["-dim", "3", "-npts", "33", "-levels", "5", "-ksp_richardson_scale", "0.857142857142857095", "-mg_fuse", "1087"], 3, 33, 5, 6.0 / 7.0),
 ])
 def test_own_driver_under_sanitizers_matches_the_oracle(san, tmp_path, args, dim, npts, levels, scale):
     out = _run(san["mgpoisson"], args + ["-pc_type", "jacobi", "-write_fields", "1"], tmp_path)

@@ -659,3 +659,60 @@ def test_lds_tail_kernel_on_row_tables(mgk, orc, n0, nlev):
     assert np.array_equal(got, U[0]), f"max diff {np.abs(got - U[0]).max()}"
     for p in [db, du] + [x for t in dts for x in t]:
         mgk.free(p)
+
+
+@pytest.mark.parametrize("nf", [127, 255])
+def test_sweep_fused_with_residual_restrict_bit_exact(mgk, orc, nf):
+    """mgk_sweep_residual_restrict_f64 == mgk_jacobi_f64 followed by mgk_residual_restrict_jz_f64 (sweep, residual, full weighting,
+    the coarse level's zero-guess sweep), bit for bit; tiles of 2 and of 4 rows, several z chunkings"""
+    rng = np.random.default_rng(9900 + nf)
+    nc = (nf - 1) // 2
+    As, Asc = _stencil(orc, 3, nf), _stencil(orc, 3, nc)
+    dinv, dinvc = 1.0 / As[3], 1.0 / Asc[3]
+    u, b = _rand(rng, nf ** 3), _rand(rng, nf ** 3)
+    gf, gc = mgk.geom(3, nf), mgk.geom(3, nc)
+    assert mgk.L.mgk_sweep_residual_restrict_ok_f64(C.byref(gf), C.byref(gc)) == 1
+    du, db, dw, dbc, duc = mgk.to_field(gf, u), mgk.to_field(gf, b), mgk.field(gf), mgk.field(gc), mgk.field(gc)
+    w_ref, bc_ref, uc_ref = mgk.field(gf), mgk.field(gc), mgk.field(gc)
+    mgk._chk(mgk.L.mgk_jacobi_f64(mgk.ctx, C.byref(gf), mgk.coef(As), dinv, 0.8, db, du, w_ref, None))
+    mgk._chk(mgk.L.mgk_residual_restrict_jz_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), db, w_ref, bc_ref, uc_ref, dinvc, 0.8, None))
+    want = [mgk.raw_field(gf, w_ref), mgk.raw_field(gc, bc_ref), mgk.raw_field(gc, uc_ref)]
+    assert np.array_equal(mgk.from_field(gf, w_ref), orc.jacobi(3, nf, As, 0.8, b, u))
+    for var, zc in [(-1, -1), (-1, 5), (-1, 16), (41, -1), (41, 7)]:
+        mgk.L.mgk_set_tuning(var, zc)
+        for f, g in ((dw, gf), (dbc, gc), (duc, gc)):
+            mgk._chk(mgk.L.mgk_memset0(mgk.ctx, f, 8 * g.total, None))
+        mgk._chk(mgk.L.mgk_sweep_residual_restrict_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), dinv, 0.8, db, du, dw, dbc, duc,
+                                                       dinvc, 0.8, None))
+        got = [mgk.raw_field(gf, dw), mgk.raw_field(gc, dbc), mgk.raw_field(gc, duc)]
+        for name, x, y in zip(("swept field", "coarse rhs", "coarse first sweep"), got, want):
+            assert np.array_equal(x, y), f"variant={var} zc={zc} {name}: max diff {np.abs(x - y).max()}"
+    mgk.L.mgk_set_tuning(-1, -1)
+    assert np.array_equal(mgk.from_field(gf, du), u)
+    for p in (du, db, dw, dbc, duc, w_ref, bc_ref, uc_ref):
+        mgk.free(p)
+
+
+@pytest.mark.parametrize("n", [127, 255])
+def test_two_sweeps_with_the_norm_of_the_input_residual(mgk, orc, n):
+    """mgk_jacobi2_sumsq_f64: the field of mgk_jacobi2_f64 (bit for bit) and || b - A u ||^2 of the INPUT field (1e-13)"""
+    rng = np.random.default_rng(9950 + n)
+    As = _stencil(orc, 3, n)
+    dinv = 1.0 / As[3]
+    u, b = _rand(rng, n ** 3), _rand(rng, n ** 3)
+    g = mgk.geom(3, n)
+    assert mgk.L.mgk_jacobi2_sumsq_ok_f64(C.byref(g)) == 1
+    du, db, dout, dref = mgk.to_field(g, u), mgk.to_field(g, b), mgk.field(g), mgk.field(g)
+    mgk._chk(mgk.L.mgk_jacobi2_f64(mgk.ctx, C.byref(g), mgk.coef(As), dinv, 0.8, db, du, dref, None))
+    want = mgk.raw_field(g, dref)
+    r = orc.residual(3, n, As, b, u)
+    ss = C.c_double(0.0)
+    for zc in (-1, 8, 29):
+        mgk.L.mgk_set_tuning(-1, zc)
+        mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dout, 8 * g.total, None))
+        mgk._chk(mgk.L.mgk_jacobi2_sumsq_f64(mgk.ctx, C.byref(g), mgk.coef(As), dinv, 0.8, db, du, dout, C.byref(ss), None))
+        assert np.array_equal(mgk.raw_field(g, dout), want), f"zc={zc}"
+        assert abs(ss.value - float(np.dot(r, r))) <= 1e-13 * float(np.dot(r, r)), f"zc={zc}"
+    mgk.L.mgk_set_tuning(-1, -1)
+    for p in (du, db, dout, dref):
+        mgk.free(p)

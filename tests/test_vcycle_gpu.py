@@ -101,7 +101,9 @@ def test_hip_graph_replay_of_coarse_levels_is_bit_identical(orc, dim, npts, leve
         res.append(first)
         s.close()
     assert res[0][0] == res[1][0]
-    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    # (norms: the pass that forms them may differ between the two -- two sweeps per pass when level 0 does not feed the graph --
+    # and with it the order of the sum; the fields are the same bits)
+    assert np.allclose(res[0][1], res[1][1], rtol=1e-13, atol=0) and np.array_equal(res[0][2], res[1][2])
     if npts <= 129:
         ref = orc.vcycle(dim, npts, levels, v[0], v[1], maxiter=40, scale=scale)
         assert res[0][0] == ref["iters"] and np.array_equal(res[0][2], ref["u"])
@@ -222,6 +224,33 @@ def test_two_sweep_passes_change_nothing(dim, npts, levels):
     assert res[31][0] == res[63][0]
     assert np.abs(res[31][1] / res[63][1] - 1).max() <= 1e-13
     assert np.array_equal(res[31][2], res[63][2])
+
+
+@pytest.mark.parametrize("npts,levels,v,kw", [
+    (129, 6, (3, 3), {"pair_min_n": 63}), (257, 7, (3, 3), {"pair_min_n": 127}), (257, 7, (2, 2), {"pair_min_n": 127}),
+    (257, 7, (3, 3), {"pair_min_n": 127, "graph": 0}), (257, 7, (2, 2), {"pair_min_n": 127, "graph": 0}),
+    (257, 4, (4, 3), {"pair_min_n": 127, "graph": 0}), (257, 7, (5, 1), {"pair_min_n": 127, "graph": 0}), (129, 6, (1, 2), {}),
+    (257, 8, (3, 3), {}), (129, 3, (3, 3), {"pair_min_n": 31}), (257, 8, (3, 3), {"graph": 0}),
+])
+def test_two_sweep_norm_pass_and_sweep_inside_the_restriction(orc, npts, levels, v, kw):
+    """fuse bit 10 on shapes its kernels are built for (n = 127, 255): the pass that closes a cycle makes the norm and the first TWO
+    sweeps of the next cycle (mgk_jacobi2_sumsq_f64), the last pre-smoothing sweep runs in the restriction's pass
+    (mgk_sweep_residual_restrict_f64), for odd and even sweep counts, with and without the coarse-level graph: bit-identical to the
+    oracle, and to the same cycle without bit 10"""
+    from multigrid_petsc_amd.solver import Solver
+    s = Solver(3, npts, levels, v=v, maxiter=80, scale=6.0 / 7.0, **kw)
+    s.set_rhs_problem()
+    it = s.solve()
+    ref = orc.vcycle(3, npts, levels, v[0], v[1], maxiter=80, scale=6.0 / 7.0)
+    assert it == ref["iters"]
+    assert np.abs(s.rnorm / ref["rnorm"] - 1).max() <= RTOL
+    u = s.solution()
+    assert np.array_equal(u, ref["u"])
+    s.close()
+    s = Solver(3, npts, levels, v=v, maxiter=80, scale=6.0 / 7.0, fuse=63 | 256 | 512, **kw)
+    s.set_rhs_problem()
+    assert s.solve() == it and np.array_equal(s.solution(), u)
+    s.close()
 
 
 @pytest.mark.parametrize("dim,npts,levels,v", [(3, 33, 4, (1, 1)), (3, 33, 4, (2, 3)), (3, 65, 5, (4, 2)), (3, 65, 6, (5, 5)),
