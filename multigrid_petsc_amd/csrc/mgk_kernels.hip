@@ -1946,6 +1946,212 @@ __global__ void __launch_bounds__(64 * WX) k_srr(const SRRArgs<T> a) {
     }
 }
 
+// Tiles of 4 rows (half the redundant row loads and first-sweep work of the 2-row tiles) do not fit in 256 registers with the swept
+// planes t-1, t, t+1 of the lane's own columns in registers: this form keeps them in LDS -- a ring of three planes of the 5 residual
+// rows plus the two outer rows of the centre plane, double buffered: 19 rows of 1028 doubles, 156 KB of the CU's 160 KB.
+template <typename T, int WX>
+__global__ void __launch_bounds__(64 * WX) k_srr4(const SRRArgs<T> a) {
+    constexpr int TY = 4;
+    constexpr int VX = 16 / sizeof(T), NCJ = VX / 2, NCR = TY / 2, RS = TY + 1, R2 = TY + 3, R1 = TY + 5;
+    constexpr int TX = 64 * VX * WX, LW = TX + 2 * VX;
+    __shared__ __attribute__((aligned(16))) T ring[3][RS][LW];       // swept plane p, rows yb .. yb+TY, in slot p % 3
+    __shared__ __attribute__((aligned(16))) T halo[2][2][LW];        // its rows yb-1 and yb+TY+1 (read while it is the centre plane), slot p & 1
+    __shared__ T edgeW[2][R2][WX], edgeE[2][R2][WX], eR[2][RS][WX];
+    using VT = V16<T>;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int ty = bid % a.nty, tz = bid / a.nty;
+    const int yb = TY * ty;
+    const int kc0 = tz * a.kcc, kc1 = min(kc0 + a.kcc, a.nzc);
+    if (kc0 >= kc1) return;
+    const int z0 = 2 * kc0, z1 = min(2 * kc1 + 1, a.nz);          // planes whose residual this chunk forms: [z0, z1)
+    const int zs1 = (kc1 == a.nzc) ? a.nz : 2 * kc1;              // planes of the swept field this chunk stores: [z0, zs1)
+    const int xl = VX * tid, x0 = xl;
+    const bool lastlane = (tid == 64 * WX - 1);                   // its last element is the ghost column x = nx: stays 0
+    const unsigned lb = (unsigned)(x0 * (int)sizeof(T));
+    bool s1ok[R2], rok[RS];
+#pragma unroll
+    for (int q = 0; q < R2; q++) { const int y = yb - 1 + q; s1ok[q] = y >= 0 && y < a.ny; }
+#pragma unroll
+    for (int j = 0; j < RS; j++) rok[j] = (yb + j < a.ny);
+    bool crow[NCR];
+#pragma unroll
+    for (int cl = 0; cl < NCR; cl++) crow[cl] = (NCR * ty + cl < a.nyc);
+    long uro[R1], bro[R2];
+#pragma unroll
+    for (int rr = 0; rr < R1; rr++) uro[rr] = (long)max(-1, min(yb - 2 + rr, a.ny)) * a.rs;
+#pragma unroll
+    for (int q = 0; q < R2; q++) bro[q] = (long)max(0, min(yb - 1 + q, a.ny)) * a.rs;
+    // unconditional loads, rows / planes clamped on the scalar unit: whatever a clamped load brings in only reaches first-sweep
+    // values that are forced to 0
+    auto LDU = [&](int p, int rr) -> VT { return ldrow(a.u + (long)max(-1, min(p, a.nz)) * a.ms + uro[rr], lb); };
+    auto LDB = [&](int p, int q, bool stream) -> VT {
+        const T *pl = a.b + (long)max(0, min(p, a.nz - 1)) * a.ms + bro[q];
+        return stream ? ldrow_stream(pl, lb) : ldrow(pl, lb);
+    };
+    for (int i = tid; i < 3 * RS * LW; i += 64 * WX) (&ring[0][0][0])[i] = (T)0;
+    for (int i = tid; i < 2 * 2 * LW; i += 64 * WX) (&halo[0][0][0])[i] = (T)0;
+    const int jc0 = NCJ * tid;
+    const T w2[3][3] = {{(T)0.0625, (T)0.125, (T)0.0625}, {(T)0.125, (T)0.25, (T)0.125}, {(T)0.0625, (T)0.125, (T)0.0625}};
+
+    VT ua[R1], ub[R1], uc[R1], b1[R2], bn[R2], b0[RS];
+    const int t0 = z0 - 2;                                        // first step: the sweep of plane z0 - 1
+#pragma unroll
+    for (int rr = 0; rr < R1; rr++) { ua[rr] = LDU(t0, rr); ub[rr] = LDU(t0 + 1, rr); uc[rr] = LDU(t0 + 2, rr); }
+#pragma unroll
+    for (int q = 0; q < R2; q++) { b1[q] = LDB(t0 + 1, q, false); bn[q] = v16_zero<T>(); }
+#pragma unroll
+    for (int j = 0; j < RS; j++) b0[j] = v16_zero<T>();
+    if (lane == 0 || lane == 63) {
+#pragma unroll
+        for (int q = 0; q < R2; q++) {
+            if (lane == 0) edgeW[(t0 + 1) & 1][q][w] = ub[q + 1].v[0];
+            else edgeE[(t0 + 1) & 1][q][w] = ub[q + 1].v[VX - 1];
+        }
+    }
+    T acc[NCR][NCJ], accn[NCR][NCJ];
+#pragma unroll
+    for (int cl = 0; cl < NCR; cl++)
+#pragma unroll
+        for (int q = 0; q < NCJ; q++) { acc[cl][q] = (T)0; accn[cl][q] = (T)0; }
+    __syncthreads();
+
+    for (int t = t0; t < z1; t++) {
+        const int p = t + 1;                                      // plane the sweep produces in this step
+#pragma unroll
+        for (int q = 0; q < R2; q++) bn[q] = LDB(t + 2, q, q >= 2 && q < R2 - 2);      // b of the next step; rows shared with neighbours: cached
+        // ---- the sweep of plane p on rows yb-1 .. yb+TY+1 ----
+        {
+            const bool pin = (p >= 0 && p < a.nz);
+            const bool pst = (p >= z0 && p < zs1);
+            const int eb = p & 1, hb = p & 1, sl = (p + 3) % 3;
+#pragma unroll
+            for (int q = 0; q < R2; q++) {
+                const int rr = q + 1;
+                T Wv = lane_up<true>(ub[rr].v[VX - 1]), Ev = lane_dn<true>(ub[rr].v[0]);
+                if (lane == 0) Wv = (w > 0) ? edgeE[eb][q][w - 1] : (T)0;
+                if (lane == 63) Ev = (w < WX - 1) ? edgeW[eb][q][w + 1] : (T)0;
+                VT o;
+#pragma unroll
+                for (int e = 0; e < VX; e++) {
+                    const T wv = (e == 0) ? Wv : ub[rr].v[e - 1 < 0 ? 0 : e - 1];
+                    const T ev = (e == VX - 1) ? Ev : ub[rr].v[e + 1 > VX - 1 ? VX - 1 : e + 1];
+                    T s = a.a0 * ua[rr].v[e];
+                    s = s + a.a1 * ub[rr - 1].v[e];
+                    s = s + a.a2 * wv;
+                    s = s + a.a3 * ub[rr].v[e];
+                    s = s + a.a4 * ev;
+                    s = s + a.a5 * ub[rr + 1].v[e];
+                    s = s + a.a6 * uc[rr].v[e];
+                    const T res = b1[q].v[e] - s;
+                    const T zz = res * a.dinv;
+                    o.v[e] = ub[rr].v[e] + a.scale * zz;
+                    if (!pin || !s1ok[q] || (lastlane && e == VX - 1)) o.v[e] = (T)0;
+                }
+                if (q == 0) *reinterpret_cast<VT *>(&halo[hb][0][xl + VX]) = o;
+                else if (q == R2 - 1) *reinterpret_cast<VT *>(&halo[hb][1][xl + VX]) = o;
+                else *reinterpret_cast<VT *>(&ring[sl][q - 1][xl + VX]) = o;
+                if (q >= 1 && q <= TY) { if (pst && s1ok[q]) stv_stream(a.out + (long)p * a.ms + (long)(yb + q - 1) * a.rs + x0, o); }
+            }
+            if (lane == 0 || lane == 63) {
+#pragma unroll
+                for (int q = 0; q < R2; q++) {
+                    if (lane == 0) edgeW[eb ^ 1][q][w] = uc[q + 1].v[0];
+                    else edgeE[eb ^ 1][q][w] = uc[q + 1].v[VX - 1];
+                }
+            }
+        }
+        // plane t+3 of u into the registers of plane t (the sweep is done with them)
+#pragma unroll
+        for (int rr = 0; rr < R1; rr++) ua[rr] = LDU(t + 3, rr);
+        // ---- residual of the swept plane t on rows yb .. yb+TY: everything from LDS (plane t and its x / y neighbours were
+        //      written in step t-1, plane t+1 at the lane's own columns a moment ago by the lane itself) ----
+        VT res[RS];
+        if (t >= z0) {
+            const int cb = t & 1, sm = (t + 2) % 3, sc = t % 3, sp = (t + 1) % 3;
+#pragma unroll
+            for (int j = 0; j < RS; j++) {
+                const VT cv = *reinterpret_cast<const VT *>(&ring[sc][j][xl + VX]);
+                const VT dn = *reinterpret_cast<const VT *>(&ring[sm][j][xl + VX]);
+                const VT upv = *reinterpret_cast<const VT *>(&ring[sp][j][xl + VX]);
+                const VT sv = (j == 0) ? *reinterpret_cast<const VT *>(&halo[cb][0][xl + VX]) : *reinterpret_cast<const VT *>(&ring[sc][j > 0 ? j - 1 : 0][xl + VX]);
+                const VT nv = (j == RS - 1) ? *reinterpret_cast<const VT *>(&halo[cb][1][xl + VX]) : *reinterpret_cast<const VT *>(&ring[sc][j < RS - 1 ? j + 1 : j][xl + VX]);
+                const T Wv = ring[sc][j][xl + VX - 1], Ev = ring[sc][j][xl + 2 * VX];
+#pragma unroll
+                for (int e = 0; e < VX; e++) {
+                    const T wv = (e == 0) ? Wv : cv.v[e - 1 < 0 ? 0 : e - 1];
+                    const T ev = (e == VX - 1) ? Ev : cv.v[e + 1 > VX - 1 ? VX - 1 : e + 1];
+                    T s = a.a0 * dn.v[e];
+                    s = s + a.a1 * sv.v[e];
+                    s = s + a.a2 * wv;
+                    s = s + a.a3 * cv.v[e];
+                    s = s + a.a4 * ev;
+                    s = s + a.a5 * nv.v[e];
+                    s = s + a.a6 * upv.v[e];
+                    res[j].v[e] = rok[j] ? b0[j].v[e] - s : (T)0;
+                }
+                if (lastlane) res[j].v[VX - 1] = (T)0;
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < RS; j++) eR[cb][j][w] = res[j].v[0];
+            }
+        }
+        __syncthreads();            // the swept plane t+1 complete in LDS; wave-edge values of this residual plane visible
+        // ---- full weighting: running sums of the coarse planes t/2-1 (dk = 2) and t/2 (dk = 0) / (t-1)/2 (dk = 1) ----
+        if (t >= z0) {
+            const bool even = ((t & 1) == 0);
+            const T wk = even ? (T)0.25 : (T)0.5;
+            T nx_[RS];
+#pragma unroll
+            for (int j = 0; j < RS; j++) {
+                nx_[j] = lane_dn<true>(res[j].v[0]);
+                if (lane == 63) nx_[j] = (w < WX - 1) ? eR[t & 1][j][w + 1] : (T)0;
+            }
+#pragma unroll
+            for (int cl = 0; cl < NCR; cl++) {
+                if (!crow[cl]) continue;
+#pragma unroll
+                for (int q = 0; q < NCJ; q++) {
+#pragma unroll
+                    for (int di = 0; di < 3; di++) {
+#pragma unroll
+                        for (int dj = 0; dj < 3; dj++) {
+                            const int e = 2 * q + dj;
+                            const T val = (e < VX) ? res[2 * cl + di].v[e < VX ? e : 0] : nx_[2 * cl + di];
+                            const T pr = (wk * w2[di][dj]) * val;
+                            acc[cl][q] += pr;
+                            if (even) accn[cl][q] += pr;
+                        }
+                    }
+                }
+            }
+            if (even) {
+                const int kc = t / 2 - 1;     // completed coarse plane
+#pragma unroll
+                for (int cl = 0; cl < NCR; cl++)
+#pragma unroll
+                    for (int q = 0; q < NCJ; q++) {
+                        if (kc >= kc0 && crow[cl] && jc0 + q < a.nxc) {
+                            const long oc = (long)kc * a.cms + (long)(NCR * ty + cl) * a.crs + jc0 + q;
+                            a.bc[oc] = acc[cl][q];
+                            if (a.uc0) { const T zq = acc[cl][q] * a.dinv_c; a.uc0[oc] = a.scale_c * zq; }
+                        }
+                        acc[cl][q] = accn[cl][q]; accn[cl][q] = (T)0;
+                    }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RS; j++) b0[j] = b1[j + 1];
+#pragma unroll
+        for (int q = 0; q < R2; q++) b1[q] = bn[q];
+#pragma unroll
+        for (int rr = 0; rr < R1; rr++) { VT tmpv = ua[rr]; ua[rr] = ub[rr]; ub[rr] = uc[rr]; uc[rr] = tmpv; }
+    }
+}
+
 // shapes the fused sweep + residual + restriction is built for: full rows of 1 / 2 / 4 / 8 waves, whole 3-D grid
 template <typename T>
 static bool srr_shape_ok(const mgk_geom *gf, const mgk_geom *gc) {
@@ -1981,19 +2187,28 @@ extern "C" int mgk_sweep_residual_restrict_f64(mgk_ctx *c, const mgk_geom *gf, c
     a.dinv = dinv; a.scale = scale; a.dinv_c = dinv_c; a.scale_c = scale_c;
     constexpr int VX = 16 / sizeof(T);
     const int w = (gf->nx + 1) / (64 * VX);
-    const int TYsel = (g_variant == 41) ? 4 : 2;                     // tuning variant 41: tiles of 4 rows
+    // tiles of 4 rows with the swept planes in LDS (1023^3: 5.44 ms against 6.22 ms for tiles of 2 rows with them in registers;
+    // 511^3: 0.72 against 0.82); tuning variants: 40 tiles of 2 rows, 42 tiles of 4 rows all in registers (spills at 8 waves)
+    // (rows of <= 2 waves, n <= 255: tiles of 2 rows, two blocks per CU -- 255^3 0.119 against 0.136 ms);  41 forces tiles of 4
+    const int TYsel = (g_variant == 40) ? 2 : (g_variant == 41 || g_variant == 42) ? 4 : ((gf->nx + 1) / (64 * 2) >= 4 ? 4 : 2);
     a.nty = (gf->ny + TYsel - 1) / TYsel;
     // blocks: a multiple of what the chip holds at once (512-thread blocks: one per CU); every chunk recomputes three planes
-    const long target = (w > 4) ? 512 : 1024;
+    const long target = (w > 4) ? (TYsel == 4 ? 256 : 512) : 1024;
     long nch = (a.nty >= target) ? 1 : (target + a.nty - 1) / a.nty;
     if (g_zchunk > 0) nch = (gc->nz + g_zchunk - 1) / g_zchunk;
     int kcc = (int)((gc->nz + nch - 1) / nch);
-    if (kcc < 4) kcc = 4;
+    if (kcc < 4 && g_zchunk <= 0) kcc = 4;
     if (kcc > gc->nz) kcc = gc->nz;
     a.kcc = kcc;
     const unsigned nblk = (unsigned)(a.nty * ((gc->nz + kcc - 1) / kcc));
-    if (TYsel == 4) launch_srr<T, 4>(w, nblk, S(c, stream), a);
-    else launch_srr<T, 2>(w, nblk, S(c, stream), a);
+    if (TYsel == 4 && g_variant == 42) launch_srr<T, 4>(w, nblk, S(c, stream), a);      // (registers only: spills at 8 waves)
+    else if (TYsel == 4) {
+        hipStream_t st = S(c, stream);
+        if (w <= 1) hipLaunchKernelGGL((k_srr4<T, 1>), dim3(nblk), dim3(64), 0, st, a);
+        else if (w <= 2) hipLaunchKernelGGL((k_srr4<T, 2>), dim3(nblk), dim3(128), 0, st, a);
+        else if (w <= 4) hipLaunchKernelGGL((k_srr4<T, 4>), dim3(nblk), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_srr4<T, 8>), dim3(nblk), dim3(512), 0, st, a);
+    } else launch_srr<T, 2>(w, nblk, S(c, stream), a);
     HIPCHK(hipGetLastError());
     return 0;
 }

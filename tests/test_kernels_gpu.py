@@ -678,7 +678,7 @@ def test_sweep_fused_with_residual_restrict_bit_exact(mgk, orc, nf):
     mgk._chk(mgk.L.mgk_residual_restrict_jz_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), db, w_ref, bc_ref, uc_ref, dinvc, 0.8, None))
     want = [mgk.raw_field(gf, w_ref), mgk.raw_field(gc, bc_ref), mgk.raw_field(gc, uc_ref)]
     assert np.array_equal(mgk.from_field(gf, w_ref), orc.jacobi(3, nf, As, 0.8, b, u))
-    for var, zc in [(-1, -1), (-1, 5), (-1, 16), (41, -1), (41, 7)]:
+    for var, zc in [(-1, -1), (-1, 5), (-1, 16), (40, -1), (40, 7), (41, -1), (41, 9)]:
         mgk.L.mgk_set_tuning(var, zc)
         for f, g in ((dw, gf), (dbc, gc), (duc, gc)):
             mgk._chk(mgk.L.mgk_memset0(mgk.ctx, f, 8 * g.total, None))
@@ -715,4 +715,36 @@ def test_two_sweeps_with_the_norm_of_the_input_residual(mgk, orc, n):
         assert abs(ss.value - float(np.dot(r, r))) <= 1e-13 * float(np.dot(r, r)), f"zc={zc}"
     mgk.L.mgk_set_tuning(-1, -1)
     for p in (du, db, dout, dref):
+        mgk.free(p)
+
+
+@pytest.mark.parametrize("nx,ny,nz", [(1023, 7, 9), (1023, 11, 5), (511, 11, 7), (255, 15, 3)])
+def test_sweep_fused_with_residual_restrict_wide_rows(mgk, nx, ny, nz):
+    """the 4- and 8-wave instances of mgk_sweep_residual_restrict_f64 (rows of 511 / 1023) on thin grids, against the two kernels it
+    replaces (themselves pinned to the oracle): bit for bit, both tile heights"""
+    rng = np.random.default_rng(9970 + nx + ny)
+    nxc, nyc, nzc = (nx - 1) // 2, (ny - 1) // 2, (nz - 1) // 2
+    q = float((nx + 1) ** 2)
+    As = [q, q, q, -6.0 * q, q, q, q]
+    dinv = 1.0 / As[3]
+    gf, gc = mgk.geom(3, nx, ny, nz), mgk.geom(3, nxc, nyc, nzc)
+    assert mgk.L.mgk_sweep_residual_restrict_ok_f64(C.byref(gf), C.byref(gc)) == 1
+    u, b = _rand(rng, nx * ny * nz), _rand(rng, nx * ny * nz)
+    du, db, dw, dbc, duc = mgk.to_field(gf, u), mgk.to_field(gf, b), mgk.field(gf), mgk.field(gc), mgk.field(gc)
+    w_ref, bc_ref, uc_ref = mgk.field(gf), mgk.field(gc), mgk.field(gc)
+    mgk._chk(mgk.L.mgk_jacobi_f64(mgk.ctx, C.byref(gf), mgk.coef(As), dinv, 0.8, db, du, w_ref, None))
+    mgk._chk(mgk.L.mgk_residual_restrict_jz_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), db, w_ref, bc_ref, uc_ref, 0.25 * dinv, 0.8, None))
+    want = [mgk.raw_field(gf, w_ref), mgk.raw_field(gc, bc_ref), mgk.raw_field(gc, uc_ref)]
+    assert np.abs(want[1]).max() > 0
+    for var, zc in [(-1, -1), (-1, 1), (40, -1), (40, 1), (41, -1), (41, 1), (42, -1)]:
+        mgk.L.mgk_set_tuning(var, zc)
+        for f, g in ((dw, gf), (dbc, gc), (duc, gc)):
+            mgk._chk(mgk.L.mgk_memset0(mgk.ctx, f, 8 * g.total, None))
+        mgk._chk(mgk.L.mgk_sweep_residual_restrict_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), dinv, 0.8, db, du, dw, dbc, duc,
+                                                       0.25 * dinv, 0.8, None))
+        got = [mgk.raw_field(gf, dw), mgk.raw_field(gc, dbc), mgk.raw_field(gc, duc)]
+        for name, x, y in zip(("swept field", "coarse rhs", "coarse first sweep"), got, want):
+            assert np.array_equal(x, y), f"variant={var} zc={zc} {name}: max diff {np.abs(x - y).max()}"
+    mgk.L.mgk_set_tuning(-1, -1)
+    for p in (du, db, dw, dbc, duc, w_ref, bc_ref, uc_ref):
         mgk.free(p)
