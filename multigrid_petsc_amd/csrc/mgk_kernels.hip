@@ -1819,7 +1819,7 @@ __global__ void __launch_bounds__(64 * WX) k_srr(const SRRArgs<T> a) {
     for (int t = t0; t < z1; t++) {
         const int p = t + 1;                                      // plane the sweep produces in this step
 #pragma unroll
-        for (int q = 0; q < R2; q++) bn[q] = LDB(t + 2, q, q >= 2 && q < R2 - 2);      // b of the next step; rows shared with neighbours: cached
+        for (int q = 0; q < R2; q++) bn[q] = LDB(t + 2, q, q >= 3 && q <= R2 - 4);     // b of the next step; rows a neighbouring tile reads too (three on either side): cached
         // ---- the sweep of plane p on rows yb-1 .. yb+TY+1 ----
         {
             const bool pin = (p >= 0 && p < a.nz);
@@ -1947,18 +1947,54 @@ __global__ void __launch_bounds__(64 * WX) k_srr(const SRRArgs<T> a) {
 }
 
 // Tiles of 4 rows (half the redundant row loads and first-sweep work of the 2-row tiles) do not fit in 256 registers with the swept
-// planes t-1, t, t+1 of the lane's own columns in registers: this form keeps them in LDS -- a ring of three planes of the 5 residual
+// planes t-1, t, t+1 of the lane's own columns in registers: k_srr4b keeps them in LDS -- a ring of three planes of the 5 residual
 // rows plus the two outer rows of the centre plane, double buffered: 19 rows of 1028 doubles, 156 KB of the CU's 160 KB.
-template <typename T, int WX>
-__global__ void __launch_bounds__(64 * WX) k_srr4(const SRRArgs<T> a) {
+// Its instruction overhead is taken out (a first version spent a third of its vector instructions on addressing, masking and SGPR
+// reloads; 888 -> 699 vector instructions per step, 5.45 -> 5.31 ms at 1023^3 -- the pass is bound by its HBM traffic, 28.2 B per
+// unknown at ~5.7 TB/s, the re-reads of rows shared between tiles that miss the 4 MB L2 included):
+//  * loads / stores through buffer descriptors (one per plane, built on the scalar unit): the row offset is a 32-bit SGPR operand, the
+//    lane offset one constant VGPR -- no 64-bit vector address arithmetic, no spilled 64-bit row offsets (was 3 vector instructions
+//    and 2 VGPRs per load);
+//  * wave-edge neighbours: the DPP shift keeps the `old` operand in the lane that has no source, so the value from the neighbouring
+//    wave (or the zero pad at the ends of the row) is passed as `old`: no lane-0 / lane-63 selects;
+//  * rows / planes outside the grid are skipped by wave-uniform branches instead of per-element selects.
+typedef unsigned int mgk_u4v __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ V16<T> bufld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    mgk_u4v v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return __builtin_bit_cast(V16<T>, v);
+}
+template <typename T> __device__ __forceinline__ V16<T> bufld_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    mgk_u4v v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2);
+    return __builtin_bit_cast(V16<T>, v);
+}
+template <typename T> __device__ __forceinline__ void bufst_nt(const V16<T> &x, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mgk_u4v, x), r, voff, soff, 2);
+}
+// lane shifts that deliver `old` to the lane without a source (lane 0 / lane 63)
+__device__ __forceinline__ double lane_up_old(double v, double old) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x138, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_dn_old(double v, double old) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x130, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int WX>
+__global__ void __launch_bounds__(64 * WX) k_srr4b(const SRRArgs<double> a) {
+    typedef double T;
     constexpr int TY = 4;
-    constexpr int VX = 16 / sizeof(T), NCJ = VX / 2, NCR = TY / 2, RS = TY + 1, R2 = TY + 3, R1 = TY + 5;
+    constexpr int VX = 2, NCR = TY / 2, RS = TY + 1, R2 = TY + 3, R1 = TY + 5;
     constexpr int TX = 64 * VX * WX, LW = TX + 2 * VX;
     __shared__ __attribute__((aligned(16))) T ring[3][RS][LW];       // swept plane p, rows yb .. yb+TY, in slot p % 3
     __shared__ __attribute__((aligned(16))) T halo[2][2][LW];        // its rows yb-1 and yb+TY+1 (read while it is the centre plane), slot p & 1
-    __shared__ T edgeW[2][R2][WX], edgeE[2][R2][WX], eR[2][RS][WX];
+    // wave-edge values: [.][.][0] of edgeE and [.][.][WX] of edgeW / eR are zero pads (the ends of the row)
+    __shared__ T edgeW[2][R2][WX + 1], edgeE[2][R2][WX + 1], eR[2][RS][WX + 1];
     using VT = V16<T>;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bid = blockIdx.x;
     const int nblk = gridDim.x;
     if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
@@ -1968,106 +2004,125 @@ __global__ void __launch_bounds__(64 * WX) k_srr4(const SRRArgs<T> a) {
     if (kc0 >= kc1) return;
     const int z0 = 2 * kc0, z1 = min(2 * kc1 + 1, a.nz);          // planes whose residual this chunk forms: [z0, z1)
     const int zs1 = (kc1 == a.nzc) ? a.nz : 2 * kc1;              // planes of the swept field this chunk stores: [z0, zs1)
-    const int xl = VX * tid, x0 = xl;
+    const int xl = VX * tid;
     const bool lastlane = (tid == 64 * WX - 1);                   // its last element is the ghost column x = nx: stays 0
-    const unsigned lb = (unsigned)(x0 * (int)sizeof(T));
-    bool s1ok[R2], rok[RS];
+    const unsigned lb = (unsigned)(xl * (int)sizeof(T));
+    // rows q of the sweep (y = yb - 1 + q) inside the grid: qlo <= q <= qhi.  Rows outside are never written: their LDS rows keep the
+    // zeros of the initial fill.  (Two integers instead of a predicate per row: the kernel is short of scalar registers.)
+    const int qlo = max(0, 1 - yb), qhi = min(R2 - 1, a.ny - yb);
+    const bool crow0 = (NCR * ty < a.nyc), crow1 = (NCR * ty + 1 < a.nyc);
+    // byte offsets of the rows from row -1 of a plane (rows beyond the ghost rows alias them: whatever such a load brings in only
+    // reaches sweep values that are skipped)
+    const unsigned rowb = (unsigned)(a.rs * (long)sizeof(T));
+    const unsigned plane_bytes = (unsigned)(a.ny + 2) * rowb;
+    unsigned urb[R1], brb[R2];
 #pragma unroll
-    for (int q = 0; q < R2; q++) { const int y = yb - 1 + q; s1ok[q] = y >= 0 && y < a.ny; }
+    for (int rr = 0; rr < R1; rr++) urb[rr] = (unsigned)(max(-1, min(yb - 2 + rr, a.ny)) + 1) * rowb;
 #pragma unroll
-    for (int j = 0; j < RS; j++) rok[j] = (yb + j < a.ny);
-    bool crow[NCR];
-#pragma unroll
-    for (int cl = 0; cl < NCR; cl++) crow[cl] = (NCR * ty + cl < a.nyc);
-    long uro[R1], bro[R2];
-#pragma unroll
-    for (int rr = 0; rr < R1; rr++) uro[rr] = (long)max(-1, min(yb - 2 + rr, a.ny)) * a.rs;
-#pragma unroll
-    for (int q = 0; q < R2; q++) bro[q] = (long)max(0, min(yb - 1 + q, a.ny)) * a.rs;
-    // unconditional loads, rows / planes clamped on the scalar unit: whatever a clamped load brings in only reaches first-sweep
-    // values that are forced to 0
-    auto LDU = [&](int p, int rr) -> VT { return ldrow(a.u + (long)max(-1, min(p, a.nz)) * a.ms + uro[rr], lb); };
-    auto LDB = [&](int p, int q, bool stream) -> VT {
-        const T *pl = a.b + (long)max(0, min(p, a.nz - 1)) * a.ms + bro[q];
-        return stream ? ldrow_stream(pl, lb) : ldrow(pl, lb);
-    };
+    for (int q = 0; q < R2; q++) brb[q] = (unsigned)(max(0, min(yb - 1 + q, a.ny)) + 1) * rowb;
+    auto URS = [&](int p) { return __builtin_amdgcn_make_buffer_rsrc((void *)(a.u - a.rs + (long)max(-1, min(p, a.nz)) * a.ms), 0, (int)plane_bytes, 0x00020000); };
+    auto BRS = [&](int p) { return __builtin_amdgcn_make_buffer_rsrc((void *)(a.b - a.rs + (long)max(0, min(p, a.nz - 1)) * a.ms), 0, (int)plane_bytes, 0x00020000); };
     for (int i = tid; i < 3 * RS * LW; i += 64 * WX) (&ring[0][0][0])[i] = (T)0;
     for (int i = tid; i < 2 * 2 * LW; i += 64 * WX) (&halo[0][0][0])[i] = (T)0;
-    const int jc0 = NCJ * tid;
+    for (int i = tid; i < 2 * R2 * (WX + 1); i += 64 * WX) { (&edgeW[0][0][0])[i] = (T)0; (&edgeE[0][0][0])[i] = (T)0; }
+    for (int i = tid; i < 2 * RS * (WX + 1); i += 64 * WX) (&eR[0][0][0])[i] = (T)0;
+    const int jc0 = tid;
     const T w2[3][3] = {{(T)0.0625, (T)0.125, (T)0.0625}, {(T)0.125, (T)0.25, (T)0.125}, {(T)0.0625, (T)0.125, (T)0.0625}};
 
-    VT ua[R1], ub[R1], uc[R1], b1[R2], bn[R2], b0[RS];
+    // u planes: rows yb-1 .. yb+TY+1 (the rows of the sweep, index q); the two outer rows yb-2 / yb+TY+2 are read of the CENTRE plane
+    // only (its y neighbours of the first / last sweep row): they are loaded one step later into h0 / h8
+    VT ua[R2], ub[R2], uc[R2], h0, h8, b1[R2], bn[R2], b0[RS];
     const int t0 = z0 - 2;                                        // first step: the sweep of plane z0 - 1
+    {
+        const auto r0 = URS(t0), r1 = URS(t0 + 1), r2 = URS(t0 + 2);
+        const auto rb = BRS(t0 + 1);
 #pragma unroll
-    for (int rr = 0; rr < R1; rr++) { ua[rr] = LDU(t0, rr); ub[rr] = LDU(t0 + 1, rr); uc[rr] = LDU(t0 + 2, rr); }
+        for (int q = 0; q < R2; q++) { ua[q] = bufld<T>(r0, lb, urb[q + 1]); ub[q] = bufld<T>(r1, lb, urb[q + 1]); uc[q] = bufld<T>(r2, lb, urb[q + 1]); }
+        h0 = bufld<T>(r1, lb, urb[0]); h8 = bufld<T>(r1, lb, urb[R1 - 1]);
 #pragma unroll
-    for (int q = 0; q < R2; q++) { b1[q] = LDB(t0 + 1, q, false); bn[q] = v16_zero<T>(); }
+        for (int q = 0; q < R2; q++) { b1[q] = bufld<T>(rb, lb, brb[q]); bn[q] = v16_zero<T>(); }
+    }
 #pragma unroll
     for (int j = 0; j < RS; j++) b0[j] = v16_zero<T>();
+    __syncthreads();                                              // the zero fill is complete before the first edge values land
     if (lane == 0 || lane == 63) {
 #pragma unroll
         for (int q = 0; q < R2; q++) {
-            if (lane == 0) edgeW[(t0 + 1) & 1][q][w] = ub[q + 1].v[0];
-            else edgeE[(t0 + 1) & 1][q][w] = ub[q + 1].v[VX - 1];
+            if (lane == 0) edgeW[(t0 + 1) & 1][q][w] = ub[q].v[0];
+            else edgeE[(t0 + 1) & 1][q][w + 1] = ub[q].v[VX - 1];
         }
     }
-    T acc[NCR][NCJ], accn[NCR][NCJ];
-#pragma unroll
-    for (int cl = 0; cl < NCR; cl++)
-#pragma unroll
-        for (int q = 0; q < NCJ; q++) { acc[cl][q] = (T)0; accn[cl][q] = (T)0; }
+    T acc0 = (T)0, acc1 = (T)0, accn0 = (T)0, accn1 = (T)0;
     __syncthreads();
 
-    for (int t = t0; t < z1; t++) {
+    // one marching step; A: plane t, B: t+1, C: t+2 of u; A is reloaded with plane t+3.  (Unrolling the loop by three with the
+    // roles permuted instead of copying the planes spills at 8 waves and is no faster: the pass is not issue bound.)
+    auto step = [&](VT (&A)[R2], VT (&B)[R2], VT (&C)[R2], const int t) __attribute__((always_inline)) {
         const int p = t + 1;                                      // plane the sweep produces in this step
+        {
+            const auto rb = BRS(t + 2);
 #pragma unroll
-        for (int q = 0; q < R2; q++) bn[q] = LDB(t + 2, q, q >= 2 && q < R2 - 2);      // b of the next step; rows shared with neighbours: cached
+            for (int q = 0; q < R2; q++) bn[q] = (q == 3) ? bufld_nt<T>(rb, lb, brb[q]) : bufld<T>(rb, lb, brb[q]);     // rows a neighbouring tile reads too: cached
+        }
         // ---- the sweep of plane p on rows yb-1 .. yb+TY+1 ----
         {
             const bool pin = (p >= 0 && p < a.nz);
             const bool pst = (p >= z0 && p < zs1);
             const int eb = p & 1, hb = p & 1, sl = (p + 3) % 3;
+            // (loop-variant bounds: planes outside the grid have no valid row)
+            const int qlo_t = pin ? qlo : R2;
+            const unsigned span_t = (unsigned)(qhi - qlo_t);
+            const auto ro = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out - a.rs + (long)max(0, min(p, a.nz - 1)) * a.ms), 0, (int)plane_bytes, 0x00020000);
 #pragma unroll
             for (int q = 0; q < R2; q++) {
-                const int rr = q + 1;
-                T Wv = lane_up<true>(ub[rr].v[VX - 1]), Ev = lane_dn<true>(ub[rr].v[0]);
-                if (lane == 0) Wv = (w > 0) ? edgeE[eb][q][w - 1] : (T)0;
-                if (lane == 63) Ev = (w < WX - 1) ? edgeW[eb][q][w + 1] : (T)0;
-                VT o;
+                if ((unsigned)(q - qlo_t) <= span_t && qhi >= qlo_t) {      // wave-uniform: the row is inside the grid
+                    const T Wv = lane_up_old(B[q].v[VX - 1], edgeE[eb][q][w]);
+                    const T Ev = lane_dn_old(B[q].v[0], edgeW[eb][q][w + 1]);
+                    const VT &Sr = (q == 0) ? h0 : B[q > 0 ? q - 1 : 0];
+                    const VT &Nr = (q == R2 - 1) ? h8 : B[q < R2 - 1 ? q + 1 : q];
+                    VT o;
 #pragma unroll
-                for (int e = 0; e < VX; e++) {
-                    const T wv = (e == 0) ? Wv : ub[rr].v[e - 1 < 0 ? 0 : e - 1];
-                    const T ev = (e == VX - 1) ? Ev : ub[rr].v[e + 1 > VX - 1 ? VX - 1 : e + 1];
-                    T s = a.a0 * ua[rr].v[e];
-                    s = s + a.a1 * ub[rr - 1].v[e];
-                    s = s + a.a2 * wv;
-                    s = s + a.a3 * ub[rr].v[e];
-                    s = s + a.a4 * ev;
-                    s = s + a.a5 * ub[rr + 1].v[e];
-                    s = s + a.a6 * uc[rr].v[e];
-                    const T res = b1[q].v[e] - s;
-                    const T zz = res * a.dinv;
-                    o.v[e] = ub[rr].v[e] + a.scale * zz;
-                    if (!pin || !s1ok[q] || (lastlane && e == VX - 1)) o.v[e] = (T)0;
+                    for (int e = 0; e < VX; e++) {
+                        const T wv = (e == 0) ? Wv : B[q].v[e - 1 < 0 ? 0 : e - 1];
+                        const T ev = (e == VX - 1) ? Ev : B[q].v[e + 1 > VX - 1 ? VX - 1 : e + 1];
+                        T s = a.a0 * A[q].v[e];
+                        s = s + a.a1 * Sr.v[e];
+                        s = s + a.a2 * wv;
+                        s = s + a.a3 * B[q].v[e];
+                        s = s + a.a4 * ev;
+                        s = s + a.a5 * Nr.v[e];
+                        s = s + a.a6 * C[q].v[e];
+                        const T res = b1[q].v[e] - s;
+                        const T zz = res * a.dinv;
+                        o.v[e] = B[q].v[e] + a.scale * zz;
+                    }
+                    if (lastlane) o.v[VX - 1] = (T)0;
+                    if (q == 0) *reinterpret_cast<VT *>(&halo[hb][0][xl + VX]) = o;
+                    else if (q == R2 - 1) *reinterpret_cast<VT *>(&halo[hb][1][xl + VX]) = o;
+                    else *reinterpret_cast<VT *>(&ring[sl][q - 1][xl + VX]) = o;
+                    if (q >= 1 && q <= TY) { if (pst) bufst_nt<T>(o, ro, lb, (unsigned)(yb + q) * rowb); }
+                } else if (!pin && q >= 1 && q <= RS) {
+                    // plane -1 / nz: zeros where the residual of the plane next to it reads the lane's own columns
+                    *reinterpret_cast<VT *>(&ring[sl][q - 1][xl + VX]) = v16_zero<T>();
                 }
-                if (q == 0) *reinterpret_cast<VT *>(&halo[hb][0][xl + VX]) = o;
-                else if (q == R2 - 1) *reinterpret_cast<VT *>(&halo[hb][1][xl + VX]) = o;
-                else *reinterpret_cast<VT *>(&ring[sl][q - 1][xl + VX]) = o;
-                if (q >= 1 && q <= TY) { if (pst && s1ok[q]) stv_stream(a.out + (long)p * a.ms + (long)(yb + q - 1) * a.rs + x0, o); }
             }
             if (lane == 0 || lane == 63) {
 #pragma unroll
                 for (int q = 0; q < R2; q++) {
-                    if (lane == 0) edgeW[eb ^ 1][q][w] = uc[q + 1].v[0];
-                    else edgeE[eb ^ 1][q][w] = uc[q + 1].v[VX - 1];
+                    if (lane == 0) edgeW[eb ^ 1][q][w] = C[q].v[0];
+                    else edgeE[eb ^ 1][q][w + 1] = C[q].v[VX - 1];
                 }
             }
         }
         // plane t+3 of u into the registers of plane t (the sweep is done with them)
+        {
+            const auto r3 = URS(t + 3), r2 = URS(t + 2);
 #pragma unroll
-        for (int rr = 0; rr < R1; rr++) ua[rr] = LDU(t + 3, rr);
-        // ---- residual of the swept plane t on rows yb .. yb+TY: everything from LDS (plane t and its x / y neighbours were
-        //      written in step t-1, plane t+1 at the lane's own columns a moment ago by the lane itself) ----
+            for (int q = 0; q < R2; q++) A[q] = bufld<T>(r3, lb, urb[q + 1]);
+            h0 = bufld<T>(r2, lb, urb[0]); h8 = bufld<T>(r2, lb, urb[R1 - 1]);      // outer rows of the next centre plane
+        }
+        // ---- residual of the swept plane t on rows yb .. yb+TY: everything from LDS.  (Rows beyond the grid give values that no
+        //      valid coarse row reads, and the ghost column of the last lane is not read either: no masking here.) ----
         VT res[RS];
         if (t >= z0) {
             const int cb = t & 1, sm = (t + 2) % 3, sc = t % 3, sp = (t + 1) % 3;
@@ -2090,9 +2145,8 @@ __global__ void __launch_bounds__(64 * WX) k_srr4(const SRRArgs<T> a) {
                     s = s + a.a4 * ev;
                     s = s + a.a5 * nv.v[e];
                     s = s + a.a6 * upv.v[e];
-                    res[j].v[e] = rok[j] ? b0[j].v[e] - s : (T)0;
+                    res[j].v[e] = b0[j].v[e] - s;
                 }
-                if (lastlane) res[j].v[VX - 1] = (T)0;
             }
             if (lane == 0) {
 #pragma unroll
@@ -2106,49 +2160,49 @@ __global__ void __launch_bounds__(64 * WX) k_srr4(const SRRArgs<T> a) {
             const T wk = even ? (T)0.25 : (T)0.5;
             T nx_[RS];
 #pragma unroll
-            for (int j = 0; j < RS; j++) {
-                nx_[j] = lane_dn<true>(res[j].v[0]);
-                if (lane == 63) nx_[j] = (w < WX - 1) ? eR[t & 1][j][w + 1] : (T)0;
-            }
+            for (int j = 0; j < RS; j++) nx_[j] = lane_dn_old(res[j].v[0], eR[t & 1][j][w + 1]);
 #pragma unroll
             for (int cl = 0; cl < NCR; cl++) {
-                if (!crow[cl]) continue;
+                if (!(cl == 0 ? crow0 : crow1)) continue;
+                T sa = (cl == 0) ? acc0 : acc1, sn = (cl == 0) ? accn0 : accn1;
 #pragma unroll
-                for (int q = 0; q < NCJ; q++) {
+                for (int di = 0; di < 3; di++) {
 #pragma unroll
-                    for (int di = 0; di < 3; di++) {
-#pragma unroll
-                        for (int dj = 0; dj < 3; dj++) {
-                            const int e = 2 * q + dj;
-                            const T val = (e < VX) ? res[2 * cl + di].v[e < VX ? e : 0] : nx_[2 * cl + di];
-                            const T pr = (wk * w2[di][dj]) * val;
-                            acc[cl][q] += pr;
-                            if (even) accn[cl][q] += pr;
-                        }
+                    for (int dj = 0; dj < 3; dj++) {
+                        const T val = (dj < VX) ? res[2 * cl + di].v[dj < VX ? dj : 0] : nx_[2 * cl + di];
+                        const T pr = (wk * w2[di][dj]) * val;
+                        sa += pr;
+                        if (even) sn += pr;
                     }
                 }
+                if (cl == 0) { acc0 = sa; accn0 = sn; } else { acc1 = sa; accn1 = sn; }
             }
             if (even) {
                 const int kc = t / 2 - 1;     // completed coarse plane
-#pragma unroll
-                for (int cl = 0; cl < NCR; cl++)
-#pragma unroll
-                    for (int q = 0; q < NCJ; q++) {
-                        if (kc >= kc0 && crow[cl] && jc0 + q < a.nxc) {
-                            const long oc = (long)kc * a.cms + (long)(NCR * ty + cl) * a.crs + jc0 + q;
-                            a.bc[oc] = acc[cl][q];
-                            if (a.uc0) { const T zq = acc[cl][q] * a.dinv_c; a.uc0[oc] = a.scale_c * zq; }
-                        }
-                        acc[cl][q] = accn[cl][q]; accn[cl][q] = (T)0;
+                if (kc >= kc0 && jc0 < a.nxc) {
+                    if (crow0) {
+                        const long oc = (long)kc * a.cms + (long)(NCR * ty) * a.crs + jc0;
+                        a.bc[oc] = acc0;
+                        if (a.uc0) { const T zq = acc0 * a.dinv_c; a.uc0[oc] = a.scale_c * zq; }
                     }
+                    if (crow1) {
+                        const long oc = (long)kc * a.cms + (long)(NCR * ty + 1) * a.crs + jc0;
+                        a.bc[oc] = acc1;
+                        if (a.uc0) { const T zq = acc1 * a.dinv_c; a.uc0[oc] = a.scale_c * zq; }
+                    }
+                }
+                acc0 = accn0; accn0 = (T)0; acc1 = accn1; accn1 = (T)0;
             }
         }
 #pragma unroll
         for (int j = 0; j < RS; j++) b0[j] = b1[j + 1];
 #pragma unroll
         for (int q = 0; q < R2; q++) b1[q] = bn[q];
+    };
+    for (int t = t0; t < z1; t++) {
+        step(ua, ub, uc, t);
 #pragma unroll
-        for (int rr = 0; rr < R1; rr++) { VT tmpv = ua[rr]; ua[rr] = ub[rr]; ub[rr] = uc[rr]; uc[rr] = tmpv; }
+        for (int q = 0; q < R2; q++) { VT tmpv = ua[q]; ua[q] = ub[q]; ub[q] = uc[q]; uc[q] = tmpv; }
     }
 }
 
@@ -2201,13 +2255,13 @@ extern "C" int mgk_sweep_residual_restrict_f64(mgk_ctx *c, const mgk_geom *gf, c
     if (kcc > gc->nz) kcc = gc->nz;
     a.kcc = kcc;
     const unsigned nblk = (unsigned)(a.nty * ((gc->nz + kcc - 1) / kcc));
-    if (TYsel == 4 && g_variant == 42) launch_srr<T, 4>(w, nblk, S(c, stream), a);      // (registers only: spills at 8 waves)
+    if (TYsel == 4 && g_variant == 42) launch_srr<T, 4>(w, nblk, S(c, stream), a);      // (all in registers: spills at 8 waves)
     else if (TYsel == 4) {
         hipStream_t st = S(c, stream);
-        if (w <= 1) hipLaunchKernelGGL((k_srr4<T, 1>), dim3(nblk), dim3(64), 0, st, a);
-        else if (w <= 2) hipLaunchKernelGGL((k_srr4<T, 2>), dim3(nblk), dim3(128), 0, st, a);
-        else if (w <= 4) hipLaunchKernelGGL((k_srr4<T, 4>), dim3(nblk), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_srr4<T, 8>), dim3(nblk), dim3(512), 0, st, a);
+        if (w <= 1) hipLaunchKernelGGL((k_srr4b<1>), dim3(nblk), dim3(64), 0, st, a);
+        else if (w <= 2) hipLaunchKernelGGL((k_srr4b<2>), dim3(nblk), dim3(128), 0, st, a);
+        else if (w <= 4) hipLaunchKernelGGL((k_srr4b<4>), dim3(nblk), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_srr4b<8>), dim3(nblk), dim3(512), 0, st, a);
     } else launch_srr<T, 2>(w, nblk, S(c, stream), a);
     HIPCHK(hipGetLastError());
     return 0;

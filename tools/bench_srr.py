@@ -26,10 +26,10 @@ sw = timeit(lambda: L.mgk_jacobi_f64(m.ctx, C.byref(g), coef, dinv, 0.85, b, u, 
 rr = timeit(lambda: L.mgk_residual_restrict_jz_f64(m.ctx, C.byref(g), C.byref(gc), coef, b, u, bc, uc0, dinv, 0.85, None))
 p2 = timeit(lambda: L.mgk_jacobi2_f64(m.ctx, C.byref(g), coef, dinv, 0.85, b, u, out, None))
 print(f"n={n}: sweep {sw:.3f} ms, residual+restriction(+jz) {rr:.3f} ms, sum {sw + rr:.3f} ms; two-sweep pass {p2:.3f} ms", flush=True)
-for v in (-1, 40):
+for v in [int(x) for x in os.environ.get('SRR_VARIANTS', '-1,40').split(',')]:
     for zc in [int(x) for x in os.environ.get("SRR_ZC", "-1,256,128,64").split(",")]:
         L.mgk_set_tuning(v, zc)
         s = timeit(lambda: L.mgk_sweep_residual_restrict_f64(m.ctx, C.byref(g), C.byref(gc), coef, dinv, 0.85, b, u, out, bc, uc0, dinv, 0.85, None))
-        print(f"fused sweep+residual+restriction, tiles of {2 if v == 40 else 4} rows, coarse planes per chunk {zc:4d}: {s:7.3f} ms  {26 * N / s / 1e6:7.1f} GB/s", flush=True)
+        print(f"fused sweep+residual+restriction, variant {v}, coarse planes per chunk {zc:4d}: {s:7.3f} ms  {26 * N / s / 1e6:7.1f} GB/s", flush=True)
 L.mgk_set_tuning(-1, -1)
 m.close()

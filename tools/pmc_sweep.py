@@ -34,5 +34,8 @@ for _ in range(2):
     m._chk(L.mgk_prolong_add_f64(m.ctx, C.byref(g), C.byref(gc), uc, u, None))
     m._chk(L.mgk_residual_restrict_f64(m.ctx, C.byref(g), C.byref(gc), coef, b, u, bc, None))
     m._chk(L.mgk_prolong_jacobi_f64(m.ctx, C.byref(g), C.byref(gc), coef, dinv, 6.0 / 7.0, b, uc, u, out, None))
+    # round 2: last pre-smoothing sweep + residual + restriction (+ coarse first sweep) in one pass; two sweeps + norm
+    m._chk(L.mgk_sweep_residual_restrict_f64(m.ctx, C.byref(g), C.byref(gc), coef, dinv, 6.0 / 7.0, b, u, out, bc, uc, dinv, 6.0 / 7.0, None))
+    m._chk(L.mgk_jacobi2_sumsq_f64(m.ctx, C.byref(g), coef, dinv, 6.0 / 7.0, b, u, out, C.byref(ss), None))
 m.sync()
 m.close()
