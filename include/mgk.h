@@ -293,6 +293,20 @@ int  mgk_sweep_residual_restrict_ok_f64(const mgk_geom *gf, const mgk_geom *gc);
 int  mgk_sweep_residual_restrict_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
                                      const double *b, const double *u, double *unew, double *bc, double *uc0,
                                      double dinv_c, double scale_c, void *stream);
+/* the two on a z-slab of a multi-GPU run.  far / far2 / bfar: fields of geometry gfar = (nx, ny, 2) (as for mgk_jacobi2_slab_f64) whose
+ * ghost planes hold, after a halo exchange, -- far: lo = plane nz-2 of the rank below, hi = plane 1 of the rank above (the
+ * sender puts its planes 1 and nz-2 into the two interior planes); far2: hi = plane 2 of u of the rank above (sender: interior
+ * plane 0 = its plane 2); bfar: hi = plane 1 of b of the rank above (sender: interior plane 0 = its b plane 1).  u's and b's own ghost
+ * planes must be valid.  A slab with a rank above (has_hi) has nzf = 2 nzc and completes its last coarse plane itself; the last one
+ * has nzf = 2 nzc + 1.  [kcbeg, kcend): coarse planes of this launch; [zbeg, zend) / part_off / nparts as mgk_jacobi_sumsq_range_f64. */
+int  mgk_jacobi2_sumsq_slab_f64(mgk_ctx *ctx, const mgk_geom *g, const mgk_geom *gfar, const double *coef, double dinv, double scale,
+                                const double *b, const double *u, double *unew, const double *far, int has_lo, int has_hi,
+                                int zbeg, int zend, int part_off, int *nparts, void *stream);
+int  mgk_sweep_residual_restrict_slab_ok_f64(const mgk_geom *gf, const mgk_geom *gc);
+int  mgk_sweep_residual_restrict_slab_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const mgk_geom *gfar, const double *coef,
+                                          double dinv, double scale, const double *b, const double *u, double *unew,
+                                          const double *far, const double *far2, const double *bfar, int has_lo, int has_hi,
+                                          double *bc, int kcbeg, int kcend, void *stream);
 
 /* ---- flat BLAS-1 / AIJ kernels behind the PETSc-surface shim (include/petscksp.h) ----
  * n counts doubles of a whole allocation (padded fields: ghosts are 0 and stay 0). */

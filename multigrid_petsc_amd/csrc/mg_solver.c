@@ -44,6 +44,9 @@ typedef struct mg_fset {
     int last_sweep_pending; /* pre-smoothing stopped one sweep short: the restriction that follows makes it (mgk_sweep_residual_restrict_f64) */
     int b_ghost_ok;         /* z ghost planes of `b` hold the neighbours' boundary planes (two-sweep passes on slabs) */
     void *far;              /* distributed levels: field of geometry gfar = (nx, ny, 2) for the neighbours' SECOND planes of u */
+    void *far2, *bfar;      /* fp64, fuse bit 10: same geometry; hi ghost = the rank above's THIRD plane of u / SECOND plane of b (sweep fused
+                             * with residual + restriction on a slab: mgk_sweep_residual_restrict_slab_f64) */
+    int bfar_ok;            /* bfar's hi ghost plane is valid (b of a level changes only when the restriction above rewrites it) */
     mgk_geom gfar;
 } mg_fset;
 
@@ -329,6 +332,15 @@ static int alloc_far(mg_solver *s, mg_level *L, int P) {
     CHK(mgk_malloc(s->ctx, &q, bytes));
     CHK(mgk_memset0(s->ctx, q, bytes, NULL));
     F->far = q;
+    if (P == 0 && (s->cfg.fuse & 1024)) {
+        void *q2 = NULL, *q3 = NULL;
+        CHK(mgk_malloc(s->ctx, &q2, bytes));
+        F->far2 = q2;
+        CHK(mgk_malloc(s->ctx, &q3, bytes));
+        F->bfar = q3;
+        CHK(mgk_memset0(s->ctx, q2, bytes, NULL));
+        CHK(mgk_memset0(s->ctx, q3, bytes, NULL));
+    }
     return 0;
 }
 
@@ -482,8 +494,8 @@ void mg_solver_destroy(mg_solver *s) {
         for (int l = 0; l < s->levels; l++) {
             mg_level *L = &s->L[l];
             for (int p = 0; p < 2; p++) {
-                void *f[5] = {L->f[p].u, L->f[p].b, L->f[p].rv, L->f[p].tmp, L->f[p].far};
-                for (int k = 0; k < 5; k++) if (f[k]) mgk_free(s->ctx, f[k]);
+                void *f[7] = {L->f[p].u, L->f[p].b, L->f[p].rv, L->f[p].tmp, L->f[p].far, L->f[p].far2, L->f[p].bfar};
+                for (int k = 0; k < 7; k++) if (f[k]) mgk_free(s->ctx, f[k]);
             }
             if (L->p2) mgk_free(s->ctx, L->p2);
             if (L->ctab) mgk_free(s->ctx, L->ctab);
@@ -696,7 +708,14 @@ static int smooth_chebyshev(mg_solver *s, int l, int maxit) {
  * this level's sweeps run outside it (the replayed kernel would keep the buffers of the recording cycle; the swap is made on the host) */
 static int srr_ok(const mg_solver *s, int P, int l) {
     if (!(s->cfg.fuse & 1024) || P != 0 || s->cfg.dim != 3 || s->cfg.mesh || s->cfg.ksp_type != MG_KSP_RICHARDSON) return 0;
-    if (l + 1 >= s->levels || s->L[l].distributed || (s->lgraph && l + 1 == s->lgraph)) return 0;
+    if (l + 1 >= s->levels || (s->lgraph && l + 1 == s->lgraph)) return 0;
+    if (s->L[l].distributed) {
+        /* z-slab: the neighbours' planes arrive in ONE grouped exchange (u and b ghosts, far, far2, bfar) */
+        const mg_fset *F = &s->L[l].f[0];
+        mgk_geom gc = s->L[l + 1].f[0].g;
+        if (!s->L[l + 1].distributed) gc.nz = s->zstart[s->cfg.rank + 1] - s->zstart[s->cfg.rank];
+        return F->far && F->far2 && F->bfar && s->L[l].nz_min >= 6 && mgk_sweep_residual_restrict_slab_ok_f64(&F->g, &gc);
+    }
     return mgk_sweep_residual_restrict_ok_f64(&s->L[l].f[0].g, &s->L[l + 1].f[0].g);
 }
 
@@ -881,7 +900,7 @@ static int restrict_to(mg_solver *s, int P, int l) {
     mg_level *Lf = &s->L[l - 1], *Lc = &s->L[l];
     mg_fset *F = &Lf->f[P], *Cq = &Lc->f[P];
     const mg_ops *O = &OPS[P];
-    Cq->b_ghost_ok = 0;
+    Cq->b_ghost_ok = 0; Cq->bfar_ok = 0;
     CHK(halo(s, P, Lf, F->rv));
     if (Lf->distributed && !Lc->distributed) {
         /* slab -> replicated: produce my coarse planes in place, then all-gather them */
@@ -1002,6 +1021,59 @@ static int descend_restrict(mg_solver *s, int P, int l, int no_jz) {
     const int levels = s->levels, *v = s->cfg.v;
     mg_level *Lf = &s->L[l - 1];
     const mg_ops *O = &OPS[P];
+    if (Lf->f[P].last_sweep_pending && Lf->distributed) {
+        /* the same pass on a z-slab.  ONE grouped exchange brings everything the slab needs to sweep one plane below and two planes
+         * above itself and to evaluate the residual of the plane above: u's and b's ghost planes, the neighbours' second planes of u
+         * (far), the upper neighbour's third plane of u (far2) and second plane of b (bfar; b of a level is rewritten only by the
+         * restriction above it).  It travels while the coarse planes that read none of it are produced. */
+        mg_level *Lc = &s->L[l];
+        mg_fset *F = &Lf->f[P], *Cq = &Lc->f[P];
+        void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
+        const int me = s->cfg.rank, lo = me > 0, hi = me < s->cfg.nranks - 1;
+        mgk_geom gc = Cq->g;
+        void *bc = Cq->b;
+        Cq->b_ghost_ok = 0; Cq->bfar_ok = 0;
+        if (!Lc->distributed) {                 /* slab -> replicated: my coarse planes land in place, then all-gather */
+            const int c0 = s->zstart[me], c1 = s->zstart[me + 1];
+            gc.nz = c1 - c0;
+            bc = (char *)Cq->b + (size_t)O->esz * (size_t)c0 * (size_t)Cq->g.plane;
+        }
+        const size_t pb = (size_t)O->esz * (size_t)F->g.plane;
+        const int nz = F->g.nz, nzc = gc.nz;
+        CHK(mgk_d2d(s->ctx, (char *)F->far + pb, (char *)F->u + 2 * pb, pb, cs));                       /* my plane 1 */
+        CHK(mgk_d2d(s->ctx, (char *)F->far + 2 * pb, (char *)F->u + (size_t)(nz - 1) * pb, pb, cs));   /* my plane nz-2 */
+        CHK(mgk_d2d(s->ctx, (char *)F->far2 + pb, (char *)F->u + 3 * pb, pb, cs));                      /* my plane 2 */
+        if (!F->bfar_ok) CHK(mgk_d2d(s->ctx, (char *)F->bfar + pb, (char *)F->b + 2 * pb, pb, cs));     /* my plane 1 of b */
+        CHK(mgk_stream_wait(s->ctx, ms, cs));
+        {
+            void *ff[5];
+            const mgk_geom *gg[5];
+            int nf = 0;
+            if (!F->u_ghost_pending && !F->u_ghost_ok) { ff[nf] = F->u; gg[nf++] = &F->g; }
+            if (!F->b_ghost_ok) { ff[nf] = F->b; gg[nf++] = &F->g; }
+            ff[nf] = F->far; gg[nf++] = &F->gfar;
+            ff[nf] = F->far2; gg[nf++] = &F->gfar;
+            if (!F->bfar_ok) { ff[nf] = F->bfar; gg[nf++] = &F->gfar; }
+            CHK(mg_comm_halo_n(s->comm, s->ctx, nf, ff, gg, O->esz, ms));
+        }
+        /* coarse planes 1 .. nzc-3 read the fine planes 0 .. nz-2 of u only */
+        const int split = s->cfg.overlap && nzc >= 5 && Lf->nz_min >= 10;
+#define SRRS(k0, k1) mgk_sweep_residual_restrict_slab_f64(s->ctx, &F->g, &gc, &F->gfar, Lf->coef, Lf->dinv, s->cfg.scale, (const double *)F->b, \
+                        (const double *)F->u, (double *)F->tmp, (const double *)F->far, (const double *)F->far2, (const double *)F->bfar, lo, hi, (double *)bc, k0, k1, cs)
+        if (split) CHK(SRRS(1, nzc - 2));
+        CHK(mgk_stream_wait(s->ctx, cs, ms));
+        if (split) { CHK(SRRS(0, 1)); CHK(SRRS(nzc - 2, nzc)); }
+        else CHK(SRRS(0, nzc));
+#undef SRRS
+        swap_ptr(&F->u, &F->tmp);
+        F->u_ghost_ok = 0; F->u_ghost_pending = 0; F->b_ghost_ok = 1; F->bfar_ok = 1; F->last_sweep_pending = 0;
+        if (!Lc->distributed) {
+            CHK(mgk_stream_wait(s->ctx, ms, cs));
+            CHK(s->comm->allgather_planes(s->comm, s->ctx, Cq->b, &Cq->g, s->zstart, O->esz, ms));
+            CHK(mgk_stream_wait(s->ctx, cs, ms));
+        }
+        return 0;
+    }
     if (Lf->f[P].last_sweep_pending) {
         /* the last pre-smoothing sweep, the residual and its restriction in one pass (:1531 / :1536 last iteration, :1534-1535) */
         mg_fset *F = &Lf->f[P], *Cq = &s->L[l].f[P];
@@ -1011,7 +1083,7 @@ static int descend_restrict(mg_solver *s, int P, int l, int no_jz) {
                                             (double *)F->tmp, (double *)Cq->b, jz ? (double *)Cq->tmp : NULL, s->L[l].dinv, s->cfg.scale, NULL));
         swap_ptr(&F->u, &F->tmp);
         F->u_ghost_ok = 0; F->u_ghost_pending = 0; F->last_sweep_pending = 0;
-        Cq->b_ghost_ok = 0;
+        Cq->b_ghost_ok = 0; Cq->bfar_ok = 0;
         if (jz) Cq->jz_ready = 1;
         return 0;
     }
@@ -1039,7 +1111,7 @@ static int descend_restrict(mg_solver *s, int P, int l, int no_jz) {
         mg_fset *F = &Lf->f[P], *Cq = &Lc->f[P];
         void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
         const int me = s->cfg.rank, last = (me == s->cfg.nranks - 1);
-        Cq->b_ghost_ok = 0;
+        Cq->b_ghost_ok = 0; Cq->bfar_ok = 0;
         mgk_geom gc = Cq->g;
         void *bc = Cq->b;
         if (!Lc->distributed) {                 /* slab -> replicated: my coarse planes land in place, then all-gather */
@@ -1204,6 +1276,39 @@ static int vcycle_once(mg_solver *s) {
         CHK(cycle_body(s, 0, s->iter == 0));
         /* :1545-1546  r0 = b0 - A0 u0 ; ||r0|| */
         const int jnorm = (s->cfg.fuse & 8) && (s->cfg.fuse & 1) && s->cfg.ksp_type == MG_KSP_RICHARDSON && s->cfg.v[0] >= 1;
+        if (jnorm && L->distributed && s->cfg.dim == 3 && (s->cfg.fuse & 1024) && (s->cfg.fuse & 32) && F->far && L->nz_min >= 6 &&
+            s->cfg.v[0] >= 2 && L->n >= s->cfg.pair_min_n && L->n + 1 <= 1024 && s->lgraph != 1 && mgk_jacobi2_sumsq_ok_f64(&F->g)) {
+            /* slab: the norm and the first TWO sweeps of the next cycle in one pass (the two-sweep slab pass with the norm of its
+             * input's residual): the planes 2 .. nz-3 while the grouped exchange (u's ghosts, b's once, the far planes) travels */
+            const size_t pb = sizeof(double) * (size_t)F->g.plane;
+            const int nz = F->g.nz, lo = s->cfg.rank > 0, hi = s->cfg.rank < s->cfg.nranks - 1;
+            void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
+            int n1 = 0, n2 = 0, n3 = 0;
+            CHK(mgk_d2d(s->ctx, (char *)F->far + pb, (char *)F->u + 2 * pb, pb, cs));
+            CHK(mgk_d2d(s->ctx, (char *)F->far + 2 * pb, (char *)F->u + (size_t)(nz - 1) * pb, pb, cs));
+            CHK(mgk_stream_wait(s->ctx, ms, cs));
+            {
+                void *ff[3];
+                const mgk_geom *gg[3];
+                int nf = 0;
+                if (!F->u_ghost_pending && !F->u_ghost_ok) { ff[nf] = F->u; gg[nf++] = &F->g; }
+                if (!F->b_ghost_ok) { ff[nf] = F->b; gg[nf++] = &F->g; }
+                ff[nf] = F->far; gg[nf++] = &F->gfar;
+                CHK(mg_comm_halo_n(s->comm, s->ctx, nf, ff, gg, 8, ms));
+            }
+#define J2N(z0, z1, off, np) mgk_jacobi2_sumsq_slab_f64(s->ctx, &F->g, &F->gfar, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u, \
+                                (double *)F->tmp, (const double *)F->far, lo, hi, z0, z1, off, np, cs)
+            const int split = s->cfg.overlap && nz >= 6;
+            if (split) CHK(J2N(2, nz - 2, 0, &n1));
+            CHK(mgk_stream_wait(s->ctx, cs, ms));
+            F->u_ghost_pending = 0; F->u_ghost_ok = 1; F->b_ghost_ok = 1;
+            if (split) { CHK(J2N(0, 2, n1, &n2)); CHK(J2N(nz - 2, nz, n1 + n2, &n3)); }
+            else CHK(J2N(0, nz, 0, &n1));
+#undef J2N
+            CHK(mgk_partials_finish(s->ctx, n1 + n2 + n3, &ss, NULL));
+            s->spec_valid = 2;
+            goto norm_done;
+        }
         if (jnorm && L->distributed && s->cfg.overlap && L->nz_min >= 3 && s->cfg.dim == 3) {
             /* the same on a slab with the exchange of u's ghost planes hidden: inner planes first, the two boundary planes
              * once the ghosts have arrived; one reduction over the block partials of the three launches */
@@ -1260,7 +1365,7 @@ static int start(mg_solver *s) {
     CHK(mgk_sumsq_f64(s->ctx, &F->g, (const double *)F->b, &ss, NULL)); /* VecNorm(b[0]) :1512 */
     CHK(norm_from_sumsq(s, ss, &s->bnorm));
     for (int l = 0; l < s->levels; l++)
-        for (int p = 0; p < 2; p++) { s->L[l].f[p].guess_nonzero = 0; s->L[l].f[p].u_ghost_ok = 0; s->L[l].f[p].u_ghost_pending = 0; s->L[l].f[p].b_ghost_ok = 0; s->L[l].f[p].jz_ready = 0; s->L[l].f[p].last_sweep_pending = 0; }
+        for (int p = 0; p < 2; p++) { s->L[l].f[p].guess_nonzero = 0; s->L[l].f[p].u_ghost_ok = 0; s->L[l].f[p].u_ghost_pending = 0; s->L[l].f[p].b_ghost_ok = 0; s->L[l].f[p].jz_ready = 0; s->L[l].f[p].last_sweep_pending = 0; s->L[l].f[p].bfar_ok = 0; }
     CHK(mgk_memset0(s->ctx, F->u, sizeof(double) * (size_t)F->g.total, NULL));   /* VecSet(u[0],0) :1514 */
     /* rv = A u - b with u = 0 (:1516-1517); ||A u - b|| = ||b - A u||, evaluated by the same residual kernel */
     if (s->cfg.precision == MG_PREC_MIXED)

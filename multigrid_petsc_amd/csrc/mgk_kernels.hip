@@ -1603,7 +1603,7 @@ template <> struct j2norm<double> { static constexpr bool built = true; };
 template <typename T>
 static int jacobi2(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
                    const T *b, const T *u, T *unew, const T *far_lo, const T *far_hi, int zbeg, int zend, void *stream,
-                   int *norm_parts = nullptr) {
+                   int *norm_parts = nullptr, int part_off = 0) {
     constexpr int VX = 16 / sizeof(T);
     if (!c || !g || !coef || !b || !u || !unew || u == unew || g->dim != 3) return fail(MGK_EINVAL, "mgk_jacobi2: bad arguments (3-D)");
     if (g->nx + 1 > 1024) return fail(MGK_EINVAL, "mgk_jacobi2: nx + 1 > 1024 is not built");
@@ -1635,9 +1635,9 @@ static int jacobi2(mgk_ctx *c, const mgk_geom *g, const double *coef, double din
     if (norm_parts) {
         // with the residual norm of the input field: the register form on full-row shapes only
         constexpr int WRn = 64 * VX;
-        if (!j2norm<T>::built || (g->nx + 1) % WRn != 0 || (g->ny + 1) % 4 != 0 || (long)nblk > c->max_partials)
+        if (!j2norm<T>::built || (g->nx + 1) % WRn != 0 || (g->ny + 1) % 4 != 0 || part_off < 0 || (long)nblk > c->max_partials - part_off)
             return fail(MGK_EINVAL, "mgk_jacobi2_sumsq: built for fp64 full-row shapes (n = 127, 255, 511, 1023)");
-        a.partials = c->partials;
+        a.partials = c->partials + part_off;
         if constexpr (j2norm<T>::built) {
             if (w <= 1) hipLaunchKernelGGL((k_jacobi2r<T, 1, 3, true>), dim3(nblk), dim3(64), 0, s, a);
             else if (w <= 2) hipLaunchKernelGGL((k_jacobi2r<T, 2, 3, true>), dim3(nblk), dim3(128), 0, s, a);
@@ -1706,6 +1706,18 @@ extern "C" int mgk_jacobi2_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const double
     if (rc) return rc;
     return finish_to_host(c, nparts, 1, S(c, stream), sumsq_host);
 }
+// ... on the planes [zbeg, zend) of a z-slab (far planes as for mgk_jacobi2_slab_f64), block partials deposited from slot part_off on and
+// NOT reduced: interior planes while the ghosts travel, then the boundary planes, then ONE mgk_partials_finish (fixed order)
+extern "C" int mgk_jacobi2_sumsq_slab_f64(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gfar, const double *coef, double dinv, double scale,
+                                          const double *b, const double *u, double *unew, const double *far, int has_lo, int has_hi,
+                                          int zbeg, int zend, int part_off, int *nparts, void *stream) {
+    if (!g || !nparts) return fail(MGK_EINVAL, "mgk_jacobi2_sumsq_slab_f64: bad arguments");
+    if ((has_lo || has_hi) && (!gfar || !far || gfar->dim != 3 || gfar->nz != 2 || gfar->nx != g->nx || gfar->ny != g->ny || gfar->pitch != g->pitch || g->nz < 2))
+        return fail(MGK_EINVAL, "mgk_jacobi2_sumsq_slab_f64: the far-plane field must have the geometry (nx, ny, 2) of the slab");
+    const double *lo = has_lo ? far + gfar->org - gfar->plane : nullptr;
+    const double *hi = has_hi ? far + gfar->org + 2 * gfar->plane : nullptr;
+    return jacobi2<double>(c, g, coef, dinv, scale, b, u, unew, lo, hi, zbeg, zend, stream, nparts, part_off);
+}
 // The same on a z-slab.  `far` is a field of geometry (nx, ny, nz = 2) whose ghost planes hold the neighbours' second plane
 // (lo ghost: plane nz-2 of the rank below, hi ghost: plane 1 of the rank above; mgk_geom of it in gfar); u's own ghost
 // planes hold their last / first plane and b's ghost planes their b.  has_lo / has_hi: a neighbour exists on that side.
@@ -1749,6 +1761,12 @@ struct SRRArgs {
     long rs, ms, crs, cms;
     int nty, kcc;            // tiles in y, coarse planes per chunk
     T a0, a1, a2, a3, a4, a5, a6, dinv, scale, dinv_c, scale_c;
+    // z-slab of a multi-GPU run (k_srr4b): planes -1 / nz of u and b are the fields' ghost planes; plane -2 of u (far_lo), planes
+    // nz+1 and nz+2 of u (far_hi, far2_hi) and plane nz+1 of b (bfar_hi) come in separate plane buffers (pointers at their interior
+    // origin).  An inner slab (has_hi) owns nz = 2 nzc fine planes and completes its last coarse plane with the residual of plane nz.
+    const T *far_lo, *far_hi, *far2_hi, *bfar_hi;
+    int has_lo, has_hi;
+    int kcbeg, kcend;        // coarse planes [kcbeg, kcend) produced by this launch (whole grid / slab: 0, nzc)
 };
 template <typename T, int WX, int TY>
 __global__ void __launch_bounds__(64 * WX) k_srr(const SRRArgs<T> a) {
@@ -1763,7 +1781,7 @@ __global__ void __launch_bounds__(64 * WX) k_srr(const SRRArgs<T> a) {
     if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
     const int ty = bid % a.nty, tz = bid / a.nty;
     const int yb = TY * ty;
-    const int kc0 = tz * a.kcc, kc1 = min(kc0 + a.kcc, a.nzc);
+    const int kc0 = a.kcbeg + tz * a.kcc, kc1 = min(kc0 + a.kcc, a.kcend);      // (whole grids only: no far planes in this form)
     if (kc0 >= kc1) return;
     const int z0 = 2 * kc0, z1 = min(2 * kc1 + 1, a.nz);          // planes whose residual this chunk forms: [z0, z1)
     const int zs1 = (kc1 == a.nzc) ? a.nz : 2 * kc1;              // planes of the swept field this chunk stores: [z0, zs1)
@@ -2000,9 +2018,11 @@ __global__ void __launch_bounds__(64 * WX) k_srr4b(const SRRArgs<double> a) {
     if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
     const int ty = bid % a.nty, tz = bid / a.nty;
     const int yb = TY * ty;
-    const int kc0 = tz * a.kcc, kc1 = min(kc0 + a.kcc, a.nzc);
+    const int kc0 = a.kcbeg + tz * a.kcc, kc1 = min(kc0 + a.kcc, a.kcend);
     if (kc0 >= kc1) return;
-    const int z0 = 2 * kc0, z1 = min(2 * kc1 + 1, a.nz);          // planes whose residual this chunk forms: [z0, z1)
+    const int pmin = a.has_lo ? -2 : -1, pmax = a.has_hi ? a.nz + 2 : a.nz;      // u planes that exist
+    const int smin = a.has_lo ? -1 : 0, smax = a.has_hi ? a.nz + 1 : a.nz - 1;   // planes on which the sweep is real
+    const int z0 = 2 * kc0, z1 = min(2 * kc1 + 1, a.has_hi ? a.nz + 1 : a.nz);   // planes whose residual this chunk forms: [z0, z1)
     const int zs1 = (kc1 == a.nzc) ? a.nz : 2 * kc1;              // planes of the swept field this chunk stores: [z0, zs1)
     const int xl = VX * tid;
     const bool lastlane = (tid == 64 * WX - 1);                   // its last element is the ghost column x = nx: stays 0
@@ -2020,8 +2040,16 @@ __global__ void __launch_bounds__(64 * WX) k_srr4b(const SRRArgs<double> a) {
     for (int rr = 0; rr < R1; rr++) urb[rr] = (unsigned)(max(-1, min(yb - 2 + rr, a.ny)) + 1) * rowb;
 #pragma unroll
     for (int q = 0; q < R2; q++) brb[q] = (unsigned)(max(0, min(yb - 1 + q, a.ny)) + 1) * rowb;
-    auto URS = [&](int p) { return __builtin_amdgcn_make_buffer_rsrc((void *)(a.u - a.rs + (long)max(-1, min(p, a.nz)) * a.ms), 0, (int)plane_bytes, 0x00020000); };
-    auto BRS = [&](int p) { return __builtin_amdgcn_make_buffer_rsrc((void *)(a.b - a.rs + (long)max(0, min(p, a.nz - 1)) * a.ms), 0, (int)plane_bytes, 0x00020000); };
+    auto URS = [&](int p) {
+        const int pp = max(pmin, min(p, pmax));
+        const T *pl = (pp == -2) ? a.far_lo : (pp == a.nz + 1) ? a.far_hi : (pp == a.nz + 2) ? a.far2_hi : a.u + (long)pp * a.ms;
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(pl - a.rs), 0, (int)plane_bytes, 0x00020000);
+    };
+    auto BRS = [&](int p) {
+        const int pp = max(smin, min(p, smax));
+        const T *pl = (pp == a.nz + 1) ? a.bfar_hi : a.b + (long)pp * a.ms;
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(pl - a.rs), 0, (int)plane_bytes, 0x00020000);
+    };
     for (int i = tid; i < 3 * RS * LW; i += 64 * WX) (&ring[0][0][0])[i] = (T)0;
     for (int i = tid; i < 2 * 2 * LW; i += 64 * WX) (&halo[0][0][0])[i] = (T)0;
     for (int i = tid; i < 2 * R2 * (WX + 1); i += 64 * WX) { (&edgeW[0][0][0])[i] = (T)0; (&edgeE[0][0][0])[i] = (T)0; }
@@ -2066,7 +2094,7 @@ __global__ void __launch_bounds__(64 * WX) k_srr4b(const SRRArgs<double> a) {
         }
         // ---- the sweep of plane p on rows yb-1 .. yb+TY+1 ----
         {
-            const bool pin = (p >= 0 && p < a.nz);
+            const bool pin = (p >= smin && p <= smax);
             const bool pst = (p >= z0 && p < zs1);
             const int eb = p & 1, hb = p & 1, sl = (p + 3) % 3;
             // (loop-variant bounds: planes outside the grid have no valid row)
@@ -2227,35 +2255,42 @@ static void launch_srr(int w, unsigned nblk, hipStream_t s, const SRRArgs<T> &a)
     else hipLaunchKernelGGL((k_srr<T, 8, TY>), dim3(nblk), dim3(512), 0, s, a);
 }
 // out = J(u); bc = R (b - A out); uc0 (optional) = scale_c * (bc * dinv_c)
-extern "C" int mgk_sweep_residual_restrict_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
-                                               const double *b, const double *u, double *unew, double *bc, double *uc0,
-                                               double dinv_c, double scale_c, void *stream) {
+static int sweep_residual_restrict(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
+                                   const double *b, const double *u, double *unew, double *bc, double *uc0, double dinv_c, double scale_c,
+                                   const double *far_lo, const double *far_hi, const double *far2_hi, const double *bfar_hi,
+                                   int kcbeg, int kcend, void *stream) {
     typedef double T;
+    const bool slab = far_lo || far_hi;
     if (!c || !gf || !gc || !coef || !b || !u || !unew || u == unew || !bc) return fail(MGK_EINVAL, "mgk_sweep_residual_restrict_f64: bad arguments");
-    if (!srr_shape_ok<T>(gf, gc)) return fail(MGK_EINVAL, "mgk_sweep_residual_restrict_f64: built for full-row 3-D shapes (n = 127, 255, 511, 1023), whole grid");
+    if (kcbeg < 0 || kcend > gc->nz || kcbeg >= kcend) return fail(MGK_EINVAL, "mgk_sweep_residual_restrict: empty or out-of-range coarse plane range");
     SRRArgs<T> a; memset(&a, 0, sizeof(a));
     a.u = u + gf->org; a.b = b + gf->org; a.out = unew + gf->org; a.bc = bc + gc->org; a.uc0 = uc0 ? uc0 + gc->org : nullptr;
     a.nx = gf->nx; a.ny = gf->ny; a.nz = gf->nz; a.nxc = gc->nx; a.nyc = gc->ny; a.nzc = gc->nz;
     a.rs = gf->pitch; a.ms = gf->plane; a.crs = gc->pitch; a.cms = gc->plane;
     a.a0 = coef[0]; a.a1 = coef[1]; a.a2 = coef[2]; a.a3 = coef[3]; a.a4 = coef[4]; a.a5 = coef[5]; a.a6 = coef[6];
     a.dinv = dinv; a.scale = scale; a.dinv_c = dinv_c; a.scale_c = scale_c;
+    a.far_lo = far_lo; a.far_hi = far_hi; a.far2_hi = far2_hi; a.bfar_hi = bfar_hi;
+    a.has_lo = far_lo != nullptr; a.has_hi = far_hi != nullptr;
+    a.kcbeg = kcbeg; a.kcend = kcend;
     constexpr int VX = 16 / sizeof(T);
     const int w = (gf->nx + 1) / (64 * VX);
-    // tiles of 4 rows with the swept planes in LDS (1023^3: 5.44 ms against 6.22 ms for tiles of 2 rows with them in registers;
+    const int nkc = kcend - kcbeg;
+    // tiles of 4 rows with the swept planes in LDS (1023^3: 5.3 ms against 6.2 ms for tiles of 2 rows with them in registers;
     // 511^3: 0.72 against 0.82); tuning variants: 40 tiles of 2 rows, 42 tiles of 4 rows all in registers (spills at 8 waves)
     // (rows of <= 2 waves, n <= 255: tiles of 2 rows, two blocks per CU -- 255^3 0.119 against 0.136 ms);  41 forces tiles of 4
-    const int TYsel = (g_variant == 40) ? 2 : (g_variant == 41 || g_variant == 42) ? 4 : ((gf->nx + 1) / (64 * 2) >= 4 ? 4 : 2);
+    const int TYsel = slab ? 4 : (g_variant == 40) ? 2 : (g_variant == 41 || g_variant == 42) ? 4 : (w >= 4 ? 4 : 2);
     a.nty = (gf->ny + TYsel - 1) / TYsel;
     // blocks: a multiple of what the chip holds at once (512-thread blocks: one per CU); every chunk recomputes three planes
     const long target = (w > 4) ? (TYsel == 4 ? 256 : 512) : 1024;
     long nch = (a.nty >= target) ? 1 : (target + a.nty - 1) / a.nty;
-    if (g_zchunk > 0) nch = (gc->nz + g_zchunk - 1) / g_zchunk;
-    int kcc = (int)((gc->nz + nch - 1) / nch);
+    if (g_zchunk > 0) nch = (nkc + g_zchunk - 1) / g_zchunk;
+    else if (slab && c->chunk_planes > 0 && nch < (2 * nkc + c->chunk_planes - 1) / c->chunk_planes) nch = (2 * nkc + c->chunk_planes - 1) / c->chunk_planes;
+    int kcc = (int)((nkc + nch - 1) / nch);
     if (kcc < 4 && g_zchunk <= 0) kcc = 4;
-    if (kcc > gc->nz) kcc = gc->nz;
+    if (kcc > nkc) kcc = nkc;
     a.kcc = kcc;
-    const unsigned nblk = (unsigned)(a.nty * ((gc->nz + kcc - 1) / kcc));
-    if (TYsel == 4 && g_variant == 42) launch_srr<T, 4>(w, nblk, S(c, stream), a);      // (all in registers: spills at 8 waves)
+    const unsigned nblk = (unsigned)(a.nty * ((nkc + kcc - 1) / kcc));
+    if (TYsel == 4 && g_variant == 42 && !slab) launch_srr<T, 4>(w, nblk, S(c, stream), a);      // (all in registers: spills at 8 waves)
     else if (TYsel == 4) {
         hipStream_t st = S(c, stream);
         if (w <= 1) hipLaunchKernelGGL((k_srr4b<1>), dim3(nblk), dim3(64), 0, st, a);
@@ -2265,6 +2300,39 @@ extern "C" int mgk_sweep_residual_restrict_f64(mgk_ctx *c, const mgk_geom *gf, c
     } else launch_srr<T, 2>(w, nblk, S(c, stream), a);
     HIPCHK(hipGetLastError());
     return 0;
+}
+extern "C" int mgk_sweep_residual_restrict_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
+                                               const double *b, const double *u, double *unew, double *bc, double *uc0,
+                                               double dinv_c, double scale_c, void *stream) {
+    if (!srr_shape_ok<double>(gf, gc)) return fail(MGK_EINVAL, "mgk_sweep_residual_restrict_f64: built for full-row 3-D shapes (n = 127, 255, 511, 1023), whole grid");
+    return sweep_residual_restrict(c, gf, gc, coef, dinv, scale, b, u, unew, bc, uc0, dinv_c, scale_c, nullptr, nullptr, nullptr, nullptr, 0, gc->nz, stream);
+}
+// The same on a z-slab, coarse planes [kcbeg, kcend) of the slab's share.  `far` (geometry gfar = (nx, ny, 2), see mgk_jacobi2_slab_*):
+// lo ghost = plane nz-2 of the rank below, hi ghost = plane 1 of the rank above; `far2`: hi ghost = plane 2 of the rank above; `bfar`:
+// hi ghost = plane 1 of b of the rank above; u's and b's own ghost planes hold the neighbours' last / first plane.  A slab with a rank
+// above has nzf = 2 nzc and evaluates the sweep on the planes nz, nz+1 and the residual of plane nz itself (same operands, same
+// arithmetic as the owner: same bits), so its last coarse plane is complete; the last slab has nzf = 2 nzc + 1.
+extern "C" int mgk_sweep_residual_restrict_slab_ok_f64(const mgk_geom *gf, const mgk_geom *gc) {
+    if (!gf || !gc || gf->dim != 3 || gc->dim != 3 || gf->nx != 2 * gc->nx + 1 || gf->ny != 2 * gc->ny + 1) return 0;
+    if (gf->nz != 2 * gc->nz && gf->nz != 2 * gc->nz + 1) return 0;
+    if ((gf->nx + 1) % 128 != 0 || (gf->ny + 1) % 4 != 0) return 0;
+    const int w = (gf->nx + 1) / 128;
+    return (w == 1 || w == 2 || w == 4 || w == 8) && gc->nz >= 1 && gf->nz >= 4;
+}
+extern "C" int mgk_sweep_residual_restrict_slab_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const mgk_geom *gfar, const double *coef,
+                                                    double dinv, double scale, const double *b, const double *u, double *unew,
+                                                    const double *far, const double *far2, const double *bfar, int has_lo, int has_hi,
+                                                    double *bc, int kcbeg, int kcend, void *stream) {
+    if (!mgk_sweep_residual_restrict_slab_ok_f64(gf, gc)) return fail(MGK_EINVAL, "mgk_sweep_residual_restrict_slab_f64: shape not built");
+    if ((has_lo || has_hi) && (!gfar || !far || gfar->dim != 3 || gfar->nz != 2 || gfar->nx != gf->nx || gfar->ny != gf->ny || gfar->pitch != gf->pitch))
+        return fail(MGK_EINVAL, "mgk_sweep_residual_restrict_slab_f64: the far-plane fields must have the geometry (nx, ny, 2) of the slab");
+    if (has_hi && (!far2 || !bfar || gf->nz != 2 * gc->nz)) return fail(MGK_EINVAL, "mgk_sweep_residual_restrict_slab_f64: a slab with a rank above has nzf = 2 nzc and needs far2 / bfar");
+    if (!has_hi && gf->nz != 2 * gc->nz + 1) return fail(MGK_EINVAL, "mgk_sweep_residual_restrict_slab_f64: the last slab has nzf = 2 nzc + 1");
+    const double *lo = has_lo ? far + gfar->org - gfar->plane : nullptr;
+    const double *hi = has_hi ? far + gfar->org + 2 * gfar->plane : nullptr;
+    const double *hi2 = has_hi ? far2 + gfar->org + 2 * gfar->plane : nullptr;
+    const double *bhi = has_hi ? bfar + gfar->org + 2 * gfar->plane : nullptr;
+    return sweep_residual_restrict(c, gf, gc, coef, dinv, scale, b, u, unew, bc, nullptr, 0.0, 0.0, lo, hi, hi2, bhi, kcbeg, kcend, stream);
 }
 
 // 2-D version of the two-sweep pass: blocks of 64*WX lanes march along y over an x tile of 128*WX columns; a lane owns one

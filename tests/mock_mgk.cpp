@@ -496,6 +496,54 @@ int mgk_sweep_residual_restrict_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_ge
     });
 }
 
+// the two on a z-slab (far planes as the halo exchange delivers them; see include/mgk.h)
+static int g_calls_j2n_slab = 0, g_calls_srr_slab = 0, g_calls_srr = 0, g_calls_j2n = 0;
+static void print_stats() { if (getenv("MOCK_MGK_STATS")) fprintf(stderr, "MOCK_MGK_STATS j2n=%d srr=%d j2n_slab=%d srr_slab=%d\n", g_calls_j2n, g_calls_srr, g_calls_j2n_slab, g_calls_srr_slab); }
+static struct StatsAtExit { StatsAtExit() { atexit(print_stats); } } g_stats_at_exit;
+int mgk_jacobi2_sumsq_slab_f64(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gf, const double *coef, double dinv, double scale, const double *b, const double *u, double *o,
+                               const double *far, int lo, int hi, int z0, int z1, int part_off, int *nparts, void *) {
+    if (!c || !g || g->dim != 3 || !coef || !b || !u || !o || u == o || !nparts || part_off < 0 || part_off >= (int)c->partials.size()) return fail(MGK_EINVAL, "mgk_jacobi2_sumsq_slab_f64");
+    if (z0 < 0 || z1 > g->nz || z0 >= z1) return fail(MGK_EINVAL, "mgk_jacobi2_sumsq_slab_f64: range");
+    __atomic_fetch_add(&g_calls_j2n_slab, 1, __ATOMIC_RELAXED);
+    std::vector<double> r(g->total, 0.0);
+    st_op<double>(M_RESIDUAL, *g, coef, 1, 1, 0, 0, 0, b, u, (const double *)nullptr, r.data(), z0, z1);      // u's ghost planes are valid
+    c->partials[part_off] = sumsq_field<double>(*g, r.data(), z0, z1);
+    *nparts = 1;
+    return jacobi2_api<double>(c, g, gf, coef, dinv, scale, b, u, o, far, lo, hi, z0, z1);
+}
+int mgk_sweep_residual_restrict_slab_ok_f64(const mgk_geom *gf, const mgk_geom *gc) {
+    return (gf && gc && gf->dim == 3 && gc->dim == 3 && gf->nx == 2 * gc->nx + 1 && gf->ny == 2 * gc->ny + 1 && (gf->nz == 2 * gc->nz || gf->nz == 2 * gc->nz + 1) &&
+            gf->nx >= 7 && gf->nz >= 4 && gc->nz >= 1) ? 1 : 0;
+}
+int mgk_sweep_residual_restrict_slab_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const mgk_geom *gfar, const double *coef, double dinv, double scale,
+                                         const double *b, const double *u, double *o, const double *far, const double *far2, const double *bfar, int has_lo, int has_hi,
+                                         double *bc, int k0, int k1, void *) {
+    if (!c || !coef || !b || !u || !o || u == o || !bc || !mgk_sweep_residual_restrict_slab_ok_f64(gf, gc)) return fail(MGK_EINVAL, "mgk_sweep_residual_restrict_slab_f64");
+    if ((has_lo || has_hi) && (!far || !far_ok(gf, gfar))) return fail(MGK_EINVAL, "mgk_sweep_residual_restrict_slab_f64: far field");
+    if (has_hi && (!far2 || !bfar || gf->nz != 2 * gc->nz)) return fail(MGK_EINVAL, "mgk_sweep_residual_restrict_slab_f64: inner slab");
+    if (!has_hi && gf->nz != 2 * gc->nz + 1) return fail(MGK_EINVAL, "mgk_sweep_residual_restrict_slab_f64: last slab");
+    if (k0 < 0 || k1 > gc->nz || k0 >= k1) return fail(MGK_EINVAL, "mgk_sweep_residual_restrict_slab_f64: coarse range");
+    __atomic_fetch_add(&g_calls_srr_slab, 1, __ATOMIC_RELAXED);
+    const mgk_geom F = *gf, Cg = *gc; std::vector<double> k(coef, coef + 7);
+    return run(c, [=] {
+        // extended slab: interior planes = planes -2 .. nz+1 of the slab (index + 2), hi ghost = plane nz+2
+        mgk_geom E; geom3<double>(&E, F.nx, F.ny, F.nz + 4);
+        std::vector<double> ue(E.total, 0.0), be(E.total, 0.0), we(E.total, 0.0), re(E.total, 0.0);
+        const size_t pl = (size_t)F.plane;
+        auto plane_e = [&](std::vector<double> &v, int p) { return &v[(size_t)(p + 3) * pl]; };      // plane p of the slab inside an extended field
+        for (int p = -1; p <= F.nz; p++) { memcpy(plane_e(ue, p), u + (size_t)(p + 1) * pl, sizeof(double) * pl); memcpy(plane_e(be, p), b + (size_t)(p + 1) * pl, sizeof(double) * pl); }
+        if (has_lo) memcpy(plane_e(ue, -2), far, sizeof(double) * pl);
+        if (has_hi) { memcpy(plane_e(ue, F.nz + 1), far + 3 * pl, sizeof(double) * pl); memcpy(plane_e(ue, F.nz + 2), far2 + 3 * pl, sizeof(double) * pl);
+                      memcpy(plane_e(be, F.nz + 1), bfar + 3 * pl, sizeof(double) * pl); }
+        const int smin = has_lo ? -1 : 0, smax = has_hi ? F.nz + 1 : F.nz - 1, rmax = has_hi ? F.nz : F.nz - 1;
+        st_op<double>(M_JACOBI, E, k.data(), dinv, scale, 0, 0, 0, be.data(), ue.data(), (const double *)nullptr, we.data(), smin + 2, smax + 3);
+        st_op<double>(M_RESIDUAL, E, k.data(), 1, 1, 0, 0, 0, be.data(), we.data(), (const double *)nullptr, re.data(), 2, rmax + 3);
+        restrict_fw<double>(E, Cg, re.data() + 2 * pl, bc, k0, k1);                                   // fine plane 0 of the slab = interior plane 2 of the extended field
+        const int zs0 = 2 * k0, zs1 = (k1 == Cg.nz) ? F.nz : 2 * k1;
+        for (int kk = zs0; kk < zs1; kk++) for (int i = 0; i < F.ny; i++) memcpy(&at(o, F, kk, i, 0), &at(we.data(), E, kk + 2, i, 0), sizeof(double) * (size_t)F.nx);
+    });
+}
+
 // the fused forms on a row-table operator (2-D stretched meshes)
 int mgk_tail_cycle_rowcoef_f64(mgk_ctx *c, const mgk_geom *g0, int nl, const int *n, const double *const *ctab, const double *const *dtab, double s, int v0, int v1, const double *b, double *u, void *) {
     if (!ctab || !dtab) return fail(MGK_EINVAL, "mgk_tail_cycle_rowcoef_f64");

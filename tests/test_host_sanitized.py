@@ -121,8 +121,11 @@ def test_own_driver_bad_options_under_sanitizers(san, tmp_path):
 
 @pytest.mark.parametrize("P,npts,levels,dmin,extra", [(2, 33, 4, 15, []), (3, 33, 4, 15, []), (4, 65, 5, 15, []), (2, 33, 4, 15, ["mixed"]), (8, 65, 4, 31, [])])
 def test_slab_ranks_under_sanitizers(san, tmp_path, P, npts, levels, dmin, extra):
-    out = _run(san["slab"], [str(P), str(npts), str(levels), str(dmin)] + extra, tmp_path)
+    out = _run(san["slab"], [str(P), str(npts), str(levels), str(dmin)] + extra, tmp_path, env={"MOCK_MGK_STATS": "1"})
     assert f"SAN_SLAB_OK P={P}" in out
+    if not extra:           # fp64: the slab forms of the norm + two sweeps pass and of the sweep inside the restriction were taken
+        m = re.search(r"MOCK_MGK_STATS j2n=(\d+) srr=(\d+) j2n_slab=(\d+) srr_slab=(\d+)", out)
+        assert m and int(m.group(3)) > 0 and int(m.group(4)) > 0, out[-400:]
 
 
 # objects the REFERENCE's own code never releases (rv[0] is duplicated twice, src/solver.c:1460 and :1515; the PCMG and

@@ -748,3 +748,78 @@ def test_sweep_fused_with_residual_restrict_wide_rows(mgk, nx, ny, nz):
     mgk.L.mgk_set_tuning(-1, -1)
     for p in (du, db, dw, dbc, duc, w_ref, bc_ref, uc_ref):
         mgk.free(p)
+
+
+def _far_field(mgk, gfar, n, lo_plane=None, hi_plane=None):
+    """far-plane field of geometry (n, n, 2): lo / hi ghost plane filled with the given n x n planes (None: zeros)"""
+    f = np.zeros(gfar.total)
+    for k, pl in ((-1, lo_plane), (2, hi_plane)):
+        if pl is None:
+            continue
+        for i in range(n):
+            o = gfar.org + k * gfar.plane + i * gfar.pitch
+            f[o:o + n] = pl[i]
+    return mgk.upload(f)
+
+
+@pytest.mark.parametrize("n,cuts", [(127, (0, 20, 44, 63)), (127, (0, 2, 61, 63)), (255, (0, 64, 127))])
+def test_four_pass_kernels_on_slabs_bit_exact(mgk, orc, n, cuts):
+    """mgk_sweep_residual_restrict_slab_f64 and mgk_jacobi2_sumsq_slab_f64 on z-slabs (coarse plane ranges `cuts`): every slab, given
+    its neighbours' planes the way the halo exchange delivers them (ghost planes of u and b, far / far2 / bfar), reproduces its part
+    of the whole-grid results bit for bit -- swept field, coarse right-hand side, two-sweep field -- and the slabs' norm partials sum
+    to the whole-grid norm; plane-range launches (interior first, boundaries after) included"""
+    rng = np.random.default_rng(4100 + n + len(cuts))
+    nc = (n - 1) // 2
+    As = _stencil(orc, 3, n)
+    dinv = 1.0 / As[3]
+    u, b = _rand(rng, n ** 3), _rand(rng, n ** 3)
+    L, coef = mgk.L, mgk.coef(As)
+    # whole-grid reference from the kernels the slab forms replace (themselves pinned to the oracle)
+    g, gc = mgk.geom(3, n), mgk.geom(3, nc)
+    du, db, dw, dbc, d2 = mgk.to_field(g, u), mgk.to_field(g, b), mgk.field(g), mgk.field(gc), mgk.field(g)
+    mgk._chk(L.mgk_jacobi_f64(mgk.ctx, C.byref(g), coef, dinv, 0.8, db, du, dw, None))
+    mgk._chk(L.mgk_residual_restrict_f64(mgk.ctx, C.byref(g), C.byref(gc), coef, db, dw, dbc, None))
+    mgk._chk(L.mgk_jacobi2_f64(mgk.ctx, C.byref(g), coef, dinv, 0.8, db, du, d2, None))
+    w_ref = mgk.from_field(g, dw).reshape(n, n, n)
+    bc_ref = mgk.from_field(gc, dbc).reshape(nc, nc, nc)
+    u2_ref = mgk.from_field(g, d2).reshape(n, n, n)
+    r = orc.residual(3, n, As, b, u)
+    norm_ref = float(np.dot(r, r))
+    for p in (du, db, dw, dbc, d2):
+        mgk.free(p)
+    U, B = u.reshape(n, n, n), b.reshape(n, n, n)
+    total = 0.0
+    for s in range(len(cuts) - 1):
+        kc0, kc1 = cuts[s], cuts[s + 1]
+        last = (s == len(cuts) - 2)
+        z0, z1 = 2 * kc0, (n if last else 2 * kc1)
+        nz, nzc = z1 - z0, kc1 - kc0
+        has_lo, has_hi = int(s > 0), int(not last)
+        gs, gcs, gfar = mgk.geom(3, n, n, nz), mgk.geom(3, nc, nc, nzc), mgk.geom(3, n, n, 2)
+        assert L.mgk_sweep_residual_restrict_slab_ok_f64(C.byref(gs), C.byref(gcs)) == 1
+        us, bs = _slab_field(mgk, gs, u, n, z0), _slab_field(mgk, gs, b, n, z0)
+        far = _far_field(mgk, gfar, n, U[z0 - 2] if has_lo else None, U[z1 + 1] if has_hi else None)
+        far2 = _far_field(mgk, gfar, n, None, U[z1 + 2] if has_hi and z1 + 2 < n else None)
+        bfar = _far_field(mgk, gfar, n, None, B[z1 + 1] if has_hi else None)
+        out, bcs = mgk.field(gs), mgk.field(gcs)
+        ranges = ((1, nzc - 2), (0, 1), (nzc - 2, nzc)) if nzc >= 5 else ((0, nzc),)
+        for k0, k1 in ranges:
+            mgk._chk(L.mgk_sweep_residual_restrict_slab_f64(mgk.ctx, C.byref(gs), C.byref(gcs), C.byref(gfar), coef, dinv, 0.8, bs, us, out,
+                                                            far, far2, bfar, has_lo, has_hi, bcs, k0, k1, None))
+        assert np.array_equal(mgk.from_field(gs, out).reshape(nz, n, n), w_ref[z0:z1]), f"slab {s}: swept field"
+        assert np.array_equal(mgk.from_field(gcs, bcs).reshape(nzc, nc, nc), bc_ref[kc0:kc1]), f"slab {s}: coarse right-hand side"
+        # two sweeps + norm, plane ranges; partial slots appended
+        mgk._chk(L.mgk_memset0(mgk.ctx, out, 8 * gs.total, None))
+        n1, off = C.c_int(0), 0
+        zr = ((2, nz - 2), (0, 2), (nz - 2, nz)) if nz >= 6 else ((0, nz),)
+        for a0, a1 in zr:
+            mgk._chk(L.mgk_jacobi2_sumsq_slab_f64(mgk.ctx, C.byref(gs), C.byref(gfar), coef, dinv, 0.8, bs, us, out, far, has_lo, has_hi,
+                                                  a0, a1, off, C.byref(n1), None))
+            off += n1.value
+        ss = C.c_double(0.0)
+        mgk._chk(L.mgk_partials_finish(mgk.ctx, off, C.byref(ss), None))
+        total += ss.value
+        assert np.array_equal(mgk.from_field(gs, out).reshape(nz, n, n), u2_ref[z0:z1]), f"slab {s}: two-sweep field"
+        for p in (us, bs, far, far2, bfar, out, bcs):
+            mgk.free(p)
+    assert abs(total - norm_ref) <= 1e-13 * norm_ref
