@@ -127,10 +127,9 @@ def cycle_compulsory_bytes(dim, npts, levels, precision):
     """3-D fp64, fine level: norm + two sweeps in one pass 24 + last pre-smoothing sweep fused with residual/restriction 24+2*8/8 +
     fused prolongation sweep 24+8/8 + two sweeps in one pass 24 = 99 B/unknown on the full-row shapes those two kernels are built
     for (n = 255, 511, 1023; otherwise sweep+norm 24 + pair 24 + residual/restriction 17: 114); coarser levels have no norm pass and get their
-    first (zero-guess) sweep from the restriction kernel (+8 written): 24 + 17 + 8/8 + 25 + 24 = 91.  2-D (no fused
-    residual/restriction, pairs on levels >= 2047^2 only): fine 24 + 24 + 24 (residual) + 10 (restriction) + 26 + 24 = 132,
-    coarser levels 16 + 48 + 34 + 26 + 48 = 172 (one sweep per pass), capped at what the per-operation count of SURVEY 8(d3)
-    gives.  Mixed precision: the fp32 inner cycle moves half of the 3-D figures (no norm pass: 45 / 45.5) plus the fp64 outer
+    first (zero-guess) sweep from the restriction kernel (+8 written): 24 + 17 + 8/8 + 25 + 24 = 91.  2-D: the same four
+    passes on levels >= 2047^2 (99 / 91), 124 on the levels >= 127^2 that sweep once per pass, the per-operation count of
+    SURVEY 8(d3) (172) below.  Mixed precision: the fp32 inner cycle moves half of the 3-D figures (no norm pass: 45 / 45.5) plus the fp64 outer
     correction+residual pass, 32 B per fine unknown.  The coarsest level makes v1 = 3 plain sweeps (16 + 24 + 24)."""
     tot = 0.0
     for l in range(levels):
@@ -141,7 +140,11 @@ def cycle_compulsory_bytes(dim, npts, levels, precision):
         elif dim == 3:
             per = (99.0 if (n + 1) in (256, 512, 1024) and precision != "mixed" else 114.0) if l == 0 else 91.0
         else:
-            per = 132.0 if (l == 0 and n >= 2047) else 172.0
+            # 2-D, round 2: levels >= 2047^2 (pairs of sweeps): norm + two sweeps 24, sweep + residual + restriction 26, prolongation
+            # sweep 25, two sweeps 24 = 99 at level 0 (115 - 24 without the norm pass below it: 91); levels >= 127^2 without pairs:
+            # zero-guess sweep from the restriction above (1), one sweep 24, sweep + residual + restriction 26, prolongation sweep 25,
+            # two sweeps 48 = 124; below that the kernel-per-operation count
+            per = (99.0 if l == 0 else 91.0) if n >= 2047 else (124.0 if n >= 127 else 172.0)
         if precision == "mixed":
             per = (91.0 / 2 if l else 91.0 / 2 + 32.0) if not (l == levels - 1 and levels > 1) else 32.0
         tot += per * N

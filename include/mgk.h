@@ -293,6 +293,12 @@ int  mgk_sweep_residual_restrict_ok_f64(const mgk_geom *gf, const mgk_geom *gc);
 int  mgk_sweep_residual_restrict_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
                                      const double *b, const double *u, double *unew, double *bc, double *uc0,
                                      double dinv_c, double scale_c, void *stream);
+/* the 2-D forms of the two (any vertex-centred 2-D grid): */
+int  mgk_jacobi2_2d_sumsq_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale,
+                              const double *b, const double *u, double *unew, double *sumsq_host, void *stream);
+int  mgk_sweep_residual_restrict_2d_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
+                                        const double *b, const double *u, double *unew, double *bc, double *uc0,
+                                        double dinv_c, double scale_c, void *stream);
 /* the two on a z-slab of a multi-GPU run.  far / far2 / bfar: fields of geometry gfar = (nx, ny, 2) (as for mgk_jacobi2_slab_f64) whose
  * ghost planes hold, after a halo exchange, -- far: lo = plane nz-2 of the rank below, hi = plane 1 of the rank above (the
  * sender puts its planes 1 and nz-2 into the two interior planes); far2: hi = plane 2 of u of the rank above (sender: interior

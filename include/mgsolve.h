@@ -46,9 +46,10 @@ typedef struct mg_config {
                          * (temporal blocking, levels >= pair_min_n, both precisions); bit 7 (testing): bit 2 also below 255^3, where two short
                          * kernels are quicker; bit 8: the fused residual+restriction also writes the coarse level's first (zero-guess)
                          * sweep; bit 9: the levels that fit in LDS (n <= 15 in 3-D, <= 63 in 2-D) run as ONE kernel per cycle (mgk_tail_cycle_*);
-                         * bit 10 (fp64, 3-D, whole grids of full-row shape): the pass of bit 3 makes the first TWO sweeps of the next cycle
-                         * (mgk_jacobi2_sumsq_f64) and the last pre-smoothing sweep runs inside the restriction's pass
-                         * (mgk_sweep_residual_restrict_f64): the fine level moves 99 instead of 115 B per unknown and cycle;
+                         * bit 10 (fp64, 3-D, full-row shapes n = 127 .. 1023, whole grids and z-slabs): the pass of bit 3 makes the first TWO
+                         * sweeps of the next cycle (mgk_jacobi2_sumsq_f64 / _slab_f64) and the last pre-smoothing sweep runs inside the
+                         * restriction's pass (mgk_sweep_residual_restrict_f64 / _slab_f64): the fine level moves 99 instead of 115 B per
+                         * unknown and cycle;
                          * default (-1): bits 0-5, 8, 9 and 10 on */
     int overlap;        /* nranks > 1: halo of sweep k on the comm stream while sweep k's interior runs; default on (-1) */
     int graph;          /* replay the launch-bound coarse levels as one captured HIP graph; default on (-1) */

@@ -707,8 +707,9 @@ static int smooth_chebyshev(mg_solver *s, int l, int maxit) {
  * fuse bit 10): fp64, whole 3-D grids of full-row shape.  Not when that restriction is the first kernel of the coarse-level graph while
  * this level's sweeps run outside it (the replayed kernel would keep the buffers of the recording cycle; the swap is made on the host) */
 static int srr_ok(const mg_solver *s, int P, int l) {
-    if (!(s->cfg.fuse & 1024) || P != 0 || s->cfg.dim != 3 || s->cfg.mesh || s->cfg.ksp_type != MG_KSP_RICHARDSON) return 0;
+    if (!(s->cfg.fuse & 1024) || P != 0 || s->cfg.mesh || s->cfg.ksp_type != MG_KSP_RICHARDSON) return 0;
     if (l + 1 >= s->levels || (s->lgraph && l + 1 == s->lgraph)) return 0;
+    if (s->cfg.dim == 2) return s->L[l].n >= 127;          /* mgk_sweep_residual_restrict_2d_f64: any 2-D grid; below that two short kernels */
     if (s->L[l].distributed) {
         /* z-slab: the neighbours' planes arrive in ONE grouped exchange (u and b ghosts, far, far2, bfar) */
         const mg_fset *F = &s->L[l].f[0];
@@ -1079,6 +1080,10 @@ static int descend_restrict(mg_solver *s, int P, int l, int no_jz) {
         mg_fset *F = &Lf->f[P], *Cq = &s->L[l].f[P];
         const int sweeps = (l == levels - 1) ? v[1] : v[0];
         const int jz = (s->cfg.fuse & 256) && !no_jz && sweeps >= 1 && !Cq->guess_nonzero;
+        if (s->cfg.dim == 2)
+            CHK(mgk_sweep_residual_restrict_2d_f64(s->ctx, &F->g, &Cq->g, Lf->coef, Lf->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u,
+                                                   (double *)F->tmp, (double *)Cq->b, jz ? (double *)Cq->tmp : NULL, s->L[l].dinv, s->cfg.scale, NULL));
+        else
         CHK(mgk_sweep_residual_restrict_f64(s->ctx, &F->g, &Cq->g, Lf->coef, Lf->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u,
                                             (double *)F->tmp, (double *)Cq->b, jz ? (double *)Cq->tmp : NULL, s->L[l].dinv, s->cfg.scale, NULL));
         swap_ptr(&F->u, &F->tmp);
@@ -1333,10 +1338,12 @@ static int vcycle_once(mg_solver *s) {
              * cycle follows; u itself is untouched, so stopping here leaves the solution as the reference has it. */
             /* (not when level 0 feeds the coarse-level graph: adopting two sweeps at once changes how often level 0 swaps u / tmp in
              * a cycle from the recording cycle's count, and the recorded restriction reads level 0's buffers) */
-            const int two = (s->cfg.fuse & 1024) && (s->cfg.fuse & 32) && !s->cfg.mesh && !L->distributed && s->cfg.dim == 3 &&
-                            s->cfg.v[0] >= 2 && L->n >= s->cfg.pair_min_n && s->lgraph != 1 && mgk_jacobi2_sumsq_ok_f64(&F->g);
+            const int two = (s->cfg.fuse & 1024) && (s->cfg.fuse & 32) && !s->cfg.mesh && !L->distributed &&
+                            s->cfg.v[0] >= 2 && L->n >= s->cfg.pair_min_n && s->lgraph != 1 && (s->cfg.dim == 2 || mgk_jacobi2_sumsq_ok_f64(&F->g));
             if (s->cfg.mesh) CHK(mgk_jacobi_sumsq_rowcoef_f64(s->ctx, &F->g, L->ctab, L->dtab, s->cfg.scale, (const double *)F->b,
                                                               (const double *)F->u, (double *)F->tmp, &ss, NULL));
+            else if (two && s->cfg.dim == 2) CHK(mgk_jacobi2_2d_sumsq_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b,
+                                                                          (const double *)F->u, (double *)F->tmp, &ss, NULL));
             else if (two) CHK(mgk_jacobi2_sumsq_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u,
                                                     (double *)F->tmp, &ss, NULL));      /* ... and the second one: two sweeps in the pass */
             else CHK(mgk_jacobi_sumsq_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u,

@@ -2347,8 +2347,9 @@ struct J2dArgs {
     int ntx, yc;
     double a0, a2, a3, a4, a6, dinv, scale;
     const double *ctab, *dtab;      // optional (stretched meshes): 5 coefficients {(i-1), W, C, E, (i+1)} and 1/diag per grid row
+    double *partials;               // NORM: per-block partial of || b - A u ||^2 of the INPUT field
 };
-template <int WX>
+template <int WX, bool NORM = false>
 __global__ void __launch_bounds__(64 * WX) k_jacobi2_2d(const J2dArgs a) {
     constexpr int VX = 2, NT = 64 * WX, TXE = VX * (NT - 2);          // columns a block produces
     __shared__ double eUW[2][WX], eUE[2][WX], ePW[2][WX], ePE[2][WX];   // wave-edge values of u(row) / u'(row), double buffered
@@ -2357,7 +2358,8 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2_2d(const J2dArgs a) {
     const int tx = blockIdx.x % a.ntx, tyc = blockIdx.x / a.ntx;
     const int x0 = tx * TXE - VX + VX * tid;                          // may be -2 (left of the grid) on the first lane
     const int y0 = tyc * a.yc, y1 = min(y0 + a.yc, a.ny);
-    if (y0 >= y1) return;
+    if (y0 >= y1) { if (NORM && tid == 0) a.partials[blockIdx.x] = 0.0; return; }
+    double nacc = 0.0;
     const bool xin = x0 >= 0 && x0 < a.nx;                            // the pair holds at least one grid column
     const bool lastvec = (x0 + VX > a.nx);
     const bool outl = xin && tid >= 1 && tid <= NT - 2;               // this lane stores second-sweep values
@@ -2402,6 +2404,7 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2_2d(const J2dArgs a) {
                 const double zz = res * pd;
                 wp.v[e] = ub.v[e] + a.scale * zz;
                 if (!pin || !xin || (lastvec && x0 + e >= a.nx)) wp.v[e] = 0.0;
+                if (NORM) nacc += (outl && p >= y0 && p < y1 && !(lastvec && x0 + e >= a.nx)) ? res * res : 0.0;     // points this block owns
             }
         }
         // ---- second sweep of row t (x neighbours of u'(t): shuffles of wc, wave edges written in the previous step) ----
@@ -2432,9 +2435,14 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2_2d(const J2dArgs a) {
         __syncthreads();
         b0 = b1; b1 = bn; wm = wc; wc = wp; ua = ub; ub = uc; uc = ud;
     }
+    if (NORM) {
+        __shared__ double red[16];
+        const double sblk = block_sum(nacc, red);
+        if (tid == 0) a.partials[blockIdx.x] = sblk;
+    }
 }
 static int jacobi2_2d(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale, const double *ctab, const double *dtab,
-                      const double *b, const double *u, double *unew, void *stream) {
+                      const double *b, const double *u, double *unew, void *stream, int *norm_parts = nullptr) {
     if (!c || !g || (!coef && !ctab) || (ctab && !dtab) || !b || !u || !unew || u == unew || g->dim != 2) return fail(MGK_EINVAL, "mgk_jacobi2_2d: bad arguments (2-D)");
     J2dArgs a; memset(&a, 0, sizeof(a));
     a.u = u + g->org; a.b = b + g->org; a.out = unew + g->org;
@@ -2450,9 +2458,23 @@ static int jacobi2_2d(mgk_ctx *c, const mgk_geom *g, const double *coef, double 
     if (yc > g->ny) yc = g->ny;
     a.yc = yc;
     const long nty = (g->ny + yc - 1) / yc;
-    hipLaunchKernelGGL((k_jacobi2_2d<WX>), dim3((unsigned)(a.ntx * nty)), dim3(64 * WX), 0, S(c, stream), a);
+    if (norm_parts) {
+        if (a.ntx * nty > c->max_partials) return fail(MGK_EINVAL, "mgk_jacobi2_2d_sumsq_f64: more blocks than partial slots");
+        a.partials = c->partials;
+        hipLaunchKernelGGL((k_jacobi2_2d<WX, true>), dim3((unsigned)(a.ntx * nty)), dim3(64 * WX), 0, S(c, stream), a);
+        *norm_parts = (int)(a.ntx * nty);
+    } else hipLaunchKernelGGL((k_jacobi2_2d<WX>), dim3((unsigned)(a.ntx * nty)), dim3(64 * WX), 0, S(c, stream), a);
     HIPCHK(hipGetLastError());
     return 0;
+}
+// two sweeps and || b - A u ||^2 of the input field (2-D form of mgk_jacobi2_sumsq_f64)
+extern "C" int mgk_jacobi2_2d_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
+                                        const double *b, const double *u, double *unew, double *sumsq_host, void *stream) {
+    if (!coef || !sumsq_host) return fail(MGK_EINVAL, "mgk_jacobi2_2d_sumsq_f64: bad arguments");
+    int nparts = 0;
+    int rc = jacobi2_2d(c, g, coef, dinv, scale, nullptr, nullptr, b, u, unew, stream, &nparts);
+    if (rc) return rc;
+    return finish_to_host(c, nparts, 1, S(c, stream), sumsq_host);
 }
 extern "C" int mgk_jacobi2_2d_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
                                   const double *b, const double *u, double *unew, void *stream) {
@@ -4485,6 +4507,137 @@ extern "C" int mgk_residual_restrict_2d_rowcoef_f64(mgk_ctx *c, const mgk_geom *
                                                     const double *u, double *bc, double *uc0, const double *dtab_c, double scale_c, void *stream) {
     if (!ctab_f) return fail(MGK_EINVAL, "mgk_residual_restrict_2d_rowcoef_f64: null table");
     return residual_restrict_2d(c, gf, gc, nullptr, ctab_f, dtab_c, b, u, bc, uc0, 1.0, scale_c, stream);
+}
+
+// 2-D form of mgk_sweep_residual_restrict_f64: out = J(u); bc = R (b - A out) [; uc0 = scale_c * (bc * dinv_c)] in one pass.
+// Like k_rr2d every WAVE is independent (no LDS, no barrier): lane l holds the column pair x0 = 2 (61 tx + l - 1); all lanes make
+// the sweep (the outer column of lanes 0 / 63 is not used), lanes 1 .. 62 the residual, lanes 1 .. 61 full weighting and the stores:
+// tiles overlap by three lanes.  Marches along y over a chunk of coarse rows; the chunk re-reads four fine rows.
+struct SRR2dArgs {
+    const double *u, *b;
+    double *out, *bc, *uc0;
+    int nx, ny, nxc, nyc;
+    long rs, crs;
+    int ntx, ycc;
+    double a0, a2, a3, a4, a6, dinv, scale, dinv_c, scale_c;
+};
+__global__ void __launch_bounds__(256) k_srr2d(const SRR2dArgs a) {
+    using VT = V16<double>;
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tx = wid % a.ntx, cy = wid / a.ntx;
+    const int ic0 = cy * a.ycc, ic1 = min(ic0 + a.ycc, a.nyc);
+    if (ic0 >= ic1) return;                                   // whole wave
+    const int pidx = tx * 61 + lane - 1;                      // pair index = coarse column of this lane
+    const int x0 = 2 * pidx;
+    const bool xin = (x0 >= 0 && x0 < a.nx);
+    const bool lastvec = (x0 + 2 > a.nx);                     // its second column is the ghost column x = nx
+    const bool store = (lane >= 1 && lane <= 61 && pidx < a.nxc + 1 && xin);       // stores of the swept field (pair inside the grid)
+    const bool cstore = (lane >= 1 && lane <= 61 && pidx < a.nxc);
+    const int xc = min(max(x0, 0), a.nx - 1);                 // clamped: every lane loads from inside the row, invalid lanes are zeroed
+    const double *up_ = a.u + xc, *bp_ = a.b + xc;
+    const int y0 = 2 * ic0, y1 = min(2 * ic1 + 1, a.ny);      // rows whose residual this chunk forms: [y0, y1)
+    const int ys1 = (ic1 == a.nyc) ? a.ny : 2 * ic1;          // rows of the swept field this chunk stores: [y0, ys1)
+    auto ldu = [&](int r) -> VT {
+        VT v = *reinterpret_cast<const VT *>(up_ + (long)min(max(r, -1), a.ny) * a.rs);
+        if (!xin) { v.v[0] = 0.0; v.v[1] = 0.0; }
+        return v;
+    };
+    auto ldb = [&](int r) -> VT {
+        VT v = ldv_stream(bp_ + (long)min(max(r, 0), a.ny - 1) * a.rs, true);
+        if (!xin) { v.v[0] = 0.0; v.v[1] = 0.0; }
+        return v;
+    };
+    const double w2[3][3] = {{0.0625, 0.125, 0.0625}, {0.125, 0.25, 0.125}, {0.0625, 0.125, 0.0625}};
+    const int t0 = y0 - 2;                                    // first step: the sweep of row y0 - 1
+    VT ua = ldu(t0), ub = ldu(t0 + 1), uc = ldu(t0 + 2), ud;
+    VT b1 = ldb(t0 + 1), bn, b0 = v16_zero<double>();
+    VT wm = b0, wc = b0, wp = b0;                             // swept rows t-1, t, t+1
+    double acc = 0.0, accn = 0.0;
+    for (int t = t0; t < y1; t++) {
+        const int p = t + 1;
+        ud = ldu(t + 3);
+        bn = ldb(t + 2);
+        // ---- the sweep of row p ----
+        {
+            const double Wv = lane_up<true>(ub.v[1]), Ev = lane_dn<true>(ub.v[0]);
+            const bool pin = (p >= 0 && p < a.ny);
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const double wv = (e == 0) ? Wv : ub.v[0];
+                const double ev = (e == 1) ? Ev : ub.v[1];
+                double s = a.a0 * ua.v[e];
+                s = s + a.a2 * wv;
+                s = s + a.a3 * ub.v[e];
+                s = s + a.a4 * ev;
+                s = s + a.a6 * uc.v[e];
+                const double res = b1.v[e] - s;
+                const double zz = res * a.dinv;
+                wp.v[e] = ub.v[e] + a.scale * zz;
+                if (!pin || !xin || (lastvec && e == 1)) wp.v[e] = 0.0;
+            }
+            if (store && p >= y0 && p < ys1) stv_stream(a.out + (long)p * a.rs + x0, wp);
+        }
+        // ---- residual of the swept row t, full weighting ----
+        if (t >= y0) {
+            const double Wv = lane_up<true>(wc.v[1]), Ev = lane_dn<true>(wc.v[0]);
+            VT r;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const double wv = (e == 0) ? Wv : wc.v[0];
+                const double ev = (e == 1) ? Ev : wc.v[1];
+                double s = a.a0 * wm.v[e];
+                s = s + a.a2 * wv;
+                s = s + a.a3 * wc.v[e];
+                s = s + a.a4 * ev;
+                s = s + a.a6 * wp.v[e];
+                r.v[e] = b0.v[e] - s;
+                if (!xin || (lastvec && e == 1)) r.v[e] = 0.0;
+            }
+            const double rn = lane_dn<true>(r.v[0]);
+            const bool even = ((t & 1) == 0);
+            const int di = even ? 0 : 1;
+            double pr = w2[di][0] * r.v[0];
+            acc += pr; if (even) accn += pr;
+            pr = w2[di][1] * r.v[1];
+            acc += pr; if (even) accn += pr;
+            pr = w2[di][2] * rn;
+            acc += pr; if (even) accn += pr;
+            if (even) {
+                const int ic = t / 2 - 1;                 // completed coarse row
+                if (ic >= ic0 && cstore) {
+                    const long oc = (long)ic * a.crs + pidx;
+                    a.bc[oc] = acc;
+                    if (a.uc0) { const double zq = acc * a.dinv_c; a.uc0[oc] = a.scale_c * zq; }
+                }
+                acc = accn; accn = 0.0;
+            }
+        }
+        b0 = b1; b1 = bn; wm = wc; wc = wp; ua = ub; ub = uc; uc = ud;
+    }
+}
+extern "C" int mgk_sweep_residual_restrict_2d_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
+                                                  const double *b, const double *u, double *unew, double *bc, double *uc0,
+                                                  double dinv_c, double scale_c, void *stream) {
+    if (!c || !gf || !gc || !coef || !b || !u || !unew || u == unew || !bc || gf->dim != 2 || gc->dim != 2)
+        return fail(MGK_EINVAL, "mgk_sweep_residual_restrict_2d_f64: bad arguments (2-D)");
+    if (gf->nx != 2 * gc->nx + 1 || gf->ny != 2 * gc->ny + 1) return fail(MGK_EINVAL, "mgk_sweep_residual_restrict_2d_f64: need nf = 2 nc + 1");
+    SRR2dArgs a; memset(&a, 0, sizeof(a));
+    a.u = u + gf->org; a.b = b + gf->org; a.out = unew + gf->org; a.bc = bc + gc->org; a.uc0 = uc0 ? uc0 + gc->org : nullptr;
+    a.nx = gf->nx; a.ny = gf->ny; a.nxc = gc->nx; a.nyc = gc->ny; a.rs = gf->pitch; a.crs = gc->pitch;
+    a.a0 = coef[0]; a.a2 = coef[1]; a.a3 = coef[2]; a.a4 = coef[3]; a.a6 = coef[4];
+    a.dinv = dinv; a.scale = scale; a.dinv_c = dinv_c; a.scale_c = scale_c;
+    a.ntx = (gc->nx + 1 + 60) / 61;                           // pairs 0 .. nxc (the last one holds the last fine column and the ghost column)
+    long nch = (4096 + a.ntx - 1) / a.ntx;                    // ~4096 waves (16 per CU); every chunk re-reads four fine rows
+    if (g_zchunk > 0) nch = (gc->ny + g_zchunk - 1) / g_zchunk;
+    int ycc = (int)((gc->ny + nch - 1) / nch);
+    if (ycc < 8 && g_zchunk <= 0) ycc = 8;
+    if (ycc > gc->ny) ycc = gc->ny;
+    a.ycc = ycc;
+    const long waves = (long)a.ntx * ((gc->ny + ycc - 1) / ycc);
+    hipLaunchKernelGGL(k_srr2d, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, S(c, stream), a);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -823,3 +823,41 @@ def test_four_pass_kernels_on_slabs_bit_exact(mgk, orc, n, cuts):
         for p in (us, bs, far, far2, bfar, out, bcs):
             mgk.free(p)
     assert abs(total - norm_ref) <= 1e-13 * norm_ref
+
+
+@pytest.mark.parametrize("nf", [3, 7, 63, 121 * 2 + 1, 127, 255, 1023, 2047])
+def test_2d_forms_of_the_four_pass_kernels_bit_exact(mgk, orc, nf):
+    """mgk_sweep_residual_restrict_2d_f64 == sweep, residual, full weighting (+ the coarse level's zero-guess sweep);
+    mgk_jacobi2_2d_sumsq_f64 == two sweeps + the norm of the input's residual; several y chunkings, tile edges (61 pairs per wave)"""
+    rng = np.random.default_rng(7300 + nf)
+    nc = (nf - 1) // 2
+    As, Ac = _stencil(orc, 2, nf), _stencil(orc, 2, nc)
+    dinv, dinv_c = 1.0 / As[2], 1.0 / Ac[2]
+    u, b = _rand(rng, nf ** 2), _rand(rng, nf ** 2)
+    gf, gc = mgk.geom(2, nf), mgk.geom(2, nc)
+    du, db, dw, dbc, duc0 = mgk.to_field(gf, u), mgk.to_field(gf, b), mgk.field(gf), mgk.field(gc), mgk.field(gc)
+    w1 = orc.jacobi(2, nf, As, 0.8, b, u)
+    bc = orc.restrict(2, nf, orc.residual(2, nf, As, b, w1))
+    w2 = orc.jacobi(2, nf, As, 0.8, b, w1)
+    r = orc.residual(2, nf, As, b, u)
+    ss = C.c_double(0.0)
+    for zc in (-1, 1, 5, 64):
+        mgk.L.mgk_set_tuning(-1, zc)
+        for f, g in ((dw, gf), (dbc, gc), (duc0, gc)):
+            mgk._chk(mgk.L.mgk_memset0(mgk.ctx, f, 8 * g.total, None))
+        mgk._chk(mgk.L.mgk_sweep_residual_restrict_2d_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), dinv, 0.8, db, du, dw, dbc, duc0,
+                                                          dinv_c, 0.8, None))
+        assert np.array_equal(mgk.from_field(gf, dw), w1), f"zc={zc}: swept field"
+        assert np.array_equal(mgk.from_field(gc, dbc), bc), f"zc={zc}: coarse right-hand side"
+        assert np.array_equal(mgk.from_field(gc, duc0), 0.8 * (bc * dinv_c))
+        for f, g, x in ((dw, gf, w1), (dbc, gc, bc)):
+            raw = mgk.raw_field(g, f)
+            assert abs(np.abs(raw).sum() - np.abs(x).sum()) <= 1e-9 * max(np.abs(x).sum(), 1e-300)      # ghosts / padding stay zero
+        mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dw, 8 * gf.total, None))
+        mgk._chk(mgk.L.mgk_jacobi2_2d_sumsq_f64(mgk.ctx, C.byref(gf), mgk.coef(As), dinv, 0.8, db, du, dw, C.byref(ss), None))
+        assert np.array_equal(mgk.from_field(gf, dw), w2), f"zc={zc}: two sweeps"
+        assert abs(ss.value - float(np.dot(r, r))) <= 1e-13 * float(np.dot(r, r))
+    mgk.L.mgk_set_tuning(-1, -1)
+    assert np.array_equal(mgk.from_field(gf, du), u)
+    for p in (du, db, dw, dbc, duc0):
+        mgk.free(p)

@@ -253,6 +253,28 @@ def test_two_sweep_norm_pass_and_sweep_inside_the_restriction(orc, npts, levels,
     s.close()
 
 
+@pytest.mark.parametrize("npts,levels,v,kw", [
+    (513, 9, (3, 3), {"pair_min_n": 127, "graph": 0}), (513, 9, (3, 3), {"pair_min_n": 127}), (1025, 10, (2, 2), {"pair_min_n": 255, "graph": 0}),
+    (513, 4, (4, 3), {"pair_min_n": 63, "graph": 0}), (257, 8, (3, 3), {}), (4097, 12, (3, 3), {}),
+])
+def test_two_sweep_norm_pass_and_sweep_inside_the_restriction_2d(orc, npts, levels, v, kw):
+    """the 2-D forms (mgk_jacobi2_2d_sumsq_f64, mgk_sweep_residual_restrict_2d_f64) in the cycle: bit-identical to the oracle and to the
+    same cycle without fuse bit 10"""
+    from multigrid_petsc_amd.solver import Solver
+    s = Solver(2, npts, levels, v=v, maxiter=80, scale=0.8, **kw)
+    s.set_rhs_problem()
+    it = s.solve()
+    u, rn = s.solution(), s.rnorm.copy()
+    s.close()
+    if npts <= 1025:
+        ref = orc.vcycle(2, npts, levels, v[0], v[1], maxiter=80, scale=0.8)
+        assert it == ref["iters"] and np.abs(rn / ref["rnorm"] - 1).max() <= RTOL and np.array_equal(u, ref["u"])
+    s2 = Solver(2, npts, levels, v=v, maxiter=80, scale=0.8, fuse=63 | 256 | 512, **kw)
+    s2.set_rhs_problem()
+    assert s2.solve() == it and np.array_equal(s2.solution(), u) and np.allclose(s2.rnorm, rn, rtol=1e-13, atol=0)
+    s2.close()
+
+
 @pytest.mark.parametrize("dim,npts,levels,v", [(3, 33, 4, (1, 1)), (3, 33, 4, (2, 3)), (3, 65, 5, (4, 2)), (3, 65, 6, (5, 5)),
                                                  (2, 129, 6, (2, 1)), (2, 257, 7, (4, 4))])
 def test_other_sweep_counts_with_all_fusions(orc, dim, npts, levels, v):
