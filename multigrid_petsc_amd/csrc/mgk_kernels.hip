@@ -4089,6 +4089,109 @@ extern "C" int mgk_restrict_finish_f32(mgk_ctx *c, const mgk_geom *gf, const mgk
     return restrict_finish<float>(c, gf, gc, r, bc, stream);
 }
 
+// 2-D form of the fused prolongation sweep as independent waves (round 2; the LDS-tile k_stencil<..MODE_PJACOBI> ran at 4.0 TB/s at
+// 4095^2): lane l holds the column pair x0 = 2 (62 tx + l - 1) and its parent column pair (l - 1 and l of the coarse row, the left one by
+// a DPP shift); the corrected rows y-1, y, y+1 live in registers (the correction is added when a row arrives), lanes 1 .. 62 sweep and
+// store: tiles overlap by two lanes.  Marches along y; two coarse rows are live (an even fine row has two parent rows).
+struct PJ2dArgs {
+    const double *u, *b, *uc;
+    double *out;
+    int nx, ny, nxc, nyc;
+    long rs, crs;
+    int ntx, yc;
+    double a0, a2, a3, a4, a6, dinv, scale;
+};
+__global__ void __launch_bounds__(256) k_pj2d(const PJ2dArgs a) {
+    using VT = V16<double>;
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tx = wid % a.ntx, cy = wid / a.ntx;
+    const int y0 = cy * a.yc, y1 = min(y0 + a.yc, a.ny);
+    if (y0 >= y1) return;                                     // whole wave
+    const int pidx = tx * 62 + lane - 1;                      // pair index = coarse column of the pair's second (odd) fine column
+    const int x0 = 2 * pidx;
+    const bool xin = (x0 >= 0 && x0 < a.nx);
+    const bool lastvec = (x0 + 2 > a.nx);
+    const bool store = (lane >= 1 && lane <= 62 && xin);
+    const int xc = min(max(x0, 0), a.nx - 1);
+    const double *up_ = a.u + xc, *bp_ = a.b + xc;
+    const double *cp_ = a.uc + min(max(pidx, -1), a.nxc);     // coarse column pidx (-1 and nxc are the ghost columns: zero)
+    // coarse row ic of this lane's column and of the column to its left (rows -1 and nyc are ghost rows: zero)
+    auto ldc = [&](int ic) -> double { return cp_[(long)min(max(ic, -1), a.nyc) * a.crs]; };
+    // u + P uc on row y: y odd has ONE parent row (y-1)/2, y even two, y/2 - 1 and y/2; the even column x0 has the parent columns
+    // pidx-1, pidx (weight 1/2 each), the odd column x0+1 the parent column pidx.  Terms in the order of the prolongation's row
+    // (ascending coarse row, then column), weights w = wi * wj as there
+    auto ldraw = [&](int y) -> VT { return *reinterpret_cast<const VT *>(up_ + (long)min(max(y, -1), a.ny) * a.rs); };
+    auto correct = [&](VT v, int y, double cA, double cB) -> VT {      // cA: coarse row of the first parent, cB: of the second (even y)
+        const bool two = ((y & 1) == 0);
+        const double wi = two ? 0.5 : 1.0;
+        const double wh = wi * 0.5, w1 = wi * 1.0;
+        const double mA = lane_up<true>(cA), mB = lane_up<true>(cB);
+        double s0 = 0.0, s1 = 0.0;
+        s0 += wh * mA; s0 += wh * cA; s1 += w1 * cA;
+        if (two) { s0 += wh * mB; s0 += wh * cB; s1 += w1 * cB; }
+        v.v[0] = v.v[0] + s0; v.v[1] = v.v[1] + s1;
+        if (!xin || y < 0 || y >= a.ny) { v.v[0] = 0.0; v.v[1] = 0.0; }
+        if (lastvec) v.v[1] = 0.0;
+        return v;
+    };
+    // parent rows of fine row y: (y-1)/2 alone (odd y; returned twice) or y/2 - 1 and y/2 (even y)
+    auto pA = [&](int y) { return (y & 1) ? (y - 1) >> 1 : (y >> 1) - 1; };
+    auto pB = [&](int y) { return (y & 1) ? (y - 1) >> 1 : (y >> 1); };
+    // rows y0-1, y0, y0+1 corrected; row y0+2 and its parents in flight
+    VT ua = correct(ldraw(y0 - 1), y0 - 1, ldc(pA(y0 - 1)), ldc(pB(y0 - 1)));
+    VT ub = correct(ldraw(y0), y0, ldc(pA(y0)), ldc(pB(y0)));
+    VT uc = correct(ldraw(y0 + 1), y0 + 1, ldc(pA(y0 + 1)), ldc(pB(y0 + 1)));
+    VT ur = ldraw(y0 + 2);
+    double cA = ldc(pA(y0 + 2)), cB = ldc(pB(y0 + 2));
+    VT b0 = ldv_stream(bp_ + (long)y0 * a.rs, true);
+    for (int y = y0; y < y1; y++) {
+        // loads consumed in the next step: row y+3 with its parents, b of row y+1
+        const VT ur2 = ldraw(y + 3);
+        const double cA2 = ldc(pA(y + 3)), cB2 = ldc(pB(y + 3));
+        const VT bn = ldv_stream(bp_ + (long)min(y + 1, a.ny - 1) * a.rs, true);
+        // the row that arrived during the last step gets its correction
+        const VT un = correct(ur, y + 2, cA, cB);
+        const double Wv = lane_up<true>(ub.v[1]), Ev = lane_dn<true>(ub.v[0]);
+        VT o;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const double wv = (e == 0) ? Wv : ub.v[0];
+            const double ev = (e == 1) ? Ev : ub.v[1];
+            double s = a.a0 * ua.v[e];
+            s = s + a.a2 * wv;
+            s = s + a.a3 * ub.v[e];
+            s = s + a.a4 * ev;
+            s = s + a.a6 * uc.v[e];
+            const double res = (xin ? b0.v[e] : 0.0) - s;
+            const double zz = res * a.dinv;
+            o.v[e] = ub.v[e] + a.scale * zz;
+        }
+        if (lastvec) o.v[1] = 0.0;
+        if (store) stv_stream(a.out + (long)y * a.rs + x0, o);
+        ua = ub; ub = uc; uc = un; ur = ur2; cA = cA2; cB = cB2; b0 = bn;
+    }
+}
+static int prolong_jacobi_2d_waves(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
+                                   const double *b, const double *ucoarse, const double *u, double *unew, void *stream) {
+    PJ2dArgs a; memset(&a, 0, sizeof(a));
+    a.u = u + gf->org; a.b = b + gf->org; a.uc = ucoarse + gc->org; a.out = unew + gf->org;
+    a.nx = gf->nx; a.ny = gf->ny; a.nxc = gc->nx; a.nyc = gc->ny; a.rs = gf->pitch; a.crs = gc->pitch;
+    a.a0 = coef[0]; a.a2 = coef[1]; a.a3 = coef[2]; a.a4 = coef[3]; a.a6 = coef[4];
+    a.dinv = dinv; a.scale = scale;
+    a.ntx = (gc->nx + 1 + 61) / 62;                           // pairs 0 .. nxc
+    long nch = (4096 + a.ntx - 1) / a.ntx;                    // ~4096 waves (16 per CU); every chunk re-reads two fine rows
+    if (g_zchunk > 0) nch = (gf->ny + g_zchunk - 1) / g_zchunk;
+    int yc = (int)((gf->ny + nch - 1) / nch);
+    if (yc < 16 && g_zchunk <= 0) yc = 16;
+    if (yc > gf->ny) yc = gf->ny;
+    a.yc = yc;
+    const long waves = (long)a.ntx * ((gf->ny + yc - 1) / yc);
+    hipLaunchKernelGGL(k_pj2d, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, S(c, stream), a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // K4 fused into the first post-smoothing sweep: unew = J(u + P uc)  (src/solver.c:1540-1542)
 template <typename T>
 static int prolong_jacobi(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
@@ -4106,6 +4209,11 @@ static int prolong_jacobi(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, co
     const int nm = (gf->dim == 3) ? gf->nz : gf->ny;
     if (zbeg < 0 || zend > nm || zbeg >= zend) return fail(MGK_EINVAL, "mgk_prolong_jacobi: empty or out-of-range plane range");
     a.zbeg = zbeg; a.zend = zend;
+    if constexpr (sizeof(T) == 8) {
+        // 2-D, whole grid: independent waves (tuning variant 30 keeps the LDS-tile kernel)
+        if (gf->dim == 2 && zbeg == 0 && zend == gf->ny && gf->nx >= 127 && g_variant != 30)
+            return prolong_jacobi_2d_waves(c, gf, gc, coef, dinv, scale, (const double *)b, (const double *)ucoarse, (const double *)u, (double *)unew, stream);
+    }
     constexpr int VX = 16 / sizeof(T);
     const int w = (gf->nx + 1 + 64 * VX - 1) / (64 * VX);        // waves per full row
     const int rowpd = row_shape_ok<T>(gf) ? row_form(w, sizeof(T)) : 0;

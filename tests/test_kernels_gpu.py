@@ -278,8 +278,10 @@ def test_fused_residual_restrict_on_slabs_bit_exact(mgk, orc, n, cut):
         mgk.free(p)
 
 
-@pytest.mark.parametrize("nf,variant", [(3, -1), (7, 0), (127, 0), (255, 1), (1023, 2), (1023, 0)])
+@pytest.mark.parametrize("nf,variant", [(3, -1), (7, 0), (127, 0), (255, 1), (1023, 2), (1023, 0), (127, 30), (1023, 30), (127, -1), (243, -1),
+                                        (255, -1), (2047, -1), (4095, -1)])
 def test_fused_prolong_jacobi_2d_bit_exact(mgk, orc, nf, variant):
+    """(from 127^2 on the independent-wave kernel k_pj2d runs; variant 30 keeps the LDS-tile kernel)"""
     rng = np.random.default_rng(500 + nf)
     nc = (nf - 1) // 2
     As = _stencil(orc, 2, nf)
