@@ -276,6 +276,12 @@ int  mgk_prolong_jacobi_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_
 int  mgk_residual_restrict_2d_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *ctab_f, const double *b,
                                           const double *u, double *bc, double *uc0, const double *dtab_c, double scale_c, void *stream);
 /* ctab[l] / dtab[l]: the device tables of tail level l (n[l] x 5 and n[l] doubles) */
+int  mgk_jacobi2_2d_sumsq_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *g, const double *ctab, const double *dtab, double scale,
+                                      const double *b, const double *u, double *unew, double *sumsq_host, void *stream);      /* mgk_jacobi2_2d_sumsq_f64 */
+/* ctab_f / dtab_f: tables of the FINE level; dtab_c: 1/diag table of the COARSE level (needed only with uc0) */
+int  mgk_sweep_residual_restrict_2d_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *ctab_f, const double *dtab_f,
+                                                double scale, const double *b, const double *u, double *unew, double *bc, double *uc0,
+                                                const double *dtab_c, double scale_c, void *stream);
 int  mgk_tail_cycle_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *g0, int nlev, const int *n, const double *const *ctab,
                                 const double *const *dtab, double scale, int v0, int v1, const double *b, double *u, void *stream);
 

@@ -376,7 +376,7 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
     if (s->cfg.fuse < 0) s->cfg.fuse = 63 | 256 | 512 | 1024;
     if (s->cfg.pair_min_n <= 0) s->cfg.pair_min_n = (cfg->dim == 3) ? 255 : 2047;   /* where a two-sweep pass beats two sweeps
                                                                                       * (255^3: 0.107 ms against 2 x 0.063) */
-    if (s->cfg.mesh) s->cfg.fuse &= ~(16 | 128 | 1024);   /* row-dependent coefficients (2-D, fp64): the same fused cycle on the row-table forms of the kernels */
+    if (s->cfg.mesh) s->cfg.fuse &= ~(16 | 128);   /* row-dependent coefficients (2-D, fp64): the same fused cycle on the row-table forms of the kernels */
     if (s->cfg.overlap < 0) s->cfg.overlap = 1;
     if (s->cfg.graph < 0) s->cfg.graph = 1;
     if (s->cfg.nranks < 1) s->cfg.nranks = 1;
@@ -707,9 +707,14 @@ static int smooth_chebyshev(mg_solver *s, int l, int maxit) {
  * fuse bit 10): fp64, whole 3-D grids of full-row shape.  Not when that restriction is the first kernel of the coarse-level graph while
  * this level's sweeps run outside it (the replayed kernel would keep the buffers of the recording cycle; the swap is made on the host) */
 static int srr_ok(const mg_solver *s, int P, int l) {
-    if (!(s->cfg.fuse & 1024) || P != 0 || s->cfg.mesh || s->cfg.ksp_type != MG_KSP_RICHARDSON) return 0;
+    if (!(s->cfg.fuse & 1024) || P != 0 || s->cfg.ksp_type != MG_KSP_RICHARDSON) return 0;
     if (l + 1 >= s->levels || (s->lgraph && l + 1 == s->lgraph)) return 0;
-    if (s->cfg.dim == 2) return s->L[l].n >= 127;          /* mgk_sweep_residual_restrict_2d_f64: any 2-D grid; below that two short kernels */
+    /* 2-D (mgk_sweep_residual_restrict_2d_f64, any grid): from 2047^2 on; on the smaller levels of the 4097^2 cycle its marching waves
+     * take 15-20 us where a short sweep and the short fused restriction take 5 + 10 (MG_SRR2D_MIN_N overrides, for tests) */
+    if (s->cfg.dim == 2) {
+        const char *e = getenv("MG_SRR2D_MIN_N");
+        return s->L[l].n >= ((e && *e) ? atoi(e) : 2047);
+    }
     if (s->L[l].distributed) {
         /* z-slab: the neighbours' planes arrive in ONE grouped exchange (u and b ghosts, far, far2, bfar) */
         const mg_fset *F = &s->L[l].f[0];
@@ -1080,7 +1085,10 @@ static int descend_restrict(mg_solver *s, int P, int l, int no_jz) {
         mg_fset *F = &Lf->f[P], *Cq = &s->L[l].f[P];
         const int sweeps = (l == levels - 1) ? v[1] : v[0];
         const int jz = (s->cfg.fuse & 256) && !no_jz && sweeps >= 1 && !Cq->guess_nonzero;
-        if (s->cfg.dim == 2)
+        if (s->cfg.mesh)
+            CHK(mgk_sweep_residual_restrict_2d_rowcoef_f64(s->ctx, &F->g, &Cq->g, Lf->ctab, Lf->dtab, s->cfg.scale, (const double *)F->b, (const double *)F->u,
+                                                           (double *)F->tmp, (double *)Cq->b, jz ? (double *)Cq->tmp : NULL, s->L[l].dtab, s->cfg.scale, NULL));
+        else if (s->cfg.dim == 2)
             CHK(mgk_sweep_residual_restrict_2d_f64(s->ctx, &F->g, &Cq->g, Lf->coef, Lf->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u,
                                                    (double *)F->tmp, (double *)Cq->b, jz ? (double *)Cq->tmp : NULL, s->L[l].dinv, s->cfg.scale, NULL));
         else
@@ -1338,10 +1346,12 @@ static int vcycle_once(mg_solver *s) {
              * cycle follows; u itself is untouched, so stopping here leaves the solution as the reference has it. */
             /* (not when level 0 feeds the coarse-level graph: adopting two sweeps at once changes how often level 0 swaps u / tmp in
              * a cycle from the recording cycle's count, and the recorded restriction reads level 0's buffers) */
-            const int two = (s->cfg.fuse & 1024) && (s->cfg.fuse & 32) && !s->cfg.mesh && !L->distributed &&
+            const int two = (s->cfg.fuse & 1024) && (s->cfg.fuse & 32) && !L->distributed &&
                             s->cfg.v[0] >= 2 && L->n >= s->cfg.pair_min_n && s->lgraph != 1 && (s->cfg.dim == 2 || mgk_jacobi2_sumsq_ok_f64(&F->g));
-            if (s->cfg.mesh) CHK(mgk_jacobi_sumsq_rowcoef_f64(s->ctx, &F->g, L->ctab, L->dtab, s->cfg.scale, (const double *)F->b,
-                                                              (const double *)F->u, (double *)F->tmp, &ss, NULL));
+            if (s->cfg.mesh && two) CHK(mgk_jacobi2_2d_sumsq_rowcoef_f64(s->ctx, &F->g, L->ctab, L->dtab, s->cfg.scale, (const double *)F->b,
+                                                                         (const double *)F->u, (double *)F->tmp, &ss, NULL));
+            else if (s->cfg.mesh) CHK(mgk_jacobi_sumsq_rowcoef_f64(s->ctx, &F->g, L->ctab, L->dtab, s->cfg.scale, (const double *)F->b,
+                                                                   (const double *)F->u, (double *)F->tmp, &ss, NULL));
             else if (two && s->cfg.dim == 2) CHK(mgk_jacobi2_2d_sumsq_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b,
                                                                           (const double *)F->u, (double *)F->tmp, &ss, NULL));
             else if (two) CHK(mgk_jacobi2_sumsq_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u,

@@ -2467,6 +2467,14 @@ static int jacobi2_2d(mgk_ctx *c, const mgk_geom *g, const double *coef, double 
     HIPCHK(hipGetLastError());
     return 0;
 }
+extern "C" int mgk_jacobi2_2d_sumsq_rowcoef_f64(mgk_ctx *c, const mgk_geom *g, const double *ctab, const double *dtab, double scale,
+                                                const double *b, const double *u, double *unew, double *sumsq_host, void *stream) {
+    if (!ctab || !sumsq_host) return fail(MGK_EINVAL, "mgk_jacobi2_2d_sumsq_rowcoef_f64: bad arguments");
+    int nparts = 0;
+    int rc = jacobi2_2d(c, g, nullptr, 1.0, scale, ctab, dtab, b, u, unew, stream, &nparts);
+    if (rc) return rc;
+    return finish_to_host(c, nparts, 1, S(c, stream), sumsq_host);
+}
 // two sweeps and || b - A u ||^2 of the input field (2-D form of mgk_jacobi2_sumsq_f64)
 extern "C" int mgk_jacobi2_2d_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
                                         const double *b, const double *u, double *unew, double *sumsq_host, void *stream) {
@@ -4100,6 +4108,7 @@ struct PJ2dArgs {
     long rs, crs;
     int ntx, yc;
     double a0, a2, a3, a4, a6, dinv, scale;
+    const double *ctab, *dtab;      // optional (stretched meshes): 5 coefficients and 1/diag per grid row
 };
 __global__ void __launch_bounds__(256) k_pj2d(const PJ2dArgs a) {
     using VT = V16<double>;
@@ -4153,18 +4162,20 @@ __global__ void __launch_bounds__(256) k_pj2d(const PJ2dArgs a) {
         // the row that arrived during the last step gets its correction
         const VT un = correct(ur, y + 2, cA, cB);
         const double Wv = lane_up<true>(ub.v[1]), Ev = lane_dn<true>(ub.v[0]);
+        double k0 = a.a0, k2 = a.a2, k3 = a.a3, k4 = a.a4, k6 = a.a6, kd = a.dinv;
+        if (a.ctab) { const double *cr = a.ctab + 5 * (long)y; k0 = cr[0]; k2 = cr[1]; k3 = cr[2]; k4 = cr[3]; k6 = cr[4]; kd = a.dtab[y]; }
         VT o;
 #pragma unroll
         for (int e = 0; e < 2; e++) {
             const double wv = (e == 0) ? Wv : ub.v[0];
             const double ev = (e == 1) ? Ev : ub.v[1];
-            double s = a.a0 * ua.v[e];
-            s = s + a.a2 * wv;
-            s = s + a.a3 * ub.v[e];
-            s = s + a.a4 * ev;
-            s = s + a.a6 * uc.v[e];
+            double s = k0 * ua.v[e];
+            s = s + k2 * wv;
+            s = s + k3 * ub.v[e];
+            s = s + k4 * ev;
+            s = s + k6 * uc.v[e];
             const double res = (xin ? b0.v[e] : 0.0) - s;
-            const double zz = res * a.dinv;
+            const double zz = res * kd;
             o.v[e] = ub.v[e] + a.scale * zz;
         }
         if (lastvec) o.v[1] = 0.0;
@@ -4173,11 +4184,13 @@ __global__ void __launch_bounds__(256) k_pj2d(const PJ2dArgs a) {
     }
 }
 static int prolong_jacobi_2d_waves(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
-                                   const double *b, const double *ucoarse, const double *u, double *unew, void *stream) {
+                                   const double *b, const double *ucoarse, const double *u, double *unew, void *stream,
+                                   const double *ctab = nullptr, const double *dtab = nullptr) {
     PJ2dArgs a; memset(&a, 0, sizeof(a));
+    a.ctab = ctab; a.dtab = dtab;
     a.u = u + gf->org; a.b = b + gf->org; a.uc = ucoarse + gc->org; a.out = unew + gf->org;
     a.nx = gf->nx; a.ny = gf->ny; a.nxc = gc->nx; a.nyc = gc->ny; a.rs = gf->pitch; a.crs = gc->pitch;
-    a.a0 = coef[0]; a.a2 = coef[1]; a.a3 = coef[2]; a.a4 = coef[3]; a.a6 = coef[4];
+    if (coef) { a.a0 = coef[0]; a.a2 = coef[1]; a.a3 = coef[2]; a.a4 = coef[3]; a.a6 = coef[4]; }
     a.dinv = dinv; a.scale = scale;
     a.ntx = (gc->nx + 1 + 61) / 62;                           // pairs 0 .. nxc
     long nch = (4096 + a.ntx - 1) / a.ntx;                    // ~4096 waves (16 per CU); every chunk re-reads two fine rows
@@ -4210,8 +4223,9 @@ static int prolong_jacobi(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, co
     if (zbeg < 0 || zend > nm || zbeg >= zend) return fail(MGK_EINVAL, "mgk_prolong_jacobi: empty or out-of-range plane range");
     a.zbeg = zbeg; a.zend = zend;
     if constexpr (sizeof(T) == 8) {
-        // 2-D, whole grid: independent waves (tuning variant 30 keeps the LDS-tile kernel)
-        if (gf->dim == 2 && zbeg == 0 && zend == gf->ny && gf->nx >= 127 && g_variant != 30)
+        // 2-D, whole grid: independent waves from 2047^2 on (a wave marches >= 16 rows: on the small levels of the 4097^2 cycle this form
+        // takes 14-18 us where the LDS-tile kernel takes 5-8); tuning variant 30 keeps the LDS-tile kernel, 38 forces the waves
+        if (gf->dim == 2 && zbeg == 0 && zend == gf->ny && ((gf->nx >= 2047 && g_variant != 30) || (g_variant == 38 && gf->nx >= 3)))
             return prolong_jacobi_2d_waves(c, gf, gc, coef, dinv, scale, (const double *)b, (const double *)ucoarse, (const double *)u, (double *)unew, stream);
     }
     constexpr int VX = 16 / sizeof(T);
@@ -4628,6 +4642,7 @@ struct SRR2dArgs {
     long rs, crs;
     int ntx, ycc;
     double a0, a2, a3, a4, a6, dinv, scale, dinv_c, scale_c;
+    const double *ctab, *dtab, *dtab_c;     // optional (stretched meshes): coefficients and 1/diag per FINE grid row, 1/diag per COARSE grid row
 };
 __global__ void __launch_bounds__(256) k_srr2d(const SRR2dArgs a) {
     using VT = V16<double>;
@@ -4670,17 +4685,19 @@ __global__ void __launch_bounds__(256) k_srr2d(const SRR2dArgs a) {
         {
             const double Wv = lane_up<true>(ub.v[1]), Ev = lane_dn<true>(ub.v[0]);
             const bool pin = (p >= 0 && p < a.ny);
+            double k0 = a.a0, k2 = a.a2, k3 = a.a3, k4 = a.a4, k6 = a.a6, kd = a.dinv;
+            if (a.ctab) { const int pr_ = min(max(p, 0), a.ny - 1); const double *cr = a.ctab + 5 * (long)pr_; k0 = cr[0]; k2 = cr[1]; k3 = cr[2]; k4 = cr[3]; k6 = cr[4]; kd = a.dtab[pr_]; }
 #pragma unroll
             for (int e = 0; e < 2; e++) {
                 const double wv = (e == 0) ? Wv : ub.v[0];
                 const double ev = (e == 1) ? Ev : ub.v[1];
-                double s = a.a0 * ua.v[e];
-                s = s + a.a2 * wv;
-                s = s + a.a3 * ub.v[e];
-                s = s + a.a4 * ev;
-                s = s + a.a6 * uc.v[e];
+                double s = k0 * ua.v[e];
+                s = s + k2 * wv;
+                s = s + k3 * ub.v[e];
+                s = s + k4 * ev;
+                s = s + k6 * uc.v[e];
                 const double res = b1.v[e] - s;
-                const double zz = res * a.dinv;
+                const double zz = res * kd;
                 wp.v[e] = ub.v[e] + a.scale * zz;
                 if (!pin || !xin || (lastvec && e == 1)) wp.v[e] = 0.0;
             }
@@ -4689,16 +4706,18 @@ __global__ void __launch_bounds__(256) k_srr2d(const SRR2dArgs a) {
         // ---- residual of the swept row t, full weighting ----
         if (t >= y0) {
             const double Wv = lane_up<true>(wc.v[1]), Ev = lane_dn<true>(wc.v[0]);
+            double k0 = a.a0, k2 = a.a2, k3 = a.a3, k4 = a.a4, k6 = a.a6;
+            if (a.ctab) { const double *cr = a.ctab + 5 * (long)t; k0 = cr[0]; k2 = cr[1]; k3 = cr[2]; k4 = cr[3]; k6 = cr[4]; }
             VT r;
 #pragma unroll
             for (int e = 0; e < 2; e++) {
                 const double wv = (e == 0) ? Wv : wc.v[0];
                 const double ev = (e == 1) ? Ev : wc.v[1];
-                double s = a.a0 * wm.v[e];
-                s = s + a.a2 * wv;
-                s = s + a.a3 * wc.v[e];
-                s = s + a.a4 * ev;
-                s = s + a.a6 * wp.v[e];
+                double s = k0 * wm.v[e];
+                s = s + k2 * wv;
+                s = s + k3 * wc.v[e];
+                s = s + k4 * ev;
+                s = s + k6 * wp.v[e];
                 r.v[e] = b0.v[e] - s;
                 if (!xin || (lastvec && e == 1)) r.v[e] = 0.0;
             }
@@ -4716,7 +4735,7 @@ __global__ void __launch_bounds__(256) k_srr2d(const SRR2dArgs a) {
                 if (ic >= ic0 && cstore) {
                     const long oc = (long)ic * a.crs + pidx;
                     a.bc[oc] = acc;
-                    if (a.uc0) { const double zq = acc * a.dinv_c; a.uc0[oc] = a.scale_c * zq; }
+                    if (a.uc0) { const double zq = acc * (a.dtab_c ? a.dtab_c[ic] : a.dinv_c); a.uc0[oc] = a.scale_c * zq; }
                 }
                 acc = accn; accn = 0.0;
             }
@@ -4724,17 +4743,19 @@ __global__ void __launch_bounds__(256) k_srr2d(const SRR2dArgs a) {
         b0 = b1; b1 = bn; wm = wc; wc = wp; ua = ub; ub = uc; uc = ud;
     }
 }
-extern "C" int mgk_sweep_residual_restrict_2d_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
-                                                  const double *b, const double *u, double *unew, double *bc, double *uc0,
-                                                  double dinv_c, double scale_c, void *stream) {
-    if (!c || !gf || !gc || !coef || !b || !u || !unew || u == unew || !bc || gf->dim != 2 || gc->dim != 2)
+static int sweep_residual_restrict_2d(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
+                                      const double *ctab, const double *dtab, const double *dtab_c,
+                                      const double *b, const double *u, double *unew, double *bc, double *uc0,
+                                      double dinv_c, double scale_c, void *stream) {
+    if (!c || !gf || !gc || (!coef && !ctab) || (ctab && !dtab) || (ctab && uc0 && !dtab_c) || !b || !u || !unew || u == unew || !bc || gf->dim != 2 || gc->dim != 2)
         return fail(MGK_EINVAL, "mgk_sweep_residual_restrict_2d_f64: bad arguments (2-D)");
     if (gf->nx != 2 * gc->nx + 1 || gf->ny != 2 * gc->ny + 1) return fail(MGK_EINVAL, "mgk_sweep_residual_restrict_2d_f64: need nf = 2 nc + 1");
     SRR2dArgs a; memset(&a, 0, sizeof(a));
     a.u = u + gf->org; a.b = b + gf->org; a.out = unew + gf->org; a.bc = bc + gc->org; a.uc0 = uc0 ? uc0 + gc->org : nullptr;
     a.nx = gf->nx; a.ny = gf->ny; a.nxc = gc->nx; a.nyc = gc->ny; a.rs = gf->pitch; a.crs = gc->pitch;
-    a.a0 = coef[0]; a.a2 = coef[1]; a.a3 = coef[2]; a.a4 = coef[3]; a.a6 = coef[4];
+    if (coef) { a.a0 = coef[0]; a.a2 = coef[1]; a.a3 = coef[2]; a.a4 = coef[3]; a.a6 = coef[4]; }
     a.dinv = dinv; a.scale = scale; a.dinv_c = dinv_c; a.scale_c = scale_c;
+    a.ctab = ctab; a.dtab = dtab; a.dtab_c = dtab_c;
     a.ntx = (gc->nx + 1 + 60) / 61;                           // pairs 0 .. nxc (the last one holds the last fine column and the ghost column)
     long nch = (4096 + a.ntx - 1) / a.ntx;                    // ~4096 waves (16 per CU); every chunk re-reads four fine rows
     if (g_zchunk > 0) nch = (gc->ny + g_zchunk - 1) / g_zchunk;
@@ -4746,6 +4767,19 @@ extern "C" int mgk_sweep_residual_restrict_2d_f64(mgk_ctx *c, const mgk_geom *gf
     hipLaunchKernelGGL(k_srr2d, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, S(c, stream), a);
     HIPCHK(hipGetLastError());
     return 0;
+}
+extern "C" int mgk_sweep_residual_restrict_2d_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
+                                                  const double *b, const double *u, double *unew, double *bc, double *uc0,
+                                                  double dinv_c, double scale_c, void *stream) {
+    if (!coef) return fail(MGK_EINVAL, "mgk_sweep_residual_restrict_2d_f64: bad arguments (2-D)");
+    return sweep_residual_restrict_2d(c, gf, gc, coef, dinv, scale, nullptr, nullptr, nullptr, b, u, unew, bc, uc0, dinv_c, scale_c, stream);
+}
+// stretched meshes: ctab_f / dtab_f of the FINE level, dtab_c (1/diag per grid row) of the COARSE level (needed only with uc0)
+extern "C" int mgk_sweep_residual_restrict_2d_rowcoef_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *ctab_f, const double *dtab_f,
+                                                          double scale, const double *b, const double *u, double *unew, double *bc, double *uc0,
+                                                          const double *dtab_c, double scale_c, void *stream) {
+    if (!ctab_f) return fail(MGK_EINVAL, "mgk_sweep_residual_restrict_2d_rowcoef_f64: null table");
+    return sweep_residual_restrict_2d(c, gf, gc, nullptr, 1.0, scale, ctab_f, dtab_f, dtab_c, b, u, unew, bc, uc0, 1.0, scale_c, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -4798,6 +4832,8 @@ extern "C" int mgk_prolong_jacobi_rowcoef_f64(mgk_ctx *c, const mgk_geom *gf, co
     XferArgs x;
     int rc = xfer_args(gf, gc, x);
     if (rc) return rc;
+    if ((gf->nx >= 2047 && g_variant != 30) || (g_variant == 38 && gf->nx >= 3))          // independent waves, as mgk_prolong_jacobi_f64 in 2-D
+        return prolong_jacobi_2d_waves(c, gf, gc, nullptr, 1.0, scale, b, uc, u, unew, stream, ctab, dtab);
     StArgs<double> a; memset(&a, 0, sizeof(a));
     a.u = u + gf->org; a.b = b + gf->org; a.out = unew + gf->org;
     a.uc = uc + gc->org; a.crs = gc->pitch; a.cms = gc->pitch;

@@ -55,6 +55,8 @@ def _sigs(L):
         "mgk_residual_sumsq_rowcoef_f64": (i, [vp, G, vp, vp, vp, C.POINTER(d), vp]),
         "mgk_prolong_jacobi_rowcoef_f64": (i, [vp, G, G, vp, vp, d, vp, vp, vp, vp, vp]),
         "mgk_residual_restrict_2d_rowcoef_f64": (i, [vp, G, G, vp, vp, vp, vp, vp, vp, d, vp]),
+        "mgk_jacobi2_2d_sumsq_rowcoef_f64": (i, [vp, G, vp, vp, d, vp, vp, vp, C.POINTER(d), vp]),
+        "mgk_sweep_residual_restrict_2d_rowcoef_f64": (i, [vp, G, G, vp, vp, d, vp, vp, vp, vp, vp, vp, d, vp]),
         "mgk_tail_cycle_rowcoef_f64": (i, [vp, G, i, C.POINTER(i), C.POINTER(vp), C.POINTER(vp), d, i, i, vp, vp, vp]),
         "mgk_jacobi_sumsq_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp, C.POINTER(d), vp]),
         "mgk_restrict_fw_f64": (i, [vp, G, G, vp, vp, vp]),

@@ -519,6 +519,28 @@ int mgk_sweep_residual_restrict_2d_f64(mgk_ctx *c, const mgk_geom *gf, const mgk
         if (uc0) for (int i = 0; i < Cg.ny; i++) for (int j = 0; j < Cg.nx; j++) { const double zq = at(bc, Cg, 0, i, j) * dinv_c; at(uc0, Cg, 0, i, j) = scale_c * zq; }
     });
 }
+int mgk_jacobi2_2d_sumsq_rowcoef_f64(mgk_ctx *c, const mgk_geom *g, const double *ctab, const double *dtab, double scale, const double *b, const double *u, double *o, double *out, void *) {
+    if (!c || !g || g->dim != 2 || !ctab || !dtab || !b || !u || !o || u == o || !out) return fail(MGK_EINVAL, "mgk_jacobi2_2d_sumsq_rowcoef_f64");
+    if (c->capturing) return fail(MGK_EINVAL, "reduction to the host inside a capture");
+    std::vector<double> r(g->total, 0.0), w(g->total, 0.0);
+    st_op<double>(M_RESIDUAL, *g, nullptr, 1, 1, 0, 0, 0, b, u, (const double *)nullptr, r.data(), 0, g->ny, ctab, dtab);
+    st_op<double>(M_JACOBI, *g, nullptr, 1.0, scale, 0, 0, 0, b, u, (const double *)nullptr, w.data(), 0, g->ny, ctab, dtab);
+    st_op<double>(M_JACOBI, *g, nullptr, 1.0, scale, 0, 0, 0, b, w.data(), (const double *)nullptr, o, 0, g->ny, ctab, dtab);
+    deliver(c, sumsq_field<double>(*g, r.data(), 0, g->ny), out);
+    return 0;
+}
+int mgk_sweep_residual_restrict_2d_rowcoef_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *ctab, const double *dtab, double scale, const double *b, const double *u,
+                                               double *o, double *bc, double *uc0, const double *dtab_c, double scale_c, void *) {
+    if (!c || !ctab || !dtab || !b || !u || !o || u == o || !bc || !xfer_ok(gf, gc) || gf->dim != 2 || (uc0 && !dtab_c)) return fail(MGK_EINVAL, "mgk_sweep_residual_restrict_2d_rowcoef_f64");
+    const mgk_geom F = *gf, Cg = *gc;
+    return run(c, [=] {
+        st_op<double>(M_JACOBI, F, nullptr, 1.0, scale, 0, 0, 0, b, u, (const double *)nullptr, o, 0, F.ny, ctab, dtab);
+        std::vector<double> r(F.total, 0.0);
+        st_op<double>(M_RESIDUAL, F, nullptr, 1, 1, 0, 0, 0, b, o, (const double *)nullptr, r.data(), 0, F.ny, ctab, (const double *)nullptr);
+        restrict_fw<double>(F, Cg, r.data(), bc, 0, 1);
+        if (uc0) for (int i = 0; i < Cg.ny; i++) for (int j = 0; j < Cg.nx; j++) { const double zq = at(bc, Cg, 0, i, j) * dtab_c[i]; at(uc0, Cg, 0, i, j) = scale_c * zq; }
+    });
+}
 // the two on a z-slab (far planes as the halo exchange delivers them; see include/mgk.h)
 static int g_calls_j2n_slab = 0, g_calls_srr_slab = 0, g_calls_srr = 0, g_calls_j2n = 0;
 static void print_stats() { if (getenv("MOCK_MGK_STATS")) fprintf(stderr, "MOCK_MGK_STATS j2n=%d srr=%d j2n_slab=%d srr_slab=%d\n", g_calls_j2n, g_calls_srr, g_calls_j2n_slab, g_calls_srr_slab); }

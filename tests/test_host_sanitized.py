@@ -87,12 +87,13 @@ def test_own_driver_under_sanitizers_matches_the_oracle(san, tmp_path, args, dim
     assert np.array_equal(u, ref["u"])
 
 
-@pytest.mark.parametrize("mesh,npts,levels", [(1, 65, 5), (2, 33, 4), (1, 257, 8), (2, 257, 3)])
-def test_own_driver_stretched_mesh_under_sanitizers_matches_the_oracle(san, tmp_path, mesh, npts, levels):
+@pytest.mark.parametrize("mesh,npts,levels,extra", [(1, 65, 5, []), (2, 33, 4, []), (1, 257, 8, []), (2, 257, 3, []),
+                                                    (1, 129, 6, ["-mg_pair_min_n", "15", "-mg_graph", "0"]), (2, 129, 7, ["-mg_pair_min_n", "15"])])
+def test_own_driver_stretched_mesh_under_sanitizers_matches_the_oracle(san, tmp_path, mesh, npts, levels, extra):
     """-mesh 1/2: the host logic of the FUSED stretched-mesh cycle (row-table forms of PJ / JNORM / fused restriction / tail)
     against the oracle's assembled stretched-mesh leg -- iteration count, history, field"""
     out = _run(san["mgpoisson"], ["-dim", "2", "-npts", str(npts), "-levels", str(levels), "-mesh", str(mesh), "-ksp_richardson_scale", "0.8",
-                                  "-pc_type", "jacobi", "-write_fields", "1"], tmp_path)
+                                  "-pc_type", "jacobi", "-write_fields", "1"] + extra, tmp_path, env={"MG_SRR2D_MIN_N": "15"})
     ref = Oracle().vcycle(2, npts, levels, 3, 3, maxiter=100000, scale=0.8, use_csr=1, mesh=mesh)
     assert int(re.search(r"Number of iterations:\s+(\d+)", out).group(1)) == ref["iters"]
     rdat = np.array((tmp_path / "rData.dat").read_text().split(), dtype=np.float64)

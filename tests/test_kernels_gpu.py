@@ -278,10 +278,10 @@ def test_fused_residual_restrict_on_slabs_bit_exact(mgk, orc, n, cut):
         mgk.free(p)
 
 
-@pytest.mark.parametrize("nf,variant", [(3, -1), (7, 0), (127, 0), (255, 1), (1023, 2), (1023, 0), (127, 30), (1023, 30), (127, -1), (243, -1),
-                                        (255, -1), (2047, -1), (4095, -1)])
+@pytest.mark.parametrize("nf,variant", [(3, -1), (7, 0), (127, 0), (255, 1), (1023, 2), (1023, 0), (2047, 30), (3, 38), (7, 38), (127, 38), (243, 38),
+                                        (255, 38), (1023, 38), (2047, -1), (4095, -1)])
 def test_fused_prolong_jacobi_2d_bit_exact(mgk, orc, nf, variant):
-    """(from 127^2 on the independent-wave kernel k_pj2d runs; variant 30 keeps the LDS-tile kernel)"""
+    """(from 2047^2 on the independent-wave kernel k_pj2d runs; variant 30 keeps the LDS-tile kernel, 38 forces the waves)"""
     rng = np.random.default_rng(500 + nf)
     nc = (nf - 1) // 2
     As = _stencil(orc, 2, nf)
@@ -581,8 +581,8 @@ def test_row_table_forms_of_the_fused_2d_kernels(mgk, orc, n):
     du, db, dout = mgk.to_field(g, u.ravel()), mgk.to_field(g, b.ravel()), mgk.field(g)
     dct, ddt, ddtc = mgk.upload(ct.ravel()), mgk.upload(dt), mgk.upload(dtc)
     ss = C.c_double(0.0)
-    for zc in (-1, 7):
-        mgk.L.mgk_set_tuning(-1, zc)
+    for var, zc in ((-1, -1), (-1, 7), (38, 5)):             # 38: the prolongation sweep as independent waves on every size
+        mgk.L.mgk_set_tuning(var, zc)
         # two sweeps in one pass
         mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dout, 8 * g.total, None))
         mgk._chk(mgk.L.mgk_jacobi2_2d_rowcoef_f64(mgk.ctx, C.byref(g), dct, ddt, 0.8, db, du, dout, None))

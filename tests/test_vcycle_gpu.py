@@ -257,10 +257,11 @@ def test_two_sweep_norm_pass_and_sweep_inside_the_restriction(orc, npts, levels,
     (513, 9, (3, 3), {"pair_min_n": 127, "graph": 0}), (513, 9, (3, 3), {"pair_min_n": 127}), (1025, 10, (2, 2), {"pair_min_n": 255, "graph": 0}),
     (513, 4, (4, 3), {"pair_min_n": 63, "graph": 0}), (257, 8, (3, 3), {}), (4097, 12, (3, 3), {}),
 ])
-def test_two_sweep_norm_pass_and_sweep_inside_the_restriction_2d(orc, npts, levels, v, kw):
+def test_two_sweep_norm_pass_and_sweep_inside_the_restriction_2d(orc, npts, levels, v, kw, monkeypatch):
     """the 2-D forms (mgk_jacobi2_2d_sumsq_f64, mgk_sweep_residual_restrict_2d_f64) in the cycle: bit-identical to the oracle and to the
-    same cycle without fuse bit 10"""
+    same cycle without fuse bit 10 (the sweep inside the restriction on every level from 127^2 on, not only from 2047^2)"""
     from multigrid_petsc_amd.solver import Solver
+    monkeypatch.setenv("MG_SRR2D_MIN_N", "127")
     s = Solver(2, npts, levels, v=v, maxiter=80, scale=0.8, **kw)
     s.set_rhs_problem()
     it = s.solve()
@@ -309,9 +310,10 @@ def test_fused_residual_restriction_on_small_levels(orc, npts, levels, precision
 @pytest.mark.parametrize("mesh,npts,levels,kw", [
     (1, 33, 4, {}), (2, 33, 4, {}), (1, 129, 6, {}), (2, 257, 7, {}), (1, 513, 8, {}), (2, 513, 9, {}),
     (1, 513, 8, {"pair_min_n": 63}), (2, 1025, 8, {"pair_min_n": 255}), (1, 257, 7, {"fuse": 0}), (2, 513, 9, {"graph": 0}),
-    (1, 2049, 11, {}),
+    (1, 2049, 11, {}), (2, 2049, 11, {"graph": 0}), (1, 513, 8, {"pair_min_n": 63, "graph": 0}), (2, 513, 7, {"pair_min_n": 63, "graph": 0}),
 ])
-def test_own_driver_on_stretched_meshes(orc, mesh, npts, levels, kw):
+def test_own_driver_on_stretched_meshes(orc, mesh, npts, levels, kw, monkeypatch):
+    monkeypatch.setenv("MG_SRR2D_MIN_N", "63")       # the sweep inside the restriction on the small test levels too
     """SURVEY 8(f) N1 in the own driver: -mesh 1/2 (src/mesh.c:45-107,165-169) -- per-row coefficient tables on every level and
     the SAME fused cycle as on the uniform mesh on the row-table forms of its kernels (fused prolongation+sweep, residual+
     restriction+zero-guess sweep, norm+speculative sweep, two-sweep passes, the LDS tail, the coarse-level graph); fuse=0 is the
