@@ -2276,9 +2276,9 @@ static int sweep_residual_restrict(mgk_ctx *c, const mgk_geom *gf, const mgk_geo
     const int w = (gf->nx + 1) / (64 * VX);
     const int nkc = kcend - kcbeg;
     // tiles of 4 rows with the swept planes in LDS (1023^3: 5.3 ms against 6.2 ms for tiles of 2 rows with them in registers;
-    // 511^3: 0.72 against 0.82); tuning variants: 40 tiles of 2 rows, 42 tiles of 4 rows all in registers (spills at 8 waves)
-    // (rows of <= 2 waves, n <= 255: tiles of 2 rows, two blocks per CU -- 255^3 0.119 against 0.136 ms);  41 forces tiles of 4
-    const int TYsel = slab ? 4 : (g_variant == 40) ? 2 : (g_variant == 41 || g_variant == 42) ? 4 : (w >= 4 ? 4 : 2);
+    // 511^3: 0.72 against 0.82; tiles of 4 rows all in registers need 316 VGPRs at 8 waves).  Rows of <= 2 waves (n <= 255): tiles of
+    // 2 rows, two blocks per CU -- 255^3 0.119 against 0.136 ms.  Tuning variants: 40 forces tiles of 2 rows, 41 tiles of 4
+    const int TYsel = slab ? 4 : (g_variant == 40) ? 2 : (g_variant == 41) ? 4 : (w >= 4 ? 4 : 2);
     a.nty = (gf->ny + TYsel - 1) / TYsel;
     // blocks: a multiple of what the chip holds at once (512-thread blocks: one per CU); every chunk recomputes three planes
     const long target = (w > 4) ? (TYsel == 4 ? 256 : 512) : 1024;
@@ -2290,8 +2290,7 @@ static int sweep_residual_restrict(mgk_ctx *c, const mgk_geom *gf, const mgk_geo
     if (kcc > nkc) kcc = nkc;
     a.kcc = kcc;
     const unsigned nblk = (unsigned)(a.nty * ((nkc + kcc - 1) / kcc));
-    if (TYsel == 4 && g_variant == 42 && !slab) launch_srr<T, 4>(w, nblk, S(c, stream), a);      // (all in registers: spills at 8 waves)
-    else if (TYsel == 4) {
+    if (TYsel == 4) {
         hipStream_t st = S(c, stream);
         if (w <= 1) hipLaunchKernelGGL((k_srr4b<1>), dim3(nblk), dim3(64), 0, st, a);
         else if (w <= 2) hipLaunchKernelGGL((k_srr4b<2>), dim3(nblk), dim3(128), 0, st, a);
