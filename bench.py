@@ -138,7 +138,9 @@ def cycle_compulsory_bytes(dim, npts, levels, precision):
         if l == levels - 1 and levels > 1:
             per = 64.0
         elif dim == 3:
-            per = (99.0 if (n + 1) in (256, 512, 1024) and precision != "mixed" else 114.0) if l == 0 else 91.0
+            # levels >= 1 that sweep in pairs (255 <= n <= 511 in fp64): the three pre-smoothing sweeps from the zero guess are ONE pass
+            # that reads b alone (16 B) instead of the zero-guess sweep written by the restriction (8) + a two-sweep pass (24): 91 - 16
+            per = (99.0 if (n + 1) in (256, 512, 1024) and precision != "mixed" else 114.0) if l == 0 else (75.0 if 255 <= n <= 511 else 91.0)
         else:
             # 2-D, round 2: levels >= 2047^2 (pairs of sweeps): norm + two sweeps 24, sweep + residual + restriction 26, prolongation
             # sweep 25, two sweeps 24 = 99 at level 0 (115 - 24 without the norm pass below it: 91); levels >= 127^2 without pairs:
@@ -146,7 +148,10 @@ def cycle_compulsory_bytes(dim, npts, levels, precision):
             # two sweeps 48 = 124; below that the kernel-per-operation count
             per = (99.0 if l == 0 else 91.0) if n >= 2047 else (124.0 if n >= 127 else 172.0)
         if precision == "mixed":
-            per = (91.0 / 2 if l else 91.0 / 2 + 32.0) if not (l == levels - 1 and levels > 1) else 32.0
+            # fp32 inner cycle: half the fp64 bytes of a level that starts from the zero guess, with the three-sweep pass where the level
+            # sweeps in pairs (n >= 255); level 0 adds the fp64 outer pass (u += e, r = b - A u -> fp32: 8 + 4 + 8 read, 8 + 4 written)
+            half = (75.0 if n >= 255 else 91.0) / 2
+            per = (half if l else half + 32.0) if not (l == levels - 1 and levels > 1) else 32.0
         tot += per * N
     return tot
 

@@ -285,6 +285,13 @@ int  mgk_sweep_residual_restrict_2d_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *gf
 int  mgk_tail_cycle_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *g0, int nlev, const int *n, const double *const *ctab,
                                 const double *const *dtab, double scale, int v0, int v1, const double *b, double *u, void *stream);
 
+/* THREE sweeps from a zero initial guess in one pass that reads b alone (the first one is pointwise: mgk_jacobi_zero_*):
+ * unew = J(J(J0(b))) -- the whole of a pre-smoothing KSPSolve with max_it = 3 on a coarse level (src/solver.c:1536), 16 B per unknown
+ * (fp32: 8) instead of 8 + 24.  Whole 3-D grids of full-row shape: fp32 n = 255 .. 1023, fp64 n = 127 .. 511; _ok_ tells (1 / 0). */
+int  mgk_jacobi2_zero_ok_f64(const mgk_geom *g);
+int  mgk_jacobi2_zero_ok_f32(const mgk_geom *g32);
+int  mgk_jacobi2_zero_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale, const double *b, double *unew, void *stream);
+int  mgk_jacobi2_zero_f32(mgk_ctx *ctx, const mgk_geom *g32, const double *coef, double dinv, double scale, const float *b, float *unew, void *stream);
 /* two sweeps in one pass AND sumsq = || b - A u ||^2 of the INPUT field (the first sweep forms that residual anyway): the norm
  * that closes cycle k (src/solver.c:1545-1546) out of the pass that makes the first two pre-smoothing sweeps of cycle k+1
  * (:1531).  fp64, full-row 3-D shapes (n = 127, 255, 511, 1023), whole grid; mgk_jacobi2_sumsq_ok_f64 tells (1 / 0). */

@@ -50,7 +50,9 @@ typedef struct mg_config {
                          * sweeps of the next cycle (mgk_jacobi2_sumsq_f64 / _slab_f64) and the last pre-smoothing sweep runs inside the
                          * restriction's pass (mgk_sweep_residual_restrict_f64 / _slab_f64): the fine level moves 99 instead of 115 B per
                          * unknown and cycle;
-                         * default (-1): bits 0-5, 8, 9 and 10 on */
+                         * bit 11 (3-D whole levels that sweep in pairs: fp32 up to 1023^3, fp64 up to 511^3): a pre-smoothing of >= 3 sweeps
+                         * from the zero guess starts with ONE pass that makes three of them and reads b alone (mgk_jacobi2_zero_*);
+                         * default (-1): bits 0-5 and 8-11 on */
     int overlap;        /* nranks > 1: halo of sweep k on the comm stream while sweep k's interior runs; default on (-1) */
     int graph;          /* replay the launch-bound coarse levels as one captured HIP graph; default on (-1) */
     int pair_min_n;     /* levels with n >= pair_min_n run their sweeps two per pass (fuse bit 5); <=0: default 255 (3-D), 2047 (2-D) */

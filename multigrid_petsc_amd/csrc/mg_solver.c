@@ -373,7 +373,7 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
         const int n0 = mg_grid_n(cfg->npts, 0);
         s->cfg.dist_min_n = n0 < 255 ? n0 : 255;
     }
-    if (s->cfg.fuse < 0) s->cfg.fuse = 63 | 256 | 512 | 1024;
+    if (s->cfg.fuse < 0) s->cfg.fuse = 63 | 256 | 512 | 1024 | 2048;
     if (s->cfg.pair_min_n <= 0) s->cfg.pair_min_n = (cfg->dim == 3) ? 255 : 2047;   /* where a two-sweep pass beats two sweeps
                                                                                       * (255^3: 0.107 ms against 2 x 0.063) */
     if (s->cfg.mesh) s->cfg.fuse &= ~(16 | 128);   /* row-dependent coefficients (2-D, fp64): the same fused cycle on the row-table forms of the kernels */
@@ -725,6 +725,16 @@ static int srr_ok(const mg_solver *s, int P, int l) {
     return mgk_sweep_residual_restrict_ok_f64(&s->L[l].f[0].g, &s->L[l + 1].f[0].g);
 }
 
+/* fuse bit 11: a pre-smoothing KSPSolve of >= 3 sweeps from the zero guess starts with ONE pass that makes three of them and reads b alone
+ * (mgk_jacobi2_zero_*): whole 3-D levels that sweep in pairs, fp32 up to 1023^3, fp64 up to 511^3.  The producers of such a level's
+ * right-hand side then do not write its zero-guess sweep (fuse bit 8). */
+static int triple_ok(const mg_solver *s, int P, int l, int maxit) {
+    const mg_level *L = &s->L[l];
+    if (!(s->cfg.fuse & 2048) || !(s->cfg.fuse & 32) || s->cfg.ksp_type != MG_KSP_RICHARDSON || s->cfg.dim != 3 || s->cfg.mesh) return 0;
+    if (maxit < 3 || L->distributed || L->n < s->cfg.pair_min_n || L->n + 1 > 1024) return 0;
+    return P == 0 ? mgk_jacobi2_zero_ok_f64(&L->f[0].g) : mgk_jacobi2_zero_ok_f32(&L->f[1].g);
+}
+
 /* pre: pre-smoothing, a restriction from this level follows (src/solver.c:1531 / :1536 before :1534 of the next level) */
 static int smooth(mg_solver *s, int P, int l, int maxit, int pre) {
     if (s->cfg.ksp_type == MG_KSP_CHEBYSHEV) return smooth_chebyshev(s, l, maxit);
@@ -755,6 +765,15 @@ static int smooth(mg_solver *s, int P, int l, int maxit, int pre) {
     if (maxit < 1 || F->guess_nonzero) F->jz_ready = 0;
     const int mesh = s->cfg.mesh != 0;                   /* -mesh 1/2 (2-D, fp64, one GPU): the row-table forms of the same kernels */
     for (int it = it0; it < maxit; it++) {
+        if (it == 0 && !F->guess_nonzero && !F->jz_ready && triple_ok(s, P, l, maxit)) {
+            /* sweeps 1-3 from the zero guess in one pass over b; u is not an input, so the result lands in u itself: no swap (the
+             * two swaps of the zero-guess sweep and the pair it replaces cancel, the pointers the coarse-level graph holds stay valid) */
+            if (P == 0) CHK(mgk_jacobi2_zero_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (double *)F->u, NULL));
+            else CHK(mgk_jacobi2_zero_f32(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const float *)F->b, (float *)F->u, NULL));
+            F->u_ghost_ok = 0; F->u_ghost_pending = 0;
+            it += 2;
+            continue;
+        }
         if (it == 0 && !F->guess_nonzero) {
             /* r = b, x = 0 + scale*(B b): u is not read (already in tmp when the fused residual+restriction wrote it) */
             if (!F->jz_ready) {
@@ -1084,7 +1103,7 @@ static int descend_restrict(mg_solver *s, int P, int l, int no_jz) {
         /* the last pre-smoothing sweep, the residual and its restriction in one pass (:1531 / :1536 last iteration, :1534-1535) */
         mg_fset *F = &Lf->f[P], *Cq = &s->L[l].f[P];
         const int sweeps = (l == levels - 1) ? v[1] : v[0];
-        const int jz = (s->cfg.fuse & 256) && !no_jz && sweeps >= 1 && !Cq->guess_nonzero;
+        const int jz = (s->cfg.fuse & 256) && !no_jz && sweeps >= 1 && !Cq->guess_nonzero && !triple_ok(s, P, l, sweeps);
         if (s->cfg.mesh)
             CHK(mgk_sweep_residual_restrict_2d_rowcoef_f64(s->ctx, &F->g, &Cq->g, Lf->ctab, Lf->dtab, s->cfg.scale, (const double *)F->b, (const double *)F->u,
                                                            (double *)F->tmp, (double *)Cq->b, jz ? (double *)Cq->tmp : NULL, s->L[l].dtab, s->cfg.scale, NULL));
@@ -1106,7 +1125,7 @@ static int descend_restrict(mg_solver *s, int P, int l, int no_jz) {
         /* :1534-1535 in one pass: b_l = R (b - A u), the fine residual is never written */
         mg_fset *Cq = &s->L[l].f[P];
         const int sweeps = (l == levels - 1) ? v[1] : v[0];
-        if ((s->cfg.fuse & 256) && !no_jz && s->cfg.ksp_type == MG_KSP_RICHARDSON && sweeps >= 1 && !Cq->guess_nonzero) {
+        if ((s->cfg.fuse & 256) && !no_jz && s->cfg.ksp_type == MG_KSP_RICHARDSON && sweeps >= 1 && !Cq->guess_nonzero && !triple_ok(s, P, l, sweeps)) {
             /* ... and the coarse level's first sweep from its zero guess comes out of the same kernel (saves re-reading b_l) */
             CHK(O->residual_restrict_jz(s->ctx, &Lf->f[P].g, &Cq->g, Lf->coef, Lf->f[P].b, Lf->f[P].u, Cq->b, Cq->tmp, s->L[l].dinv,
                                         s->cfg.scale, NULL));
@@ -1265,7 +1284,7 @@ static int vcycle_once(mg_solver *s) {
         CHK(cycle_body(s, 1, 1));
         /* the fp32 cycle that follows starts from e = 0: its first sweep, scale * (r32 * dinv), comes out of the same pass that
          * produces r32 (fuse bit 8): one launch and one read of r32 less per outer step */
-        const int jz = (s->cfg.fuse & 256) && s->cfg.v[0] >= 1 && s->levels > 1;
+        const int jz = (s->cfg.fuse & 256) && s->cfg.v[0] >= 1 && s->levels > 1 && !triple_ok(s, 1, 0, s->cfg.v[0]);
         if ((s->cfg.fuse & 16) && F->tmp && !L->distributed) {
             /* u += (double) e and r32 = (float)(b - A u) in one pass (32 B/unknown instead of 20 + 20) */
             if (jz) CHK(mgk_correct_residual_f64_f32_jz(s->ctx, &F->g, &E->g, L->coef, (const double *)F->b, (const double *)F->u,

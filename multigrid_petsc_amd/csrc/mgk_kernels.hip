@@ -1246,7 +1246,10 @@ struct J2Args {
     double *partials;        // k_jacobi2r<.., NORM = true>: one partial sum of squares per block (|| b - A u ||^2 of the INPUT field)
 };
 
-template <typename T, int WX, int FORM>
+// ZG: THREE sweeps from a zero initial guess.  The first one is pointwise, u1 = scale * (b * dinv) (k_jacobi_zero), so the pass reads
+// b alone -- at the rows and planes where it would read u -- and forms u1 on the way: 8 + 8 B per unknown (fp32: 4 + 4) instead of
+// 8 written by the zero-guess sweep + 24 for the two-sweep pass.  a.u is not read.
+template <typename T, int WX, int FORM, bool ZG = false>
 __global__ void __launch_bounds__(64 * WX) k_jacobi2(const J2Args<T> a) {
     constexpr bool UNC = (FORM & 1) != 0, DPP = (FORM & 2) != 0;      // as in k_jacobi2r
     constexpr int VX = 16 / sizeof(T), TY = 4, R1 = TY + 4, R2 = TY + 2, TX = 64 * VX * WX, LW = TX + 2 * VX;
@@ -1274,8 +1277,16 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2(const J2Args<T> a) {
     const T *bp_ = a.b + (long)(yb - 1) * a.rs + x0;          // row q  of plane p: bp_ + p*ms + q*rs
     const int pmin = a.has_lo ? -2 : -1, pmax = a.has_hi ? a.nz + 1 : a.nz;     // u planes that exist
     const int smin = a.has_lo ? -1 : 0, smax = a.has_hi ? a.nz : a.nz - 1;      // planes on which the first sweep is real
+    const T *usrc = ZG ? a.b : a.u;
     auto uplane = [&](int p) -> const T * {
-        return (p == -2 ? a.far_lo : p == a.nz + 1 ? a.far_hi : a.u + (long)p * a.ms) + uoff;
+        return (p == -2 ? a.far_lo : p == a.nz + 1 ? a.far_hi : usrc + (long)p * a.ms) + uoff;
+    };
+    auto first = [&](VT v) -> VT {                            // ZG: the zero-guess sweep of what was loaded (zeros stay zeros)
+        if (ZG) {
+#pragma unroll
+            for (int e = 0; e < VX; e++) { const T zx = v.v[e] * a.dinv; v.v[e] = a.scale * zx; }
+        }
+        return v;
     };
 
     // zero the ring (u'(-1) and the padding columns are 0) -- one pass, strided over the block
@@ -1289,10 +1300,10 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2(const J2Args<T> a) {
     auto LDU = [&](int p, int rr, bool pv) -> VT {
         if (UNC) {
             const int pp = max(pmin, min(p, pmax));
-            const T *pl = (pp == -2) ? a.far_lo : (pp == a.nz + 1) ? a.far_hi : a.u + (long)pp * a.ms;
-            return *reinterpret_cast<const VT *>(reinterpret_cast<const char *>(pl + uro[rr]) + lb);
+            const T *pl = (pp == -2) ? a.far_lo : (pp == a.nz + 1) ? a.far_hi : usrc + (long)pp * a.ms;
+            return first(*reinterpret_cast<const VT *>(reinterpret_cast<const char *>(pl + uro[rr]) + lb));
         }
-        return ldv(uplane(p) + (long)rr * a.rs, uok[rr] && pv);
+        return first(ldv(uplane(p) + (long)rr * a.rs, uok[rr] && pv));
     };
     auto LDB = [&](int p, int q, bool pv, bool stream) -> VT {
         if (UNC) {
@@ -1603,9 +1614,10 @@ template <> struct j2norm<double> { static constexpr bool built = true; };
 template <typename T>
 static int jacobi2(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
                    const T *b, const T *u, T *unew, const T *far_lo, const T *far_hi, int zbeg, int zend, void *stream,
-                   int *norm_parts = nullptr, int part_off = 0) {
+                   int *norm_parts = nullptr, int part_off = 0, bool zero_guess = false) {
     constexpr int VX = 16 / sizeof(T);
-    if (!c || !g || !coef || !b || !u || !unew || u == unew || g->dim != 3) return fail(MGK_EINVAL, "mgk_jacobi2: bad arguments (3-D)");
+    if (zero_guess) u = b;                                       // (not read as u: the kernel forms the first sweep from b)
+    if (!c || !g || !coef || !b || !u || !unew || (u == unew && !zero_guess) || b == unew || g->dim != 3) return fail(MGK_EINVAL, "mgk_jacobi2: bad arguments (3-D)");
     if (g->nx + 1 > 1024) return fail(MGK_EINVAL, "mgk_jacobi2: nx + 1 > 1024 is not built");
     J2Args<T> a; memset(&a, 0, sizeof(a));
     a.u = u + g->org; a.b = b + g->org; a.out = unew + g->org;
@@ -1655,6 +1667,15 @@ static int jacobi2(mgk_ctx *c, const mgk_geom *g, const double *coef, double din
     // full-row shapes: unconditional loads + DPP lane shifts (tuning variants 36 / 37 keep the predicated / ds_bpermute form)
     constexpr int WR = 64 * VX;
     const bool full = (g->nx + 1) % WR == 0 && (g->ny + 1) % 4 == 0 && g_variant != 36 && g_variant != 37;
+    if (zero_guess) {
+        if (!ring || !full || far_lo || far_hi || norm_parts) return fail(MGK_EINVAL, "mgk_jacobi2_zero: built for whole grids of full-row shape on the LDS-ring form (fp32; fp64 up to 511^3)");
+        if (w <= 1) hipLaunchKernelGGL((k_jacobi2<T, 1, 3, true>), dim3(nblk), dim3(64), 0, s, a);
+        else if (w <= 2) hipLaunchKernelGGL((k_jacobi2<T, 2, 3, true>), dim3(nblk), dim3(128), 0, s, a);
+        else if (w <= 4) hipLaunchKernelGGL((k_jacobi2<T, 4, 3, true>), dim3(nblk), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_jacobi2<T, 8, 3, true>), dim3(nblk), dim3(512), 0, s, a);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (ring) {
         if (full) {
             if (w <= 1) hipLaunchKernelGGL((k_jacobi2<T, 1, 3>), dim3(nblk), dim3(64), 0, s, a);
@@ -1692,6 +1713,28 @@ extern "C" int mgk_jacobi2_f32(mgk_ctx *c, const mgk_geom *g, const double *coef
                                const float *b, const float *u, float *unew, void *stream) {
     if (!g) return fail(MGK_EINVAL, "mgk_jacobi2_f32: bad arguments");
     return jacobi2<float>(c, g, coef, dinv, scale, b, u, unew, nullptr, nullptr, 0, g->nz, stream);
+}
+// THREE sweeps from a zero initial guess in one pass that reads b alone: unew = J(J(J0(b))), J0(b) = scale * (b * dinv) (k_jacobi_zero).
+// Whole grids of full-row shape on the LDS-ring form (fp32: n = 255 .. 1023; fp64: n = 127 .. 511); mgk_jacobi2_zero_ok_* tells.
+template <typename T>
+static bool j2zero_ok(const mgk_geom *g) {
+    constexpr int VX = 16 / sizeof(T);
+    if (!g || g->dim != 3 || (g->nx + 1) % (64 * VX) != 0 || (g->ny + 1) % 4 != 0 || g->nx + 1 > 1024) return false;
+    const int w = (g->nx + 1) / (64 * VX);
+    if (g_variant == 2 || g_variant == 36 || g_variant == 37) return false;
+    return !(sizeof(T) == 8 && w > 4);                           // the shapes the ring form is chosen for
+}
+extern "C" int mgk_jacobi2_zero_ok_f64(const mgk_geom *g) { return j2zero_ok<double>(g) ? 1 : 0; }
+extern "C" int mgk_jacobi2_zero_ok_f32(const mgk_geom *g) { return j2zero_ok<float>(g) ? 1 : 0; }
+extern "C" int mgk_jacobi2_zero_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
+                                    const double *b, double *unew, void *stream) {
+    if (!g) return fail(MGK_EINVAL, "mgk_jacobi2_zero_f64: bad arguments");
+    return jacobi2<double>(c, g, coef, dinv, scale, b, nullptr, unew, nullptr, nullptr, 0, g->nz, stream, nullptr, 0, true);
+}
+extern "C" int mgk_jacobi2_zero_f32(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
+                                    const float *b, float *unew, void *stream) {
+    if (!g) return fail(MGK_EINVAL, "mgk_jacobi2_zero_f32: bad arguments");
+    return jacobi2<float>(c, g, coef, dinv, scale, b, nullptr, unew, nullptr, nullptr, 0, g->nz, stream, nullptr, 0, true);
 }
 // Two sweeps AND || b - A u ||^2 of the input field (formed by the first sweep anyway): closes cycle k (src/solver.c:1545-1546)
 // and makes the first two pre-smoothing sweeps of cycle k+1 (:1531) in one pass.  unew is only adopted if another cycle runs.

@@ -468,6 +468,24 @@ extern "C" {
 int mgk_tail_cycle_f64(mgk_ctx *c, const mgk_geom *g0, int nl, const int *n, const double *k7, const double *di, double s, int v0, int v1, const double *b, double *u, void *) { return tail_api<double>(c, g0, nl, n, k7, di, s, v0, v1, b, u); }
 int mgk_tail_cycle_f32(mgk_ctx *c, const mgk_geom *g0, int nl, const int *n, const double *k7, const double *di, double s, int v0, int v1, const float *b, float *u, void *) { return tail_api<float>(c, g0, nl, n, k7, di, s, v0, v1, b, u); }
 
+}   // extern "C"
+// three sweeps from a zero guess in one pass
+template <class T> static int j2zero_api(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale, const T *b, T *o) {
+    if (!c || !g || g->dim != 3 || !coef || !b || !o || b == o) return fail(MGK_EINVAL, "mgk_jacobi2_zero");
+    const mgk_geom G = *g; std::vector<double> k(coef, coef + 7);
+    return run(c, [=] {
+        std::vector<T> w1(G.total, (T)0), w2(G.total, (T)0);
+        for (int kk = 0; kk < G.nz; kk++) for (int i = 0; i < G.ny; i++) for (int j = 0; j < G.nx; j++) { const T zx = at(b, G, kk, i, j) * (T)dinv; at(w1.data(), G, kk, i, j) = (T)scale * zx; }
+        st_op<T>(M_JACOBI, G, k.data(), dinv, scale, 0, 0, 0, b, w1.data(), (const T *)nullptr, w2.data(), 0, G.nz);
+        st_op<T>(M_JACOBI, G, k.data(), dinv, scale, 0, 0, 0, b, w2.data(), (const T *)nullptr, w1.data(), 0, G.nz);
+        for (int kk = 0; kk < G.nz; kk++) for (int i = 0; i < G.ny; i++) memcpy(&at(o, G, kk, i, 0), &at(w1.data(), G, kk, i, 0), sizeof(T) * (size_t)G.nx);
+    });
+}
+extern "C" {
+int mgk_jacobi2_zero_ok_f64(const mgk_geom *g) { return (g && g->dim == 3 && g->nx >= 7) ? 1 : 0; }
+int mgk_jacobi2_zero_ok_f32(const mgk_geom *g) { return (g && g->dim == 3 && g->nx >= 7) ? 1 : 0; }
+int mgk_jacobi2_zero_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale, const double *b, double *o, void *) { return j2zero_api<double>(c, g, coef, dinv, scale, b, o); }
+int mgk_jacobi2_zero_f32(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale, const float *b, float *o, void *) { return j2zero_api<float>(c, g, coef, dinv, scale, b, o); }
 // two sweeps + the norm of the input field's residual; the last pre-smoothing sweep fused with residual + restriction
 int mgk_jacobi2_sumsq_ok_f64(const mgk_geom *g) { return (g && g->dim == 3 && g->nx >= 7) ? 1 : 0; }     // (the mock takes any 3-D shape: host logic only)
 int mgk_jacobi2_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale, const double *b, const double *u, double *o, double *out, void *) {

@@ -863,3 +863,43 @@ def test_2d_forms_of_the_four_pass_kernels_bit_exact(mgk, orc, nf):
     assert np.array_equal(mgk.from_field(gf, du), u)
     for p in (du, db, dw, dbc, duc0):
         mgk.free(p)
+
+
+@pytest.mark.parametrize("n,prec", [(127, "f64"), (255, "f64"), (255, "f32")])
+def test_three_sweeps_from_the_zero_guess_in_one_pass(mgk, orc, n, prec):
+    """mgk_jacobi2_zero_*: J(J(J0(b))) reading b alone == mgk_jacobi_zero_* followed by mgk_jacobi2_* (themselves pinned to the oracle)"""
+    rng = np.random.default_rng(5600 + n)
+    As = _stencil(orc, 3, n)
+    dinv = 1.0 / As[3]
+    b = _rand(rng, n ** 3)
+    if prec == "f64":
+        g = mgk.geom(3, n)
+        assert mgk.L.mgk_jacobi2_zero_ok_f64(C.byref(g)) == 1
+        db, d1, d2, dout = mgk.to_field(g, b), mgk.field(g), mgk.field(g), mgk.field(g)
+        mgk._chk(mgk.L.mgk_jacobi_zero_f64(mgk.ctx, C.byref(g), dinv, 0.8, db, d1, None))
+        mgk._chk(mgk.L.mgk_jacobi2_f64(mgk.ctx, C.byref(g), mgk.coef(As), dinv, 0.8, db, d1, d2, None))
+        want = mgk.raw_field(g, d2)
+        assert np.array_equal(mgk.from_field(g, d2), orc.jacobi(3, n, As, 0.8, b, orc.jacobi(3, n, As, 0.8, b, orc.jacobi(3, n, As, 0.8, b, np.zeros(n ** 3), zero_guess=True))))
+        for zc in (-1, 8, 21):
+            mgk.L.mgk_set_tuning(-1, zc)
+            mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dout, 8 * g.total, None))
+            mgk._chk(mgk.L.mgk_jacobi2_zero_f64(mgk.ctx, C.byref(g), mgk.coef(As), dinv, 0.8, db, dout, None))
+            assert np.array_equal(mgk.raw_field(g, dout), want), f"zc={zc}"
+        esz = 8
+    else:
+        g = mgk.geom32(n)
+        assert mgk.L.mgk_jacobi2_zero_ok_f32(C.byref(g)) == 1
+        db, d1, d2, dout = mgk.to_field32(g, b), mgk.alloc(4 * g.total), mgk.alloc(4 * g.total), mgk.alloc(4 * g.total)
+        for f in (d1, d2, dout):
+            mgk._chk(mgk.L.mgk_memset0(mgk.ctx, f, 4 * g.total, None))
+        mgk._chk(mgk.L.mgk_jacobi_zero_f32(mgk.ctx, C.byref(g), dinv, 0.8, db, d1, None))
+        mgk._chk(mgk.L.mgk_jacobi2_f32(mgk.ctx, C.byref(g), mgk.coef(As), dinv, 0.8, db, d1, d2, None))
+        want = mgk.from_field32(g, d2)
+        for zc in (-1, 8, 21):
+            mgk.L.mgk_set_tuning(-1, zc)
+            mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dout, 4 * g.total, None))
+            mgk._chk(mgk.L.mgk_jacobi2_zero_f32(mgk.ctx, C.byref(g), mgk.coef(As), dinv, 0.8, db, dout, None))
+            assert np.array_equal(mgk.from_field32(g, dout), want), f"zc={zc}"
+    mgk.L.mgk_set_tuning(-1, -1)
+    for p in (db, d1, d2, dout):
+        mgk.free(p)
