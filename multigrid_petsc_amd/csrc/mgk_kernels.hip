@@ -1174,6 +1174,38 @@ template <bool DPP> __device__ __forceinline__ float lane_dn(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xf, 0xf, false));
 }
 
+// lane shifts that deliver `old` to the lane without a source (lane 0 / lane 63): the DPP shift keeps the old operand there
+__device__ __forceinline__ double lane_up_old(double v, double old) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x138, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_dn_old(double v, double old) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x130, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float lane_up_old(float v, float old) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_dn_old(float v, float old) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+// loads / stores through a buffer descriptor (one per plane, built on the scalar unit): the row offset is a 32-bit SGPR operand, the lane
+// offset one constant VGPR -- no 64-bit vector address arithmetic
+typedef unsigned int mgk_u4v __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ V16<T> bufld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    mgk_u4v v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return __builtin_bit_cast(V16<T>, v);
+}
+template <typename T> __device__ __forceinline__ V16<T> bufld_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    mgk_u4v v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2);
+    return __builtin_bit_cast(V16<T>, v);
+}
+template <typename T> __device__ __forceinline__ void bufst_nt(const V16<T> &x, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mgk_u4v, x), r, voff, soff, 2);
+}
+
 template <typename T>
 __device__ __forceinline__ V16<T> jac7(T a0, T a1, T a2, T a3, T a4, T a5, T a6, T dinv, T scale, const V16<T> &dn, const V16<T> &sv,
                                        const V16<T> &c, const V16<T> &nv, const V16<T> &upv, T Wv, T Ev, const V16<T> &b) {
@@ -1409,6 +1441,153 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2(const J2Args<T> a) {
         for (int q = 0; q < R2; q++) b1[q] = bn[q];
 #pragma unroll
         for (int rr = 0; rr < R1; rr++) { ua[rr] = ub[rr]; ub[rr] = uc[rr]; uc[rr] = ud[rr]; }
+    }
+}
+
+// k_jacobi2 on full-row shapes with the instruction overhead taken out (fp32 1023^3: the LDS-ring form issued 725 vector instructions per
+// step of which 160 register copies of the plane rotation, 86 selects, 57 SGPR reloads and 19 64-bit address adds; two waves per SIMD were
+// issue bound): buffer-descriptor loads / stores with 32-bit scalar row offsets, wave-edge neighbours as the DPP `old` operand (zero pads
+// at the ends of the row), rows / planes outside the grid skipped by wave-uniform branches, and the marching loop unrolled by four with the
+// roles of the four register planes permuted instead of copied.  Same arithmetic (jac7), same results.
+template <typename T, int WX, bool ZG>
+__global__ void __launch_bounds__(64 * WX) k_jacobi2b(const J2Args<T> a) {
+    constexpr int VX = 16 / sizeof(T), TY = 4, R1 = TY + 4, R2 = TY + 2, TX = 64 * VX * WX, LW = TX + 2 * VX;
+    __shared__ __attribute__((aligned(16))) T ring[3][R2][LW];
+    __shared__ T edgeW[2][R2][WX + 1], edgeE[2][R2][WX + 1];      // [.][.][0] of edgeE and [.][.][WX] of edgeW: zero pads
+    using VT = V16<T>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int ty = bid % a.nty, tz = bid / a.nty;
+    const int yb = TY * ty;
+    const int z0 = a.zbeg + tz * a.zc, z1 = min(z0 + a.zc, a.zend);
+    if (z0 >= z1) return;
+    const int xl = VX * tid;
+    const bool lastlane = (tid == 64 * WX - 1);                   // its last element is the ghost column x = nx: stays 0
+    const unsigned lb = (unsigned)(xl * (int)sizeof(T));
+    const int pmin = a.has_lo ? -2 : -1, pmax = a.has_hi ? a.nz + 1 : a.nz;     // u planes that exist
+    const int smin = a.has_lo ? -1 : 0, smax = a.has_hi ? a.nz : a.nz - 1;      // planes on which the first sweep is real
+    const int qlo = max(0, 1 - yb), qhi = min(R2 - 1, a.ny - yb);               // first-sweep rows q (y = yb-1+q) inside the grid
+    const unsigned rowb = (unsigned)(a.rs * (long)sizeof(T));
+    const unsigned plane_bytes = (unsigned)(a.ny + 2) * rowb;
+    unsigned urb[R1], brb[R2];                                    // byte offsets of the rows from row -1 of a plane (clamped to the ghost rows)
+#pragma unroll
+    for (int rr = 0; rr < R1; rr++) urb[rr] = (unsigned)(max(-1, min(yb - 2 + rr, a.ny)) + 1) * rowb;
+#pragma unroll
+    for (int q = 0; q < R2; q++) brb[q] = (unsigned)(max(0, min(yb - 1 + q, a.ny)) + 1) * rowb;
+    const T *usrc = ZG ? a.b : a.u;
+    auto URS = [&](int p) {
+        const int pp = max(pmin, min(p, pmax));
+        const T *pl = (pp == -2) ? a.far_lo : (pp == a.nz + 1) ? a.far_hi : usrc + (long)pp * a.ms;
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(pl - a.rs), 0, (int)plane_bytes, 0x00020000);
+    };
+    auto BRS = [&](int p) { return __builtin_amdgcn_make_buffer_rsrc((void *)(a.b - a.rs + (long)max(smin, min(p, smax)) * a.ms), 0, (int)plane_bytes, 0x00020000); };
+    auto first = [&](VT v) -> VT {                                // ZG: the zero-guess sweep of what was loaded (zeros stay zeros)
+        if (ZG) {
+#pragma unroll
+            for (int e = 0; e < VX; e++) { const T zx = v.v[e] * a.dinv; v.v[e] = a.scale * zx; }
+        }
+        return v;
+    };
+    for (int i = tid; i < 3 * R2 * LW; i += 64 * WX) (&ring[0][0][0])[i] = (T)0;
+    for (int i = tid; i < 2 * R2 * (WX + 1); i += 64 * WX) { (&edgeW[0][0][0])[i] = (T)0; (&edgeE[0][0][0])[i] = (T)0; }
+
+    VT ua[R1], ub[R1], uc[R1], ud[R1], b1[R2], bn[R2], b0[TY];
+    const int t0 = z0 - 2;                                        // first step: stage 1 of plane z0 - 1
+    {
+        const auto r0 = URS(t0), r1 = URS(t0 + 1), r2 = URS(t0 + 2);
+        const auto rb = BRS(t0 + 1);
+#pragma unroll
+        for (int rr = 0; rr < R1; rr++) { ua[rr] = first(bufld<T>(r0, lb, urb[rr])); ub[rr] = first(bufld<T>(r1, lb, urb[rr])); uc[rr] = first(bufld<T>(r2, lb, urb[rr])); ud[rr] = v16_zero<T>(); }
+#pragma unroll
+        for (int q = 0; q < R2; q++) { b1[q] = bufld<T>(rb, lb, brb[q]); bn[q] = v16_zero<T>(); }
+    }
+#pragma unroll
+    for (int j = 0; j < TY; j++) b0[j] = v16_zero<T>();
+    __syncthreads();                                              // the zero fill is complete before the first edge values land
+    if (lane == 0 || lane == 63) {
+#pragma unroll
+        for (int q = 0; q < R2; q++) {
+            if (lane == 0) edgeW[(t0 + 1) & 1][q][w] = ub[q + 1].v[0];
+            else edgeE[(t0 + 1) & 1][q][w + 1] = ub[q + 1].v[VX - 1];
+        }
+    }
+    __syncthreads();
+
+    // one marching step; A: plane t, B: t+1, C: t+2 of u, D receives plane t+3
+    auto step = [&](VT (&A)[R1], VT (&B)[R1], VT (&C)[R1], VT (&D)[R1], const int t) __attribute__((always_inline)) {
+        const int p = t + 1;                                      // plane of stage 1
+        {
+            const auto r3 = URS(t + 3);
+            const auto rb = BRS(t + 2);
+#pragma unroll
+            for (int rr = 0; rr < R1; rr++) D[rr] = bufld<T>(r3, lb, urb[rr]);
+#pragma unroll
+            for (int q = 0; q < R2; q++) bn[q] = (q >= 2 && q < R2 - 2) ? bufld_nt<T>(rb, lb, brb[q]) : bufld<T>(rb, lb, brb[q]);     // rows shared with neighbours: cached
+        }
+        // ---- stage 1: u'(p) on rows yb-1 .. yb+TY ----
+        {
+            const bool pin = (p >= smin && p <= smax);
+            const int slot = (p + 3) % 3, eb = p & 1;
+            const int qlo_t = pin ? qlo : R2;                     // (loop-variant bounds: planes outside the grid have no valid row)
+            const unsigned span_t = (unsigned)(qhi - qlo_t);
+#pragma unroll
+            for (int q = 0; q < R2; q++) {
+                const int rr = q + 1;
+                if ((unsigned)(q - qlo_t) <= span_t && qhi >= qlo_t) {          // wave-uniform: the row is inside the grid
+                    const T Wv = lane_up_old(B[rr].v[VX - 1], edgeE[eb][q][w]);
+                    const T Ev = lane_dn_old(B[rr].v[0], edgeW[eb][q][w + 1]);
+                    VT o = jac7(a.a0, a.a1, a.a2, a.a3, a.a4, a.a5, a.a6, a.dinv, a.scale, A[rr], B[rr - 1], B[rr], B[rr + 1], C[rr], Wv, Ev, b1[q]);
+                    if (lastlane) o.v[VX - 1] = (T)0;
+                    *reinterpret_cast<VT *>(&ring[slot][q][xl + VX]) = o;
+                } else if (!pin) {
+                    *reinterpret_cast<VT *>(&ring[slot][q][xl + VX]) = v16_zero<T>();   // plane outside the grid: zeros (rows outside keep their initial zeros)
+                }
+            }
+            if (lane == 0 || lane == 63) {
+#pragma unroll
+                for (int q = 0; q < R2; q++) {
+                    if (lane == 0) edgeW[eb ^ 1][q][w] = C[q + 1].v[0];
+                    else edgeE[eb ^ 1][q][w + 1] = C[q + 1].v[VX - 1];
+                }
+            }
+        }
+        __syncthreads();                                          // u'(p) complete
+        // ---- stage 2: out(t) on rows yb .. yb+TY-1 from u'(t-1), u'(t), u'(t+1) ----
+        if (t >= z0) {
+            const int sm = (t + 2) % 3, sc = t % 3, sp = (t + 1) % 3;
+            const auto ro = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out - a.rs + (long)t * a.ms), 0, (int)plane_bytes, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < TY; j++) {
+                const int q = j + 1;
+                if (yb + j < a.ny) {                                            // wave-uniform
+                    const VT c = *reinterpret_cast<const VT *>(&ring[sc][q][xl + VX]);
+                    const VT dn = *reinterpret_cast<const VT *>(&ring[sm][q][xl + VX]);
+                    const VT upv = *reinterpret_cast<const VT *>(&ring[sp][q][xl + VX]);
+                    const VT sv = *reinterpret_cast<const VT *>(&ring[sc][q - 1][xl + VX]);
+                    const VT nv = *reinterpret_cast<const VT *>(&ring[sc][q + 1][xl + VX]);
+                    const T Wv = ring[sc][q][xl + VX - 1], Ev = ring[sc][q][xl + 2 * VX];
+                    VT o = jac7(a.a0, a.a1, a.a2, a.a3, a.a4, a.a5, a.a6, a.dinv, a.scale, dn, sv, c, nv, upv, Wv, Ev, b0[j]);
+                    if (lastlane) o.v[VX - 1] = (T)0;
+                    bufst_nt<T>(o, ro, lb, (unsigned)(yb + j + 1) * rowb);
+                }
+            }
+        }
+        __syncthreads();                                          // ring slot (t-1)%3 is free for u'(t+2)
+#pragma unroll
+        for (int j = 0; j < TY; j++) b0[j] = b1[j + 1];
+#pragma unroll
+        for (int q = 0; q < R2; q++) b1[q] = bn[q];
+#pragma unroll
+        for (int rr = 0; rr < R1; rr++) D[rr] = first(D[rr]);     // (ZG: the plane that arrived becomes the zero-guess sweep of b; loads are awaited here)
+    };
+    for (int t = t0; t < z1; t += 4) {
+        step(ua, ub, uc, ud, t);
+        if (t + 1 < z1) step(ub, uc, ud, ua, t + 1);
+        if (t + 2 < z1) step(uc, ud, ua, ub, t + 2);
+        if (t + 3 < z1) step(ud, ua, ub, uc, t + 3);
     }
 }
 
@@ -1669,15 +1848,26 @@ static int jacobi2(mgk_ctx *c, const mgk_geom *g, const double *coef, double din
     const bool full = (g->nx + 1) % WR == 0 && (g->ny + 1) % 4 == 0 && g_variant != 36 && g_variant != 37;
     if (zero_guess) {
         if (!ring || !full || far_lo || far_hi || norm_parts) return fail(MGK_EINVAL, "mgk_jacobi2_zero: built for whole grids of full-row shape on the LDS-ring form (fp32; fp64 up to 511^3)");
-        if (w <= 1) hipLaunchKernelGGL((k_jacobi2<T, 1, 3, true>), dim3(nblk), dim3(64), 0, s, a);
-        else if (w <= 2) hipLaunchKernelGGL((k_jacobi2<T, 2, 3, true>), dim3(nblk), dim3(128), 0, s, a);
-        else if (w <= 4) hipLaunchKernelGGL((k_jacobi2<T, 4, 3, true>), dim3(nblk), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((k_jacobi2<T, 8, 3, true>), dim3(nblk), dim3(512), 0, s, a);
+        if (g_variant == 39 || (sizeof(T) == 8 && g_variant != 45)) {   // the form before the instruction diet: 39 forces it; fp64 keeps it
+                                                                        // (511^3: 0.471 against 0.488 ms; 45 forces the new form)
+            if (w <= 1) hipLaunchKernelGGL((k_jacobi2<T, 1, 3, true>), dim3(nblk), dim3(64), 0, s, a);
+            else if (w <= 2) hipLaunchKernelGGL((k_jacobi2<T, 2, 3, true>), dim3(nblk), dim3(128), 0, s, a);
+            else if (w <= 4) hipLaunchKernelGGL((k_jacobi2<T, 4, 3, true>), dim3(nblk), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_jacobi2<T, 8, 3, true>), dim3(nblk), dim3(512), 0, s, a);
+        } else if (w <= 1) hipLaunchKernelGGL((k_jacobi2b<T, 1, true>), dim3(nblk), dim3(64), 0, s, a);
+        else if (w <= 2) hipLaunchKernelGGL((k_jacobi2b<T, 2, true>), dim3(nblk), dim3(128), 0, s, a);
+        else if (w <= 4) hipLaunchKernelGGL((k_jacobi2b<T, 4, true>), dim3(nblk), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_jacobi2b<T, 8, true>), dim3(nblk), dim3(512), 0, s, a);
         HIPCHK(hipGetLastError());
         return 0;
     }
     if (ring) {
-        if (full) {
+        if (full && g_variant != 39) {
+            if (w <= 1) hipLaunchKernelGGL((k_jacobi2b<T, 1, false>), dim3(nblk), dim3(64), 0, s, a);
+            else if (w <= 2) hipLaunchKernelGGL((k_jacobi2b<T, 2, false>), dim3(nblk), dim3(128), 0, s, a);
+            else if (w <= 4) hipLaunchKernelGGL((k_jacobi2b<T, 4, false>), dim3(nblk), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_jacobi2b<T, 8, false>), dim3(nblk), dim3(512), 0, s, a);
+        } else if (full) {
             if (w <= 1) hipLaunchKernelGGL((k_jacobi2<T, 1, 3>), dim3(nblk), dim3(64), 0, s, a);
             else if (w <= 2) hipLaunchKernelGGL((k_jacobi2<T, 2, 3>), dim3(nblk), dim3(128), 0, s, a);
             else if (w <= 4) hipLaunchKernelGGL((k_jacobi2<T, 4, 3>), dim3(nblk), dim3(256), 0, s, a);
@@ -2019,30 +2209,6 @@ __global__ void __launch_bounds__(64 * WX) k_srr(const SRRArgs<T> a) {
 //  * wave-edge neighbours: the DPP shift keeps the `old` operand in the lane that has no source, so the value from the neighbouring
 //    wave (or the zero pad at the ends of the row) is passed as `old`: no lane-0 / lane-63 selects;
 //  * rows / planes outside the grid are skipped by wave-uniform branches instead of per-element selects.
-typedef unsigned int mgk_u4v __attribute__((ext_vector_type(4)));
-template <typename T> __device__ __forceinline__ V16<T> bufld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    mgk_u4v v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    return __builtin_bit_cast(V16<T>, v);
-}
-template <typename T> __device__ __forceinline__ V16<T> bufld_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    mgk_u4v v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2);
-    return __builtin_bit_cast(V16<T>, v);
-}
-template <typename T> __device__ __forceinline__ void bufst_nt(const V16<T> &x, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mgk_u4v, x), r, voff, soff, 2);
-}
-// lane shifts that deliver `old` to the lane without a source (lane 0 / lane 63)
-__device__ __forceinline__ double lane_up_old(double v, double old) {
-    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x138, 0xf, 0xf, false);
-    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x138, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double lane_dn_old(double v, double old) {
-    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x130, 0xf, 0xf, false);
-    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x130, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-
 template <int WX>
 __global__ void __launch_bounds__(64 * WX) k_srr4b(const SRRArgs<double> a) {
     typedef double T;

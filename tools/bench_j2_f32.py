@@ -21,9 +21,15 @@ def timeit(fn, reps=5):
 N = float(n) ** 3
 one = timeit(lambda: L.mgk_jacobi_f32(m.ctx, C.byref(g), coef, dinv, 0.85, b, u, out, None))
 print(f"n={n} plain fp32 sweep: {one:.3f} ms ({12 * N / one / 1e6:.0f} GB/s) -> two sweeps {2 * one:.3f} ms", flush=True)
-NAMES = {1: "ring", 37: "ring, predicated loads + ds_bpermute"}
-for var, zc in [(v, z) for v in (1, 37) for z in zcs]:
+NAMES = {-1: "default (ring, instruction diet)", 39: "ring before the diet", 37: "ring, predicated loads + ds_bpermute"}
+for var, zc in [(v, z) for v in (-1, 39, 37) for z in zcs]:
     L.mgk_set_tuning(var, zc)
     two = timeit(lambda: L.mgk_jacobi2_f32(m.ctx, C.byref(g), coef, dinv, 0.85, b, u, out, None))
     print(f"n={n} variant={NAMES[var]} zc={zc}: two-in-one {two:.3f} ms  ({12 * N / two / 1e6:.0f} GB/s of the 12 B/unknown minimum; {two / (2 * one):.2f} x two plain sweeps)", flush=True)
+L.mgk_set_tuning(-1, -1)
+z3 = timeit(lambda: L.mgk_jacobi2_zero_f32(m.ctx, C.byref(g), coef, dinv, 0.85, b, out, None))
+L.mgk_set_tuning(39, -1)
+z3o = timeit(lambda: L.mgk_jacobi2_zero_f32(m.ctx, C.byref(g), coef, dinv, 0.85, b, out, None))
+print(f"n={n} three sweeps from the zero guess: {z3:.3f} ms (before the diet {z3o:.3f})", flush=True)
+L.mgk_set_tuning(-1, -1)
 m.close()
