@@ -3664,6 +3664,20 @@ __global__ void __launch_bounds__(64 * WX) k_rrrow(const RRArgs<T> a) {
                     T Wv = lane_up<DPP>(c.v[VX - 1]), Ev = lane_dn<DPP>(c.v[0]);
                     if (lane == 0) Wv = (w > 0) ? eE[z & 1][r][w - 1] : (T)0;
                     if (lane == 63) Ev = (w < WX - 1) ? eW[z & 1][r][w + 1] : (T)0;
+                    if constexpr (sizeof(T) == 4) {
+                        // fp32: the same sums on the 4-wide vector type, so that the compiler issues packed v_pk_mul_f32 / v_pk_add_f32
+                        auto ld4 = [](const VT &x) { f4v q; q.x = x.v[0]; q.y = x.v[1]; q.z = x.v[2]; q.w = x.v[3]; return q; };
+                        const f4v C4 = ld4(c);
+                        f4v W4; W4.x = Wv; W4.y = c.v[0]; W4.z = c.v[1]; W4.w = c.v[2];
+                        f4v E4; E4.x = c.v[1]; E4.y = c.v[2]; E4.z = c.v[3]; E4.w = Ev;
+                        f4v t4 = a.a0 * ld4(U[cm][r + 1]);
+                        t4 = t4 + a.a1 * ld4(U[cc][r]);
+                        t4 = t4 + a.a2 * W4;
+                        t4 = t4 + a.a3 * C4;
+                        t4 = t4 + a.a4 * E4;
+                        t4 = t4 + a.a5 * ld4(U[cc][r + 2]);
+                        res[r].v[0] = t4.x; res[r].v[1] = t4.y; res[r].v[2] = t4.z; res[r].v[VX - 1] = t4.w;
+                    } else {
 #pragma unroll
                     for (int e = 0; e < VX; e++) {
                         const T wv = (e == 0) ? Wv : c.v[e > 0 ? e - 1 : 0];
@@ -3676,13 +3690,21 @@ __global__ void __launch_bounds__(64 * WX) k_rrrow(const RRArgs<T> a) {
                         t = t + a.a5 * U[cc][r + 2].v[e];
                         res[r].v[e] = t;
                     }
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < RR; r++) {
+                    if constexpr (sizeof(T) == 4) {
+                        auto ld4 = [](const VT &x) { f4v q; q.x = x.v[0]; q.y = x.v[1]; q.z = x.v[2]; q.w = x.v[3]; return q; };
+                        const f4v t4 = ld4(res[r]) + a.a6 * ld4(U[cp][r + 1]);
+                        const f4v r4 = ld4(B[cc][r]) - t4;
+                        res[r].v[0] = rok[r] ? r4.x : (T)0; res[r].v[1] = rok[r] ? r4.y : (T)0; res[r].v[2] = rok[r] ? r4.z : (T)0; res[r].v[VX - 1] = rok[r] ? r4.w : (T)0;
+                    } else {
 #pragma unroll
                     for (int e = 0; e < VX; e++) {
                         const T t = res[r].v[e] + a.a6 * U[cp][r + 1].v[e];
                         res[r].v[e] = rok[r] ? B[cc][r].v[e] - t : (T)0;
+                    }
                     }
                     if (lastlane) res[r].v[VX - 1] = (T)0;
                 }
