@@ -285,6 +285,16 @@ int  mgk_sweep_residual_restrict_2d_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *gf
 int  mgk_tail_cycle_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *g0, int nlev, const int *n, const double *const *ctab,
                                 const double *const *dtab, double scale, int v0, int v1, const double *b, double *u, void *stream);
 
+/* two sweeps in one pass and sumsq = || b - A J(u) ||^2: the residual of the FIRST sweep's output J(u), which is NOT stored --
+ * the norm that closes a cycle whose last post-smoothing sweep is this pass's first one (the caller keeps u and owes that sweep
+ * if the iteration stops).  Shapes as mgk_jacobi2_sumsq_f64. */
+int  mgk_jacobi2_sumsq_mid_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale,
+                               const double *b, const double *u, double *unew, double *sumsq_host, void *stream);
+/* the prolongation, its correction and the first TWO post-smoothing sweeps in one pass: unew = J(J(u + P uc))
+ * (src/solver.c:1540-1542).  fp64, rows of 1024 (n = 1023), whole grid; _ok_ tells. */
+int  mgk_prolong_jacobi2_ok_f64(const mgk_geom *gf, const mgk_geom *gc);
+int  mgk_prolong_jacobi2_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
+                             const double *b, const double *uc, const double *u, double *unew, void *stream);
 /* THREE sweeps from a zero initial guess in one pass that reads b alone (the first one is pointwise: mgk_jacobi_zero_*):
  * unew = J(J(J0(b))) -- the whole of a pre-smoothing KSPSolve with max_it = 3 on a coarse level (src/solver.c:1536), 16 B per unknown
  * (fp32: 8) instead of 8 + 24.  Whole 3-D grids of full-row shape: fp32 n = 255 .. 1023, fp64 n = 127 .. 511; _ok_ tells (1 / 0). */

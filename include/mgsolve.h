@@ -52,7 +52,11 @@ typedef struct mg_config {
                          * unknown and cycle;
                          * bit 11 (3-D whole levels that sweep in pairs: fp32 up to 1023^3, fp64 up to 511^3): a pre-smoothing of >= 3 sweeps
                          * from the zero guess starts with ONE pass that makes three of them and reads b alone (mgk_jacobi2_zero_*);
-                         * default (-1): bits 0-5 and 8-11 on */
+                         * bit 12 (fp64, 3-D, level 0 of 1023-wide whole grids, v0 = 3): post-smoothing is ONE pass for the prolongation and two
+                         * sweeps (mgk_prolong_jacobi2_f64); the third sweep is the first stage of the two-sweep pass that evaluates the
+                         * norm (mgk_jacobi2_sumsq_mid_f64): 91 B per fine unknown and cycle.  The iterate the norm belongs to is not
+                         * stored; when the iteration stops one more sweep materialises it;
+                         * default (-1): bits 0-5 and 8-12 on */
     int overlap;        /* nranks > 1: halo of sweep k on the comm stream while sweep k's interior runs; default on (-1) */
     int graph;          /* replay the launch-bound coarse levels as one captured HIP graph; default on (-1) */
     int pair_min_n;     /* levels with n >= pair_min_n run their sweeps two per pass (fuse bit 5); <=0: default 255 (3-D), 2047 (2-D) */

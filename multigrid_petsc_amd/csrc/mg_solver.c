@@ -142,6 +142,10 @@ struct mg_solver {
     double *d_norms; int d_norms_cap;
     double *pin; int pin_cap; /* pinned host landing area of the reduced norms */
     int spec_valid;         /* > 0: level-0 tmp holds that many sweeps of u, made by the sweep(s)+norm kernel that closed the last cycle */
+    int sweep_owed;         /* fuse bit 12: the post-smoothing of level 0 stopped one sweep short (prolongation + two sweeps in one pass); the
+                             * pass that evaluates the norm makes that sweep first */
+    int iterate_behind;     /* ... and after that pass u is still ONE sweep behind the iterate the norm belongs to (it was never stored:
+                             * tmp holds the sweep after it); finalize_iterate() makes the sweep if the iteration stops here */
     double solve_seconds;
     int lgraph;             /* levels >= lgraph form the launch-bound coarse part replayed as one HIP graph (0: off) */
     int ltail;              /* levels >= ltail (n <= 15 in 3-D, <= 63 in 2-D) run as ONE kernel with their fields in LDS (0: off) */
@@ -373,7 +377,7 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
         const int n0 = mg_grid_n(cfg->npts, 0);
         s->cfg.dist_min_n = n0 < 255 ? n0 : 255;
     }
-    if (s->cfg.fuse < 0) s->cfg.fuse = 63 | 256 | 512 | 1024 | 2048;
+    if (s->cfg.fuse < 0) s->cfg.fuse = 63 | 256 | 512 | 1024 | 2048 | 4096;
     if (s->cfg.pair_min_n <= 0) s->cfg.pair_min_n = (cfg->dim == 3) ? 255 : 2047;   /* where a two-sweep pass beats two sweeps
                                                                                       * (255^3: 0.107 ms against 2 x 0.063) */
     if (s->cfg.mesh) s->cfg.fuse &= ~(16 | 128);   /* row-dependent coefficients (2-D, fp64): the same fused cycle on the row-table forms of the kernels */
@@ -567,7 +571,9 @@ int mg_solver_set_rhs_host(mg_solver *s, const double *b_compact) {
     return mg_solver_reset(s);
 }
 
+static int finalize_iterate(mg_solver *s);
 int mg_solver_get_solution(mg_solver *s, double *u_compact) {
+    CHK(finalize_iterate(s));
     mg_fset *F = &s->L[0].f[0];
     size_t n = (size_t)F->g.nx * F->g.ny * F->g.nz;
     void *d = NULL;
@@ -579,6 +585,7 @@ int mg_solver_get_solution(mg_solver *s, double *u_compact) {
 }
 
 int mg_solver_error_norms(mg_solver *s, double err[3]) {
+    CHK(finalize_iterate(s));
     double *sx = NULL, *sy = NULL, *sz = NULL;
     mg_fset *F = &s->L[0].f[0];
     CHK(sin_tables(s, NULL, &sx, &sy, &sz));
@@ -753,6 +760,7 @@ static int smooth(mg_solver *s, int P, int l, int maxit, int pre) {
         F->u_ghost_ok = 0; F->u_ghost_pending = 0;
         it0 = s->spec_valid;
         s->spec_valid = 0;
+        s->iterate_behind = 0;              /* (u is now the sweep AFTER the iterate the last norm belongs to) */
     }
     const int defer_last = pre && srr_ok(s, P, l);
     /* two sweeps per pass (temporal blocking) where it pays (3-D from 255^3, 2-D from 2047^2).  Also on the level whose buffers
@@ -962,6 +970,28 @@ static int prolong_from(mg_solver *s, int P, int l) {
     return 0;
 }
 
+/* fuse bit 12 (fp64, 3-D, level 0 of 1023-wide whole grids, v0 = 3): post-smoothing = ONE pass for the prolongation and two sweeps; the third
+ * sweep is the first stage of the two-sweep pass that evaluates the norm (mgk_jacobi2_sumsq_mid_f64), whose second stage is the first
+ * pre-smoothing sweep of the next cycle: 25 + 24 + 24 (two more pre-sweeps) + 18 (restriction) = 91 B per fine unknown and cycle.  The
+ * iterate the norm belongs to is never stored: if the iteration stops, finalize_iterate() makes that one sweep. */
+static int pjp_ok(const mg_solver *s, int P) {
+    const mg_level *L = &s->L[0];
+    const int need = 4096 | 1024 | 32 | 8 | 2 | 1;
+    if ((s->cfg.fuse & need) != need || P != 0 || s->cfg.dim != 3 || s->cfg.mesh || s->cfg.ksp_type != MG_KSP_RICHARDSON) return 0;
+    if (s->cfg.v[0] != 3 || s->levels < 2 || L->distributed || s->lgraph == 1 || L->n < s->cfg.pair_min_n) return 0;
+    return mgk_prolong_jacobi2_ok_f64(&L->f[0].g, &s->L[1].f[0].g) && mgk_jacobi2_sumsq_ok_f64(&L->f[0].g);
+}
+static int finalize_iterate(mg_solver *s) {
+    if (!s->iterate_behind) return 0;
+    mg_level *L = &s->L[0];
+    mg_fset *F = &L->f[0];
+    CHK(mgk_jacobi_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u, (double *)F->tmp, NULL));
+    swap_ptr(&F->u, &F->tmp);
+    F->u_ghost_ok = 0; F->u_ghost_pending = 0;
+    s->iterate_behind = 0; s->spec_valid = 0;
+    return 0;
+}
+
 /* prolongation fused into the first post-smoothing sweep: u <- Jacobi(u + P u_c)  (src/solver.c:1540-1542) */
 static int prolong_smooth(mg_solver *s, int P, int l) {
     mg_level *Lf = &s->L[l], *Lc = &s->L[l + 1];
@@ -971,6 +1001,16 @@ static int prolong_smooth(mg_solver *s, int P, int l) {
     if (!(s->cfg.fuse & 2) || s->cfg.ksp_type != MG_KSP_RICHARDSON || v0 < 1) {
         CHK(prolong_from(s, P, l));
         return smooth(s, P, l, v0, 0);
+    }
+    if (l == 0 && pjp_ok(s, P)) {
+        /* the prolongation and the first TWO post-smoothing sweeps in one pass; the third one is made by the pass that evaluates the
+         * norm (vcycle_once), which reads this field anyway */
+        CHK(mgk_prolong_jacobi2_f64(s->ctx, &F->g, &Cq->g, Lf->coef, Lf->dinv, s->cfg.scale, (const double *)F->b, (const double *)Cq->u,
+                                    (const double *)F->u, (double *)F->tmp, NULL));
+        swap_ptr(&F->u, &F->tmp);
+        F->u_ghost_ok = 0; F->u_ghost_pending = 0;
+        s->sweep_owed = 1;
+        return 0;
     }
     mgk_geom gc = Cq->g;
     const void *ucoarse = Cq->u;
@@ -1308,6 +1348,19 @@ static int vcycle_once(mg_solver *s) {
         CHK(cycle_body(s, 0, s->iter == 0));
         /* :1545-1546  r0 = b0 - A0 u0 ; ||r0|| */
         const int jnorm = (s->cfg.fuse & 8) && (s->cfg.fuse & 1) && s->cfg.ksp_type == MG_KSP_RICHARDSON && s->cfg.v[0] >= 1;
+        if (s->sweep_owed) {
+            /* the third post-smoothing sweep, the norm of ITS result and the first pre-smoothing sweep of the next cycle in one pass;
+             * u stays one sweep behind the iterate, tmp is one sweep ahead of it */
+            s->prof_kind = 1;
+            void *t = prof_begin(s, 0);
+            s->prof_kind = 0;
+            int rc2 = mgk_jacobi2_sumsq_mid_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u,
+                                                (double *)F->tmp, &ss, NULL);
+            prof_end(s, t);
+            CHK(rc2);
+            s->sweep_owed = 0; s->iterate_behind = 1; s->spec_valid = 1;
+            goto norm_done;
+        }
         if (jnorm && L->distributed && s->cfg.dim == 3 && (s->cfg.fuse & 1024) && (s->cfg.fuse & 32) && F->far && L->nz_min >= 6 &&
             s->cfg.v[0] >= 2 && L->n >= s->cfg.pair_min_n && L->n + 1 <= 1024 && s->lgraph != 1 && mgk_jacobi2_sumsq_ok_f64(&F->g)) {
             /* slab: the norm and the first TWO sweeps of the next cycle in one pass (the two-sweep slab pass with the norm of its
@@ -1415,7 +1468,7 @@ static int start(mg_solver *s) {
         CHK(mgk_residual_f64_to_f32(s->ctx, &F->g, &L->f[1].g, L->coef, (const double *)F->b, (const double *)F->u, (float *)L->f[1].b, &ss, NULL));
     else CHK(mgk_residual_sumsq_f64(s->ctx, &F->g, L->coef, (const double *)F->b, (const double *)F->u, &ss, NULL));
     CHK(norm_from_sumsq(s, ss, &s->rchk));
-    s->spec_valid = 0;
+    s->spec_valid = 0; s->sweep_owed = 0; s->iterate_behind = 0;
     s->iter = 0;
     s->rnorm[0] = s->rchk;                                              /* :1520 */
     s->started = 1;
@@ -1451,6 +1504,7 @@ int mg_solver_solve(mg_solver *s) {
         s->rchk = sqrt(ss);
         if (s->iter < s->rnorm_cap) s->rnorm[s->iter] = s->rchk;
     }
+    CHK(finalize_iterate(s));
     CHK(mgk_sync(s->ctx, NULL));
     s->solve_seconds = wall() - t0;                                      /* :1553 */
     return 0;
@@ -1476,6 +1530,7 @@ int mg_solver_cycles(mg_solver *s, int ncycles) {
     }
     mgk_defer_result(s->ctx, NULL);
     s->deferring = 0;
+    if (!rc) rc = finalize_iterate(s);
     if (rc) return rc;
     double *ss = (double *)malloc(sizeof(double) * (size_t)(ncycles > 0 ? ncycles : 1));
     if (!ss) return mgfail(MGK_EINVAL, "mg_solver_cycles: out of host memory");

@@ -106,6 +106,9 @@ def _sigs(L):
         "mgk_sweep_residual_restrict_ok_f64": (i, [G, G]),
         "mgk_jacobi2_sumsq_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp, C.POINTER(d), vp]),
         "mgk_jacobi2_sumsq_ok_f64": (i, [G]),
+        "mgk_jacobi2_sumsq_mid_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp, C.POINTER(d), vp]),
+        "mgk_prolong_jacobi2_ok_f64": (i, [G, G]),
+        "mgk_prolong_jacobi2_f64": (i, [vp, G, G, c_dp, d, d, vp, vp, vp, vp, vp]),
         "mgk_jacobi2_zero_ok_f64": (i, [G]),
         "mgk_jacobi2_zero_ok_f32": (i, [G]),
         "mgk_jacobi2_zero_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp]),

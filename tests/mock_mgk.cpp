@@ -559,9 +559,33 @@ int mgk_sweep_residual_restrict_2d_rowcoef_f64(mgk_ctx *c, const mgk_geom *gf, c
         if (uc0) for (int i = 0; i < Cg.ny; i++) for (int j = 0; j < Cg.nx; j++) { const double zq = at(bc, Cg, 0, i, j) * dtab_c[i]; at(uc0, Cg, 0, i, j) = scale_c * zq; }
     });
 }
+// (fuse bit 12) prolongation + two sweeps in one pass; two sweeps + the norm of the residual of the first one's output
+static int g_calls_pj2 = 0, g_calls_mid = 0;
+int mgk_prolong_jacobi2_ok_f64(const mgk_geom *gf, const mgk_geom *gc) { return (xfer_ok(gf, gc) && gf->dim == 3 && gf->nz == 2 * gc->nz + 1 && gf->nx >= 7) ? 1 : 0; }
+int mgk_prolong_jacobi2_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale, const double *b, const double *uc, const double *u, double *o, void *) {
+    if (!c || !coef || !b || !uc || !u || !o || u == o || !mgk_prolong_jacobi2_ok_f64(gf, gc)) return fail(MGK_EINVAL, "mgk_prolong_jacobi2_f64");
+    __atomic_fetch_add(&g_calls_pj2, 1, __ATOMIC_RELAXED);
+    const mgk_geom F = *gf, Cg = *gc; std::vector<double> k(coef, coef + 7);
+    return run(c, [=] {
+        std::vector<double> t = corrected<double>(F, Cg, uc, u), w(F.total, 0.0);
+        st_op<double>(M_JACOBI, F, k.data(), dinv, scale, 0, 0, 0, b, t.data(), (const double *)nullptr, w.data(), 0, F.nz);
+        st_op<double>(M_JACOBI, F, k.data(), dinv, scale, 0, 0, 0, b, w.data(), (const double *)nullptr, o, 0, F.nz);
+    });
+}
+int mgk_jacobi2_sumsq_mid_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale, const double *b, const double *u, double *o, double *out, void *) {
+    if (!c || !g || g->dim != 3 || !coef || !b || !u || !o || u == o || !out) return fail(MGK_EINVAL, "mgk_jacobi2_sumsq_mid_f64");
+    __atomic_fetch_add(&g_calls_mid, 1, __ATOMIC_RELAXED);
+    if (c->capturing) return fail(MGK_EINVAL, "reduction to the host inside a capture");
+    std::vector<double> r(g->total, 0.0), w(g->total, 0.0);
+    st_op<double>(M_JACOBI, *g, coef, dinv, scale, 0, 0, 0, b, u, (const double *)nullptr, w.data(), 0, g->nz);
+    st_op<double>(M_RESIDUAL, *g, coef, 1, 1, 0, 0, 0, b, w.data(), (const double *)nullptr, r.data(), 0, g->nz);
+    st_op<double>(M_JACOBI, *g, coef, dinv, scale, 0, 0, 0, b, w.data(), (const double *)nullptr, o, 0, g->nz);
+    deliver(c, sumsq_field<double>(*g, r.data(), 0, g->nz), out);
+    return 0;
+}
 // the two on a z-slab (far planes as the halo exchange delivers them; see include/mgk.h)
 static int g_calls_j2n_slab = 0, g_calls_srr_slab = 0, g_calls_srr = 0, g_calls_j2n = 0;
-static void print_stats() { if (getenv("MOCK_MGK_STATS")) fprintf(stderr, "MOCK_MGK_STATS j2n=%d srr=%d j2n_slab=%d srr_slab=%d\n", g_calls_j2n, g_calls_srr, g_calls_j2n_slab, g_calls_srr_slab); }
+static void print_stats() { if (getenv("MOCK_MGK_STATS")) fprintf(stderr, "MOCK_MGK_STATS j2n=%d srr=%d j2n_slab=%d srr_slab=%d pj2=%d mid=%d\n", g_calls_j2n, g_calls_srr, g_calls_j2n_slab, g_calls_srr_slab, g_calls_pj2, g_calls_mid); }
 static struct StatsAtExit { StatsAtExit() { atexit(print_stats); } } g_stats_at_exit;
 int mgk_jacobi2_sumsq_slab_f64(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gf, const double *coef, double dinv, double scale, const double *b, const double *u, double *o,
                                const double *far, int lo, int hi, int z0, int z1, int part_off, int *nparts, void *) {

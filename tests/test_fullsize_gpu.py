@@ -102,7 +102,7 @@ def test_full_size_fused_cycle_equals_unfused_cycle(precision):
     from multigrid_petsc_amd.solver import Solver
     out = {}
     # -1: the default cycle (all fusions, sweeps two per pass, register / shuffle kernels, two-sweep norm pass, sweep inside the restriction)
-    for fuse in (0, 31, 63 | 256 | 512, -1):
+    for fuse in (0, 31, 63 | 256 | 512, 63 | 256 | 512 | 1024 | 2048, -1):
         s = Solver(3, 1025, 10, scale=6.0 / 7.0, maxiter=12, precision=precision, fuse=fuse)
         s.set_rhs_problem()
         s.cycles(5)
@@ -110,7 +110,7 @@ def test_full_size_fused_cycle_equals_unfused_cycle(precision):
         e = s.error_norms()             # max, sum, sqrt(sum of squares) of |u - exact|: three checksums of the field
         out[fuse] = (s.rnorm.copy(), e)
         s.close()
-    for f in (31, 63 | 256 | 512, -1):
+    for f in (31, 63 | 256 | 512, 63 | 256 | 512 | 1024 | 2048, -1):
         assert np.abs(out[0][0] / out[f][0] - 1).max() <= 1e-12
         assert out[0][1][0] == out[f][1][0]
         assert abs(out[0][1][1] - out[f][1][1]) <= 1e-13 * out[0][1][1] and abs(out[0][1][2] - out[f][1][2]) <= 1e-13 * out[0][1][2]

@@ -76,7 +76,10 @@ def _run(exe, args, cwd, env=None, ok_codes=(0,)):
     (["-dim", "3", "-npts", "33", "-levels", "5", "-ksp_richardson_scale", "0.857142857142857095", "-mg_fuse", "1087"], 3, 33, 5, 6.0 / 7.0),
 ])
 def test_own_driver_under_sanitizers_matches_the_oracle(san, tmp_path, args, dim, npts, levels, scale):
-    out = _run(san["mgpoisson"], args + ["-pc_type", "jacobi", "-write_fields", "1"], tmp_path)
+    out = _run(san["mgpoisson"], args + ["-pc_type", "jacobi", "-write_fields", "1"], tmp_path, env={"MOCK_MGK_STATS": "1"})
+    if "-mg_graph" in args and dim == 3:        # level 0 does not feed a graph: prolongation + two sweeps, norm of the mid iterate, final sweep
+        m = re.search(r"pj2=(\d+) mid=(\d+)", out)
+        assert m and int(m.group(1)) > 0 and int(m.group(2)) > 0, out[-300:]
     ref = Oracle().vcycle(dim, npts, levels, 3, 3, maxiter=100000, scale=scale, use_csr=0)
     it = int(re.search(r"Number of iterations:\s+(\d+)", out).group(1))
     assert it == ref["iters"]

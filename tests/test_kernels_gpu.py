@@ -903,3 +903,57 @@ def test_three_sweeps_from_the_zero_guess_in_one_pass(mgk, orc, n, prec):
     mgk.L.mgk_set_tuning(-1, -1)
     for p in (db, d1, d2, dout):
         mgk.free(p)
+
+
+@pytest.mark.parametrize("ny,nz", [(7, 9), (11, 5), (15, 17), (3, 33)])
+def test_prolongation_fused_into_a_two_sweep_pass(mgk, ny, nz):
+    """mgk_prolong_jacobi2_f64: J(J(u + P uc)) == mgk_prolong_jacobi_f64 followed by mgk_jacobi_f64, bit for bit, on thin
+    grids with rows of 1023 (the 8-wave instance), several z chunkings"""
+    nx = 1023
+    rng = np.random.default_rng(6600 + ny + nz)
+    nxc, nyc, nzc = (nx - 1) // 2, (ny - 1) // 2, (nz - 1) // 2
+    q = float((nx + 1) ** 2)
+    As = [q, q, q, -6.0 * q, q, q, q]
+    dinv = 1.0 / As[3]
+    gf, gc = mgk.geom(3, nx, ny, nz), mgk.geom(3, nxc, nyc, nzc)
+    assert mgk.L.mgk_prolong_jacobi2_ok_f64(C.byref(gf), C.byref(gc)) == 1
+    u, b, uc = _rand(rng, nx * ny * nz), _rand(rng, nx * ny * nz), _rand(rng, nxc * nyc * nzc)
+    du, db, duc, d1, d2, dout = mgk.to_field(gf, u), mgk.to_field(gf, b), mgk.to_field(gc, uc), mgk.field(gf), mgk.field(gf), mgk.field(gf)
+    mgk._chk(mgk.L.mgk_prolong_jacobi_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), dinv, 0.8, db, duc, du, d1, None))
+    mgk._chk(mgk.L.mgk_jacobi_f64(mgk.ctx, C.byref(gf), mgk.coef(As), dinv, 0.8, db, d1, d2, None))
+    want = mgk.raw_field(gf, d2)
+    assert np.abs(want).max() > 0
+    for zc in (-1, 2, 4):
+        mgk.L.mgk_set_tuning(-1, zc)
+        mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dout, 8 * gf.total, None))
+        mgk._chk(mgk.L.mgk_prolong_jacobi2_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), dinv, 0.8, db, duc, du, dout, None))
+        got = mgk.raw_field(gf, dout)
+        assert np.array_equal(got, want), f"zc={zc}: max diff {np.abs(got - want).max()}"
+    mgk.L.mgk_set_tuning(-1, -1)
+    for p in (du, db, duc, d1, d2, dout):
+        mgk.free(p)
+
+
+@pytest.mark.parametrize("n", [127, 255])
+def test_two_sweeps_with_the_norm_of_the_mid_iterate(mgk, orc, n):
+    """mgk_jacobi2_sumsq_mid_f64: the field of mgk_jacobi2_f64 (bit for bit) and || b - A J(u) ||^2, the residual of the first sweep's
+    output (1e-13)"""
+    rng = np.random.default_rng(9960 + n)
+    As = _stencil(orc, 3, n)
+    dinv = 1.0 / As[3]
+    u, b = _rand(rng, n ** 3), _rand(rng, n ** 3)
+    g = mgk.geom(3, n)
+    du, db, dout, dref = mgk.to_field(g, u), mgk.to_field(g, b), mgk.field(g), mgk.field(g)
+    mgk._chk(mgk.L.mgk_jacobi2_f64(mgk.ctx, C.byref(g), mgk.coef(As), dinv, 0.8, db, du, dref, None))
+    want = mgk.raw_field(g, dref)
+    r = orc.residual(3, n, As, b, orc.jacobi(3, n, As, 0.8, b, u))
+    ss = C.c_double(0.0)
+    for zc in (-1, 8, 29):
+        mgk.L.mgk_set_tuning(-1, zc)
+        mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dout, 8 * g.total, None))
+        mgk._chk(mgk.L.mgk_jacobi2_sumsq_mid_f64(mgk.ctx, C.byref(g), mgk.coef(As), dinv, 0.8, db, du, dout, C.byref(ss), None))
+        assert np.array_equal(mgk.raw_field(g, dout), want), f"zc={zc}"
+        assert abs(ss.value - float(np.dot(r, r))) <= 1e-13 * float(np.dot(r, r)), f"zc={zc}"
+    mgk.L.mgk_set_tuning(-1, -1)
+    for p in (du, db, dout, dref):
+        mgk.free(p)
