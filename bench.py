@@ -140,10 +140,10 @@ def cycle_compulsory_bytes(dim, npts, levels, precision):
         elif dim == 3:
             # levels >= 1 that sweep in pairs (255 <= n <= 511 in fp64): the three pre-smoothing sweeps from the zero guess are ONE pass
             # that reads b alone (16 B) instead of the zero-guess sweep written by the restriction (8) + a two-sweep pass (24): 91 - 16
-            # fine level, rows of 1024 (fuse bit 12): prolongation + two sweeps 25, third sweep + norm + next first sweep 24, two sweeps 24,
+            # fine level, rows of 512 / 1024 (fuse bit 12): prolongation + two sweeps 25, third sweep + norm + next first sweep 24, two sweeps 24,
             # restriction 18 = 91 (the one sweep that materialises the last iterate when the iteration stops is not a per-cycle cost:
             # it is inside the timed region all the same)
-            fine = 91.0 if n + 1 == 1024 else (99.0 if (n + 1) in (256, 512) else 114.0)
+            fine = 91.0 if (n + 1) in (512, 1024) else (99.0 if n + 1 == 256 else 114.0)
             per = (fine if precision != "mixed" else 114.0) if l == 0 else (75.0 if 255 <= n <= 511 else 91.0)
         else:
             # 2-D, round 2: levels >= 2047^2 (pairs of sweeps): norm + two sweeps 24, sweep + residual + restriction 26, prolongation

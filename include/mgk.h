@@ -291,7 +291,7 @@ int  mgk_tail_cycle_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *g0, int nlev, cons
 int  mgk_jacobi2_sumsq_mid_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale,
                                const double *b, const double *u, double *unew, double *sumsq_host, void *stream);
 /* the prolongation, its correction and the first TWO post-smoothing sweeps in one pass: unew = J(J(u + P uc))
- * (src/solver.c:1540-1542).  fp64, rows of 1024 (n = 1023), whole grid; _ok_ tells. */
+ * (src/solver.c:1540-1542).  fp64, rows of 512 / 1024 (n = 511, 1023), whole grid; _ok_ tells. */
 int  mgk_prolong_jacobi2_ok_f64(const mgk_geom *gf, const mgk_geom *gc);
 int  mgk_prolong_jacobi2_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
                              const double *b, const double *uc, const double *u, double *unew, void *stream);

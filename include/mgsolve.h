@@ -52,7 +52,7 @@ typedef struct mg_config {
                          * unknown and cycle;
                          * bit 11 (3-D whole levels that sweep in pairs: fp32 up to 1023^3, fp64 up to 511^3): a pre-smoothing of >= 3 sweeps
                          * from the zero guess starts with ONE pass that makes three of them and reads b alone (mgk_jacobi2_zero_*);
-                         * bit 12 (fp64, 3-D, level 0 of 1023-wide whole grids, v0 = 3): post-smoothing is ONE pass for the prolongation and two
+                         * bit 12 (fp64, 3-D, level 0 of 511- / 1023-wide whole grids, v0 = 3): post-smoothing is ONE pass for the prolongation and two
                          * sweeps (mgk_prolong_jacobi2_f64); the third sweep is the first stage of the two-sweep pass that evaluates the
                          * norm (mgk_jacobi2_sumsq_mid_f64): 91 B per fine unknown and cycle.  The iterate the norm belongs to is not
                          * stored; when the iteration stops one more sweep materialises it;

@@ -2014,7 +2014,9 @@ __global__ void __launch_bounds__(64 * WX) k_pj2r(const PJ2Args a) {
 }
 extern "C" int mgk_prolong_jacobi2_ok_f64(const mgk_geom *gf, const mgk_geom *gc) {
     if (!gf || !gc || gf->dim != 3 || gc->dim != 3 || gf->nx != 2 * gc->nx + 1 || gf->ny != 2 * gc->ny + 1 || gf->nz != 2 * gc->nz + 1) return 0;
-    return ((gf->nx + 1) == 1024 && (gf->ny + 1) % 4 == 0) ? 1 : 0;          // (the 8-wave instance only: what the experiment measures)
+    if ((gf->nx + 1) % 128 != 0 || (gf->ny + 1) % 4 != 0) return 0;
+    const int w = (gf->nx + 1) / 128;
+    return (w == 4 || w == 8) ? 1 : 0;                                         // rows of 512 / 1024 (n = 511, 1023)
 }
 // unew = J(J(u + P uc)): the prolongation, its correction and the first two post-smoothing sweeps in one pass
 extern "C" int mgk_prolong_jacobi2_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
@@ -2027,14 +2029,16 @@ extern "C" int mgk_prolong_jacobi2_f64(mgk_ctx *c, const mgk_geom *gf, const mgk
     a.a0 = coef[0]; a.a1 = coef[1]; a.a2 = coef[2]; a.a3 = coef[3]; a.a4 = coef[4]; a.a5 = coef[5]; a.a6 = coef[6];
     a.dinv = dinv; a.scale = scale;
     a.nty = (gf->ny + 3) / 4;
-    long nch = (a.nty >= 256) ? 1 : (256 + a.nty - 1) / a.nty;
+    const long target = ((gf->nx + 1) / 128 > 4) ? 256 : 512;    // 512-thread blocks: one per CU; 256-thread blocks: two
+    long nch = (a.nty >= target) ? 1 : (target + a.nty - 1) / a.nty;
     if (g_zchunk > 0) nch = (gf->nz + g_zchunk - 1) / g_zchunk;
     int zc = (int)((gf->nz + nch - 1) / nch);
     zc = (zc + 1) & ~1;                                          // even: every chunk starts on an even plane
     if (zc < 8) zc = 8;
     a.zc = zc;
     const unsigned nblk = (unsigned)(a.nty * ((gf->nz + zc - 1) / zc));
-    hipLaunchKernelGGL((k_pj2r<8>), dim3(nblk), dim3(512), 0, S(c, stream), a);
+    if ((gf->nx + 1) / 128 == 4) hipLaunchKernelGGL((k_pj2r<4>), dim3(nblk), dim3(256), 0, S(c, stream), a);
+    else hipLaunchKernelGGL((k_pj2r<8>), dim3(nblk), dim3(512), 0, S(c, stream), a);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -905,12 +905,11 @@ def test_three_sweeps_from_the_zero_guess_in_one_pass(mgk, orc, n, prec):
         mgk.free(p)
 
 
-@pytest.mark.parametrize("ny,nz", [(7, 9), (11, 5), (15, 17), (3, 33)])
-def test_prolongation_fused_into_a_two_sweep_pass(mgk, ny, nz):
+@pytest.mark.parametrize("nx,ny,nz", [(1023, 7, 9), (1023, 11, 5), (1023, 15, 17), (1023, 3, 33), (511, 7, 9), (511, 15, 33), (511, 511, 5)])
+def test_prolongation_fused_into_a_two_sweep_pass(mgk, nx, ny, nz):
     """mgk_prolong_jacobi2_f64: J(J(u + P uc)) == mgk_prolong_jacobi_f64 followed by mgk_jacobi_f64, bit for bit, on thin
-    grids with rows of 1023 (the 8-wave instance), several z chunkings"""
-    nx = 1023
-    rng = np.random.default_rng(6600 + ny + nz)
+    grids with rows of 1023 / 511 (the 8- and 4-wave instances), several z chunkings"""
+    rng = np.random.default_rng(6600 + nx + ny + nz)
     nxc, nyc, nzc = (nx - 1) // 2, (ny - 1) // 2, (nz - 1) // 2
     q = float((nx + 1) ** 2)
     As = [q, q, q, -6.0 * q, q, q, q]
