@@ -297,7 +297,7 @@ int  mgk_prolong_jacobi2_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *g
                              const double *b, const double *uc, const double *u, double *unew, void *stream);
 /* THREE sweeps from a zero initial guess in one pass that reads b alone (the first one is pointwise: mgk_jacobi_zero_*):
  * unew = J(J(J0(b))) -- the whole of a pre-smoothing KSPSolve with max_it = 3 on a coarse level (src/solver.c:1536), 16 B per unknown
- * (fp32: 8) instead of 8 + 24.  Whole 3-D grids of full-row shape: fp32 n = 255 .. 1023, fp64 n = 127 .. 511; _ok_ tells (1 / 0). */
+ * (fp32: 8) instead of 8 + 24.  Whole 3-D grids of full-row shape: fp32 n = 255 .. 1023, fp64 n = 127 .. 1023; _ok_ tells (1 / 0). */
 int  mgk_jacobi2_zero_ok_f64(const mgk_geom *g);
 int  mgk_jacobi2_zero_ok_f32(const mgk_geom *g32);
 int  mgk_jacobi2_zero_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale, const double *b, double *unew, void *stream);

@@ -144,6 +144,8 @@ struct mg_solver {
     int spec_valid;         /* > 0: level-0 tmp holds that many sweeps of u, made by the sweep(s)+norm kernel that closed the last cycle */
     int sweep_owed;         /* fuse bit 12: the post-smoothing of level 0 stopped one sweep short (prolongation + two sweeps in one pass); the
                              * pass that evaluates the norm makes that sweep first */
+    int last_cycle;         /* the caller knows (fixed cycle count) or expects (contraction so far) that this cycle is the last one: no sweep is
+                             * owed and no speculative sweep is made -- the norm comes from the store-free residual + norm pass */
     int iterate_behind;     /* ... and after that pass u is still ONE sweep behind the iterate the norm belongs to (it was never stored:
                              * tmp holds the sweep after it); finalize_iterate() makes the sweep if the iteration stops here */
     double solve_seconds;
@@ -978,7 +980,7 @@ static int pjp_ok(const mg_solver *s, int P) {
     const mg_level *L = &s->L[0];
     const int need = 4096 | 1024 | 32 | 8 | 2 | 1;
     if ((s->cfg.fuse & need) != need || P != 0 || s->cfg.dim != 3 || s->cfg.mesh || s->cfg.ksp_type != MG_KSP_RICHARDSON) return 0;
-    if (s->cfg.v[0] != 3 || s->levels < 2 || L->distributed || s->lgraph == 1 || L->n < s->cfg.pair_min_n) return 0;
+    if (s->cfg.v[0] != 3 || s->levels < 2 || L->distributed || s->lgraph == 1 || L->n < s->cfg.pair_min_n || s->last_cycle) return 0;
     return mgk_prolong_jacobi2_ok_f64(&L->f[0].g, &s->L[1].f[0].g) && mgk_jacobi2_sumsq_ok_f64(&L->f[0].g);
 }
 static int finalize_iterate(mg_solver *s) {
@@ -1347,7 +1349,7 @@ static int vcycle_once(mg_solver *s) {
     } else {
         CHK(cycle_body(s, 0, s->iter == 0));
         /* :1545-1546  r0 = b0 - A0 u0 ; ||r0|| */
-        const int jnorm = (s->cfg.fuse & 8) && (s->cfg.fuse & 1) && s->cfg.ksp_type == MG_KSP_RICHARDSON && s->cfg.v[0] >= 1;
+        const int jnorm = (s->cfg.fuse & 8) && (s->cfg.fuse & 1) && s->cfg.ksp_type == MG_KSP_RICHARDSON && s->cfg.v[0] >= 1 && !s->last_cycle;
         if (s->sweep_owed) {
             /* the third post-smoothing sweep, the norm of ITS result and the first pre-smoothing sweep of the next cycle in one pass;
              * u stays one sweep behind the iterate, tmp is one sweep ahead of it */
@@ -1490,7 +1492,11 @@ int mg_solver_solve(mg_solver *s) {
     const int devnorm = s->cfg.nranks > 1 && s->comm->allreduce_sum_dev != NULL;
     if (devnorm) CHK(need_slots(s, 1));
     while (s->iter < s->cfg.maxiter && 100000000 * s->bnorm > s->rchk && s->rchk > s->cfg.rtol * s->bnorm) {   /* :1530 */
-        if (!devnorm) { CHK(vcycle_once(s)); continue; }
+        /* expected to be the last cycle (the contraction of the previous one would reach the tolerance, or the count runs out): skip the
+         * speculative work; a wrong guess costs nothing but that saving */
+        s->last_cycle = (s->iter + 1 >= s->cfg.maxiter) ||
+                        (s->iter >= 1 && s->rnorm[s->iter - 1] > 0.0 && s->rchk * (s->rchk / s->rnorm[s->iter - 1]) <= s->cfg.rtol * s->bnorm);
+        if (!devnorm) { int rc1 = vcycle_once(s); s->last_cycle = 0; CHK(rc1); continue; }
         /* N ranks: the cycle leaves its sum of squares in a device slot; all-reduce + read-back on the comm stream, one
          * synchronisation (of that stream) per cycle -- the convergence test needs the norm on the host */
         double ss = 0.0;
@@ -1498,6 +1504,7 @@ int mg_solver_solve(mg_solver *s) {
         s->deferring = 1;
         if (!rc) rc = vcycle_once(s);
         s->deferring = 0;
+        s->last_cycle = 0;
         mgk_defer_result(s->ctx, NULL);
         if (rc) return rc;
         CHK(reduce_slots(s, s->d_norms, 1, &ss));
@@ -1526,8 +1533,10 @@ int mg_solver_cycles(mg_solver *s, int ncycles) {
     int rc = 0;
     for (int q = 0; q < ncycles && !rc; q++) {
         rc = mgk_defer_result(s->ctx, s->d_norms + q);
+        s->last_cycle = (q == ncycles - 1);          /* nothing follows: no speculative sweep, no owed sweep */
         if (!rc) rc = vcycle_once(s);
     }
+    s->last_cycle = 0;
     mgk_defer_result(s->ctx, NULL);
     s->deferring = 0;
     if (!rc) rc = finalize_iterate(s);

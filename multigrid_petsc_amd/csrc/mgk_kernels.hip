@@ -2107,7 +2107,7 @@ static int jacobi2(mgk_ctx *c, const mgk_geom *g, const double *coef, double din
     constexpr int WR = 64 * VX;
     const bool full = (g->nx + 1) % WR == 0 && (g->ny + 1) % 4 == 0 && g_variant != 36 && g_variant != 37;
     if (zero_guess) {
-        if (!ring || !full || far_lo || far_hi || norm_parts) return fail(MGK_EINVAL, "mgk_jacobi2_zero: built for whole grids of full-row shape on the LDS-ring form (fp32; fp64 up to 511^3)");
+        if (!full || far_lo || far_hi || norm_parts) return fail(MGK_EINVAL, "mgk_jacobi2_zero: built for whole grids of full-row shape (the LDS-ring form of the two-sweep kernel)");
         if (g_variant == 39 || (sizeof(T) == 8 && g_variant != 45)) {   // the form before the instruction diet: 39 forces it; fp64 keeps it
                                                                         // (511^3: 0.471 against 0.488 ms; 45 forces the new form)
             if (w <= 1) hipLaunchKernelGGL((k_jacobi2<T, 1, 3, true>), dim3(nblk), dim3(64), 0, s, a);
@@ -2172,7 +2172,7 @@ static bool j2zero_ok(const mgk_geom *g) {
     if (!g || g->dim != 3 || (g->nx + 1) % (64 * VX) != 0 || (g->ny + 1) % 4 != 0 || g->nx + 1 > 1024) return false;
     const int w = (g->nx + 1) / (64 * VX);
     if (g_variant == 2 || g_variant == 36 || g_variant == 37) return false;
-    return !(sizeof(T) == 8 && w > 4);                           // the shapes the ring form is chosen for
+    return w == 1 || w == 2 || w == 4 || w == 8;                 // (fp64 rows of 1024 too: the ring form, 148 KB of LDS, only from the zero guess)
 }
 extern "C" int mgk_jacobi2_zero_ok_f64(const mgk_geom *g) { return j2zero_ok<double>(g) ? 1 : 0; }
 extern "C" int mgk_jacobi2_zero_ok_f32(const mgk_geom *g) { return j2zero_ok<float>(g) ? 1 : 0; }
