@@ -922,12 +922,12 @@ def test_prolongation_fused_into_a_two_sweep_pass(mgk, nx, ny, nz):
     mgk._chk(mgk.L.mgk_jacobi_f64(mgk.ctx, C.byref(gf), mgk.coef(As), dinv, 0.8, db, d1, d2, None))
     want = mgk.raw_field(gf, d2)
     assert np.abs(want).max() > 0
-    for zc in (-1, 2, 4):
-        mgk.L.mgk_set_tuning(-1, zc)
+    for var, zc in ((-1, -1), (-1, 2), (-1, 4), (46, -1), (46, 4)):
+        mgk.L.mgk_set_tuning(var, zc)
         mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dout, 8 * gf.total, None))
         mgk._chk(mgk.L.mgk_prolong_jacobi2_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), dinv, 0.8, db, duc, du, dout, None))
         got = mgk.raw_field(gf, dout)
-        assert np.array_equal(got, want), f"zc={zc}: max diff {np.abs(got - want).max()}"
+        assert np.array_equal(got, want), f"variant={var} zc={zc}: max diff {np.abs(got - want).max()}"
     mgk.L.mgk_set_tuning(-1, -1)
     for p in (du, db, duc, d1, d2, dout):
         mgk.free(p)

@@ -25,8 +25,8 @@ pj = timeit(lambda: L.mgk_prolong_jacobi_f64(m.ctx, C.byref(g), C.byref(gc), coe
 sw = timeit(lambda: L.mgk_jacobi_f64(m.ctx, C.byref(g), coef, dinv, 0.85, b, u, out, None))
 p2 = timeit(lambda: L.mgk_jacobi2_f64(m.ctx, C.byref(g), coef, dinv, 0.85, b, u, out, None))
 print(f"prolongation sweep {pj:.3f} ms, sweep {sw:.3f} ms, two-sweep pass {p2:.3f} ms", flush=True)
-for zc in (-1, 512, 256):
-    L.mgk_set_tuning(-1, zc)
+for var, zc in ((-1, -1), (46, -1), (-1, 512), (46, 512)):
+    L.mgk_set_tuning(var, zc)
     x = timeit(lambda: L.mgk_prolong_jacobi2_f64(m.ctx, C.byref(g), C.byref(gc), coef, dinv, 0.85, b, uc, u, out, None))
-    print(f"prolongation + two sweeps, planes per chunk {zc}: {x:.3f} ms ({25 * N / x / 1e6:.0f} GB/s)", flush=True)
+    print(f"prolongation + two sweeps, variant {var}, planes per chunk {zc}: {x:.3f} ms ({25 * N / x / 1e6:.0f} GB/s)", flush=True)
 m.close()
