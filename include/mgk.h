@@ -211,6 +211,13 @@ int  mgk_restrict_fw_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc,
 int  mgk_prolong_add_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc,
                          const double *uc, double *uf, void *stream);
 
+/* The parts of the I-cycle's coupled two-grid level operator M = [[A_h, W], [R A_h, A_H]] that read the coarse half of x
+ * (src/solver.c:347-470 fillProlongationPortion: W = A_h P cut to P's 3 x 3 window, w9 row-major by window offset; :214-251 A_H):
+ *   yf += W xc,  yc += A_H xc   (2-D, square grids, nf = 2 nc + 1; xc with a zero ghost ring).
+ * M x is mgk_apply_f64 (yf = A_h xf), mgk_restrict_fw_f64 (yc = R yf), then this launch. */
+int  mgk_block2_finish_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *w9, const double *coef_c,
+                           const double *xc, double *yf, double *yc, void *stream);
+
 /* K4 fused into the first post-smoothing sweep (src/solver.c:1540-1542): unew = Jacobi(u + P uc); the corrected
  * u is never written.  Needs valid z ghost planes of u AND of uc on a slab.  3-D only. */
 int  mgk_prolong_jacobi_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv,

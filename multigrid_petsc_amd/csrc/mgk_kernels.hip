@@ -3508,6 +3508,59 @@ extern "C" int mgk_prolong_add_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geo
 }
 
 // ------------------------------------------------------------------------------------------
+// The off-diagonal and coarse parts of the I-cycle's coupled two-grid level operator (src/solver.c:255-487),
+//     M = [[A_h, W], [R A_h, A_H]],   W = (A_h P) cut to P's 3 x 3 window (fillProlongationPortion, :347-470).
+// After yf = A_h xf (mgk_apply_f64) and yc = R yf (mgk_restrict_fw_f64) one launch adds what reads xc:
+//     yf(i,j)  += sum over the <= 4 coarse parents (ic,jc) of w[i-2ic][j-2jc] * xc(ic,jc)   (ascending coarse index,
+//                 the column order of the assembled row), and, where (i,j) = (2ic+1, 2jc+1) is a coarse point,
+//     yc(ic,jc) += A_H xc  (the five terms in ascending column order).
+// One lane per fine point; xc's ghost ring is zero, so parents / neighbours outside the grid add an exact zero.
+// ------------------------------------------------------------------------------------------
+struct Block2Args { int nf, nc, pf, pc; double w[9]; double cc[5]; };
+__global__ void __launch_bounds__(256) k_block2_finish(Block2Args a, const double *xc, double *yf, double *yc) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= a.nf) return;
+    for (int i = blockIdx.y; i < a.nf; i += gridDim.y) {
+        // parents along an axis: odd p -> the one coarse point (p-1)/2 (window offset 1); even p -> p/2-1 (offset 2), p/2 (offset 0)
+        const int ic0 = (i & 1) ? (i - 1) / 2 : i / 2 - 1, ni = (i & 1) ? 1 : 2;
+        const int jc0 = (j & 1) ? (j - 1) / 2 : j / 2 - 1, nj = (j & 1) ? 1 : 2;
+        double y = yf[(long)i * a.pf + j];
+        for (int p = 0; p < ni; p++) {
+            const int ic = ic0 + p, di = i - 2 * ic;
+            for (int q = 0; q < nj; q++) {
+                const int jc = jc0 + q, dj = j - 2 * jc;
+                y = y + a.w[di * 3 + dj] * xc[(long)ic * a.pc + jc];
+            }
+        }
+        yf[(long)i * a.pf + j] = y;
+        if ((i & 1) && (j & 1)) {
+            const long o = (long)ic0 * a.pc + jc0;
+            double z = yc[o];
+            z = z + a.cc[0] * xc[o - a.pc];
+            z = z + a.cc[1] * xc[o - 1];
+            z = z + a.cc[2] * xc[o];
+            z = z + a.cc[3] * xc[o + 1];
+            z = z + a.cc[4] * xc[o + a.pc];
+            yc[o] = z;
+        }
+    }
+}
+extern "C" int mgk_block2_finish_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *w9, const double *coef_c,
+                                     const double *xc, double *yf, double *yc, void *stream) {
+    if (!c || !gf || !gc || !w9 || !coef_c || !xc || !yf || !yc) return fail(MGK_EINVAL, "mgk_block2_finish_f64: bad arguments");
+    if (gf->dim != 2 || gc->dim != 2 || gf->nx != gf->ny || gc->nx != gc->ny || gf->nx != 2 * gc->nx + 1)
+        return fail(MGK_EINVAL, "mgk_block2_finish_f64: needs square 2-D grids with nf = 2 nc + 1");
+    Block2Args a;
+    a.nf = gf->nx; a.nc = gc->nx; a.pf = gf->pitch; a.pc = gc->pitch;
+    for (int k = 0; k < 9; k++) a.w[k] = w9[k];
+    for (int k = 0; k < 5; k++) a.cc[k] = coef_c[k];
+    dim3 block(256), grid((a.nf + 255) / 256, (unsigned)(a.nf < 2048 ? a.nf : 2048));
+    hipLaunchKernelGGL(k_block2_finish, grid, block, 0, S(c, stream), a, xc + gc->org, yf + gf->org, yc + gc->org);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // flat vector kernels (PETSc Vec BLAS-1 surface of the shim) and a generic CSR SpMV.
 // They run over a whole allocation (padded fields included: ghosts are zero and stay zero under
 // every linear combination), one element per lane-iteration, grid-stride.

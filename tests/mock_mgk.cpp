@@ -381,6 +381,32 @@ int mgk_jacobi2_2d_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double
 }
 int mgk_restrict_fw_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *r, double *bc, void *) { return restrict_api<double>(c, gf, gc, r, bc); }
 int mgk_restrict_fw_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const float *r, float *bc, void *) { return restrict_api<float>(c, gf, gc, r, bc); }
+int mgk_block2_finish_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *w9, const double *coef_c,
+                          const double *xc, double *yf, double *yc, void *) {
+    if (!c || !gf || !gc || !w9 || !coef_c || !xc || !yf || !yc) return fail(MGK_EINVAL, "mgk_block2_finish_f64: bad arguments");
+    if (gf->dim != 2 || gc->dim != 2 || gf->nx != gf->ny || gc->nx != gc->ny || gf->nx != 2 * gc->nx + 1) return fail(MGK_EINVAL, "mgk_block2_finish_f64: grids");
+    const mgk_geom F = *gf, Cg = *gc;
+    std::vector<double> w(w9, w9 + 9), cc(coef_c, coef_c + 5);
+    return run(c, [=] {
+        const double *X = xc + Cg.org;
+        for (int i = 0; i < F.ny; i++) for (int j = 0; j < F.nx; j++) {
+            const int ic0 = (i & 1) ? (i - 1) / 2 : i / 2 - 1, ni = (i & 1) ? 1 : 2;
+            const int jc0 = (j & 1) ? (j - 1) / 2 : j / 2 - 1, nj = (j & 1) ? 1 : 2;
+            double y = yf[F.org + (long)i * F.pitch + j];
+            for (int p = 0; p < ni; p++) for (int q = 0; q < nj; q++) {
+                const int ic = ic0 + p, jc = jc0 + q;
+                y = y + w[(i - 2 * ic) * 3 + (j - 2 * jc)] * X[(long)ic * Cg.pitch + jc];
+            }
+            yf[F.org + (long)i * F.pitch + j] = y;
+            if ((i & 1) && (j & 1)) {
+                const long o = (long)ic0 * Cg.pitch + jc0;
+                double z = yc[Cg.org + o];
+                z = z + cc[0] * X[o - Cg.pitch]; z = z + cc[1] * X[o - 1]; z = z + cc[2] * X[o]; z = z + cc[3] * X[o + 1]; z = z + cc[4] * X[o + Cg.pitch];
+                yc[Cg.org + o] = z;
+            }
+        }
+    });
+}
 int mgk_prolong_add_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *uc, double *uf, void *) { return prolong_add_api<double>(c, gf, gc, uc, uf); }
 int mgk_prolong_add_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const float *uc, float *uf, void *) { return prolong_add_api<float>(c, gf, gc, uc, uf); }
 int mgk_prolong_jacobi_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *k, double d, double s, const double *b, const double *uc, const double *u, double *o, void *) { return gf ? prolong_jacobi_api<double>(c, gf, gc, k, d, s, b, uc, u, o, 0, NMARCH(gf)) : fail(MGK_EINVAL, "g"); }

@@ -362,10 +362,13 @@ def _dense(orc, which, npts, l):
 
 
 @pytest.mark.skipif(not os.path.exists(REFDRV), reason="build/refdriver/poisson absent")
-@pytest.mark.parametrize("npts,iters", [(9, 25), (17, 25)])
-def test_reference_driver_cycle1_two_grids_in_one_level(orc, tmp_path, npts, iters):
+@pytest.mark.parametrize("npts,iters,env", [(9, 25, None), (17, 25, None), (65, 25, None), (17, 25, {"MGPETSC_NO_RECOGNITION": "1"}),
+                                            (65, 25, {"MGPETSC_NO_RECOGNITION": "1"})])
+def test_reference_driver_cycle1_two_grids_in_one_level(orc, tmp_path, npts, iters, env):
     """-cycle 1 with two grids in ONE level: the reference assembles its coupled level operator (src/solver.c:255-487)
-    with its own unmodified code; the drop-in keeps it as an assembled AIJ matrix and iterates with the generic CSR kernels.
+    with its own unmodified code; the drop-in recognises the block structure at MatAssemblyEnd (entry by entry) and applies it with
+    the stencil and transfer kernels on [fine | coarse] vectors (mgk_apply, mgk_restrict_fw, mgk_block2_finish); with recognition
+    off it stays an assembled AIJ matrix on the generic CSR kernels.
     Restated here in dense numpy from the oracle's A, R, P:   M = [[A_h, (A_h P) masked to P's 3x3 window], [R A_h, A_H]],
     b = [f, R f] (levelvecb, :558-620), x += s D^-1 (b - M x).  Point-Jacobi Richardson does not converge on this
     operator (the author's runs rely on PETSc PCs the drop-in does not provide), so a fixed number of iterations
@@ -373,9 +376,10 @@ def test_reference_driver_cycle1_two_grids_in_one_level(orc, tmp_path, npts, ite
     s = 0.3
     opts = (f"-npts {npts}\n-mesh 0\n-iter {iters}\n-grids 2\n-levels 1\n-cycle 1\n-map 2\n-v 3,3\n-moreNorm 0\n"
             f"-pc_type jacobi\n-ksp_richardson_scale {s!r}\n")
-    it, rdat, u, e, out = _run_reference_driver(tmp_path, opts)
+    it, rdat, u, e, out = _run_reference_driver(tmp_path, opts, env)
     assert it == iters and rdat.size == iters + 1
-    assert "assembled AIJ (generic CSR kernel)" in out
+    assert ("matrix-free two-grid level operator" in out) == (env is None)
+    assert ("assembled AIJ (generic CSR kernel)" in out) == (env is not None)
     Ah, AH, R, P = _dense(orc, "A", npts, 0), _dense(orc, "A", npts, 1), _dense(orc, "R", npts, 0), _dense(orc, "P", npts, 0)
     nf, nc = Ah.shape[0], AH.shape[0]
     M = np.block([[Ah, (Ah @ P) * (P != 0)], [R @ Ah, AH]])
@@ -393,3 +397,91 @@ def test_reference_driver_cycle1_two_grids_in_one_level(orc, tmp_path, npts, ite
     # solve runs out of iterations
     assert np.max(np.abs(rdat[:-1] / hist[:-1] - 1)) <= 1e-9
     assert np.max(np.abs(u - x[:nf])) <= 1e-9 * np.abs(x[:nf]).max()
+
+
+def _two_grid_level_operator(orc, npts):
+    Ah, AH, R, P = _dense(orc, "A", npts, 0), _dense(orc, "A", npts, 1), _dense(orc, "R", npts, 0), _dense(orc, "P", npts, 0)
+    W = (Ah @ P) * (P != 0)
+    # the reference evaluates ONE expression per window offset (src/solver.c:395-466): the same bits wherever the offset recurs,
+    # which a BLAS product does not promise
+    nf, nc = npts - 2, (npts - 3) // 2
+    first = {}
+    for f, c in np.argwhere(W != 0):
+        d = (f // nf - 2 * (c // nc), f % nf - 2 * (c % nc))
+        W[f, c] = first.setdefault(d, W[f, c])
+    return np.block([[Ah, W], [R @ Ah, AH]])
+
+
+def _assemble(L, M):
+    m = C.c_void_p()
+    N = M.shape[0]
+    L.MatCreateAIJ(1, N, N, -1, -1, 30, None, 0, None, C.byref(m))
+    for r, c in zip(*np.nonzero(M)):
+        L.MatSetValue(m, int(r), int(c), float(M[r, c]), ADD)
+    L.MatAssemblyBegin(m, FINAL)
+    L.MatAssemblyEnd(m, FINAL)
+    return m
+
+
+def _set(L, v, a):
+    for q, val in enumerate(a):
+        L.VecSetValue(v, q, float(val), INSERT)
+    L.VecAssemblyBegin(v)
+    L.VecAssemblyEnd(v)
+
+
+def _get(L, v, n):
+    p = C.POINTER(C.c_double)()
+    L.VecGetArray(v, C.byref(p))
+    a = np.ctypeslib.as_array(p, shape=(n,)).copy()
+    L.VecRestoreArray(v, C.byref(p))
+    return a
+
+
+@pytest.mark.parametrize("npts", [5, 9, 33])
+def test_two_grid_level_operator_runs_on_the_stencil_and_transfer_kernels(orc, capfd, npts):
+    """The coupled operator of the I-cycle (src/solver.c:255-487), entered value by value through MatSetValue: recognised at
+    MatAssemblyEnd, MatMult / MatMultAdd / MatResidual on [fine | coarse] vectors equal the dense product to rounding;
+    a matrix that differs from the pattern in ONE entry stays on the generic CSR kernel."""
+    L = _shim()
+    L.PetscInitialize(None, None, None, None)
+    L.MatMultAdd.argtypes = [C.c_void_p] * 4
+    L.MatResidual.argtypes = [C.c_void_p] * 4
+    M = _two_grid_level_operator(orc, npts)
+    N = M.shape[0]
+    rng = np.random.default_rng(npts)
+    for variant in ("exact", "perturbed W", "perturbed R A_h"):
+        Mv = M.copy()
+        nf = (npts - 2) ** 2
+        if variant == "perturbed W":
+            r, c = np.argwhere(Mv[:nf, nf:] != 0)[3]
+            Mv[r, nf + c] *= 1.0 + 1e-6
+        if variant == "perturbed R A_h":
+            r, c = np.argwhere(Mv[nf:, :nf] != 0)[2]
+            Mv[nf + r, c] *= 1.0 + 1e-6
+        m = _assemble(L, Mv)
+        L.MatView(m, None)
+        out = capfd.readouterr().out
+        # (one coarse point: every window offset occurs once, so ANY nine weights are a member of the family the kernel applies)
+        expect = variant == "exact" or (variant == "perturbed W" and npts == 5)
+        assert ("matrix-free two-grid level operator" in out) == expect, (variant, out)
+        x, y, z, w = (C.c_void_p() for _ in range(4))
+        L.MatCreateVecs(m, C.byref(x), C.byref(y))
+        L.VecDuplicate(y, C.byref(z))
+        L.VecDuplicate(y, C.byref(w))
+        xv, bv = rng.standard_normal(N), rng.standard_normal(N)
+        _set(L, x, xv)
+        _set(L, z, bv)
+        L.MatMult(m, x, y)
+        ref = Mv @ xv
+        tol = 1e-13 * np.abs(Mv).max() * np.abs(xv).max() * 30
+        assert np.max(np.abs(_get(L, y, N) - ref)) <= tol
+        L.MatResidual(m, z, x, w)
+        assert np.max(np.abs(_get(L, w, N) - (bv - ref))) <= tol
+        L.MatMultAdd(m, x, z, w)
+        assert np.max(np.abs(_get(L, w, N) - (bv + ref))) <= tol
+        L.MatMultAdd(m, x, z, z)
+        assert np.max(np.abs(_get(L, z, N) - (bv + ref))) <= tol
+        for v in (x, y, z, w):
+            L.VecDestroy(C.byref(v))
+        L.MatDestroy(C.byref(m))
