@@ -23,6 +23,7 @@ for tag, env in (("recognised", {}), ("generic CSR", {"MGPETSC_NO_RECOGNITION": 
         out = p.stdout
         wall = [float(x) for x in re.findall(r"Solver walltime:\s+([0-9.eE+-]+)", out)]
         kind = re.search(r"device operator: ([^\n]*)", out)
-        print(f"npts={npts} iters={iters} {tag}: rc={p.returncode} walltime={wall} operator={kind.group(1) if kind else '?'}", flush=True)
+        its = re.search(r"Number of iterations:\s+(\d+)", out)
+        print(f"npts={npts} iters={iters} {tag}: rc={p.returncode} walltime={wall} iterations={its.group(1) if its else '?'} operator={kind.group(1) if kind else '?'}", flush=True)
         if p.returncode:
             print(out[-1500:])
