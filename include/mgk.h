@@ -266,6 +266,9 @@ int  mgk_apply_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, const do
  * mode 1: out = b - A u; mode 4: out = A u. */
 int  mgk_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *g, int mode, const double *ctab, const double *dtab, double scale,
                      const double *b, const double *u, double *out, void *stream);
+/* Chebyshev step on the same operators (KSPCHEBYSHEV + PCJACOBI on -mesh 1/2): pkp1 = (c_km1*pkm1 + c_k*pk) + c_z*((b - A pk)*dtab[i]) */
+int  mgk_cheby_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *g, const double *ctab, const double *dtab, double c_km1, double c_k, double c_z,
+                           const double *b, const double *pk, const double *pkm1, double *pkp1, void *stream);
 int  mgk_jacobi_zero_rowcoef_f64(mgk_ctx *ctx, const mgk_geom *g, const double *dtab, double scale,
                                  const double *b, double *unew, void *stream);
 /* the fused forms of the cycle on a row-table operator (the constant-coefficient entry points of the same names with the

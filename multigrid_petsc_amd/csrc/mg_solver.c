@@ -364,9 +364,8 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
         if (n < 1 || (cfg->npts - 1) % f != 0 || (n & 1) == 0)
             return mgfail(MGK_EINVAL, "mg_solver_create: npts-1 must be 2^m with m >= levels (vertex-centred coarsening, src/matbuild.c:62-66)");
     }
-    if (cfg->mesh != 0 && (cfg->mesh < 0 || cfg->mesh > 2 || cfg->dim != 2 || cfg->precision != MG_PREC_FP64 || cfg->nranks > 1 ||
-                           cfg->ksp_type != MG_KSP_RICHARDSON))
-        return mgfail(MGK_EINVAL, "mg_solver_create: -mesh 1/2 is built for 2-D, fp64, one GPU, Richardson + Jacobi");
+    if (cfg->mesh != 0 && (cfg->mesh < 0 || cfg->mesh > 2 || cfg->dim != 2 || cfg->precision != MG_PREC_FP64 || cfg->nranks > 1))
+        return mgfail(MGK_EINVAL, "mg_solver_create: -mesh 1/2 is built for 2-D, fp64, one GPU");
     if (cfg->nranks > 1 && (!comm || cfg->dim != 3))
         return mgfail(MGK_EINVAL, "mg_solver_create: nranks > 1 needs a communicator and dim == 3");
     if (cfg->ksp_type == MG_KSP_CHEBYSHEV && !(cfg->emax > cfg->emin && cfg->emin > 0.0))
@@ -688,20 +687,25 @@ static int smooth_chebyshev(mg_solver *s, int l, int maxit) {
     double scale = 2.0 / (s->cfg.emax + s->cfg.emin), alpha = 1.0 - scale * s->cfg.emin, Gamma = 1.0;
     double mu = 1.0 / alpha, omegaprod = 2.0 / alpha, ckm1 = 1.0, ck = mu, ckp1;
     double *pkm1 = (double *)F->u, *pk = (double *)F->tmp, *pkp1 = L->p2;
+    const int mesh = s->cfg.mesh != 0;                              /* -mesh 1/2: the same steps on the level's row tables (2-D, one rank) */
     if (!F->guess_nonzero) {
         CHK(mgk_memset0(s->ctx, pkm1, bytes, NULL));
         F->u_ghost_ok = 0; F->u_ghost_pending = 0;
-        if (maxit > 0) CHK(mgk_jacobi_zero_f64(s->ctx, &F->g, L->dinv, scale, (const double *)F->b, pk, NULL));
+        if (maxit > 0 && mesh) CHK(mgk_jacobi_zero_rowcoef_f64(s->ctx, &F->g, L->dtab, scale, (const double *)F->b, pk, NULL));
+        else if (maxit > 0) CHK(mgk_jacobi_zero_f64(s->ctx, &F->g, L->dinv, scale, (const double *)F->b, pk, NULL));
     } else if (maxit > 0) {
         CHK(ensure_u_ghosts(s, 0, L));
-        CHK(mgk_jacobi_f64(s->ctx, &F->g, L->coef, L->dinv, scale, (const double *)F->b, pkm1, pk, NULL));
+        if (mesh) CHK(mgk_rowcoef_f64(s->ctx, &F->g, 0, L->ctab, L->dtab, scale, (const double *)F->b, pkm1, pk, NULL));
+        else CHK(mgk_jacobi_f64(s->ctx, &F->g, L->coef, L->dinv, scale, (const double *)F->b, pkm1, pk, NULL));
     }
     if (maxit == 0) return 0;
     for (int it = 1; it < maxit; it++) {
         ckp1 = 2.0 * mu * ck - ckm1;
         double omega = omegaprod * ck / ckp1;
         CHK(halo(s, 0, L, pk));
-        CHK(mgk_cheby_f64(s->ctx, &F->g, L->coef, L->dinv, 1.0 - omega, omega, omega * Gamma * scale,
+        if (mesh) CHK(mgk_cheby_rowcoef_f64(s->ctx, &F->g, L->ctab, L->dtab, 1.0 - omega, omega, omega * Gamma * scale,
+                                            (const double *)F->b, pk, pkm1, pkp1, NULL));
+        else CHK(mgk_cheby_f64(s->ctx, &F->g, L->coef, L->dinv, 1.0 - omega, omega, omega * Gamma * scale,
                           (const double *)F->b, pk, pkm1, pkp1, NULL));
         double *t = pkm1; pkm1 = pk; pk = pkp1; pkp1 = t;
         ckm1 = ck; ck = ckp1;

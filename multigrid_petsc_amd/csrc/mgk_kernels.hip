@@ -5563,6 +5563,16 @@ extern "C" int mgk_rowcoef_f64(mgk_ctx *c, const mgk_geom *g, int mode, const do
     if (mode == MODE_APPLY) return dispatch_st<MODE_APPLY>(c, g, a, s, nullptr);
     return fail(MGK_EINVAL, "mgk_rowcoef_f64: unknown mode");
 }
+// Chebyshev step on the row-table operator (stretched meshes, 2-D): pkp1 = (c_km1 * pkm1 + c_k * pk) + c_z * ((b - A pk) * dtab[i])
+extern "C" int mgk_cheby_rowcoef_f64(mgk_ctx *c, const mgk_geom *g, const double *ctab, const double *dtab, double c_km1, double c_k, double c_z,
+                                     const double *b, const double *pk, const double *pkm1, double *pkp1, void *stream) {
+    if (!c || !g || g->dim != 2 || !ctab || !dtab || !b || !pk || !pkm1 || !pkp1 || pk == pkp1 || pkm1 == pkp1)
+        return fail(MGK_EINVAL, "mgk_cheby_rowcoef_f64: bad arguments (2-D only)");
+    StArgs<double> a; memset(&a, 0, sizeof(a));
+    a.u = pk + g->org; a.b = b + g->org; a.aux = pkm1 + g->org; a.out = pkp1 + g->org;
+    a.ctab = ctab; a.dtab = dtab; a.dinv = 1.0; a.ckm1 = c_km1; a.ck = c_k; a.cz = c_z;
+    return dispatch_st<MODE_CHEBY>(c, g, a, S(c, stream), nullptr);
+}
 // stretched meshes (2-D): the fused forms of the cycle on the row-table operator -- k_stencil reads its coefficients per marching
 // step in every mode, so these are the constant-coefficient entry points with the tables in place of the constants
 extern "C" int mgk_jacobi_sumsq_rowcoef_f64(mgk_ctx *c, const mgk_geom *g, const double *ctab, const double *dtab, double scale,

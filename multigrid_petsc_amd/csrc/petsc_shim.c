@@ -1206,7 +1206,8 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
      * whole interior without reading x, so the fill is only issued when no sweep follows or on the AIJ path */
     if (!k->guess_nonzero) {
         x->host_dirty = 0;
-        if (maxit <= 0 || (A->kind != MAT_STENCIL && A->kind != MAT_STENCIL_ROW)) DEV(mgk_memset0(G, x->dev, sizeof(double) * (size_t)x->nalloc, NULL));
+        /* (the Chebyshev recurrence reads the zero guess as p_{k-1} in its second step) */
+        if (maxit <= 0 || k->type == K_CHEBYSHEV || (A->kind != MAT_STENCIL && A->kind != MAT_STENCIL_ROW)) DEV(mgk_memset0(G, x->dev, sizeof(double) * (size_t)x->nalloc, NULL));
     }
     if (maxit <= 0) return 0;
 
@@ -1251,11 +1252,29 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
     }
 
     if (A->kind == MAT_STENCIL_ROW) {
-        if (k->type != K_RICHARDSON) UNSUPPORTED("chebyshev on a stretched-mesh operator");
         need_vec(x, 1, &A->gf, A->n, "KSPSolve");
         mat_device_rowtabs(A);
         const double *dt = (pc == P_JACOBI) ? A->d_dtab : A->d_ones;
         Vec w = ksp_work(k, 0, x);
+        if (k->type == K_CHEBYSHEV) {                       /* the recurrence of the constant-coefficient branch on the row tables */
+            if (!(k->emax > k->emin && k->emin > 0.0)) UNSUPPORTED("chebyshev without -ksp_chebyshev_eigenvalues emin,emax (no eigenvalue estimation)");
+            Vec w2 = ksp_work(k, 1, x);
+            double scale = 2.0 / (k->emax + k->emin), alpha = 1.0 - scale * k->emin, Gamma = 1.0;
+            double mu = 1.0 / alpha, omegaprod = 2.0 / alpha, ckm1 = 1.0, ck = mu, ckp1;
+            double *pkm1 = x->dev, *pk = w->dev, *pkp1 = w2->dev, *t;
+            if (!k->guess_nonzero) DEV(mgk_jacobi_zero_rowcoef_f64(G, &A->gf, dt, scale, b->dev, pk, NULL));
+            else DEV(mgk_rowcoef_f64(G, &A->gf, 0, A->d_ctab, dt, scale, b->dev, pkm1, pk, NULL));
+            for (PetscInt it = 1; it < maxit; it++) {
+                ckp1 = 2.0 * mu * ck - ckm1;
+                double omega = omegaprod * ck / ckp1;
+                DEV(mgk_cheby_rowcoef_f64(G, &A->gf, A->d_ctab, dt, 1.0 - omega, omega, omega * Gamma * scale, b->dev, pk, pkm1, pkp1, NULL));
+                t = pkm1; pkm1 = pk; pk = pkp1; pkp1 = t;
+                ckm1 = ck; ck = ckp1;
+            }
+            x->dev = pk; w->dev = pkm1; w2->dev = pkp1;
+            k->its = maxit;
+            return 0;
+        }
         for (PetscInt it = 0; it < maxit; it++) {
             if (it == 0 && !k->guess_nonzero) DEV(mgk_jacobi_zero_rowcoef_f64(G, &A->gf, dt, k->scale, b->dev, w->dev, NULL));
             else DEV(mgk_rowcoef_f64(G, &A->gf, 0, A->d_ctab, dt, k->scale, b->dev, x->dev, w->dev, NULL));

@@ -330,6 +330,11 @@ int mgk_rowcoef_f64(mgk_ctx *c, const mgk_geom *g, int mode, const double *ctab,
     if (m < 0) return fail(MGK_EINVAL, "mgk_rowcoef_f64: mode");
     return run(c, [=] { st_op<double>(m, G, nullptr, 1.0, scale, 0, 0, 0, m == M_APPLY ? (const double *)nullptr : b, u, (const double *)nullptr, o, 0, G.ny, ctab, dtab); });
 }
+int mgk_cheby_rowcoef_f64(mgk_ctx *c, const mgk_geom *g, const double *ctab, const double *dtab, double ckm1, double ck, double cz, const double *b, const double *pk, const double *pkm1, double *o, void *) {
+    if (!c || !g || g->dim != 2 || !ctab || !dtab || !b || !pk || !pkm1 || !o || pk == o || pkm1 == o) return fail(MGK_EINVAL, "mgk_cheby_rowcoef_f64");
+    const mgk_geom G = *g;
+    return run(c, [=] { st_op<double>(M_CHEBY, G, nullptr, 1.0, 1, ckm1, ck, cz, b, pk, pkm1, o, 0, G.ny, ctab, dtab); });
+}
 int mgk_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const double *x, double *out, void *) {
     if (!c || !g || !x || !out) return fail(MGK_EINVAL, "mgk_sumsq_f64");
     if (c->capturing) return fail(MGK_EINVAL, "reduction to the host inside a capture");

@@ -106,6 +106,21 @@ def test_own_driver_stretched_mesh_under_sanitizers_matches_the_oracle(san, tmp_
     assert np.array_equal(u, ref["u"])
 
 
+@pytest.mark.parametrize("mesh,npts,levels", [(1, 65, 5), (2, 33, 4), (1, 129, 3)])
+def test_own_driver_chebyshev_on_stretched_meshes_under_sanitizers_matches_the_oracle(san, tmp_path, mesh, npts, levels):
+    """-mesh 1/2 with -ksp_type chebyshev: the three-term recurrence on the level's row tables (mgk_jacobi_zero_rowcoef, mgk_rowcoef mode 0,
+    mgk_cheby_rowcoef) against the oracle's assembled stretched-mesh leg with its Chebyshev smoother"""
+    out = _run(san["mgpoisson"], ["-dim", "2", "-npts", str(npts), "-levels", str(levels), "-mesh", str(mesh), "-ksp_type", "chebyshev",
+                                  "-ksp_chebyshev_eigenvalues", "0.2,2.0", "-pc_type", "jacobi", "-write_fields", "1"], tmp_path)
+    ref = Oracle().vcycle(2, npts, levels, 3, 3, maxiter=100000, ksp_type=1, emin=0.2, emax=2.0, use_csr=1, mesh=mesh)
+    assert int(re.search(r"Number of iterations:\s+(\d+)", out).group(1)) == ref["iters"]
+    rdat = np.array((tmp_path / "rData.dat").read_text().split(), dtype=np.float64)
+    want = ref["rnorm"] / ref["rnorm"][0]
+    assert np.max(np.abs(rdat - want) / want) <= 1e-12
+    u = np.array((tmp_path / "uData.dat").read_text().split(), dtype=np.float64)
+    assert np.array_equal(u, ref["u"])
+
+
 @pytest.mark.parametrize("args", [
     ["-dim", "3", "-npts", "33", "-levels", "4", "-precision", "mixed", "-ksp_richardson_scale", "0.857142857142857095"],
     ["-dim", "2", "-npts", "65", "-levels", "5", "-ksp_type", "chebyshev", "-ksp_chebyshev_eigenvalues", "0.2,2.0"],
@@ -164,6 +179,18 @@ def test_reference_driver_over_the_shim_under_sanitizers(san, tmp_path, npts, le
         assert it == ref["iters"]
         u = np.array((tmp_path / "uData.dat").read_text().split(), dtype=np.float64)
         assert np.array_equal(u, ref["u"])
+
+
+@pytest.mark.parametrize("mesh,npts,levels", [(0, 65, 5), (1, 65, 5), (2, 33, 3)])
+def test_reference_driver_chebyshev_under_sanitizers(san, tmp_path, mesh, npts, levels):
+    """-ksp_type chebyshev through the reference's own -cycle 0 driver (uniform and stretched meshes): KSPSolve restarts the recurrence
+    from the zero guess on every coarse level of every cycle, so the guess must really be zero-filled (a stale x was read as p_{k-1})"""
+    out = _refdrv(san, tmp_path, f"-npts {npts}\n-mesh {mesh}\n-iter 200\n-grids {levels}\n-levels {levels}\n-cycle 0\n-map 0\n-v 3,3\n-moreNorm 0\n"
+                  "-pc_type jacobi\n-ksp_type chebyshev\n-ksp_chebyshev_eigenvalues 0.2,2.0\n")
+    ref = Oracle().vcycle(2, npts, levels, 3, 3, maxiter=200, ksp_type=1, emin=0.2, emax=2.0, use_csr=1, mesh=mesh)
+    assert int(re.search(r"Number of iterations:\s+(\d+)", out).group(1)) == ref["iters"]
+    u = np.array((tmp_path / "uData.dat").read_text().split(), dtype=np.float64)
+    assert np.array_equal(u, ref["u"])
 
 
 def test_reference_driver_pcmg_and_icycle_under_sanitizers(san, tmp_path):

@@ -271,6 +271,23 @@ def test_reference_driver_stretched_meshes(orc, tmp_path, mesh, npts, levels, en
     assert ("assembled AIJ (generic CSR kernel)" if env else "row-dependent coefficients") in out
 
 
+@pytest.mark.skipif(not os.path.exists(REFDRV), reason="build/refdriver/poisson absent")
+@pytest.mark.parametrize("mesh,npts,levels", [(0, 65, 5), (0, 257, 7), (1, 65, 5), (2, 129, 6), (1, 513, 8)])
+def test_reference_driver_chebyshev_on_stretched_meshes(orc, tmp_path, mesh, npts, levels):
+    """KSPCHEBYSHEV + PCJACOBI through the unmodified reference driver over the drop-in: on the constant stencil (-mesh 0) and on
+    the row-table operator of -mesh 1/2.  (Every coarse-level KSPSolve restarts the recurrence from a zero guess that must really
+    be zero-filled: a stale x was once read as p_{k-1}, which only this test sees -- PCMG zero-fills x itself.)"""
+    opts = (f"-npts {npts}\n-mesh {mesh}\n-iter 200\n-grids {levels}\n-levels {levels}\n-cycle 0\n-map 0\n-v 3,3\n-moreNorm 0\n"
+            "-pc_type jacobi\n-ksp_type chebyshev\n-ksp_chebyshev_eigenvalues 0.2,2.0\n")
+    it, rdat, u, e, out = _run_reference_driver(tmp_path, opts)
+    ref = orc.vcycle(2, npts, levels, 3, 3, maxiter=200, ksp_type=1, emin=0.2, emax=2.0, use_csr=1, mesh=mesh)
+    assert it == ref["iters"]
+    want = ref["rnorm"] / ref["rnorm"][0]
+    assert np.max(np.abs(rdat - want) / want) <= 1e-12
+    assert np.array_equal(u, ref["u"])
+    assert ("row-dependent coefficients" if mesh else "matrix-free 5-point stencil") in out
+
+
 MGPOISSON = os.path.join(ROOT, "multigrid_petsc_amd", "mgpoisson")
 
 

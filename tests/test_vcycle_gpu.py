@@ -331,6 +331,21 @@ def test_own_driver_on_stretched_meshes(orc, mesh, npts, levels, kw, monkeypatch
     s.close()
 
 
+@pytest.mark.parametrize("mesh,npts,levels", [(1, 65, 5), (2, 129, 6), (1, 513, 8), (2, 1025, 4)])
+def test_own_driver_chebyshev_on_stretched_meshes(orc, mesh, npts, levels):
+    """-mesh 1/2 with the Chebyshev smoother: the recurrence of the uniform mesh on the level's row tables (mgk_cheby_rowcoef_f64);
+    bit-identical to the oracle's assembled stretched-mesh leg with its Chebyshev smoother"""
+    from multigrid_petsc_amd.solver import Solver
+    s = Solver(2, npts, levels, v=(3, 3), maxiter=200, ksp_type="chebyshev", eigenvalues=(0.2, 2.0), mesh=mesh)
+    s.set_rhs_problem()
+    it = s.solve()
+    ref = orc.vcycle(2, npts, levels, 3, 3, maxiter=200, ksp_type=1, emin=0.2, emax=2.0, use_csr=1, mesh=mesh)
+    assert it == ref["iters"]
+    assert np.abs(s.rnorm / ref["rnorm"] - 1).max() <= RTOL
+    assert np.array_equal(s.solution(), ref["u"])
+    s.close()
+
+
 @pytest.mark.parametrize("dim,npts,levels,precision", [
     (3, 33, 5, "fp64"), (3, 65, 6, "fp64"), (3, 65, 4, "fp64"), (3, 17, 4, "fp64"), (3, 129, 7, "fp64"),
     (2, 129, 7, "fp64"), (2, 65, 6, "fp64"), (2, 513, 9, "fp64"), (2, 129, 3, "fp64"), (3, 65, 6, "mixed"), (3, 129, 7, "mixed"),
