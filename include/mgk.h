@@ -211,12 +211,16 @@ int  mgk_restrict_fw_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc,
 int  mgk_prolong_add_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc,
                          const double *uc, double *uf, void *stream);
 
-/* The parts of the I-cycle's coupled two-grid level operator M = [[A_h, W], [R A_h, A_H]] that read the coarse half of x
- * (src/solver.c:347-470 fillProlongationPortion: W = A_h P cut to P's 3 x 3 window, w9 row-major by window offset; :214-251 A_H):
- *   yf += W xc,  yc += A_H xc   (2-D, square grids, nf = 2 nc + 1; xc with a zero ghost ring).
- * M x is mgk_apply_f64 (yf = A_h xf), mgk_restrict_fw_f64 (yc = R yf), then this launch. */
-int  mgk_block2_finish_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *w9, const double *coef_c,
-                           const double *xc, double *yf, double *yc, void *stream);
+/* The I-cycle's coupled level operator for G grids in one level (src/solver.c:489-510; 2-D, square grids, constant stencils):
+ * lower triangle + diagonal as the cascade s_0 = A_0 x_0, s_g = R s_(g-1) + A_g x_g (mgk_apply_f64, mgk_restrict_fw_f64 and)
+ *   mgk_apply_add_f64:   y += A x
+ * and the upper blocks (fillProlongationPortion :347-470: A_g1 P^(g0-g1) cut to P's window) by
+ *   mgk_window_add_f64:  yf(i,j) += sum over the coarse points (ic,jc) with |i - (S ic + S-1)|, |j - (S jc + S-1)| <= S-1 of
+ *                        wtab[(i - S ic)*(2S-1) + (j - S jc)] * xc(ic,jc);  S = stride = 2^(g0-g1), nf + 1 = S (nc + 1);
+ *                        wtab: (2S-1)^2 DEVICE doubles; xc with a zero ghost ring. */
+int  mgk_apply_add_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, const double *x, double *y, void *stream);
+int  mgk_window_add_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, int stride, const double *wtab_dev,
+                        const double *xc, double *yf, void *stream);
 
 /* K4 fused into the first post-smoothing sweep (src/solver.c:1540-1542): unew = Jacobi(u + P uc); the corrected
  * u is never written.  Needs valid z ghost planes of u AND of uc on a slab.  3-D only. */

@@ -3508,54 +3508,68 @@ extern "C" int mgk_prolong_add_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geo
 }
 
 // ------------------------------------------------------------------------------------------
-// The off-diagonal and coarse parts of the I-cycle's coupled two-grid level operator (src/solver.c:255-487),
-//     M = [[A_h, W], [R A_h, A_H]],   W = (A_h P) cut to P's 3 x 3 window (fillProlongationPortion, :347-470).
-// After yf = A_h xf (mgk_apply_f64) and yc = R yf (mgk_restrict_fw_f64) one launch adds what reads xc:
-//     yf(i,j)  += sum over the <= 4 coarse parents (ic,jc) of w[i-2ic][j-2jc] * xc(ic,jc)   (ascending coarse index,
-//                 the column order of the assembled row), and, where (i,j) = (2ic+1, 2jc+1) is a coarse point,
-//     yc(ic,jc) += A_H xc  (the five terms in ascending column order).
-// One lane per fine point; xc's ghost ring is zero, so parents / neighbours outside the grid add an exact zero.
+// The I-cycle's coupled level operator for G grids in one level (src/solver.c:489-510 levelMatrixA):
+//     M(g,g) = A_g,   M(g0,g1) = R^(g0-g1) A_g1  (g1 < g0, fillRestrictionPortion :255-345),
+//     M(g1,g0) = W    (g1 < g0, fillProlongationPortion :347-470: A_g1 P^(g0-g1) cut to P's window of 2S-1 points, S = 2^(g0-g1)).
+// With s_0 = A_0 x_0, s_g = R s_(g-1) + A_g x_g (mgk_apply_f64, mgk_restrict_fw_f64, k_apply_add) the lower triangle and the
+// diagonal are one cascade; k_window_add then adds the upper blocks: yf(i,j) += sum over the <= 4 coarse points (ic,jc) whose
+// window holds (i,j) of w[i - S ic][j - S jc] * xc(ic,jc), ascending coarse index (the column order of the assembled row).
+// One lane per point; xc's ghost ring is zero, so a parent outside the grid adds an exact zero.
 // ------------------------------------------------------------------------------------------
-struct Block2Args { int nf, nc, pf, pc; double w[9]; double cc[5]; };
-__global__ void __launch_bounds__(256) k_block2_finish(Block2Args a, const double *xc, double *yf, double *yc) {
+struct ApplyAddArgs { int n, pitch; double c[5]; };
+__global__ void __launch_bounds__(256) k_apply_add_2d(ApplyAddArgs a, const double *x, double *y) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= a.n) return;
+    for (int i = blockIdx.y; i < a.n; i += gridDim.y) {
+        const long o = (long)i * a.pitch + j;
+        double z = y[o];
+        z = z + a.c[0] * x[o - a.pitch];
+        z = z + a.c[1] * x[o - 1];
+        z = z + a.c[2] * x[o];
+        z = z + a.c[3] * x[o + 1];
+        z = z + a.c[4] * x[o + a.pitch];
+        y[o] = z;
+    }
+}
+extern "C" int mgk_apply_add_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, const double *x, double *y, void *stream) {
+    if (!c || !g || !coef || !x || !y || x == y || g->dim != 2 || g->nx != g->ny) return fail(MGK_EINVAL, "mgk_apply_add_f64: bad arguments (square 2-D grids)");
+    ApplyAddArgs a;
+    a.n = g->nx; a.pitch = g->pitch;
+    for (int k = 0; k < 5; k++) a.c[k] = coef[k];
+    dim3 block(256), grid((a.n + 255) / 256, (unsigned)(a.n < 2048 ? a.n : 2048));
+    hipLaunchKernelGGL(k_apply_add_2d, grid, block, 0, S(c, stream), a, x + g->org, y + g->org);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+struct WindowArgs { int nf, nc, pf, pc, S, W; };
+__global__ void __launch_bounds__(256) k_window_add(WindowArgs a, const double *wtab, const double *xc, double *yf) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= a.nf) return;
+    // parents along an axis: (p+1) % S == 0 -> the one coarse point p / S; otherwise p / S - 1 and p / S
+    const int jm = j / a.S, nj = ((j + 1) % a.S == 0) ? 1 : 2, jc0 = jm - (nj - 1);
     for (int i = blockIdx.y; i < a.nf; i += gridDim.y) {
-        // parents along an axis: odd p -> the one coarse point (p-1)/2 (window offset 1); even p -> p/2-1 (offset 2), p/2 (offset 0)
-        const int ic0 = (i & 1) ? (i - 1) / 2 : i / 2 - 1, ni = (i & 1) ? 1 : 2;
-        const int jc0 = (j & 1) ? (j - 1) / 2 : j / 2 - 1, nj = (j & 1) ? 1 : 2;
+        const int im = i / a.S, ni = ((i + 1) % a.S == 0) ? 1 : 2, ic0 = im - (ni - 1);
         double y = yf[(long)i * a.pf + j];
         for (int p = 0; p < ni; p++) {
-            const int ic = ic0 + p, di = i - 2 * ic;
+            const int ic = ic0 + p, di = i - a.S * ic;
             for (int q = 0; q < nj; q++) {
-                const int jc = jc0 + q, dj = j - 2 * jc;
-                y = y + a.w[di * 3 + dj] * xc[(long)ic * a.pc + jc];
+                const int jc = jc0 + q, dj = j - a.S * jc;
+                y = y + wtab[di * a.W + dj] * xc[(long)ic * a.pc + jc];
             }
         }
         yf[(long)i * a.pf + j] = y;
-        if ((i & 1) && (j & 1)) {
-            const long o = (long)ic0 * a.pc + jc0;
-            double z = yc[o];
-            z = z + a.cc[0] * xc[o - a.pc];
-            z = z + a.cc[1] * xc[o - 1];
-            z = z + a.cc[2] * xc[o];
-            z = z + a.cc[3] * xc[o + 1];
-            z = z + a.cc[4] * xc[o + a.pc];
-            yc[o] = z;
-        }
     }
 }
-extern "C" int mgk_block2_finish_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *w9, const double *coef_c,
-                                     const double *xc, double *yf, double *yc, void *stream) {
-    if (!c || !gf || !gc || !w9 || !coef_c || !xc || !yf || !yc) return fail(MGK_EINVAL, "mgk_block2_finish_f64: bad arguments");
-    if (gf->dim != 2 || gc->dim != 2 || gf->nx != gf->ny || gc->nx != gc->ny || gf->nx != 2 * gc->nx + 1)
-        return fail(MGK_EINVAL, "mgk_block2_finish_f64: needs square 2-D grids with nf = 2 nc + 1");
-    Block2Args a;
-    a.nf = gf->nx; a.nc = gc->nx; a.pf = gf->pitch; a.pc = gc->pitch;
-    for (int k = 0; k < 9; k++) a.w[k] = w9[k];
-    for (int k = 0; k < 5; k++) a.cc[k] = coef_c[k];
+extern "C" int mgk_window_add_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, int stride, const double *wtab_dev,
+                                  const double *xc, double *yf, void *stream) {
+    if (!c || !gf || !gc || !wtab_dev || !xc || !yf) return fail(MGK_EINVAL, "mgk_window_add_f64: bad arguments");
+    if (gf->dim != 2 || gc->dim != 2 || gf->nx != gf->ny || gc->nx != gc->ny || stride < 2 || (stride & (stride - 1)) ||
+        (long)gf->nx + 1 != (long)stride * (gc->nx + 1))
+        return fail(MGK_EINVAL, "mgk_window_add_f64: needs square 2-D grids with nf + 1 = stride (nc + 1), stride a power of two");
+    WindowArgs a;
+    a.nf = gf->nx; a.nc = gc->nx; a.pf = gf->pitch; a.pc = gc->pitch; a.S = stride; a.W = 2 * stride - 1;
     dim3 block(256), grid((a.nf + 255) / 256, (unsigned)(a.nf < 2048 ? a.nf : 2048));
-    hipLaunchKernelGGL(k_block2_finish, grid, block, 0, S(c, stream), a, xc + gc->org, yf + gf->org, yc + gc->org);
+    hipLaunchKernelGGL(k_window_add, grid, block, 0, S(c, stream), a, wtab_dev, xc + gc->org, yf + gf->org);
     HIPCHK(hipGetLastError());
     return 0;
 }

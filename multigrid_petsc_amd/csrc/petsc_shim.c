@@ -188,11 +188,14 @@ int MPI_Recv(void *b, int c, MPI_Datatype t, int s, int tag, MPI_Comm comm, MPI_
 /* ------------------------------------------------------------------ */
 /* Vec                                                                 */
 /* ------------------------------------------------------------------ */
+#define MGP_MAXG 8          /* grids in one level the matrix-free level operator handles (more: assembled AIJ) */
 struct _p_Vec {
     PetscInt n;             /* logical length */
     int padded;             /* 1: grid field in the padded layout `g`; 0: flat array of n doubles;
-                             * 2: [fine grid field `g` | coarse grid field `g2`] back to back (vectors of the I-cycle's two-grid level operator) */
-    mgk_geom g, g2;
+                             * 2: the `ng` grid fields `gg[0] | gg[1] | ...` back to back, finest first (vectors of the I-cycle's
+                             *    several-grids-in-one-level operator); field q starts at goff[q] */
+    mgk_geom g;
+    int ng; mgk_geom gg[MGP_MAXG]; long goff[MGP_MAXG + 1];
     long nalloc;            /* doubles on the device */
     double *dev;
     double *host;           /* compact lexicographic mirror (VecSetValue staging / VecGetArray) */
@@ -212,13 +215,16 @@ static Vec vec_new(PetscInt n, const mgk_geom *g) {
     v->ranges[0] = 0; v->ranges[1] = n;
     return v;
 }
-/* [fine | coarse] composite: both halves keep the padded layout the stencil / transfer kernels work on, the flat BLAS-1
+/* composite of grid fields: every part keeps the padded layout the stencil / transfer kernels work on, the flat BLAS-1
  * kernels run over the whole allocation (ghosts are zero and stay zero) */
-static Vec vec_new2(const mgk_geom *gf, const mgk_geom *gc) {
+static Vec vec_newg(int ng, const mgk_geom *gg) {
     need_ctx();
     Vec v = (Vec)calloc(1, sizeof(*v));
-    v->n = (PetscInt)((long)gf->nx * gf->ny + (long)gc->nx * gc->ny);
-    v->padded = 2; v->g = *gf; v->g2 = *gc; v->nalloc = gf->total + gc->total;
+    v->padded = 2; v->ng = ng; v->g = gg[0];
+    long n = 0, tot = 0;
+    for (int q = 0; q < ng; q++) { v->gg[q] = gg[q]; v->goff[q] = tot; tot += gg[q].total; n += (long)gg[q].nx * gg[q].ny; }
+    v->goff[ng] = tot;
+    v->n = (PetscInt)n; v->nalloc = tot;
     void *p = NULL;
     DEV(mgk_malloc(G, &p, sizeof(double) * (size_t)v->nalloc));
     v->dev = (double *)p;
@@ -232,8 +238,10 @@ static void vec_upload(Vec v) {          /* host mirror -> device */
         void *tmp = NULL;
         DEV(mgk_malloc(G, &tmp, sizeof(double) * (size_t)v->n));
         DEV(mgk_h2d(G, tmp, v->host, sizeof(double) * (size_t)v->n));
-        DEV(mgk_pack_f64(G, &v->g, (const double *)tmp, v->dev, NULL));
-        if (v->padded == 2) DEV(mgk_pack_f64(G, &v->g2, (const double *)tmp + (long)v->g.nx * v->g.ny, v->dev + v->g.total, NULL));
+        if (v->padded == 2) {
+            long o = 0;
+            for (int q = 0; q < v->ng; q++) { DEV(mgk_pack_f64(G, &v->gg[q], (const double *)tmp + o, v->dev + v->goff[q], NULL)); o += (long)v->gg[q].nx * v->gg[q].ny; }
+        } else DEV(mgk_pack_f64(G, &v->g, (const double *)tmp, v->dev, NULL));
         DEV(mgk_sync(G, NULL));
         mgk_free(G, tmp);
     }
@@ -245,8 +253,10 @@ static void vec_download(Vec v) {        /* device -> host mirror */
     else {
         void *tmp = NULL;
         DEV(mgk_malloc(G, &tmp, sizeof(double) * (size_t)v->n));
-        DEV(mgk_unpack_f64(G, &v->g, v->dev, (double *)tmp, NULL));
-        if (v->padded == 2) DEV(mgk_unpack_f64(G, &v->g2, v->dev + v->g.total, (double *)tmp + (long)v->g.nx * v->g.ny, NULL));
+        if (v->padded == 2) {
+            long o = 0;
+            for (int q = 0; q < v->ng; q++) { DEV(mgk_unpack_f64(G, &v->gg[q], v->dev + v->goff[q], (double *)tmp + o, NULL)); o += (long)v->gg[q].nx * v->gg[q].ny; }
+        } else DEV(mgk_unpack_f64(G, &v->g, v->dev, (double *)tmp, NULL));
         DEV(mgk_d2h(G, v->host, tmp, sizeof(double) * (size_t)v->n));
         mgk_free(G, tmp);
     }
@@ -254,7 +264,7 @@ static void vec_download(Vec v) {        /* device -> host mirror */
 static double *vdev(Vec v) { if (v->host_dirty) vec_upload(v); return v->dev; }
 static int same_layout(Vec a, Vec b) {
     if (a->n != b->n || a->padded != b->padded) return 0;
-    if (a->padded == 2 && !(a->g2.dim == b->g2.dim && a->g2.nx == b->g2.nx && a->g2.ny == b->g2.ny && a->g2.nz == b->g2.nz)) return 0;
+    if (a->padded == 2 && a->ng != b->ng) return 0;         /* (same finest grid, same count: same chain of grids) */
     if (a->padded) return a->g.dim == b->g.dim && a->g.nx == b->g.nx && a->g.ny == b->g.ny && a->g.nz == b->g.nz;
     return 1;
 }
@@ -263,7 +273,7 @@ static void need_same(Vec a, Vec b, const char *who) {
 }
 
 PetscErrorCode VecCreateSeq(MPI_Comm comm, PetscInt n, Vec *v) { (void)comm; *v = vec_new(n, NULL); return 0; }
-PetscErrorCode VecDuplicate(Vec v, Vec *nv) { *nv = v->padded == 2 ? vec_new2(&v->g, &v->g2) : vec_new(v->n, v->padded ? &v->g : NULL); return 0; }
+PetscErrorCode VecDuplicate(Vec v, Vec *nv) { *nv = v->padded == 2 ? vec_newg(v->ng, v->gg) : vec_new(v->n, v->padded ? &v->g : NULL); return 0; }
 PetscErrorCode VecDestroy(Vec *v) {
     if (!v || !*v) return 0;
     if (G) mgk_free(G, (*v)->dev);
@@ -352,7 +362,7 @@ PetscErrorCode ISView(IS is, PetscViewer v) { (void)is; (void)v; return 0; }
 /* ------------------------------------------------------------------ */
 /* Mat                                                                 */
 /* ------------------------------------------------------------------ */
-enum { MAT_GENERIC = 0, MAT_STENCIL = 1, MAT_RESTRICT = 2, MAT_PROLONG = 3, MAT_STENCIL_ROW = 4, MAT_BLOCK2 = 5 };
+enum { MAT_GENERIC = 0, MAT_STENCIL = 1, MAT_RESTRICT = 2, MAT_PROLONG = 3, MAT_STENCIL_ROW = 4, MAT_LEVELG = 5 };
 struct _p_Mat {
     PetscInt m, n;
     int *crow, *ccol; double *cval; long cnz, ccap;     /* MatSetValue stash (COO, insertion order) */
@@ -362,7 +372,9 @@ struct _p_Mat {
     mgk_geom gf, gc;                                     /* STENCIL: gf; RESTRICT/PROLONG: fine gf, coarse gc */
     int grow_ok, gcol_ok; mgk_geom grow, gcol;           /* GENERIC on n^2 index spaces (n odd): row / column vectors stay padded grid fields */
     double coef[7];
-    double coef2[5], w9[9];                              /* BLOCK2: coarse stencil A_H and the windowed A_h P weights (by window offset) */
+    int ng; mgk_geom gg[MGP_MAXG]; long goff[MGP_MAXG + 1];   /* LEVELG: the grids of the level, finest first, and their offsets in a vector */
+    double coefg[MGP_MAXG][5];                           /*         A_g */
+    double *h_wtab[MGP_MAXG][MGP_MAXG], *d_wtab[MGP_MAXG][MGP_MAXG];   /*  [g1][g0], g1 < g0: A_g1 P^(g0-g1) cut to P's window, (2S-1)^2 weights by window offset */
     long *d_rowptr; int *d_col; double *d_val; double *d_dinv;   /* device CSR (generic), lazily built */
     long d_dinv_len;
     double *h_ctab, *h_dtab;                             /* STENCIL_ROW: per-grid-row coefficients (n x 5) and 1/diag (n) */
@@ -551,120 +563,183 @@ static int recognise_prolong(Mat A) {
     return 1;
 }
 
-/* The I-cycle's coupled level operator for TWO grids in one level (src/solver.c:489-510 levelMatrixA = fillJacobians :214-251 +
+/* The I-cycle's coupled level operator for G >= 2 grids in one level (src/solver.c:489-510 levelMatrixA = fillJacobians :214-251 +
  * fillRestrictionPortion :255-345 + fillProlongationPortion :347-470), uniform mesh, grids numbered one after the other
- * (-map 0/2 on one rank):
- *     M = [[A_h, W], [R A_h, A_H]],  W(f, c) = sum over the 5-point neighbours n of f INSIDE P's 3 x 3 window of c of A_h(f,n) P(n,c).
- * Checked entry by entry: the diagonal blocks are constant 5-point rows; W has one value per window offset (an offset whose
- * weight came out 0.0 is absent everywhere -- the reference skips zero weights, :398); every row of the lower-left block equals
- * the full-weighting stencil times the recognised A_h, accumulated here in the reference's order (differences of a few ulp from
- * the ADD_VALUES order are accepted: 1e-12 of the row's largest entry).  Then M x runs on the stencil / transfer kernels. */
-static int recognise_block2(Mat A) {
-    if (A->m != A->n || A->m < 10) return 0;
-    int nf = -1, nc = -1;
-    for (int n = 3; (long)n * n < A->m; n += 2) {
-        const long c = (n - 1) / 2;
-        if ((long)n * n + c * c == A->m) { nf = n; nc = (int)c; break; }
-    }
-    if (nf < 0) return 0;
-    const long NF = (long)nf * nf;
-    double cf[5], cc[5], w[9];
-    int havef[5] = {0, 0, 0, 0, 0}, havec[5] = {0, 0, 0, 0, 0}, havew[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   /* w: 0 unknown, 1 value, 2 absent */
-    /* fine rows: [A_h | W] */
-    for (long r = 0; r < NF; r++) {
-        const int i = (int)(r / nf), j = (int)(r % nf);
-        long q = A->rowptr[r];
-        const long e = A->rowptr[r + 1];
-        const long want[5] = {i > 0 ? r - nf : -1, j > 0 ? r - 1 : -1, r, j < nf - 1 ? r + 1 : -1, i < nf - 1 ? r + nf : -1};
-        for (int k = 0; k < 5; k++) {
-            if (want[k] < 0) continue;
-            if (q >= e || A->col[q] != want[k]) return 0;
-            if (!havef[k]) { cf[k] = A->val[q]; havef[k] = 1; }
-            else if (A->val[q] != cf[k]) return 0;
-            q++;
-        }
-        const int ic0 = (i & 1) ? (i - 1) / 2 : i / 2 - 1, ic1 = (i & 1) ? ic0 : i / 2;
-        const int jc0 = (j & 1) ? (j - 1) / 2 : j / 2 - 1, jc1 = (j & 1) ? jc0 : j / 2;
-        for (int ic = ic0; ic <= ic1; ic++) {
-            if (ic < 0 || ic >= nc) continue;
-            for (int jc = jc0; jc <= jc1; jc++) {
-                if (jc < 0 || jc >= nc) continue;
-                const int d = (i - 2 * ic) * 3 + (j - 2 * jc);
-                const long colw = NF + (long)ic * nc + jc;
-                if (q < e && A->col[q] == colw) {
-                    if (havew[d] == 2) return 0;
-                    if (!havew[d]) { w[d] = A->val[q]; havew[d] = 1; }
-                    else if (A->val[q] != w[d]) return 0;
-                    q++;
-                } else {
-                    if (havew[d] == 1) return 0;
-                    havew[d] = 2; w[d] = 0.0;
-                }
+ * (-map 0/2 on one rank), n_(g+1) = (n_g - 1)/2:
+ *     M(g,g) = A_g;   M(g0,g1) = R_k A_g1 for g1 < g0, k = g0 - g1, R_k the composite full weighting of 2S-1 points, S = 2^k
+ *     (op->res[k-1], src/matbuild.c:355-396);   M(g1,g0)(f,c) = sum over the 5-point neighbours n of f INSIDE P_k's window of c of
+ *     A_g1(f,n) P_k(n,c) for f in that window.
+ * Checked entry by entry: the diagonal blocks are constant 5-point rows; an upper block has one value per window offset (an offset
+ * whose weight came out 0.0 is absent everywhere -- the reference skips zero weights, :398); every row of a lower block equals the
+ * composite weights times the recognised A_g1, accumulated here in the reference's order (differences of a few ulp from the
+ * ADD_VALUES order are accepted: 1e-12 of the row's largest entry; a sum that cancels may be stored or not).  Then M x runs on the
+ * stencil / transfer kernels (levelg_apply).  Windows wider than 63 points (k > 5) or more than MGP_MAXG grids: not recognised. */
+static double *composite_weights(int k) {                  /* op->res[k-1]: (2^(k+1)-1)^2, built like GridTransferOperator */
+    static const double r0[9] = {0.0625, 0.125, 0.0625, 0.125, 0.25, 0.125, 0.0625, 0.125, 0.0625};
+    int nl = 3;
+    double *dl = (double *)malloc(sizeof(double) * 9);
+    memcpy(dl, r0, sizeof(r0));
+    for (int l = 1; l < k; l++) {
+        const int nu = 2 * nl + 1;
+        double *du = (double *)calloc((size_t)nu * nu, sizeof(double));
+        for (int il = 0; il < nl; il++)
+            for (int jl = 0; jl < nl; jl++) {
+                const int iu = 2 * (il + 1) - 1 - 1, ju = 2 * (jl + 1) - 1 - 1;
+                for (int i0 = 0; i0 < 3; i0++)
+                    for (int j0 = 0; j0 < 3; j0++) du[(iu + i0) * nu + (ju + j0)] += r0[i0 * 3 + j0] * dl[il * nl + jl];
             }
-        }
-        if (q != e) return 0;
+        free(dl); dl = du; nl = nu;
     }
-    for (int k = 0; k < 5; k++) if (!havef[k]) return 0;
-    for (int d = 0; d < 9; d++) if (!havew[d]) return 0;
-    if (cf[2] == 0.0) return 0;
-    /* coarse rows: [R A_h | A_H] */
-    static const double res[3][3] = {{0.0625, 0.125, 0.0625}, {0.125, 0.25, 0.125}, {0.0625, 0.125, 0.0625}};
-    for (long r = NF; r < A->m; r++) {
-        const int ci = (int)((r - NF) / nc), cj = (int)((r - NF) % nc);
-        double ex[5][5]; char on[5][5];
-        memset(ex, 0, sizeof(ex)); memset(on, 0, sizeof(on));
-        double big = 0.0;
-        for (int di = 0; di < 3; di++)
-            for (int dj = 0; dj < 3; dj++) {                   /* window point (2ci+di, 2cj+dj) -> its 5-point row, :316-337 */
-                const int i = 2 * ci + di, j = 2 * cj + dj;
-                const double wt = res[di][dj];
-                if (i - 1 >= 0) { ex[di][dj + 1] += wt * cf[0]; on[di][dj + 1] = 1; }
-                if (j - 1 >= 0) { ex[di + 1][dj] += wt * cf[1]; on[di + 1][dj] = 1; }
-                ex[di + 1][dj + 1] += wt * cf[2]; on[di + 1][dj + 1] = 1;
-                if (j + 1 < nf) { ex[di + 1][dj + 2] += wt * cf[3]; on[di + 1][dj + 2] = 1; }
-                if (i + 1 < nf) { ex[di + 2][dj + 1] += wt * cf[4]; on[di + 2][dj + 1] = 1; }
-            }
-        for (int a = 0; a < 5; a++) for (int b = 0; b < 5; b++) if (fabs(ex[a][b]) > big) big = fabs(ex[a][b]);
-        long q = A->rowptr[r];
-        const long e = A->rowptr[r + 1];
-        for (int a = 0; a < 5; a++)                            /* ascending column = ascending (row, column) of the 5 x 5 patch */
-            for (int b = 0; b < 5; b++) {
-                if (!on[a][b]) continue;
-                const long colx = (long)(2 * ci - 1 + a) * nf + (2 * cj - 1 + b);
-                if (q < e && A->col[q] == colx) {
-                    if (fabs(A->val[q] - ex[a][b]) > 1e-12 * big) return 0;
-                    q++;
-                } else if (fabs(ex[a][b]) > 1e-12 * big) return 0;      /* a sum that cancels may be stored (the reference adds it up to 0.0) or not */
-            }
-        const long rc = r - NF;
-        const long want[5] = {ci > 0 ? rc - nc : -1, cj > 0 ? rc - 1 : -1, rc, cj < nc - 1 ? rc + 1 : -1, ci < nc - 1 ? rc + nc : -1};
-        for (int k = 0; k < 5; k++) {
-            if (want[k] < 0) continue;
-            if (q >= e || A->col[q] != NF + want[k]) return 0;
-            if (!havec[k]) { cc[k] = A->val[q]; havec[k] = 1; }
-            else if (A->val[q] != cc[k]) return 0;
-            q++;
-        }
-        if (q != e) return 0;
-    }
-    if (!havec[2] || cc[2] == 0.0) return 0;
-    if (mgk_geom_init(&A->gf, 2, nf, nf, 1) || mgk_geom_init(&A->gc, 2, nc, nc, 1)) return 0;
-    for (int k = 0; k < 5; k++) { A->coef[k] = cf[k]; A->coef2[k] = havec[k] ? cc[k] : 0.0; }
-    for (int d = 0; d < 9; d++) A->w9[d] = w[d];
-    A->kind = MAT_BLOCK2;
-    return 1;
+    return dl;
 }
-/* 1/diag(M) in the [fine | coarse] layout (PCJACOBI on the coupled operator) */
-static void mat_device_block2(Mat A) {
+static int check_levelop(Mat A, int ng, const int *n) {
+    long off[MGP_MAXG + 1];
+    off[0] = 0;
+    for (int g = 0; g < ng; g++) off[g + 1] = off[g] + (long)n[g] * n[g];
+    double cf[MGP_MAXG][5]; int havef[MGP_MAXG][5];
+    memset(havef, 0, sizeof(havef));
+    double *wt[MGP_MAXG][MGP_MAXG]; char *hw[MGP_MAXG][MGP_MAXG];       /* hw: 0 unknown, 1 value, 2 absent */
+    double *rk[MGP_MAXG];
+    memset(wt, 0, sizeof(wt)); memset(hw, 0, sizeof(hw)); memset(rk, 0, sizeof(rk));
+    for (int k = 1; k < ng; k++) rk[k] = composite_weights(k);
+    for (int g1 = 0; g1 < ng; g1++)
+        for (int g0 = g1 + 1; g0 < ng; g0++) {
+            const int W = 2 * (1 << (g0 - g1)) - 1;
+            wt[g1][g0] = (double *)calloc((size_t)W * W, sizeof(double));
+            hw[g1][g0] = (char *)calloc((size_t)W * W, 1);
+        }
+    const int Wmax = 2 * (1 << (ng - 1)) - 1, Pm = Wmax + 2;
+    double *ex = (double *)malloc(sizeof(double) * (size_t)Pm * Pm);
+    char *on = (char *)malloc((size_t)Pm * Pm);
+    int ok = 1;
+    /* pass 1: diagonal blocks and upper blocks of every row (they define A_g and the window weights); pass 2: lower blocks */
+    for (int pass = 0; pass < 2 && ok; pass++)
+        for (int g = 0; g < ng && ok; g++)
+            for (long rr = 0; rr < (long)n[g] * n[g] && ok; rr++) {
+                const long r = off[g] + rr;
+                const int i = (int)(rr / n[g]), j = (int)(rr % n[g]);
+                long q = A->rowptr[r];
+                const long e = A->rowptr[r + 1];
+                for (int g1 = 0; g1 < g && ok; g1++) {                 /* lower blocks: R_k A_g1 */
+                    const int k = g - g1, S = 1 << k, W = 2 * S - 1, Pn = W + 2, nn = n[g1];
+                    if (pass == 0) { while (q < e && A->col[q] < off[g1 + 1]) q++; continue; }
+                    memset(ex, 0, sizeof(double) * (size_t)Pn * Pn); memset(on, 0, (size_t)Pn * Pn);
+                    for (int wi = 0; wi < W; wi++)
+                        for (int wj = 0; wj < W; wj++) {           /* window point (S i + wi, S j + wj) -> its 5-point row, :316-337 */
+                            const int fi = S * i + wi, fj = S * j + wj;
+                            const double w = rk[k][wi * W + wj];
+                            if (fi - 1 >= 0) { ex[wi * Pn + wj + 1] += w * cf[g1][0]; on[wi * Pn + wj + 1] = 1; }
+                            if (fj - 1 >= 0) { ex[(wi + 1) * Pn + wj] += w * cf[g1][1]; on[(wi + 1) * Pn + wj] = 1; }
+                            ex[(wi + 1) * Pn + wj + 1] += w * cf[g1][2]; on[(wi + 1) * Pn + wj + 1] = 1;
+                            if (fj + 1 < nn) { ex[(wi + 1) * Pn + wj + 2] += w * cf[g1][3]; on[(wi + 1) * Pn + wj + 2] = 1; }
+                            if (fi + 1 < nn) { ex[(wi + 2) * Pn + wj + 1] += w * cf[g1][4]; on[(wi + 2) * Pn + wj + 1] = 1; }
+                        }
+                    double big = 0.0;
+                    for (int t = 0; t < Pn * Pn; t++) if (fabs(ex[t]) > big) big = fabs(ex[t]);
+                    for (int a = 0; a < Pn && ok; a++)                 /* ascending column = ascending (row, column) of the patch */
+                        for (int b = 0; b < Pn; b++) {
+                            if (!on[a * Pn + b]) continue;
+                            const long colx = off[g1] + (long)(S * i - 1 + a) * nn + (S * j - 1 + b);
+                            if (q < e && A->col[q] == colx) {
+                                if (fabs(A->val[q] - ex[a * Pn + b]) > 1e-12 * big) { ok = 0; break; }
+                                q++;
+                            } else if (fabs(ex[a * Pn + b]) > 1e-12 * big) { ok = 0; break; }
+                        }
+                    if (ok && q < e && A->col[q] < off[g1 + 1]) ok = 0;      /* an entry of this block outside the patch */
+                }
+                if (!ok || pass == 1) continue;
+                {                                                   /* diagonal block: constant 5-point rows (:239-251) */
+                    const long want[5] = {i > 0 ? r - n[g] : -1, j > 0 ? r - 1 : -1, r, j < n[g] - 1 ? r + 1 : -1, i < n[g] - 1 ? r + n[g] : -1};
+                    for (int k = 0; k < 5; k++) {
+                        if (want[k] < 0) continue;
+                        if (q >= e || A->col[q] != want[k]) { ok = 0; break; }
+                        if (!havef[g][k]) { cf[g][k] = A->val[q]; havef[g][k] = 1; }
+                        else if (A->val[q] != cf[g][k]) { ok = 0; break; }
+                        q++;
+                    }
+                }
+                for (int g0 = g + 1; g0 < ng && ok; g0++) {            /* upper blocks: window weights by offset */
+                    const int S = 1 << (g0 - g), W = 2 * S - 1, nc = n[g0];
+                    const int ni = ((i + 1) % S == 0) ? 1 : 2, ic0 = i / S - (ni - 1);
+                    const int nj = ((j + 1) % S == 0) ? 1 : 2, jc0 = j / S - (nj - 1);
+                    for (int ic = ic0; ic < ic0 + ni && ok; ic++) {
+                        if (ic < 0 || ic >= nc) continue;
+                        for (int jc = jc0; jc < jc0 + nj; jc++) {
+                            if (jc < 0 || jc >= nc) continue;
+                            const int d = (i - S * ic) * W + (j - S * jc);
+                            const long colw = off[g0] + (long)ic * nc + jc;
+                            if (q < e && A->col[q] == colw) {
+                                if (hw[g][g0][d] == 2) { ok = 0; break; }
+                                if (!hw[g][g0][d]) { wt[g][g0][d] = A->val[q]; hw[g][g0][d] = 1; }
+                                else if (A->val[q] != wt[g][g0][d]) { ok = 0; break; }
+                                q++;
+                            } else {
+                                if (hw[g][g0][d] == 1) { ok = 0; break; }
+                                hw[g][g0][d] = 2;
+                            }
+                        }
+                    }
+                }
+                if (ok && q != e) ok = 0;
+            }
+    for (int g = 0; g < ng && ok; g++) {
+        for (int k = 0; k < 5; k++) if (!havef[g][k] && n[g] > 1) ok = 0;
+        if (ok && (!havef[g][2] || cf[g][2] == 0.0)) ok = 0;
+        if (ok && mgk_geom_init(&A->gg[g], 2, n[g], n[g], 1)) ok = 0;
+    }
+    if (ok) {
+        A->ng = ng;
+        long tot = 0;
+        for (int g = 0; g < ng; g++) {
+            A->goff[g] = tot; tot += A->gg[g].total;
+            for (int k = 0; k < 5; k++) A->coefg[g][k] = havef[g][k] ? cf[g][k] : 0.0;
+        }
+        A->goff[ng] = tot;
+        A->gf = A->gg[0];
+        for (int g1 = 0; g1 < ng; g1++) for (int g0 = g1 + 1; g0 < ng; g0++) { A->h_wtab[g1][g0] = wt[g1][g0]; wt[g1][g0] = NULL; }
+        A->kind = MAT_LEVELG;
+    }
+    for (int g1 = 0; g1 < ng; g1++) for (int g0 = g1 + 1; g0 < ng; g0++) { free(wt[g1][g0]); free(hw[g1][g0]); }
+    for (int k = 1; k < ng; k++) free(rk[k]);
+    free(ex); free(on);
+    return ok;
+}
+static int recognise_levelop(Mat A) {
+    if (A->m != A->n || A->m < 10) return 0;
+    for (int nf = 3; (long)nf * nf < A->m; nf += 2) {         /* every chain nf, (nf-1)/2, ... of odd sizes whose squares add up to m */
+        int n[MGP_MAXG];
+        long sum = (long)nf * nf;
+        n[0] = nf;
+        for (int g = 1; g < MGP_MAXG && g <= 5; g++) {          /* windows of at most 63 points */
+            if ((n[g - 1] & 1) == 0 || n[g - 1] < 3) break;
+            n[g] = (n[g - 1] - 1) / 2;
+            if ((n[g] & 1) == 0) break;
+            sum += (long)n[g] * n[g];
+            if (sum > A->m) break;
+            if (sum == A->m) { if (check_levelop(A, g + 1, n)) return 1; break; }
+        }
+    }
+    return 0;
+}
+/* 1/diag(M) in the layout of the operator's vectors (PCJACOBI on the coupled operator) and the window weights on the device */
+static void mat_device_levelg(Mat A) {
     if (!A->dev_stale && A->d_dinv) return;
-    const long dlen = A->gf.total + A->gc.total;
+    const long dlen = A->goff[A->ng];
     if (!A->d_dinv) { void *pp; DEV(mgk_malloc(G, &pp, sizeof(double) * (size_t)dlen)); A->d_dinv = (double *)pp; A->d_dinv_len = dlen; }
     double *dinv = (double *)calloc((size_t)dlen, sizeof(double));
-    if (!dinv) { fprintf(stderr, "[mgpetsc] FATAL: out of memory (diagonal of the two-grid level operator)\n"); exit(88); }
-    for (int i = 0; i < A->gf.ny; i++) for (int j = 0; j < A->gf.nx; j++) dinv[A->gf.org + (long)i * A->gf.pitch + j] = 1.0 / A->coef[2];
-    for (int i = 0; i < A->gc.ny; i++) for (int j = 0; j < A->gc.nx; j++) dinv[A->gf.total + A->gc.org + (long)i * A->gc.pitch + j] = 1.0 / A->coef2[2];
+    if (!dinv) { fprintf(stderr, "[mgpetsc] FATAL: out of memory (diagonal of the level operator)\n"); exit(88); }
+    for (int g = 0; g < A->ng; g++) {
+        const mgk_geom *gg = &A->gg[g];
+        for (int i = 0; i < gg->ny; i++) for (int j = 0; j < gg->nx; j++) dinv[A->goff[g] + gg->org + (long)i * gg->pitch + j] = 1.0 / A->coefg[g][2];
+    }
     DEV(mgk_h2d(G, A->d_dinv, dinv, sizeof(double) * (size_t)dlen));
     free(dinv);
+    for (int g1 = 0; g1 < A->ng; g1++)
+        for (int g0 = g1 + 1; g0 < A->ng; g0++) {
+            const int W = 2 * (1 << (g0 - g1)) - 1;
+            if (!A->d_wtab[g1][g0]) { void *pp; DEV(mgk_malloc(G, &pp, sizeof(double) * (size_t)W * W)); A->d_wtab[g1][g0] = (double *)pp; }
+            DEV(mgk_h2d(G, A->d_wtab[g1][g0], A->h_wtab[g1][g0], sizeof(double) * (size_t)W * W));
+        }
     A->dev_stale = 0;
 }
 
@@ -674,7 +749,7 @@ PetscErrorCode MatAssemblyEnd(Mat A, MatAssemblyType t) {
     A->assembled = 1;
     A->kind = MAT_GENERIC;
     if (!getenv("MGPETSC_NO_RECOGNITION"))
-        if (!recognise_stencil(A) && !recognise_restrict(A) && !recognise_prolong(A) && !recognise_stencil_rowvar(A)) recognise_block2(A);
+        if (!recognise_stencil(A) && !recognise_restrict(A) && !recognise_prolong(A) && !recognise_stencil_rowvar(A)) recognise_levelop(A);
     if (A->kind == MAT_GENERIC) {
         /* a matrix between n^2-sized index spaces keeps the padded grid layout for its vectors, so that it can
          * be mixed with recognised operators on the same grids (e.g. variable-coefficient A with the transfer
@@ -730,9 +805,9 @@ PetscErrorCode MatCreateVecs(Mat A, Vec *right, Vec *left) {       /* src/solver
     if (A->kind == MAT_STENCIL || A->kind == MAT_STENCIL_ROW) gr = gl = &A->gf;
     else if (A->kind == MAT_RESTRICT) { gr = &A->gf; gl = &A->gc; }
     else if (A->kind == MAT_PROLONG) { gr = &A->gc; gl = &A->gf; }
-    else if (A->kind == MAT_BLOCK2) {
-        if (right) *right = vec_new2(&A->gf, &A->gc);
-        if (left) *left = vec_new2(&A->gf, &A->gc);
+    else if (A->kind == MAT_LEVELG) {
+        if (right) *right = vec_newg(A->ng, A->gg);
+        if (left) *left = vec_newg(A->ng, A->gg);
         return 0;
     }
     else { if (A->gcol_ok) gr = &A->gcol; if (A->grow_ok) gl = &A->grow; }
@@ -759,24 +834,32 @@ static void csr_apply(Mat A, Vec x, Vec y, double alpha, Vec addto, const char *
                          A->grow_ok ? A->grow.nx : 0, A->grow_ok ? A->grow.pitch : 0, A->grow_ok ? A->grow.org : 0, NULL));
 }
 
-/* the same on the recognised two-grid level operator: M x = [A_h xf + W xc | R (A_h xf) + A_H xc], vectors in the [fine | coarse] layout */
+/* the same on the recognised level operator of several grids: with s_0 = A_0 x_0, s_g = R s_(g-1) + A_g x_g the lower triangle and
+ * the diagonal are one cascade down the grids; then every upper block adds its window sums.  Vectors in the composite layout */
 static Vec mat_work(Mat A, Vec like);
-static void need_vec2(Mat A, Vec v, const char *who) {
-    if (!(v->padded == 2 && geom_eq(&v->g, &A->gf) && geom_eq(&v->g2, &A->gc))) {
+static void need_vecg(Mat A, Vec v, const char *who) {
+    if (!(v->padded == 2 && v->ng == A->ng && geom_eq(&v->gg[0], &A->gg[0]))) {
         fprintf(stderr, "[mgpetsc] FATAL: %s: vector does not match the operator's layout (create it with MatCreateVecs/VecDuplicate)\n", who); exit(88);
     }
 }
-static void block2_apply(Mat A, Vec x, Vec y, double alpha, Vec addto, const char *who) {
-    need_vec2(A, x, who); need_vec2(A, y, who);
-    if (addto) need_vec2(A, addto, who);
-    if (x == y) UNSUPPORTED("the two-grid level operator applied in place");
+static void levelg_apply(Mat A, Vec x, Vec y, double alpha, Vec addto, const char *who) {
+    need_vecg(A, x, who); need_vecg(A, y, who);
+    if (addto) need_vecg(A, addto, who);
+    if (x == y) UNSUPPORTED("the level operator applied in place");
+    mat_device_levelg(A);
     const double *xd = vdev(x), *ad = addto ? vdev(addto) : NULL;
     Vec t = (addto || alpha != 1.0) ? mat_work(A, y) : y;    /* M x first, then the combination (x may be read until the end) */
-    if (t == x) UNSUPPORTED("the two-grid level operator applied onto its own work vector");
-    double *tf = t->dev, *tc = t->dev + A->gf.total;
-    DEV(mgk_apply_f64(G, &A->gf, A->coef, xd, tf, NULL));
-    DEV(mgk_restrict_fw_f64(G, &A->gf, &A->gc, tf, tc, NULL));
-    DEV(mgk_block2_finish_f64(G, &A->gf, &A->gc, A->w9, A->coef2, xd + A->gf.total, tf, tc, NULL));
+    if (t == x) UNSUPPORTED("the level operator applied onto its own work vector");
+    for (int g = 0; g < A->ng; g++) {
+        if (g == 0) DEV(mgk_apply_f64(G, &A->gg[0], A->coefg[0], xd, t->dev, NULL));
+        else {
+            DEV(mgk_restrict_fw_f64(G, &A->gg[g - 1], &A->gg[g], t->dev + A->goff[g - 1], t->dev + A->goff[g], NULL));
+            DEV(mgk_apply_add_f64(G, &A->gg[g], A->coefg[g], xd + A->goff[g], t->dev + A->goff[g], NULL));
+        }
+    }
+    for (int g1 = 0; g1 < A->ng; g1++)
+        for (int g0 = g1 + 1; g0 < A->ng; g0++)
+            DEV(mgk_window_add_f64(G, &A->gg[g1], &A->gg[g0], 1 << (g0 - g1), A->d_wtab[g1][g0], xd + A->goff[g0], t->dev + A->goff[g1], NULL));
     t->host_dirty = 0;
     y->host_dirty = 0;
     if (t != y) {
@@ -810,8 +893,8 @@ PetscErrorCode MatMult(Mat A, Vec x, Vec y) {                       /* src/solve
         DEV(mgk_memset0(G, y->dev, sizeof(double) * (size_t)y->nalloc, NULL));      /* y = 0 + P x */
         DEV(mgk_prolong_add_f64(G, &A->gf, &A->gc, vdev(x), y->dev, NULL));
         break;
-    case MAT_BLOCK2:
-        block2_apply(A, x, y, 1.0, NULL, "MatMult");
+    case MAT_LEVELG:
+        levelg_apply(A, x, y, 1.0, NULL, "MatMult");
         break;
     default:
         csr_apply(A, x, y, 1.0, NULL, "MatMult");
@@ -821,7 +904,7 @@ PetscErrorCode MatMult(Mat A, Vec x, Vec y) {                       /* src/solve
 static Vec mat_work(Mat A, Vec like) { if (!A->work) VecDuplicate(like, &A->work); return A->work; }
 PetscErrorCode MatMultAdd(Mat A, Vec x, Vec y, Vec z) {            /* z = y + A x */
     if (A->kind == MAT_GENERIC) { csr_apply(A, x, z, 1.0, y, "MatMultAdd"); return 0; }
-    if (A->kind == MAT_BLOCK2) { block2_apply(A, x, z, 1.0, y, "MatMultAdd"); return 0; }
+    if (A->kind == MAT_LEVELG) { levelg_apply(A, x, z, 1.0, y, "MatMultAdd"); return 0; }
     if (A->kind == MAT_PROLONG && z == y) {                       /* u_f += P u_c in one pass (MatInterpolateAdd) */
         need_vec(x, 1, &A->gc, A->n, "MatMultAdd"); need_vec(y, 1, &A->gf, A->m, "MatMultAdd");
         DEV(mgk_prolong_add_f64(G, &A->gf, &A->gc, vdev(x), vdev(y), NULL));
@@ -846,15 +929,17 @@ PetscErrorCode MatResidual(Mat A, Vec b, Vec x, Vec r) {           /* r = b - A 
         return 0;
     }
     if (A->kind == MAT_GENERIC) { csr_apply(A, x, r, -1.0, b, "MatResidual"); return 0; }
-    if (A->kind == MAT_BLOCK2) { block2_apply(A, x, r, -1.0, b, "MatResidual"); return 0; }
+    if (A->kind == MAT_LEVELG) { levelg_apply(A, x, r, -1.0, b, "MatResidual"); return 0; }
     MatMult(A, x, r);
     return VecAYPX(r, -1.0, b);
 }
 PetscErrorCode MatScale(Mat A, PetscScalar a) {
     for (long q = 0; q < A->nz; q++) A->val[q] *= a;
     for (int k = 0; k < 7; k++) A->coef[k] *= a;
-    for (int k = 0; k < 5; k++) A->coef2[k] *= a;
-    for (int k = 0; k < 9; k++) A->w9[k] *= a;
+    for (int g = 0; g < A->ng; g++) {
+        for (int k = 0; k < 5; k++) A->coefg[g][k] *= a;
+        for (int g0 = g + 1; g0 < A->ng; g0++) { const int W = 2 * (1 << (g0 - g)) - 1; for (int k = 0; k < W * W; k++) A->h_wtab[g][g0][k] *= a; }
+    }
     if (A->kind == MAT_RESTRICT || A->kind == MAT_PROLONG) A->kind = MAT_GENERIC;     /* weights no longer the canonical ones */
     if (A->kind == MAT_STENCIL_ROW) {
         const int n = A->gf.nx;
@@ -869,7 +954,7 @@ PetscErrorCode MatView(Mat A, PetscViewer v) {
     (void)v;
     static const char *kinds[] = {"assembled AIJ (generic CSR kernel)", "matrix-free 5-point stencil", "matrix-free full weighting", "matrix-free bilinear prolongation",
                                   "matrix-free 5-point stencil with row-dependent coefficients",
-                                  "matrix-free two-grid level operator [[A_h, A_h P | window], [R A_h, A_H]] (stencil + transfer kernels)"};
+                                  "matrix-free level operator of several grids [A_g on the diagonal, R^k A_g below, A_g P^k | window above] (stencil + transfer kernels)"};
     printf("Mat Object: %d x %d, %ld nonzeros, device operator: %s\n", A->m, A->n, A->nz, kinds[A->kind]);
     fflush(stdout);
     return 0;
@@ -886,7 +971,9 @@ PetscErrorCode MatDestroy(Mat *pA) {
         if (A->d_ctab) mgk_free(G, A->d_ctab);
         if (A->d_dtab) mgk_free(G, A->d_dtab);
         if (A->d_ones) mgk_free(G, A->d_ones);
+        for (int a = 0; a < MGP_MAXG; a++) for (int b = 0; b < MGP_MAXG; b++) if (A->d_wtab[a][b]) mgk_free(G, A->d_wtab[a][b]);
     }
+    for (int a = 0; a < MGP_MAXG; a++) for (int b = 0; b < MGP_MAXG; b++) free(A->h_wtab[a][b]);
     if (A->work) VecDestroy(&A->work);
     free(A->h_ctab); free(A->h_dtab);
     free(A); *pA = NULL;
@@ -1283,20 +1370,20 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
         k->its = maxit;
         return 0;
     }
-    if (A->kind != MAT_GENERIC && A->kind != MAT_BLOCK2) UNSUPPORTED("KSPSolve on a transfer operator");
-    if (k->type != K_RICHARDSON) UNSUPPORTED("chebyshev on an unrecognised (assembled AIJ) or two-grid level operator");
+    if (A->kind != MAT_GENERIC && A->kind != MAT_LEVELG) UNSUPPORTED("KSPSolve on a transfer operator");
+    if (k->type != K_RICHARDSON) UNSUPPORTED("chebyshev on an unrecognised (assembled AIJ) or several-grid level operator");
     if (A->m != A->n) UNSUPPORTED("KSPSolve on a rectangular operator");
-    const int blk = (A->kind == MAT_BLOCK2);
-    if (blk) mat_device_block2(A); else mat_device_csr(A);
+    const int blk = (A->kind == MAT_LEVELG);
+    if (blk) mat_device_levelg(A); else mat_device_csr(A);
     Vec r = ksp_work(k, 0, x), z = ksp_work(k, 1, x);
     if (!k->guess_nonzero) DEV(mgk_d2d(G, r->dev, b->dev, sizeof(double) * (size_t)b->nalloc, NULL));     /* r = b */
-    else if (blk) block2_apply(A, x, r, -1.0, b, "KSPSolve");
+    else if (blk) levelg_apply(A, x, r, -1.0, b, "KSPSolve");
     else csr_apply(A, x, r, -1.0, b, "KSPSolve");                                                          /* r = b - A x */
     for (PetscInt it = 0; it < maxit; it++) {
         if (pc == P_JACOBI) DEV(mgk_flat_pointwise_mult(G, x->nalloc, r->dev, A->d_dinv, z->dev, NULL));   /* z = B r */
         else DEV(mgk_d2d(G, z->dev, r->dev, sizeof(double) * (size_t)r->nalloc, NULL));
         DEV(mgk_flat_axpy(G, x->nalloc, k->scale, z->dev, x->dev, NULL));                                  /* x += s z */
-        if (it + 1 < maxit) { if (blk) block2_apply(A, x, r, -1.0, b, "KSPSolve"); else csr_apply(A, x, r, -1.0, b, "KSPSolve"); }
+        if (it + 1 < maxit) { if (blk) levelg_apply(A, x, r, -1.0, b, "KSPSolve"); else csr_apply(A, x, r, -1.0, b, "KSPSolve"); }
     }
     k->its = maxit;
     return 0;

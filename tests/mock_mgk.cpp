@@ -386,29 +386,35 @@ int mgk_jacobi2_2d_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double
 }
 int mgk_restrict_fw_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *r, double *bc, void *) { return restrict_api<double>(c, gf, gc, r, bc); }
 int mgk_restrict_fw_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const float *r, float *bc, void *) { return restrict_api<float>(c, gf, gc, r, bc); }
-int mgk_block2_finish_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *w9, const double *coef_c,
-                          const double *xc, double *yf, double *yc, void *) {
-    if (!c || !gf || !gc || !w9 || !coef_c || !xc || !yf || !yc) return fail(MGK_EINVAL, "mgk_block2_finish_f64: bad arguments");
-    if (gf->dim != 2 || gc->dim != 2 || gf->nx != gf->ny || gc->nx != gc->ny || gf->nx != 2 * gc->nx + 1) return fail(MGK_EINVAL, "mgk_block2_finish_f64: grids");
-    const mgk_geom F = *gf, Cg = *gc;
-    std::vector<double> w(w9, w9 + 9), cc(coef_c, coef_c + 5);
+int mgk_apply_add_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, const double *x, double *y, void *) {
+    if (!c || !g || !coef || !x || !y || x == y || g->dim != 2 || g->nx != g->ny) return fail(MGK_EINVAL, "mgk_apply_add_f64");
+    const mgk_geom G = *g; std::vector<double> k(coef, coef + 5);
     return run(c, [=] {
+        for (int i = 0; i < G.ny; i++) for (int j = 0; j < G.nx; j++) {
+            const long o = G.org + (long)i * G.pitch + j;
+            double z = y[o];
+            z = z + k[0] * x[o - G.pitch]; z = z + k[1] * x[o - 1]; z = z + k[2] * x[o]; z = z + k[3] * x[o + 1]; z = z + k[4] * x[o + G.pitch];
+            y[o] = z;
+        }
+    });
+}
+int mgk_window_add_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, int S, const double *wtab, const double *xc, double *yf, void *) {
+    if (!c || !gf || !gc || !wtab || !xc || !yf) return fail(MGK_EINVAL, "mgk_window_add_f64: bad arguments");
+    if (gf->dim != 2 || gc->dim != 2 || gf->nx != gf->ny || gc->nx != gc->ny || S < 2 || (S & (S - 1)) || (long)gf->nx + 1 != (long)S * (gc->nx + 1))
+        return fail(MGK_EINVAL, "mgk_window_add_f64: grids");
+    const mgk_geom F = *gf, Cg = *gc;
+    return run(c, [=] {
+        const int W = 2 * S - 1;
         const double *X = xc + Cg.org;
         for (int i = 0; i < F.ny; i++) for (int j = 0; j < F.nx; j++) {
-            const int ic0 = (i & 1) ? (i - 1) / 2 : i / 2 - 1, ni = (i & 1) ? 1 : 2;
-            const int jc0 = (j & 1) ? (j - 1) / 2 : j / 2 - 1, nj = (j & 1) ? 1 : 2;
+            const int ni = ((i + 1) % S == 0) ? 1 : 2, ic0 = i / S - (ni - 1);
+            const int nj = ((j + 1) % S == 0) ? 1 : 2, jc0 = j / S - (nj - 1);
             double y = yf[F.org + (long)i * F.pitch + j];
             for (int p = 0; p < ni; p++) for (int q = 0; q < nj; q++) {
                 const int ic = ic0 + p, jc = jc0 + q;
-                y = y + w[(i - 2 * ic) * 3 + (j - 2 * jc)] * X[(long)ic * Cg.pitch + jc];
+                y = y + wtab[(i - S * ic) * W + (j - S * jc)] * X[(long)ic * Cg.pitch + jc];
             }
             yf[F.org + (long)i * F.pitch + j] = y;
-            if ((i & 1) && (j & 1)) {
-                const long o = (long)ic0 * Cg.pitch + jc0;
-                double z = yc[Cg.org + o];
-                z = z + cc[0] * X[o - Cg.pitch]; z = z + cc[1] * X[o - 1]; z = z + cc[2] * X[o]; z = z + cc[3] * X[o + 1]; z = z + cc[4] * X[o + Cg.pitch];
-                yc[Cg.org + o] = z;
-            }
         }
     });
 }

@@ -202,19 +202,20 @@ def test_reference_driver_pcmg_and_icycle_under_sanitizers(san, tmp_path):
     d2.mkdir()
     out = _refdrv(san, d2, "-npts 17\n-mesh 0\n-iter 50\n-grids 1\n-levels 1\n-cycle 1\n-map 2\n-v 3,3\n-moreNorm 0\n-pc_type jacobi\n-ksp_richardson_scale 0.8\n")
     assert "Number of iterations" in out
-    # two grids in one level: the coupled operator [[A_h, A_h P | window], [R A_h, A_H]] (src/solver.c:255-487) is recognised at
-    # MatAssemblyEnd and applied by the stencil / transfer kernels on [fine | coarse] vectors; with recognition off it stays an
-    # assembled AIJ matrix on the generic CSR kernel -- same residual history and solution up to summation order
+    # several grids in one level: the coupled operator (A_g on the diagonal, R^k A_g below, A_g P^k cut to P's window above;
+    # src/solver.c:255-487) is recognised at MatAssemblyEnd and applied by the stencil / transfer kernels on composite vectors; with
+    # recognition off it stays an assembled AIJ matrix on the generic CSR kernel -- same residual history and solution up to summation order
     res = {}
+    cases = ((17, 2, 5), (9, 2, 3), (5, 2, 2), (17, 3, 4), (33, 4, 3), (33, 3, 3))
     for tag, env in (("c1b", None), ("c1c", {"MGPETSC_NO_RECOGNITION": "1"})):
         d3 = tmp_path / tag
         d3.mkdir()
-        for npts, it in ((17, 5), (9, 3), (5, 2)):
-            out = _refdrv(san, d3, f"-npts {npts}\n-mesh 0\n-iter {it}\n-grids 2\n-levels 1\n-cycle 1\n-map 2\n-v 3,3\n-moreNorm 0\n-pc_type jacobi\n-ksp_richardson_scale 0.5\n", env)
-            assert ("matrix-free two-grid level operator" in out) == (env is None), out[-600:]
+        for npts, grids, it in cases:
+            out = _refdrv(san, d3, f"-npts {npts}\n-mesh 0\n-iter {it}\n-grids {grids}\n-levels 1\n-cycle 1\n-map 2\n-v 3,3\n-moreNorm 0\n-pc_type jacobi\n-ksp_richardson_scale 0.5\n", env)
+            assert ("matrix-free level operator of several grids" in out) == (env is None), out[-600:]
             assert ("assembled AIJ (generic CSR kernel)" in out) == (env is not None)
-            res[tag, npts] = (np.array((d3 / "rData.dat").read_text().split(), dtype=np.float64), np.array((d3 / "uData.dat").read_text().split(), dtype=np.float64))
-    for npts in (17, 9, 5):
-        (r1, u1), (r2, u2) = res["c1b", npts], res["c1c", npts]
+            res[tag, npts, grids] = (np.array((d3 / "rData.dat").read_text().split(), dtype=np.float64), np.array((d3 / "uData.dat").read_text().split(), dtype=np.float64))
+    for npts, grids, it in cases:
+        (r1, u1), (r2, u2) = res["c1b", npts, grids], res["c1c", npts, grids]
         assert r1.shape == r2.shape and np.max(np.abs(r1 - r2)) <= 1e-12 * np.abs(r2).max()
         assert np.max(np.abs(u1 - u2)) <= 1e-12 * np.abs(u2).max()

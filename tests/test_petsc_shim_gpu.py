@@ -378,32 +378,64 @@ def _dense(orc, which, npts, l):
     return d
 
 
+def _level_operator(orc, npts, grids):
+    """dense restatement of levelMatrixA (src/solver.c:489-510) from the oracle's A, R, P: A_g on the diagonal, R^k A_g1 below,
+    (A_g1 P^k) masked to P^k's window above; the right-hand side [f, R f, R R f, ...] (levelvecb, :558-620).  One value per window
+    offset in the upper blocks, as the reference evaluates one expression per offset (:395-466), which a BLAS product does not promise."""
+    A = [_dense(orc, "A", npts, g) for g in range(grids)]
+    R = [_dense(orc, "R", npts, g) for g in range(grids - 1)]
+    P = [_dense(orc, "P", npts, g) for g in range(grids - 1)]
+    n = [(npts - 1) // 2 ** g - 1 for g in range(grids)]
+    blocks = [[None] * grids for _ in range(grids)]
+    for g0 in range(grids):
+        for g1 in range(grids):
+            if g0 == g1:
+                blocks[g0][g1] = A[g0]
+            elif g1 < g0:
+                Rk = np.eye(n[g1] ** 2)
+                for g in range(g1, g0):
+                    Rk = R[g] @ Rk
+                blocks[g0][g1] = Rk @ A[g1]
+            else:                                   # row block g0 (finer), column block g1 (coarser)
+                Pk = np.eye(n[g1] ** 2)
+                for g in range(g1 - 1, g0 - 1, -1):
+                    Pk = P[g] @ Pk
+                W = (A[g0] @ Pk) * (Pk != 0)
+                S, first = 2 ** (g1 - g0), {}
+                for f, c in np.argwhere(W != 0):
+                    d = (f // n[g0] - S * (c // n[g1]), f % n[g0] - S * (c % n[g1]))
+                    W[f, c] = first.setdefault(d, W[f, c])
+                blocks[g0][g1] = W
+    f = orc.rhs(2, npts)
+    b = [f]
+    for g in range(grids - 1):
+        b.append(R[g] @ b[-1])
+    return np.block(blocks), np.concatenate(b), n
+
+
 @pytest.mark.skipif(not os.path.exists(REFDRV), reason="build/refdriver/poisson absent")
-@pytest.mark.parametrize("npts,iters,env", [(9, 25, None), (17, 25, None), (65, 25, None), (17, 25, {"MGPETSC_NO_RECOGNITION": "1"}),
-                                            (65, 25, {"MGPETSC_NO_RECOGNITION": "1"})])
-def test_reference_driver_cycle1_two_grids_in_one_level(orc, tmp_path, npts, iters, env):
-    """-cycle 1 with two grids in ONE level: the reference assembles its coupled level operator (src/solver.c:255-487)
+@pytest.mark.parametrize("npts,grids,iters,env", [(9, 2, 25, None), (17, 2, 25, None), (65, 2, 25, None), (17, 2, 25, {"MGPETSC_NO_RECOGNITION": "1"}),
+                                                  (65, 2, 25, {"MGPETSC_NO_RECOGNITION": "1"}), (17, 3, 25, None), (33, 3, 20, None), (33, 4, 20, None),
+                                                  (65, 3, 20, None), (33, 4, 20, {"MGPETSC_NO_RECOGNITION": "1"})])
+def test_reference_driver_cycle1_several_grids_in_one_level(orc, tmp_path, npts, grids, iters, env):
+    """-cycle 1 with 2, 3 or 4 grids in ONE level: the reference assembles its coupled level operator (src/solver.c:255-487)
     with its own unmodified code; the drop-in recognises the block structure at MatAssemblyEnd (entry by entry) and applies it with
-    the stencil and transfer kernels on [fine | coarse] vectors (mgk_apply, mgk_restrict_fw, mgk_block2_finish); with recognition
+    the stencil and transfer kernels on composite vectors (mgk_apply, mgk_restrict_fw, mgk_apply_add, mgk_window_add); with recognition
     off it stays an assembled AIJ matrix on the generic CSR kernels.
-    Restated here in dense numpy from the oracle's A, R, P:   M = [[A_h, (A_h P) masked to P's 3x3 window], [R A_h, A_H]],
-    b = [f, R f] (levelvecb, :558-620), x += s D^-1 (b - M x).  Point-Jacobi Richardson does not converge on this
-    operator (the author's runs rely on PETSc PCs the drop-in does not provide), so a fixed number of iterations
+    Restated in dense numpy from the oracle's A, R, P (_level_operator); x += s D^-1 (b - M x).  Point-Jacobi Richardson does not
+    converge on this operator (the author's runs rely on PETSc PCs the drop-in does not provide), so a fixed number of iterations
     is compared: residual history to 1e-9, fine-grid part of x to 1e-9.  Parity with PETSc itself: unpinned."""
     s = 0.3
-    opts = (f"-npts {npts}\n-mesh 0\n-iter {iters}\n-grids 2\n-levels 1\n-cycle 1\n-map 2\n-v 3,3\n-moreNorm 0\n"
+    opts = (f"-npts {npts}\n-mesh 0\n-iter {iters}\n-grids {grids}\n-levels 1\n-cycle 1\n-map 2\n-v 3,3\n-moreNorm 0\n"
             f"-pc_type jacobi\n-ksp_richardson_scale {s!r}\n")
     it, rdat, u, e, out = _run_reference_driver(tmp_path, opts, env)
     assert it == iters and rdat.size == iters + 1
-    assert ("matrix-free two-grid level operator" in out) == (env is None)
+    assert ("matrix-free level operator of several grids" in out) == (env is None)
     assert ("assembled AIJ (generic CSR kernel)" in out) == (env is not None)
-    Ah, AH, R, P = _dense(orc, "A", npts, 0), _dense(orc, "A", npts, 1), _dense(orc, "R", npts, 0), _dense(orc, "P", npts, 0)
-    nf, nc = Ah.shape[0], AH.shape[0]
-    M = np.block([[Ah, (Ah @ P) * (P != 0)], [R @ Ah, AH]])
-    f = orc.rhs(2, npts)
-    b = np.concatenate([f, R @ f])
+    M, b, n = _level_operator(orc, npts, grids)
+    nf = n[0] ** 2
     dinv = 1.0 / np.diag(M)
-    x = np.zeros(nf + nc)
+    x = np.zeros(M.shape[0])
     hist = [np.linalg.norm(b)]
     for _ in range(iters):
         x = x + s * (dinv * (b - M @ x))
@@ -414,19 +446,6 @@ def test_reference_driver_cycle1_two_grids_in_one_level(orc, tmp_path, npts, ite
     # solve runs out of iterations
     assert np.max(np.abs(rdat[:-1] / hist[:-1] - 1)) <= 1e-9
     assert np.max(np.abs(u - x[:nf])) <= 1e-9 * np.abs(x[:nf]).max()
-
-
-def _two_grid_level_operator(orc, npts):
-    Ah, AH, R, P = _dense(orc, "A", npts, 0), _dense(orc, "A", npts, 1), _dense(orc, "R", npts, 0), _dense(orc, "P", npts, 0)
-    W = (Ah @ P) * (P != 0)
-    # the reference evaluates ONE expression per window offset (src/solver.c:395-466): the same bits wherever the offset recurs,
-    # which a BLAS product does not promise
-    nf, nc = npts - 2, (npts - 3) // 2
-    first = {}
-    for f, c in np.argwhere(W != 0):
-        d = (f // nf - 2 * (c // nc), f % nf - 2 * (c % nc))
-        W[f, c] = first.setdefault(d, W[f, c])
-    return np.block([[Ah, W], [R @ Ah, AH]])
 
 
 def _assemble(L, M):
@@ -455,16 +474,16 @@ def _get(L, v, n):
     return a
 
 
-@pytest.mark.parametrize("npts", [5, 9, 33])
-def test_two_grid_level_operator_runs_on_the_stencil_and_transfer_kernels(orc, capfd, npts):
+@pytest.mark.parametrize("npts,grids", [(5, 2), (9, 2), (33, 2), (17, 3), (33, 4)])
+def test_level_operator_of_several_grids_runs_on_the_stencil_and_transfer_kernels(orc, capfd, npts, grids):
     """The coupled operator of the I-cycle (src/solver.c:255-487), entered value by value through MatSetValue: recognised at
-    MatAssemblyEnd, MatMult / MatMultAdd / MatResidual on [fine | coarse] vectors equal the dense product to rounding;
+    MatAssemblyEnd, MatMult / MatMultAdd / MatResidual on composite vectors equal the dense product to rounding;
     a matrix that differs from the pattern in ONE entry stays on the generic CSR kernel."""
     L = _shim()
     L.PetscInitialize(None, None, None, None)
     L.MatMultAdd.argtypes = [C.c_void_p] * 4
     L.MatResidual.argtypes = [C.c_void_p] * 4
-    M = _two_grid_level_operator(orc, npts)
+    M = _level_operator(orc, npts, grids)[0]
     N = M.shape[0]
     rng = np.random.default_rng(npts)
     for variant in ("exact", "perturbed W", "perturbed R A_h"):
@@ -481,7 +500,7 @@ def test_two_grid_level_operator_runs_on_the_stencil_and_transfer_kernels(orc, c
         out = capfd.readouterr().out
         # (one coarse point: every window offset occurs once, so ANY nine weights are a member of the family the kernel applies)
         expect = variant == "exact" or (variant == "perturbed W" and npts == 5)
-        assert ("matrix-free two-grid level operator" in out) == expect, (variant, out)
+        assert ("matrix-free level operator of several grids" in out) == expect, (variant, out)
         x, y, z, w = (C.c_void_p() for _ in range(4))
         L.MatCreateVecs(m, C.byref(x), C.byref(y))
         L.VecDuplicate(y, C.byref(z))
