@@ -222,6 +222,10 @@ int  mgk_apply_add_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, cons
 int  mgk_window_add_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, int stride, const double *wtab_dev,
                         const double *xc, double *yf, void *stream);
 
+/* y = B x, B dense row-major m x n on the device: the exact coarse-grid solve of PCMG (PCLU is PETSc's default coarse solver,
+ * src/solver.c:1931-1932), B = A^-1 of the coarsest grid inverted once on the host; x, y compact (unpadded) device arrays */
+int  mgk_dense_mult_f64(mgk_ctx *ctx, int m, int n, const double *B_dev, const double *x, double *y, void *stream);
+
 /* K4 fused into the first post-smoothing sweep (src/solver.c:1540-1542): unew = Jacobi(u + P uc); the corrected
  * u is never written.  Needs valid z ghost planes of u AND of uc on a slab.  3-D only. */
 int  mgk_prolong_jacobi_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv,

@@ -3575,6 +3575,27 @@ extern "C" int mgk_window_add_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom
 }
 
 // ------------------------------------------------------------------------------------------
+// y = B x for a dense row-major m x n matrix: the exact coarse-grid solve of PCMG (PETSc's default coarse solver is PCLU,
+// src/solver.c:1931-1932 takes it as it comes): B = A^-1 of the coarsest grid, inverted once on the host.  One wavefront per row,
+// lanes stride over the columns (coalesced), 64-lane shuffle tree.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_dense_mult(int m, int n, const double *B, const double *x, double *y) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= m) return;
+    const double *br = B + (long)row * n;
+    double acc = 0.0;
+    for (int j = lane; j < n; j += 64) acc += br[j] * x[j];
+    acc = wave_sum(acc);
+    if (lane == 0) y[row] = acc;
+}
+extern "C" int mgk_dense_mult_f64(mgk_ctx *c, int m, int n, const double *B_dev, const double *x, double *y, void *stream) {
+    if (!c || m < 1 || n < 1 || !B_dev || !x || !y || x == y) return fail(MGK_EINVAL, "mgk_dense_mult_f64: bad arguments");
+    hipLaunchKernelGGL(k_dense_mult, dim3((m + 3) / 4), dim3(256), 0, S(c, stream), m, n, B_dev, x, y);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // flat vector kernels (PETSc Vec BLAS-1 surface of the shim) and a generic CSR SpMV.
 // They run over a whole allocation (padded fields included: ghosts are zero and stay zero under
 // every linear combination), one element per lane-iteration, grid-stride.

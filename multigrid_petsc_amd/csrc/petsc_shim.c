@@ -188,6 +188,7 @@ int MPI_Recv(void *b, int c, MPI_Datatype t, int s, int tag, MPI_Comm comm, MPI_
 /* ------------------------------------------------------------------ */
 /* Vec                                                                 */
 /* ------------------------------------------------------------------ */
+#define MGP_LU_MAX 1024     /* unknowns the exact (PCLU) solve accepts: PCMG's coarsest grid */
 #define MGP_MAXG 8          /* grids in one level the matrix-free level operator handles (more: assembled AIJ) */
 struct _p_Vec {
     PetscInt n;             /* logical length */
@@ -380,6 +381,7 @@ struct _p_Mat {
     double *h_ctab, *h_dtab;                             /* STENCIL_ROW: per-grid-row coefficients (n x 5) and 1/diag (n) */
     double *d_ctab, *d_dtab, *d_ones;
     int dev_stale;
+    double *d_inv, *d_c1, *d_c2; int inv_stale;         /* PCLU: dense inverse (m x m, row-major) and two compact work arrays */
     Vec work;
 };
 
@@ -758,7 +760,7 @@ PetscErrorCode MatAssemblyEnd(Mat A, MatAssemblyType t) {
         A->grow_ok = (nr >= 1 && (nr & 1)) && mgk_geom_init(&A->grow, 2, nr, nr, 1) == 0;
         A->gcol_ok = (ncq >= 1 && (ncq & 1)) && mgk_geom_init(&A->gcol, 2, ncq, ncq, 1) == 0;
     }
-    A->dev_stale = 1;
+    A->dev_stale = 1; A->inv_stale = 1;
     return 0;
 }
 
@@ -946,7 +948,7 @@ PetscErrorCode MatScale(Mat A, PetscScalar a) {
         for (int i = 0; i < n * 5; i++) A->h_ctab[i] *= a;
         for (int i = 0; i < n; i++) A->h_dtab[i] = 1.0 / A->h_ctab[i * 5 + 2];
     }
-    A->dev_stale = 1;
+    A->dev_stale = 1; A->inv_stale = 1;
     return 0;
 }
 PetscErrorCode MatMatMult(Mat A, Mat B, MatReuse s, PetscReal f, Mat *C) { (void)A; (void)B; (void)s; (void)f; (void)C; UNSUPPORTED("MatMatMult (additive cycles)"); return 1; }
@@ -971,6 +973,9 @@ PetscErrorCode MatDestroy(Mat *pA) {
         if (A->d_ctab) mgk_free(G, A->d_ctab);
         if (A->d_dtab) mgk_free(G, A->d_dtab);
         if (A->d_ones) mgk_free(G, A->d_ones);
+        if (A->d_inv) mgk_free(G, A->d_inv);
+        if (A->d_c1) mgk_free(G, A->d_c1);
+        if (A->d_c2) mgk_free(G, A->d_c2);
         for (int a = 0; a < MGP_MAXG; a++) for (int b = 0; b < MGP_MAXG; b++) if (A->d_wtab[a][b]) mgk_free(G, A->d_wtab[a][b]);
     }
     for (int a = 0; a < MGP_MAXG; a++) for (int b = 0; b < MGP_MAXG; b++) free(A->h_wtab[a][b]);
@@ -983,8 +988,8 @@ PetscErrorCode MatDestroy(Mat *pA) {
 /* ------------------------------------------------------------------ */
 /* KSP / PC                                                            */
 /* ------------------------------------------------------------------ */
-enum { K_RICHARDSON = 0, K_CHEBYSHEV = 1, K_OTHER = 2 };
-enum { P_DEFAULT = 0, P_JACOBI = 1, P_NONE = 2, P_MG = 3 };
+enum { K_RICHARDSON = 0, K_CHEBYSHEV = 1, K_OTHER = 2, K_PREONLY = 3 };
+enum { P_DEFAULT = 0, P_JACOBI = 1, P_NONE = 2, P_MG = 3, P_LU = 4 };
 /* PCMG state (-cycle 8, src/solver.c:1918-1956).  PETSc numbers levels coarse-to-fine: 0 = coarsest. */
 typedef struct pcmg {
     int levels;
@@ -1025,12 +1030,14 @@ PetscErrorCode KSPCreate(MPI_Comm comm, KSP *out) {
 static int ksp_type_from(const char *t) {
     if (!strcmp(t, KSPRICHARDSON)) return K_RICHARDSON;
     if (!strcmp(t, KSPCHEBYSHEV)) return K_CHEBYSHEV;
+    if (!strcmp(t, KSPPREONLY)) return K_PREONLY;
     return K_OTHER;
 }
 static int pc_type_from(const char *t) {
     if (!strcmp(t, PCJACOBI)) return P_JACOBI;
     if (!strcmp(t, PCNONE)) return P_NONE;
-    fprintf(stderr, "[mgpetsc] FATAL: -pc_type %s is not provided by this drop-in (available: jacobi, none)\n", t);
+    if (!strcmp(t, PCLU) || !strcmp(t, "cholesky")) return P_LU;      /* exact solve on a small grid (PCMG's coarse solver) */
+    fprintf(stderr, "[mgpetsc] FATAL: -pc_type %s is not provided by this drop-in (available: jacobi, none, lu on <= 1024 unknowns)\n", t);
     exit(87);
 }
 PetscErrorCode KSPSetType(KSP k, KSPType t) { k->type = ksp_type_from(t); k->type_from_user = 1; return 0; }
@@ -1180,10 +1187,13 @@ static void mg_setup(KSP k) {
         KSP s = mg->smooth[i];
         if (!s->A) { fprintf(stderr, "[mgpetsc] FATAL: PCMG level %d has no operators (KSPSetOperators on PCMGGetSmoother/CoarseSolve)\n", i); exit(86); }
         if (i > 0 && (!mg->interp[i] || !mg->restr[i])) { fprintf(stderr, "[mgpetsc] FATAL: PCMG level %d lacks interpolation/restriction\n", i); exit(86); }
-        if (!s->type_from_user) {
+        if (!s->type_from_user && i == 0 && s->pc == P_DEFAULT && s->A->m <= MGP_LU_MAX) {
+            s->type = K_PREONLY; s->pc = P_LU;           /* PETSc's default coarse solver: preonly + LU, an exact solve */
+        } else if (!s->type_from_user) {
             if (!noted) {
-                fprintf(stderr, "[mgpetsc] note: PCMG's PETSc defaults (chebyshev+SOR smoothers, LU coarse solve) are not provided; "
-                                "level solvers without -mg_levels_ksp_type / -mg_coarse_ksp_type use richardson + jacobi, %d sweeps\n", (int)s->maxits);
+                fprintf(stderr, "[mgpetsc] note: PCMG's PETSc default smoother (chebyshev + SOR with estimated eigenvalues) is not provided; "
+                                "level solvers without -mg_levels_ksp_type use richardson + jacobi, %d sweeps (the default coarse solve is "
+                                "exact, as PETSc's preonly + LU, up to 1024 unknowns)\n", (int)s->maxits);
                 noted = 1;
             }
             s->type = K_RICHARDSON;
@@ -1277,13 +1287,79 @@ static PetscErrorCode ksp_solve_monitored(KSP k, Vec b, Vec x) {
     return 0;
 }
 
+/* PCLU (with any KSP type): x = A^-1 b.  PETSc factors; this drop-in inverts the small matrix once on the host (Gauss-Jordan with
+ * partial pivoting on the assembled values) and applies the dense inverse on the GPU (mgk_dense_mult_f64) -- the same exact solve
+ * up to rounding.  Meant for PCMG's coarsest grid (PETSc's default coarse solver, src/solver.c:1931-1932): at most 1024 unknowns. */
+static void mat_device_inverse(Mat A) {
+    if (A->d_inv && !A->inv_stale) return;
+    const int m = A->m;
+    double *M = (double *)calloc((size_t)m * 2 * m, sizeof(double));
+    if (!M) { fprintf(stderr, "[mgpetsc] FATAL: out of memory (dense inverse)\n"); exit(88); }
+    const int w = 2 * m;
+    for (int r = 0; r < m; r++) {
+        for (long q = A->rowptr[r]; q < A->rowptr[r + 1]; q++) M[(size_t)r * w + A->col[q]] += A->val[q];
+        M[(size_t)r * w + m + r] = 1.0;
+    }
+    for (int c = 0; c < m; c++) {
+        int p = c;
+        for (int r = c + 1; r < m; r++) if (fabs(M[(size_t)r * w + c]) > fabs(M[(size_t)p * w + c])) p = r;
+        if (M[(size_t)p * w + c] == 0.0) { fprintf(stderr, "[mgpetsc] FATAL: PCLU: the matrix is singular\n"); exit(88); }
+        if (p != c) for (int j = 0; j < w; j++) { double t = M[(size_t)p * w + j]; M[(size_t)p * w + j] = M[(size_t)c * w + j]; M[(size_t)c * w + j] = t; }
+        const double d = 1.0 / M[(size_t)c * w + c];
+        for (int j = c; j < w; j++) M[(size_t)c * w + j] *= d;
+        for (int r = 0; r < m; r++) {
+            if (r == c) continue;
+            const double f = M[(size_t)r * w + c];
+            if (f == 0.0) continue;
+            for (int j = c; j < w; j++) M[(size_t)r * w + j] -= f * M[(size_t)c * w + j];
+        }
+    }
+    double *inv = (double *)malloc(sizeof(double) * (size_t)m * m);
+    for (int r = 0; r < m; r++) memcpy(inv + (size_t)r * m, M + (size_t)r * w + m, sizeof(double) * (size_t)m);
+    free(M);
+    void *p;
+    if (!A->d_inv) {
+        DEV(mgk_malloc(G, &p, sizeof(double) * (size_t)m * m)); A->d_inv = (double *)p;
+        DEV(mgk_malloc(G, &p, sizeof(double) * (size_t)(m < 16 ? 16 : m))); A->d_c1 = (double *)p;
+        DEV(mgk_malloc(G, &p, sizeof(double) * (size_t)(m < 16 ? 16 : m))); A->d_c2 = (double *)p;
+    }
+    DEV(mgk_h2d(G, A->d_inv, inv, sizeof(double) * (size_t)m * m));
+    free(inv);
+    A->inv_stale = 0;
+}
+static PetscErrorCode ksp_solve_direct(KSP k, Vec b, Vec x) {
+    Mat A = k->A;
+    if (A->m != A->n) UNSUPPORTED("PCLU on a rectangular operator");
+    if (A->m > MGP_LU_MAX) UNSUPPORTED("PCLU on more than 1024 unknowns (it is meant for PCMG's coarsest grid: use more levels)");
+    need_same(b, x, "KSPSolve");
+    if (b->padded == 2 || b == x) UNSUPPORTED("PCLU on a several-grid level operator / in place");
+    mat_device_inverse(A);
+    const double *bd = vdev(b);
+    x->host_dirty = 0;
+    if (b->padded) {
+        DEV(mgk_unpack_f64(G, &b->g, bd, A->d_c1, NULL));
+        DEV(mgk_dense_mult_f64(G, A->m, A->m, A->d_inv, A->d_c1, A->d_c2, NULL));
+        DEV(mgk_pack_f64(G, &x->g, A->d_c2, x->dev, NULL));
+    } else DEV(mgk_dense_mult_f64(G, A->m, A->m, A->d_inv, bd, x->dev, NULL));
+    k->b = b; k->x = x; k->its = 1;
+    return 0;
+}
+
 /* KSPSolve, KSP_NORM_NONE: exactly max_it iterations (src/solver.c:1531,1536,1542) */
 PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
     Mat A = k->A;
     if (!A || !A->assembled) UNSUPPORTED("KSPSolve without assembled operators");
     if (k->pc == P_MG) return ksp_solve_mg(k, b, x);
+    if (k->pc == P_LU) return ksp_solve_direct(k, b, x);            /* an exact solve whatever the Krylov type */
     if (k->normtype == KSP_NORM_UNPRECONDITIONED) return ksp_solve_monitored(k, b, x);
-    if (k->type == K_OTHER) UNSUPPORTED("KSPSolve with a Krylov type other than richardson/chebyshev");
+    if (k->type == K_OTHER) UNSUPPORTED("KSPSolve with a Krylov type other than richardson/chebyshev/preonly");
+    if (k->type == K_PREONLY) {                                     /* x = B b: one undamped Richardson step from the zero guess */
+        const int g0 = k->guess_nonzero; const PetscInt m0 = k->maxits; const double s0 = k->scale;
+        k->type = K_RICHARDSON; k->guess_nonzero = 0; k->maxits = 1; k->scale = 1.0;
+        PetscErrorCode rc = KSPSolve(k, b, x);
+        k->type = K_PREONLY; k->guess_nonzero = g0; k->maxits = m0; k->scale = s0;
+        return rc;
+    }
     need_same(b, x, "KSPSolve");
     const int pc = ksp_pc(k);
     const PetscInt maxit = k->maxits;
@@ -1400,7 +1476,8 @@ PetscErrorCode KSPBuildResidual(KSP k, Vec t, Vec v, Vec *V) {
 }
 PetscErrorCode KSPView(KSP k, PetscViewer viewer) {               /* src/solver.c:1562 */
     (void)viewer;
-    static const char *tn[] = {"richardson", "chebyshev", "(unsupported)"}, *pn[] = {"jacobi (default ILU(0) unavailable)", "jacobi", "none"};
+    static const char *tn[] = {"richardson", "chebyshev", "(unsupported)", "preonly"},
+                      *pn[] = {"jacobi (default ILU(0) unavailable)", "jacobi", "none", "mg", "lu (dense inverse applied on the GPU: an exact solve)"};
     printf("KSP Object: 1 MPI process\n  type: %s\n", tn[k->type]);
     if (k->type == K_RICHARDSON) printf("    damping factor=%g\n", k->scale);
     if (k->type == K_CHEBYSHEV) printf("    eigenvalue targets used: min %g, max %g\n", k->emin, k->emax);

@@ -386,6 +386,12 @@ int mgk_jacobi2_2d_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double
 }
 int mgk_restrict_fw_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *r, double *bc, void *) { return restrict_api<double>(c, gf, gc, r, bc); }
 int mgk_restrict_fw_f32(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const float *r, float *bc, void *) { return restrict_api<float>(c, gf, gc, r, bc); }
+int mgk_dense_mult_f64(mgk_ctx *c, int m, int n, const double *B, const double *x, double *y, void *) {
+    if (!c || m < 1 || n < 1 || !B || !x || !y || x == y) return fail(MGK_EINVAL, "mgk_dense_mult_f64");
+    return run(c, [=] {
+        for (int r = 0; r < m; r++) { double acc = 0.0; for (int j = 0; j < n; j++) acc += B[(long)r * n + j] * x[j]; y[r] = acc; }
+    });
+}
 int mgk_apply_add_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, const double *x, double *y, void *) {
     if (!c || !g || !coef || !x || !y || x == y || g->dim != 2 || g->nx != g->ny) return fail(MGK_EINVAL, "mgk_apply_add_f64");
     const mgk_geom G = *g; std::vector<double> k(coef, coef + 5);

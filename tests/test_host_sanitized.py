@@ -193,6 +193,59 @@ def test_reference_driver_chebyshev_under_sanitizers(san, tmp_path, mesh, npts, 
     assert np.array_equal(u, ref["u"])
 
 
+def _pcmg_exact_coarse(orc, _dense, npts, levels, sweeps, scale, maxiter, rtol=1e-7):
+    """numpy restatement of outer Richardson + PCMG V-cycle (the recursion in petsc_shim.c: mg_cycle) with Richardson + Jacobi
+    level smoothers and an EXACT coarse solve (PETSc's default preonly + LU): residual history and solution"""
+    A = [_dense(orc, "A", npts, l) for l in range(levels)]
+    R = [_dense(orc, "R", npts, l) for l in range(levels - 1)]
+    P = [_dense(orc, "P", npts, l) for l in range(levels - 1)]
+
+    def smooth(l, b, x):
+        d = 1.0 / np.diag(A[l])
+        for _ in range(sweeps):
+            x = x + scale * (d * (b - A[l] @ x))
+        return x
+
+    def cycle(l, b):
+        if l == levels - 1:
+            return np.linalg.solve(A[l], b)
+        x = smooth(l, b, np.zeros_like(b))
+        xc = cycle(l + 1, R[l] @ (b - A[l] @ x))
+        return smooth(l, b, x + P[l] @ xc)
+
+    b = orc.rhs(2, npts)
+    x = np.zeros_like(b)
+    hist = [np.linalg.norm(b)]
+    while len(hist) - 1 < maxiter and hist[-1] > rtol * hist[0]:
+        x = x + cycle(0, b - A[0] @ x)
+        hist.append(np.linalg.norm(b - A[0] @ x))
+    return np.array(hist), x
+
+
+def _dense_from_oracle(orc, which, npts, l):
+    m = orc.build(which, 2, npts, l)
+    d = np.zeros((orc.L.mgo_csr_nrows(m), orc.L.mgo_csr_ncols(m)))
+    for r, (cols, vals) in enumerate(orc.csr_rows(m)):
+        d[r, list(cols)] = vals
+    return d
+
+
+@pytest.mark.parametrize("npts,levels,coarse", [(33, 3, "default"), (17, 2, "lu"), (33, 4, "lu")])
+def test_reference_driver_pcmg_exact_coarse_solve_under_sanitizers(san, tmp_path, npts, levels, coarse):
+    """-cycle 8 with the exact coarse solve (PETSc's default preonly + LU; host-side inversion, dense mat-vec through the kernel ABI)
+    against a dense numpy restatement with numpy.linalg.solve on the coarsest grid"""
+    lv = "-mg_levels_ksp_type richardson\n-mg_levels_pc_type jacobi\n-mg_levels_ksp_max_it 3\n-mg_levels_ksp_richardson_scale 0.8\n"
+    if coarse == "lu":
+        lv += "-mg_coarse_ksp_type preonly\n-mg_coarse_pc_type lu\n"
+    out = _refdrv(san, tmp_path, f"-npts {npts}\n-mesh 0\n-iter 100\n-grids {levels}\n-levels {levels}\n-cycle 8\n-map 2\n-v 3,3\n-moreNorm 0\n" + lv)
+    orc = Oracle()
+    hist, x = _pcmg_exact_coarse(orc, _dense_from_oracle, npts, levels, 3, 0.8, 100)
+    assert int(re.search(r"Number of iterations:\s+(\d+)", out).group(1)) == len(hist) - 1
+    u = np.array((tmp_path / "uData.dat").read_text().split(), dtype=np.float64)
+    assert np.max(np.abs(u - x)) <= 1e-10 * np.abs(x).max()
+    assert "type: lu" in out
+
+
 def test_reference_driver_pcmg_and_icycle_under_sanitizers(san, tmp_path):
     lv = ("-mg_levels_ksp_type richardson\n-mg_levels_pc_type jacobi\n-mg_levels_ksp_max_it 3\n-mg_levels_ksp_richardson_scale 0.8\n"
           "-mg_coarse_ksp_type richardson\n-mg_coarse_pc_type jacobi\n-mg_coarse_ksp_max_it 3\n-mg_coarse_ksp_richardson_scale 0.8\n")

@@ -353,6 +353,65 @@ def test_reference_driver_cycle8_pcmg(orc, tmp_path, npts, levels, scale, ksp):
         assert vc["iters"] == it
 
 
+def _dense(orc, which, npts, l):
+    m = orc.build(which, 2, npts, l)
+    rows = orc.csr_rows(m)
+    nr, nc = orc.L.mgo_csr_nrows(m), orc.L.mgo_csr_ncols(m)
+    d = np.zeros((nr, nc))
+    for r, (cols, vals) in enumerate(rows):
+        d[r, list(cols)] = vals
+    return d
+
+
+def _pcmg_exact_coarse(orc, _dense, npts, levels, sweeps, scale, maxiter, rtol=1e-7):
+    """numpy restatement of outer Richardson + PCMG V-cycle (the recursion in petsc_shim.c: mg_cycle) with Richardson + Jacobi
+    level smoothers and an EXACT coarse solve (PETSc's default preonly + LU): residual history and solution"""
+    A = [_dense(orc, "A", npts, l) for l in range(levels)]
+    R = [_dense(orc, "R", npts, l) for l in range(levels - 1)]
+    P = [_dense(orc, "P", npts, l) for l in range(levels - 1)]
+
+    def smooth(l, b, x):
+        d = 1.0 / np.diag(A[l])
+        for _ in range(sweeps):
+            x = x + scale * (d * (b - A[l] @ x))
+        return x
+
+    def cycle(l, b):
+        if l == levels - 1:
+            return np.linalg.solve(A[l], b)
+        x = smooth(l, b, np.zeros_like(b))
+        xc = cycle(l + 1, R[l] @ (b - A[l] @ x))
+        return smooth(l, b, x + P[l] @ xc)
+
+    b = orc.rhs(2, npts)
+    x = np.zeros_like(b)
+    hist = [np.linalg.norm(b)]
+    while len(hist) - 1 < maxiter and hist[-1] > rtol * hist[0]:
+        x = x + cycle(0, b - A[0] @ x)
+        hist.append(np.linalg.norm(b - A[0] @ x))
+    return np.array(hist), x
+
+
+@pytest.mark.skipif(not os.path.exists(REFDRV), reason="build/refdriver/poisson absent")
+@pytest.mark.parametrize("npts,levels,coarse", [(33, 3, "default"), (33, 2, "default"), (65, 3, "lu"), (65, 5, "default"), (129, 3, "lu")])
+def test_reference_driver_cycle8_exact_coarse_solve(orc, tmp_path, npts, levels, coarse):
+    """-cycle 8 with PETSc's default coarse solver (preonly + LU, src/solver.c:1931-1932 takes it as it comes): the drop-in inverts
+    the coarsest operator once on the host and applies the dense inverse on the GPU (mgk_dense_mult_f64) -- an exact solve, given
+    explicitly (-mg_coarse_ksp_type preonly -mg_coarse_pc_type lu) or by default.  Against a dense numpy restatement of the cycle
+    with numpy.linalg.solve on the coarsest grid: same cycle count, history and solution to 1e-10 (parity with PETSc: unpinned)."""
+    lv = "-mg_levels_ksp_type richardson\n-mg_levels_pc_type jacobi\n-mg_levels_ksp_max_it 3\n-mg_levels_ksp_richardson_scale 0.8\n"
+    if coarse == "lu":
+        lv += "-mg_coarse_ksp_type preonly\n-mg_coarse_pc_type lu\n"
+    opts = f"-npts {npts}\n-mesh 0\n-iter 100\n-grids {levels}\n-levels {levels}\n-cycle 8\n-map 2\n-v 3,3\n-moreNorm 0\n" + lv
+    it, rdat, u, e, out = _run_reference_driver(tmp_path, opts)
+    hist, x = _pcmg_exact_coarse(orc, _dense, npts, levels, 3, 0.8, 100)
+    assert it == len(hist) - 1 < 100
+    # (the two evaluate b - A x in different summation orders: their norms differ by rounding of the size of ||b||, not of ||r||)
+    assert np.max(np.abs(rdat - hist / hist[0])) <= 1e-13
+    assert np.max(np.abs(u - x)) <= 1e-10 * np.abs(x).max()
+    assert "type: lu" in out and "type: preonly" in out
+
+
 @pytest.mark.skipif(not os.path.exists(REFDRV), reason="build/refdriver/poisson absent")
 @pytest.mark.parametrize("npts,scale,env", [(9, 0.8, None), (17, 1.0, None), (33, 0.8, None), (17, 0.8, {"MGPETSC_NO_RECOGNITION": "1"})])
 def test_reference_driver_cycle1_single_grid(orc, tmp_path, npts, scale, env):
@@ -366,16 +425,6 @@ def test_reference_driver_cycle1_single_grid(orc, tmp_path, npts, scale, env):
     assert np.max(np.abs(rdat - ref["rnorm"] / ref["rnorm"][0]) / rdat) <= 1e-12
     assert np.array_equal(u, ref["u"])
     assert "I-Cycle" in out
-
-
-def _dense(orc, which, npts, l):
-    m = orc.build(which, 2, npts, l)
-    rows = orc.csr_rows(m)
-    nr, nc = orc.L.mgo_csr_nrows(m), orc.L.mgo_csr_ncols(m)
-    d = np.zeros((nr, nc))
-    for r, (cols, vals) in enumerate(rows):
-        d[r, list(cols)] = vals
-    return d
 
 
 def _level_operator(orc, npts, grids):
