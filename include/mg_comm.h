@@ -54,6 +54,8 @@ int      mg_comm_rccl_unique_id(void *id_out);
 mg_comm *mg_comm_rccl_create(int rank, int nranks, const void *id, int device);
 /* test aid: grouped ncclSend/ncclRecv with this rank as its own peer (count elements of esz 8 or 4 bytes) */
 int  mg_comm_rccl_self_sendrecv(mg_comm *c, mgk_ctx *ctx, const void *src, void *dst, long count, int esz);
+/* the same, queued on the comm stream and left running (measurement aid: tools/rccl_overlap.py) */
+int  mg_comm_rccl_self_sendrecv_async(mg_comm *c, mgk_ctx *ctx, const void *src, void *dst, long count, int esz);
 
 /* phantom: rank `rank` of `nranks` alone on its GPU (measurement aid, see above).  lat_us: latency of one exchange,
  * link_gbs: one-directional bandwidth of one link; an exchange holds its stream for lat_us + bytes_per_direction/link_gbs */

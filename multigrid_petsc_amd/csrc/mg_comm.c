@@ -180,6 +180,20 @@ int mg_comm_rccl_self_sendrecv(mg_comm *c, mgk_ctx *ctx, const void *src, void *
     return 0;
 }
 
+/* The same grouped send/recv QUEUED on the comm stream and left running (no wait for the compute stream, no synchronisation): the
+ * measurement aid of tools/rccl_overlap.py -- does RCCL's send/recv kernel run beside a marching kernel that fills the chip? */
+int mg_comm_rccl_self_sendrecv_async(mg_comm *c, mgk_ctx *ctx, const void *src, void *dst, long count, int esz) {
+    if (!c || c->halo != rccl_halo) return cfail(MGK_EINVAL, "mg_comm_rccl_self_sendrecv_async", "not an RCCL communicator");
+    rccl_impl *im = (rccl_impl *)c->impl;
+    void *s = mgk_stream_comm(ctx);
+    const int dt = (esz == 8) ? NCCL_FLOAT64 : NCCL_FLOAT32;
+    NCK(g_rccl.GroupStart());
+    NCK(g_rccl.Send(src, (size_t)count, dt, c->rank, im->comm, s));
+    NCK(g_rccl.Recv(dst, (size_t)count, dt, c->rank, im->comm, s));
+    NCK(g_rccl.GroupEnd());
+    return 0;
+}
+
 /* in place on the device, queued on the comm stream: the caller ties it to the producer of dvals with mgk_stream_wait */
 static int rccl_allreduce_sum_dev(mg_comm *c, mgk_ctx *ctx, double *dvals, int n, void *stream) {
     rccl_impl *im = (rccl_impl *)c->impl;
