@@ -6,10 +6,13 @@
  *   fills b[0] with VecSetValue                                src/solver.c:558-620
  *   runs KSPSolve / KSPBuildResidual / MatMult / VecAXPY / VecNorm in the cycle loop   :1530-1550
  *   reads the solution back with VecGetArray                   src/solver.c:1255
- * Here MatAssemblyEnd RECOGNISES the three operator families (constant 5-point rows, 9-entry full
- * weighting rows, <=4-entry bilinear rows) and replaces them by matrix-free stencil operators on the
- * padded device layout; anything else stays an assembled AIJ matrix that is multiplied on the GPU by a
- * generic CSR kernel.  There is no CPU execution path for Mat/Vec/KSP operations.
+ * Here MatAssemblyEnd RECOGNISES the operator families the reference assembles -- constant 5-point rows, 9-entry full
+ * weighting rows, <=4-entry bilinear rows, 5-point rows whose coefficients depend on the grid row (-mesh 1/2), and the
+ * I-cycle's coupled level operator of several grids (-cycle 1, src/solver.c:255-487) -- and replaces them by matrix-free
+ * stencil / transfer operators on the padded device layout; anything else stays an assembled AIJ matrix that is
+ * multiplied on the GPU by a generic CSR kernel.  KSP: richardson | chebyshev | preonly with jacobi | none | lu (an exact
+ * solve for PCMG's coarsest grid) | mg.  There is no CPU execution path for Mat/Vec/KSP operations (host work happens
+ * once per operator: CSR compression, recognition, the dense inverse of a PCLU operator).
  *
  * C99, no HIP: every device operation is a call into include/mgk.h.
  */
