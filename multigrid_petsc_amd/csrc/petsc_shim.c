@@ -28,6 +28,8 @@
 /* ------------------------------------------------------------------ */
 static mgk_ctx *G = NULL;
 static int g_notice_pc = 0;
+static long g_lzstat[6];     /* lazy temporaries: [0] residual+restriction fused, [1] prolongation fused into a sweep, [2..4] deferred values that were
+                              * computed after all (residual, prolongation, correction), [5] deferred values overwritten unread */
 
 static void die(const char *what) {
     fprintf(stderr, "[mgpetsc] FATAL: %s (kernel layer: %s)\n", what, mgk_last_error());
@@ -100,6 +102,9 @@ PetscErrorCode PetscInitialize(int *argc, char ***argv, const char file[], const
     return 0;
 }
 PetscErrorCode PetscFinalize(void) {
+    if (getenv("MGPETSC_LAZY_STATS"))
+        printf("[mgpetsc] lazy temporaries: %ld residual+restriction passes, %ld prolongation sweeps fused; computed after all: %ld residuals, "
+               "%ld prolongations, %ld corrections; %ld dropped unread\n", g_lzstat[0], g_lzstat[1], g_lzstat[2], g_lzstat[3], g_lzstat[4], g_lzstat[5]);
     if (G) { mgk_ctx_destroy(G); G = NULL; }
     for (int q = 0; q < g_nopt; q++) { free(g_opt[q].key); free(g_opt[q].val); }
     free(g_opt); g_opt = NULL; g_nopt = g_capopt = 0;
@@ -200,6 +205,8 @@ struct _p_Vec {
                              *    several-grids-in-one-level operator); field q starts at goff[q] */
     mgk_geom g;
     int ng; mgk_geom gg[MGP_MAXG]; long goff[MGP_MAXG + 1];
+    int lz;                 /* a value that has not been computed yet (lazy temporaries, below): LZ_* */
+    struct _p_Mat *lz_A; struct _p_Vec *lz_b, *lz_x;
     long nalloc;            /* doubles on the device */
     double *dev;
     double *host;           /* compact lexicographic mirror (VecSetValue staging / VecGetArray) */
@@ -265,7 +272,50 @@ static void vec_download(Vec v) {        /* device -> host mirror */
         mgk_free(G, tmp);
     }
 }
-static double *vdev(Vec v) { if (v->host_dirty) vec_upload(v); return v->dev; }
+/* ---- lazy temporaries --------------------------------------------------------------------------------------------------
+ * The reference's cycle hands every intermediate result to the next PETSc call through a vector (src/solver.c:1531-1546):
+ *   KSPBuildResidual(ksp, NULL, rv, &r); MatMult(res, r, b_coarse)          -- r is read once, by the restriction
+ *   MatMult(pro, u_coarse, rv); VecAXPY(u, 1.0, rv); KSPSolve(ksp, b, u)    -- rv is read once, the corrected u is read by the sweep
+ * Executed call by call that is 5 passes over the level and 7 launches where the fused kernels of the own driver need 2 passes and
+ * 2 launches (b_c = R(b - A u) in one pass; u' = J(u + P u_c) in one pass).  So three results are DEFERRED:
+ *   LZ_RESIDUAL  v = b - A x            (MatResidual / KSPBuildResidual on a stencil operator)
+ *   LZ_PROLONG   v = P u_c              (MatMult with a recognised prolongation)
+ *   LZ_ADDP      v = v + P u_c          (VecAXPY(v, 1.0, rv) with rv = LZ_PROLONG; the device still holds the old v)
+ * and three consumers take them as they are: MatMult(restriction, r) of an LZ_RESIDUAL r runs the fused residual + restriction,
+ * VecAXPY(u, 1, rv) of an LZ_PROLONG rv makes u LZ_ADDP, KSPSolve from the guess u of an LZ_ADDP u makes its first sweep with the
+ * fused prolongation.  PETSc's semantics are kept for every other use: ANY read of a deferred vector computes it first (vdev ->
+ * lz_settle), ANY write to a vector first computes the deferred vectors that depend on it (lz_before_write), destroying an operand
+ * likewise.  A deferred vector that is overwritten before anyone reads it is never computed -- which is what happens to r and rv in
+ * the reference's loop.  MGPETSC_LAZY=0 switches the whole mechanism off (every call executes at once, as before). */
+enum { LZ_NONE = 0, LZ_RESIDUAL = 1, LZ_PROLONG = 2, LZ_ADDP = 3 };
+#define LZ_MAX 64
+static Vec g_lz[LZ_MAX];
+static int g_nlz = 0, g_lazy = -1;
+static int lazy_on(void) { if (g_lazy < 0) { const char *e = getenv("MGPETSC_LAZY"); g_lazy = !(e && e[0] == '0'); } return g_lazy; }
+static void lz_settle(Vec v);
+static void lz_drop(Vec v) {                       /* forget v's deferred value (it is being overwritten / has been consumed) */
+    if (!v->lz) return;
+    v->lz = LZ_NONE; v->lz_A = NULL; v->lz_b = v->lz_x = NULL;
+    for (int q = 0; q < g_nlz; q++) if (g_lz[q] == v) { g_lz[q] = g_lz[--g_nlz]; break; }
+}
+static void lz_register(Vec v, int kind, struct _p_Mat *A, Vec b, Vec x) {
+    if (g_nlz == LZ_MAX) lz_settle(g_lz[0]);
+    v->lz = kind; v->lz_A = A; v->lz_b = b; v->lz_x = x;
+    g_lz[g_nlz++] = v;
+}
+/* before v's value changes: compute whatever is defined in terms of the current v; full: v is overwritten entirely, its own
+ * deferred value is dead, otherwise it is computed first */
+static void lz_before_write(Vec v, int full) {
+    for (int q = 0; q < g_nlz; ) {
+        Vec L = g_lz[q];
+        if (L != v && (L->lz_b == v || L->lz_x == v)) { lz_settle(L); q = 0; } else q++;
+    }
+    if (v->lz) { if (full) { g_lzstat[5]++; lz_drop(v); } else lz_settle(v); }
+}
+static void lz_before_mat_change(struct _p_Mat *A) {
+    for (int q = 0; q < g_nlz; ) { if (g_lz[q]->lz_A == A) { lz_settle(g_lz[q]); q = 0; } else q++; }
+}
+static double *vdev(Vec v) { if (v->lz) lz_settle(v); if (v->host_dirty) vec_upload(v); return v->dev; }
 static int same_layout(Vec a, Vec b) {
     if (a->n != b->n || a->padded != b->padded) return 0;
     if (a->padded == 2 && a->ng != b->ng) return 0;         /* (same finest grid, same count: same chain of grids) */
@@ -280,6 +330,7 @@ PetscErrorCode VecCreateSeq(MPI_Comm comm, PetscInt n, Vec *v) { (void)comm; *v 
 PetscErrorCode VecDuplicate(Vec v, Vec *nv) { *nv = v->padded == 2 ? vec_newg(v->ng, v->gg) : vec_new(v->n, v->padded ? &v->g : NULL); return 0; }
 PetscErrorCode VecDestroy(Vec *v) {
     if (!v || !*v) return 0;
+    lz_before_write(*v, 1);                                  /* deferred vectors that read *v are computed now */
     if (G) mgk_free(G, (*v)->dev);
     free((*v)->host); free(*v); *v = NULL;
     return 0;
@@ -291,13 +342,14 @@ PetscErrorCode VecGetOwnershipRanges(Vec v, const PetscInt *ranges[]) { *ranges 
 PetscErrorCode VecSetValue(Vec v, PetscInt row, PetscScalar value, InsertMode mode) {
     if (row < 0) return 0;                                   /* PETSc ignores negative indices */
     if (row >= v->n) { fprintf(stderr, "[mgpetsc] FATAL: VecSetValue: row %d out of range %d\n", row, v->n); exit(88); }
-    if (!v->host_dirty) { vec_download(v); v->host_dirty = 1; }      /* stage on the current values */
+    if (!v->host_dirty) { (void)vdev(v); lz_before_write(v, 0); vec_download(v); v->host_dirty = 1; }      /* stage on the current values */
     if (mode == ADD_VALUES) v->host[row] += value; else v->host[row] = value;
     return 0;
 }
 PetscErrorCode VecAssemblyBegin(Vec v) { (void)v; return 0; }
 PetscErrorCode VecAssemblyEnd(Vec v) { if (v->host_dirty) vec_upload(v); return 0; }
 PetscErrorCode VecSet(Vec v, PetscScalar a) {
+    lz_before_write(v, 1);
     v->host_dirty = 0;
     if (a == 0.0) { DEV(mgk_memset0(G, v->dev, sizeof(double) * (size_t)v->nalloc, NULL)); return 0; }
     if (!v->padded) { DEV(mgk_flat_fill(G, v->n, a, v->dev, NULL)); return 0; }
@@ -309,23 +361,41 @@ PetscErrorCode VecSet(Vec v, PetscScalar a) {
 }
 PetscErrorCode VecCopy(Vec x, Vec y) {
     need_same(x, y, "VecCopy");
+    if (x == y) return 0;
+    (void)vdev(x);
+    lz_before_write(y, 1);
     y->host_dirty = 0;
     DEV(mgk_d2d(G, y->dev, vdev(x), sizeof(double) * (size_t)x->nalloc, NULL));
     return 0;
 }
-PetscErrorCode VecScale(Vec v, PetscScalar a) { DEV(mgk_flat_scale(G, v->nalloc, a, vdev(v), NULL)); return 0; }
+PetscErrorCode VecScale(Vec v, PetscScalar a) { lz_before_write(v, 0); DEV(mgk_flat_scale(G, v->nalloc, a, vdev(v), NULL)); return 0; }
 PetscErrorCode VecAXPY(Vec y, PetscScalar a, Vec x) {       /* y = y + a x  (src/solver.c:1517,1541) */
     need_same(x, y, "VecAXPY");
+    if (x->lz == LZ_PROLONG && a == 1.0 && x != y && y != x->lz_x && y->padded == 1 && lazy_on()) {
+        /* u += P u_c with P u_c not computed yet (src/solver.c:1540-1541): u's correction is deferred in turn -- the KSPSolve that
+         * follows makes its first sweep on u + P u_c directly; anything else that touches u first runs mgk_prolong_add */
+        struct _p_Mat *P = x->lz_A; Vec uc = x->lz_x;
+        (void)vdev(y);                                       /* y itself concrete and on the device */
+        lz_before_write(y, 0);
+        lz_register(y, LZ_ADDP, P, NULL, uc);
+        return 0;
+    }
+    (void)vdev(x);
+    lz_before_write(y, 0);
     DEV(mgk_flat_axpy(G, y->nalloc, a, vdev(x), vdev(y), NULL));
     return 0;
 }
 PetscErrorCode VecAYPX(Vec y, PetscScalar a, Vec x) {       /* y = x + a y */
     need_same(x, y, "VecAYPX");
+    (void)vdev(x);
+    lz_before_write(y, 0);
     DEV(mgk_flat_aypx(G, y->nalloc, a, vdev(x), vdev(y), NULL));
     return 0;
 }
 PetscErrorCode VecAXPBYPCZ(Vec z, PetscScalar a, PetscScalar b, PetscScalar c, Vec x, Vec y) {
     need_same(x, z, "VecAXPBYPCZ"); need_same(y, z, "VecAXPBYPCZ");
+    (void)vdev(x); (void)vdev(y);
+    lz_before_write(z, 0);
     DEV(mgk_flat_axpbypcz(G, z->nalloc, a, b, c, vdev(x), vdev(y), vdev(z), NULL));
     return 0;
 }
@@ -343,7 +413,7 @@ PetscErrorCode VecNorm(Vec x, NormType type, PetscReal *val) {     /* src/solver
     return 0;
 }
 PetscErrorCode VecGetArray(Vec v, PetscScalar **a) {       /* src/solver.c:1255 */
-    if (!v->host_dirty) vec_download(v);
+    if (!v->host_dirty) { (void)vdev(v); lz_before_write(v, 0); vec_download(v); }
     v->host_dirty = 1;                                      /* the caller may write through the pointer */
     *a = v->host;
     return 0;
@@ -351,6 +421,7 @@ PetscErrorCode VecGetArray(Vec v, PetscScalar **a) {       /* src/solver.c:1255 
 PetscErrorCode VecRestoreArray(Vec v, PetscScalar **a) { if (a) *a = NULL; if (v->host_dirty) vec_upload(v); return 0; }
 PetscErrorCode VecView(Vec v, PetscViewer viewer) {
     (void)viewer;
+    (void)vdev(v);
     vec_download(v);
     for (PetscInt q = 0; q < v->n; q++) printf("%g\n", v->host[q]);
     return 0;
@@ -834,6 +905,8 @@ static void csr_apply(Mat A, Vec x, Vec y, double alpha, Vec addto, const char *
     need_vec(y, A->grow_ok, &A->grow, A->m, who);
     if (addto) need_vec(addto, A->grow_ok, &A->grow, A->m, who);
     mat_device_csr(A);
+    (void)vdev(x); if (addto) (void)vdev(addto);
+    lz_before_write(y, addto != y);
     y->host_dirty = 0;
     DEV(mgk_csr_mult_f64(G, A->m, A->d_rowptr, A->d_col, A->d_val, vdev(x), y->dev, alpha, addto ? vdev(addto) : NULL,
                          A->grow_ok ? A->grow.nx : 0, A->grow_ok ? A->grow.pitch : 0, A->grow_ok ? A->grow.org : 0, NULL));
@@ -853,6 +926,7 @@ static void levelg_apply(Mat A, Vec x, Vec y, double alpha, Vec addto, const cha
     if (x == y) UNSUPPORTED("the level operator applied in place");
     mat_device_levelg(A);
     const double *xd = vdev(x), *ad = addto ? vdev(addto) : NULL;
+    lz_before_write(y, addto != y);
     Vec t = (addto || alpha != 1.0) ? mat_work(A, y) : y;    /* M x first, then the combination (x may be read until the end) */
     if (t == x) UNSUPPORTED("the level operator applied onto its own work vector");
     for (int g = 0; g < A->ng; g++) {
@@ -878,6 +952,27 @@ static void levelg_apply(Mat A, Vec x, Vec y, double alpha, Vec addto, const cha
 PetscErrorCode MatMult(Mat A, Vec x, Vec y) {                       /* src/solver.c:1516,1535,1540 */
     if (!A->assembled) UNSUPPORTED("MatMult on an unassembled matrix");
     if (x == y) UNSUPPORTED("MatMult with x == y");
+    if (A->kind == MAT_RESTRICT && x->lz == LZ_RESIDUAL && x->lz_A->gf.dim == 2 && geom_eq(&x->lz_A->gf, &A->gf) && y->padded == 1 && geom_eq(&y->g, &A->gc) &&
+        y != x->lz_b && y != x->lz_x) {
+        /* b_c = R (b - A u) with the residual not computed yet (src/solver.c:1534-1535): one pass, r stays deferred */
+        struct _p_Mat *Af = x->lz_A;
+        const double *bd = vdev(x->lz_b), *ud = vdev(x->lz_x);
+        lz_before_write(y, 1);
+        y->host_dirty = 0;
+        g_lzstat[0]++;
+        if (Af->kind == MAT_STENCIL) DEV(mgk_residual_restrict_2d_f64(G, &A->gf, &A->gc, Af->coef, bd, ud, y->dev, NULL, 1.0, 1.0, NULL));
+        else { mat_device_rowtabs(Af); DEV(mgk_residual_restrict_2d_rowcoef_f64(G, &A->gf, &A->gc, Af->d_ctab, bd, ud, y->dev, NULL, NULL, 1.0, NULL)); }
+        return 0;
+    }
+    if (A->kind == MAT_PROLONG && lazy_on() && x->padded == 1 && y->padded == 1 && geom_eq(&x->g, &A->gc) && geom_eq(&y->g, &A->gf)) {
+        (void)vdev(x);                                       /* rv = P u_c: deferred (src/solver.c:1540) */
+        lz_before_write(y, 1);
+        y->host_dirty = 0;
+        lz_register(y, LZ_PROLONG, A, NULL, x);
+        return 0;
+    }
+    (void)vdev(x);
+    if (A->kind != MAT_GENERIC && A->kind != MAT_LEVELG) lz_before_write(y, 1);
     y->host_dirty = 0;
     switch (A->kind) {
     case MAT_STENCIL:
@@ -912,33 +1007,66 @@ PetscErrorCode MatMultAdd(Mat A, Vec x, Vec y, Vec z) {            /* z = y + A 
     if (A->kind == MAT_LEVELG) { levelg_apply(A, x, z, 1.0, y, "MatMultAdd"); return 0; }
     if (A->kind == MAT_PROLONG && z == y) {                       /* u_f += P u_c in one pass (MatInterpolateAdd) */
         need_vec(x, 1, &A->gc, A->n, "MatMultAdd"); need_vec(y, 1, &A->gf, A->m, "MatMultAdd");
+        (void)vdev(x); (void)vdev(y);
+        lz_before_write(y, 0);
+        if (lazy_on() && x != y) { lz_register(y, LZ_ADDP, A, NULL, x); return 0; }      /* the smoother that follows fuses it (PCMG) */
         DEV(mgk_prolong_add_f64(G, &A->gf, &A->gc, vdev(x), vdev(y), NULL));
         return 0;
     }
     Vec t = mat_work(A, y);
     MatMult(A, x, t);
+    (void)vdev(t);                                          /* the work vector is not a deferred temporary */
     if (z != y) VecCopy(y, z);
     return VecAXPY(z, 1.0, t);
 }
+static void mat_residual_now(Mat A, Vec b, Vec x, Vec r);
 PetscErrorCode MatResidual(Mat A, Vec b, Vec x, Vec r) {           /* r = b - A x */
+    if ((A->kind == MAT_STENCIL || A->kind == MAT_STENCIL_ROW) && lazy_on() && r != b && r != x && r->padded == 1 && geom_eq(&r->g, &A->gf)) {
+        need_vec(x, 1, &A->gf, A->n, "MatResidual"); need_vec(b, 1, &A->gf, A->m, "MatResidual");
+        (void)vdev(b); (void)vdev(x);                        /* operands concrete */
+        lz_before_write(r, 1);
+        r->host_dirty = 0;
+        lz_register(r, LZ_RESIDUAL, A, b, x);                /* deferred: the restriction that follows forms it on the fly */
+        return 0;
+    }
+    mat_residual_now(A, b, x, r);
+    return 0;
+}
+/* a deferred value is needed after all */
+static void lz_settle(Vec v) {
+    const int kind = v->lz;
+    struct _p_Mat *A = v->lz_A; Vec b = v->lz_b, x = v->lz_x;
+    if (!kind) return;
+    lz_drop(v);
+    g_lzstat[1 + kind]++;
+    if (kind == LZ_RESIDUAL) mat_residual_now(A, b, x, v);
+    else if (kind == LZ_PROLONG) {
+        DEV(mgk_memset0(G, v->dev, sizeof(double) * (size_t)v->nalloc, NULL));      /* v = 0 + P x */
+        DEV(mgk_prolong_add_f64(G, &A->gf, &A->gc, vdev(x), v->dev, NULL));
+    } else if (kind == LZ_ADDP) DEV(mgk_prolong_add_f64(G, &A->gf, &A->gc, vdev(x), v->dev, NULL));
+}
+static void mat_residual_now(Mat A, Vec b, Vec x, Vec r) {
+    (void)vdev(b); (void)vdev(x);
+    lz_before_write(r, r != b && r != x);
     r->host_dirty = 0;
     if (A->kind == MAT_STENCIL) {
         need_vec(x, 1, &A->gf, A->n, "MatResidual");
         DEV(mgk_residual_f64(G, &A->gf, A->coef, vdev(b), vdev(x), r->dev, NULL));
-        return 0;
+        return;
     }
     if (A->kind == MAT_STENCIL_ROW) {
         need_vec(x, 1, &A->gf, A->n, "MatResidual");
         mat_device_rowtabs(A);
         DEV(mgk_rowcoef_f64(G, &A->gf, 1, A->d_ctab, A->d_dtab, 1.0, vdev(b), vdev(x), r->dev, NULL));
-        return 0;
+        return;
     }
-    if (A->kind == MAT_GENERIC) { csr_apply(A, x, r, -1.0, b, "MatResidual"); return 0; }
-    if (A->kind == MAT_LEVELG) { levelg_apply(A, x, r, -1.0, b, "MatResidual"); return 0; }
+    if (A->kind == MAT_GENERIC) { csr_apply(A, x, r, -1.0, b, "MatResidual"); return; }
+    if (A->kind == MAT_LEVELG) { levelg_apply(A, x, r, -1.0, b, "MatResidual"); return; }
     MatMult(A, x, r);
-    return VecAYPX(r, -1.0, b);
+    VecAYPX(r, -1.0, b);
 }
 PetscErrorCode MatScale(Mat A, PetscScalar a) {
+    lz_before_mat_change(A);
     for (long q = 0; q < A->nz; q++) A->val[q] *= a;
     for (int k = 0; k < 7; k++) A->coef[k] *= a;
     for (int g = 0; g < A->ng; g++) {
@@ -967,6 +1095,7 @@ PetscErrorCode MatView(Mat A, PetscViewer v) {
 PetscErrorCode MatDestroy(Mat *pA) {
     if (!pA || !*pA) return 0;
     Mat A = *pA;
+    lz_before_mat_change(A);
     free(A->crow); free(A->ccol); free(A->cval); free(A->rowptr); free(A->col); free(A->val);
     if (G) {
         if (A->d_rowptr) mgk_free(G, A->d_rowptr);
@@ -1218,6 +1347,8 @@ static void mg_cycle(pcmg *mg, int i, Vec b, Vec x) {       /* PCMGMCycle_Privat
     KSPSolve(s, b, x);                                      /* pre-smoothing */
     MatResidual(s->A, b, x, mg->r[i]);
     MatMult(mg->restr[i], mg->r[i], mg->b[i - 1]);          /* MatRestrict */
+    if (mg->r[i]->lz) { g_lzstat[5]++; lz_drop(mg->r[i]); }  /* PCMG's residual work vector (PCMGSetR): consumed by the fused restriction, its
+                                                              * contents after the cycle are unspecified -- not computed when x changes below */
     VecSet(mg->x[i - 1], 0.0);
     mg_cycle(mg, i - 1, mg->b[i - 1], mg->x[i - 1]);
     MatMultAdd(mg->interp[i], mg->x[i - 1], x, x);          /* MatInterpolateAdd */
@@ -1338,6 +1469,7 @@ static PetscErrorCode ksp_solve_direct(KSP k, Vec b, Vec x) {
     if (b->padded == 2 || b == x) UNSUPPORTED("PCLU on a several-grid level operator / in place");
     mat_device_inverse(A);
     const double *bd = vdev(b);
+    lz_before_write(x, 1);
     x->host_dirty = 0;
     if (b->padded) {
         DEV(mgk_unpack_f64(G, &b->g, bd, A->d_c1, NULL));
@@ -1367,7 +1499,19 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
     const int pc = ksp_pc(k);
     const PetscInt maxit = k->maxits;
     k->b = b; k->x = x; k->its = 0;
-    (void)vdev(b); (void)vdev(x);
+    (void)vdev(b);
+    /* the guess is u + P u_c with the correction still deferred (VecAXPY / MatInterpolateAdd just before, src/solver.c:1540-1542):
+     * a Richardson sweep on a stencil operator makes it on the fly (first post-smoothing sweep fused with the prolongation) */
+    struct _p_Mat *addP = NULL; Vec addUc = NULL;
+    if (x->lz == LZ_ADDP && k->guess_nonzero && maxit >= 1 && k->type == K_RICHARDSON && (A->kind == MAT_STENCIL || A->kind == MAT_STENCIL_ROW) &&
+        x->padded == 1 && geom_eq(&x->g, &A->gf) && geom_eq(&x->lz_A->gf, &A->gf) && x->lz_x != b) {
+        addP = x->lz_A; addUc = x->lz_x;
+        (void)vdev(addUc);
+        if (x->host_dirty) vec_upload(x);
+        lz_before_write(x, 1);                               /* consumed here: dropped, not computed */
+        g_lzstat[1]++; g_lzstat[5]--;
+    } else if (!k->guess_nonzero) { lz_before_write(x, 1); (void)vdev(x); }
+    else { (void)vdev(x); lz_before_write(x, 0); }
     /* KSPSolve zero-fills x when the guess flag is off; on the stencil path the first sweep overwrites the
      * whole interior without reading x, so the fill is only issued when no sweep follows or on the AIJ path */
     if (!k->guess_nonzero) {
@@ -1388,6 +1532,7 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
             if (pair_min_n < 0) { const char *e = getenv("MGPETSC_PAIR_MIN_N"); pair_min_n = e ? atoi(e) : 2047; }
             for (PetscInt it = 0; it < maxit; it++) {
                 if (it == 0 && !k->guess_nonzero) DEV(mgk_jacobi_zero_f64(G, &A->gf, dinv, k->scale, b->dev, w->dev, NULL));
+                else if (it == 0 && addP) DEV(mgk_prolong_jacobi_f64(G, &A->gf, &addP->gc, A->coef, dinv, k->scale, b->dev, addUc->dev, x->dev, w->dev, NULL));
                 else if (A->gf.dim == 2 && maxit - it >= 2 && A->gf.nx >= pair_min_n) {
                     DEV(mgk_jacobi2_2d_f64(G, &A->gf, A->coef, dinv, k->scale, b->dev, x->dev, w->dev, NULL));
                     it++;
@@ -1443,6 +1588,7 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
         }
         for (PetscInt it = 0; it < maxit; it++) {
             if (it == 0 && !k->guess_nonzero) DEV(mgk_jacobi_zero_rowcoef_f64(G, &A->gf, dt, k->scale, b->dev, w->dev, NULL));
+            else if (it == 0 && addP) DEV(mgk_prolong_jacobi_rowcoef_f64(G, &A->gf, &addP->gc, A->d_ctab, dt, k->scale, b->dev, addUc->dev, x->dev, w->dev, NULL));
             else DEV(mgk_rowcoef_f64(G, &A->gf, 0, A->d_ctab, dt, k->scale, b->dev, x->dev, w->dev, NULL));
             swap_dev(x, w);
         }

@@ -246,6 +246,40 @@ def test_reference_driver_pcmg_exact_coarse_solve_under_sanitizers(san, tmp_path
     assert "type: lu" in out
 
 
+@pytest.mark.parametrize("mesh,cycle", [(0, 0), (1, 0), (0, 8)])
+def test_lazy_temporaries_of_the_reference_loop(san, tmp_path, mesh, cycle):
+    """KSPBuildResidual -> MatMult(res) and MatMult(pro) -> VecAXPY -> KSPSolve of the reference's loop (src/solver.c:1531-1546) run as the
+    fused residual + restriction and prolongation + sweep kernels; r and rv are never computed (dropped unread), results identical with
+    MGPETSC_LAZY=0 (every call executed at once) and equal to the oracle"""
+    levels, npts = 4, 65
+    lv = ("-mg_levels_ksp_type richardson\n-mg_levels_pc_type jacobi\n-mg_levels_ksp_max_it 3\n-mg_levels_ksp_richardson_scale 0.8\n"
+          "-mg_coarse_ksp_type richardson\n-mg_coarse_pc_type jacobi\n-mg_coarse_ksp_max_it 3\n-mg_coarse_ksp_richardson_scale 0.8\n") if cycle == 8 else ""
+    opts = (f"-npts {npts}\n-mesh {mesh}\n-iter 1000\n-grids {levels}\n-levels {levels}\n-cycle {cycle}\n-map 0\n-v 3,3\n-moreNorm 0\n"
+            + (lv if cycle == 8 else "-pc_type jacobi\n-ksp_richardson_scale 0.8\n"))
+    res = {}
+    for lazy in ("1", "0"):
+        d = tmp_path / lazy
+        d.mkdir()
+        out = _refdrv(san, d, opts, {"MGPETSC_LAZY": lazy, "MGPETSC_LAZY_STATS": "1"})
+        it = int(re.search(r"Number of iterations:\s+(\d+)", out).group(1))
+        m = re.search(r"lazy temporaries: (\d+) residual\+restriction passes, (\d+) prolongation sweeps fused; computed after all: (\d+) residuals, "
+                      r"(\d+) prolongations, (\d+) corrections; (\d+) dropped unread", out)
+        assert m, out[-800:]
+        st = [int(x) for x in m.groups()]
+        if lazy == "1":
+            assert st[0] == it * (levels - 1) and st[1] == it * (levels - 1), st      # every restriction and every first post-sweep fused
+            assert st[3] == 0 and st[4] == 0, st                                      # rv never computed, no correction left over
+            assert st[2] <= it + 1, st                                                # only the residual whose norm closes a cycle
+        else:
+            assert st == [0] * 6
+        res[lazy] = (it, (d / "rData.dat").read_text(), (d / "uData.dat").read_text())
+    assert res["1"] == res["0"]
+    if cycle == 0:
+        ref = Oracle().vcycle(2, npts, levels, 3, 3, maxiter=1000, scale=0.8, use_csr=1 if mesh else 0, mesh=mesh)
+        assert res["1"][0] == ref["iters"]
+        assert np.array_equal(np.array(res["1"][2].split(), dtype=np.float64), ref["u"])
+
+
 def test_reference_driver_pcmg_and_icycle_under_sanitizers(san, tmp_path):
     lv = ("-mg_levels_ksp_type richardson\n-mg_levels_pc_type jacobi\n-mg_levels_ksp_max_it 3\n-mg_levels_ksp_richardson_scale 0.8\n"
           "-mg_coarse_ksp_type richardson\n-mg_coarse_pc_type jacobi\n-mg_coarse_ksp_max_it 3\n-mg_coarse_ksp_richardson_scale 0.8\n")
