@@ -499,8 +499,7 @@ def test_reference_driver_cycle1_several_grids_in_one_level(orc, tmp_path, npts,
 
 def _assemble(L, M):
     m = C.c_void_p()
-    N = M.shape[0]
-    L.MatCreateAIJ(1, N, N, -1, -1, 30, None, 0, None, C.byref(m))
+    L.MatCreateAIJ(1, M.shape[0], M.shape[1], -1, -1, 30, None, 0, None, C.byref(m))
     for r, c in zip(*np.nonzero(M)):
         L.MatSetValue(m, int(r), int(c), float(M[r, c]), ADD)
     L.MatAssemblyBegin(m, FINAL)
@@ -569,4 +568,71 @@ def test_level_operator_of_several_grids_runs_on_the_stencil_and_transfer_kernel
         assert np.max(np.abs(_get(L, z, N) - (bv + ref))) <= tol
         for v in (x, y, z, w):
             L.VecDestroy(C.byref(v))
+        L.MatDestroy(C.byref(m))
+
+
+def test_lazy_temporaries_keep_petsc_semantics(orc):
+    """the deferred residual / prolongation / correction vectors of the drop-in in call orders the reference's loop does
+    NOT use: a deferred vector read later, an operand changed or destroyed before the deferred vector is read, a correction that no sweep
+    follows -- every value must be what call-by-call execution gives"""
+    L = _shim()
+    L.PetscInitialize(None, None, None, None)
+    L.MatResidual.argtypes = [C.c_void_p] * 4
+    L.VecCopy.argtypes = [C.c_void_p] * 2
+    L.VecScale.argtypes = [C.c_void_p, C.c_double]
+    npts = 33
+    A, P, R = _dense(orc, "A", npts, 0), _dense(orc, "P", npts, 0), _dense(orc, "R", npts, 0)
+    mA, mP, mR = _assemble(L, A), _assemble(L, P), _assemble(L, R)
+    nf, nc = A.shape[0], P.shape[1]
+    rng = np.random.default_rng(3)
+    xv, bv, ucv = rng.standard_normal(nf), rng.standard_normal(nf), rng.standard_normal(nc)
+    x, b, r, rv, u = (C.c_void_p() for _ in range(5))
+    uc, bc = C.c_void_p(), C.c_void_p()
+    L.MatCreateVecs(mA, C.byref(x), C.byref(b))
+    for v in (r, rv, u):
+        L.VecDuplicate(x, C.byref(v))
+    L.MatCreateVecs(mR, None, C.byref(bc))
+    L.MatCreateVecs(mP, C.byref(uc), None)
+    tol = 1e-12 * np.abs(A).max() * 10
+    _set(L, x, xv); _set(L, b, bv); _set(L, uc, ucv)
+    # 1. a deferred residual whose operand changes before it is read: the OLD x counts
+    L.MatResidual(mA, b, x, r)
+    L.VecScale(x, 2.0)
+    assert np.max(np.abs(_get(L, r, nf) - (bv - A @ xv))) <= tol
+    assert np.max(np.abs(_get(L, x, nf) - 2.0 * xv)) == 0.0
+    # 2. deferred residual consumed by the restriction AND read afterwards
+    _set(L, x, xv)
+    L.MatResidual(mA, b, x, r)
+    L.MatMult(mR, r, bc)
+    assert np.max(np.abs(_get(L, bc, nc) - R @ (bv - A @ xv))) <= tol
+    assert np.max(np.abs(_get(L, r, nf) - (bv - A @ xv))) <= tol
+    # 3. deferred prolongation + deferred correction, no sweep follows: u and rv read directly
+    _set(L, u, xv)
+    L.MatMult(mP, uc, rv)
+    L.VecAXPY(u, 1.0, rv)
+    assert np.max(np.abs(_get(L, u, nf) - (xv + P @ ucv))) <= 1e-13 * 10
+    assert np.max(np.abs(_get(L, rv, nf) - P @ ucv)) <= 1e-13 * 10
+    # 4. the coarse operand changes between the deferred prolongation, the deferred correction and their use
+    _set(L, u, xv)
+    L.MatMult(mP, uc, rv)
+    L.VecAXPY(u, 1.0, rv)
+    L.VecScale(uc, -3.0)                       # both deferred values were defined with the old u_c
+    assert np.max(np.abs(_get(L, u, nf) - (xv + P @ ucv))) <= 1e-13 * 10
+    assert np.max(np.abs(_get(L, rv, nf) - P @ ucv)) <= 1e-13 * 10
+    # 5. ... or is destroyed
+    _set(L, uc, ucv); _set(L, u, xv)
+    L.MatMult(mP, uc, rv)
+    L.VecAXPY(u, 1.0, rv)
+    L.VecDestroy(C.byref(uc))
+    assert np.max(np.abs(_get(L, u, nf) - (xv + P @ ucv))) <= 1e-13 * 10
+    # 6. a deferred vector that is copied, and one that is overwritten unread
+    L.MatResidual(mA, b, x, r)
+    L.VecCopy(r, rv)
+    assert np.max(np.abs(_get(L, rv, nf) - (bv - A @ xv))) <= tol
+    L.MatResidual(mA, b, x, r)
+    L.VecSet(r, 7.0)
+    assert np.all(_get(L, r, nf) == 7.0)
+    for v in (x, b, r, rv, u, bc):
+        L.VecDestroy(C.byref(v))
+    for m in (mA, mP, mR):
         L.MatDestroy(C.byref(m))
