@@ -28,7 +28,7 @@
 /* ------------------------------------------------------------------ */
 static mgk_ctx *G = NULL;
 static int g_notice_pc = 0;
-static long g_lzstat[6];     /* lazy temporaries: [0] residual+restriction fused, [1] prolongation fused into a sweep, [2..4] deferred values that were
+static long g_lzstat[8];     /* lazy temporaries: [0] residual+restriction fused, [1] prolongation fused into a sweep, [2..4] deferred values that were
                               * computed after all (residual, prolongation, correction), [5] deferred values overwritten unread */
 
 static void die(const char *what) {
@@ -104,7 +104,8 @@ PetscErrorCode PetscInitialize(int *argc, char ***argv, const char file[], const
 PetscErrorCode PetscFinalize(void) {
     if (getenv("MGPETSC_LAZY_STATS"))
         printf("[mgpetsc] lazy temporaries: %ld residual+restriction passes, %ld prolongation sweeps fused; computed after all: %ld residuals, "
-               "%ld prolongations, %ld corrections; %ld dropped unread\n", g_lzstat[0], g_lzstat[1], g_lzstat[2], g_lzstat[3], g_lzstat[4], g_lzstat[5]);
+               "%ld prolongations, %ld corrections; %ld dropped unread; %ld zero-guess sweeps out of the restriction's pass\n",
+               g_lzstat[0], g_lzstat[1], g_lzstat[2], g_lzstat[3], g_lzstat[4], g_lzstat[5], g_lzstat[7]);
     if (G) { mgk_ctx_destroy(G); G = NULL; }
     for (int q = 0; q < g_nopt; q++) { free(g_opt[q].key); free(g_opt[q].val); }
     free(g_opt); g_opt = NULL; g_nopt = g_capopt = 0;
@@ -206,7 +207,7 @@ struct _p_Vec {
     mgk_geom g;
     int ng; mgk_geom gg[MGP_MAXG]; long goff[MGP_MAXG + 1];
     int lz;                 /* a value that has not been computed yet (lazy temporaries, below): LZ_* */
-    struct _p_Mat *lz_A; struct _p_Vec *lz_b, *lz_x;
+    struct _p_Mat *lz_A, *lz_A2; struct _p_Vec *lz_b, *lz_x;
     long nalloc;            /* doubles on the device */
     double *dev;
     double *host;           /* compact lexicographic mirror (VecSetValue staging / VecGetArray) */
@@ -281,21 +282,23 @@ static void vec_download(Vec v) {        /* device -> host mirror */
  *   LZ_RESIDUAL  v = b - A x            (MatResidual / KSPBuildResidual on a stencil operator)
  *   LZ_PROLONG   v = P u_c              (MatMult with a recognised prolongation)
  *   LZ_ADDP      v = v + P u_c          (VecAXPY(v, 1.0, rv) with rv = LZ_PROLONG; the device still holds the old v)
+ *   LZ_RR        v = R (b - A x)        (MatMult(restriction, r) of an LZ_RESIDUAL r: the Richardson KSPSolve from the zero guess that
+ *                                        follows on the coarse level gets its first sweep out of the same pass, mgk_residual_restrict_2d's uc0)
  * and three consumers take them as they are: MatMult(restriction, r) of an LZ_RESIDUAL r runs the fused residual + restriction,
  * VecAXPY(u, 1, rv) of an LZ_PROLONG rv makes u LZ_ADDP, KSPSolve from the guess u of an LZ_ADDP u makes its first sweep with the
  * fused prolongation.  PETSc's semantics are kept for every other use: ANY read of a deferred vector computes it first (vdev ->
  * lz_settle), ANY write to a vector first computes the deferred vectors that depend on it (lz_before_write), destroying an operand
  * likewise.  A deferred vector that is overwritten before anyone reads it is never computed -- which is what happens to r and rv in
  * the reference's loop.  MGPETSC_LAZY=0 switches the whole mechanism off (every call executes at once, as before). */
-enum { LZ_NONE = 0, LZ_RESIDUAL = 1, LZ_PROLONG = 2, LZ_ADDP = 3 };
+enum { LZ_NONE = 0, LZ_RESIDUAL = 1, LZ_PROLONG = 2, LZ_ADDP = 3, LZ_RR = 4 };
 #define LZ_MAX 64
 static Vec g_lz[LZ_MAX];
 static int g_nlz = 0, g_lazy = -1;
-static int lazy_on(void) { if (g_lazy < 0) { const char *e = getenv("MGPETSC_LAZY"); g_lazy = !(e && e[0] == '0'); } return g_lazy; }
+static int lazy_on(void) { if (g_lazy < 0) { const char *e = getenv("MGPETSC_LAZY"); g_lazy = (e && e[0] >= '0' && e[0] <= '9') ? atoi(e) : 1; } return g_lazy; }   /* 2: b_c not deferred (measurement aid) */
 static void lz_settle(Vec v);
 static void lz_drop(Vec v) {                       /* forget v's deferred value (it is being overwritten / has been consumed) */
     if (!v->lz) return;
-    v->lz = LZ_NONE; v->lz_A = NULL; v->lz_b = v->lz_x = NULL;
+    v->lz = LZ_NONE; v->lz_A = v->lz_A2 = NULL; v->lz_b = v->lz_x = NULL;
     for (int q = 0; q < g_nlz; q++) if (g_lz[q] == v) { g_lz[q] = g_lz[--g_nlz]; break; }
 }
 static void lz_register(Vec v, int kind, struct _p_Mat *A, Vec b, Vec x) {
@@ -313,7 +316,7 @@ static void lz_before_write(Vec v, int full) {
     if (v->lz) { if (full) { g_lzstat[5]++; lz_drop(v); } else lz_settle(v); }
 }
 static void lz_before_mat_change(struct _p_Mat *A) {
-    for (int q = 0; q < g_nlz; ) { if (g_lz[q]->lz_A == A) { lz_settle(g_lz[q]); q = 0; } else q++; }
+    for (int q = 0; q < g_nlz; ) { if (g_lz[q]->lz_A == A || g_lz[q]->lz_A2 == A) { lz_settle(g_lz[q]); q = 0; } else q++; }
 }
 static double *vdev(Vec v) { if (v->lz) lz_settle(v); if (v->host_dirty) vec_upload(v); return v->dev; }
 static int same_layout(Vec a, Vec b) {
@@ -915,6 +918,7 @@ static void csr_apply(Mat A, Vec x, Vec y, double alpha, Vec addto, const char *
 /* the same on the recognised level operator of several grids: with s_0 = A_0 x_0, s_g = R s_(g-1) + A_g x_g the lower triangle and
  * the diagonal are one cascade down the grids; then every upper block adds its window sums.  Vectors in the composite layout */
 static Vec mat_work(Mat A, Vec like);
+static void rr_now(Mat Af, Mat Rm, Vec bf, Vec uf, Vec bc, double *uc0, double dinv_c, double scale_c, const double *dtab_c);
 static void need_vecg(Mat A, Vec v, const char *who) {
     if (!(v->padded == 2 && v->ng == A->ng && geom_eq(&v->gg[0], &A->gg[0]))) {
         fprintf(stderr, "[mgpetsc] FATAL: %s: vector does not match the operator's layout (create it with MatCreateVecs/VecDuplicate)\n", who); exit(88);
@@ -955,13 +959,15 @@ PetscErrorCode MatMult(Mat A, Vec x, Vec y) {                       /* src/solve
     if (A->kind == MAT_RESTRICT && x->lz == LZ_RESIDUAL && x->lz_A->gf.dim == 2 && geom_eq(&x->lz_A->gf, &A->gf) && y->padded == 1 && geom_eq(&y->g, &A->gc) &&
         y != x->lz_b && y != x->lz_x) {
         /* b_c = R (b - A u) with the residual not computed yet (src/solver.c:1534-1535): one pass, r stays deferred */
+        /* ... and b_c is deferred in turn: the coarse KSPSolve from the zero guess takes its first sweep out of the same pass */
         struct _p_Mat *Af = x->lz_A;
-        const double *bd = vdev(x->lz_b), *ud = vdev(x->lz_x);
+        Vec bf = x->lz_b, uf = x->lz_x;
+        (void)vdev(bf); (void)vdev(uf);
         lz_before_write(y, 1);
         y->host_dirty = 0;
-        g_lzstat[0]++;
-        if (Af->kind == MAT_STENCIL) DEV(mgk_residual_restrict_2d_f64(G, &A->gf, &A->gc, Af->coef, bd, ud, y->dev, NULL, 1.0, 1.0, NULL));
-        else { mat_device_rowtabs(Af); DEV(mgk_residual_restrict_2d_rowcoef_f64(G, &A->gf, &A->gc, Af->d_ctab, bd, ud, y->dev, NULL, NULL, 1.0, NULL)); }
+        if (lazy_on() == 2) { rr_now(Af, A, bf, uf, y, NULL, 1.0, 1.0, NULL); return 0; }
+        lz_register(y, LZ_RR, Af, bf, uf);
+        y->lz_A2 = A;
         return 0;
     }
     if (A->kind == MAT_PROLONG && lazy_on() && x->padded == 1 && y->padded == 1 && geom_eq(&x->g, &A->gc) && geom_eq(&y->g, &A->gf)) {
@@ -1032,12 +1038,21 @@ PetscErrorCode MatResidual(Mat A, Vec b, Vec x, Vec r) {           /* r = b - A 
     mat_residual_now(A, b, x, r);
     return 0;
 }
+/* b_c = R (b - A u) in one pass, optionally with the coarse level's first sweep from its zero guess (uc0 = scale_c * (b_c * dinv_c)) */
+static void rr_now(Mat Af, Mat Rm, Vec bf, Vec uf, Vec bc, double *uc0, double dinv_c, double scale_c, const double *dtab_c) {
+    const double *bd = vdev(bf), *ud = vdev(uf);
+    g_lzstat[0]++;
+    if (Af->kind == MAT_STENCIL) DEV(mgk_residual_restrict_2d_f64(G, &Rm->gf, &Rm->gc, Af->coef, bd, ud, bc->dev, uc0, dinv_c, scale_c, NULL));
+    else { mat_device_rowtabs(Af); DEV(mgk_residual_restrict_2d_rowcoef_f64(G, &Rm->gf, &Rm->gc, Af->d_ctab, bd, ud, bc->dev, uc0, dtab_c, scale_c, NULL)); }
+}
 /* a deferred value is needed after all */
 static void lz_settle(Vec v) {
     const int kind = v->lz;
     struct _p_Mat *A = v->lz_A; Vec b = v->lz_b, x = v->lz_x;
+    struct _p_Mat *A2 = v->lz_A2;
     if (!kind) return;
     lz_drop(v);
+    if (kind == LZ_RR) { rr_now(A, A2, b, x, v, NULL, 1.0, 1.0, NULL); return; }
     g_lzstat[1 + kind]++;
     if (kind == LZ_RESIDUAL) mat_residual_now(A, b, x, v);
     else if (kind == LZ_PROLONG) {
@@ -1499,6 +1514,18 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
     const int pc = ksp_pc(k);
     const PetscInt maxit = k->maxits;
     k->b = b; k->x = x; k->its = 0;
+    /* the right-hand side is R (b_f - A_f u_f), still deferred (MatMult(res) just before, src/solver.c:1535-1536), and the solve starts
+     * from the zero guess: restriction and first sweep in one pass */
+    struct _p_Mat *rrA = NULL, *rrR = NULL; Vec rrb = NULL, rru = NULL;
+    if (b->lz == LZ_RR && !k->guess_nonzero && maxit >= 1 && k->type == K_RICHARDSON && (A->kind == MAT_STENCIL || A->kind == MAT_STENCIL_ROW) &&
+        b->lz_A->kind == A->kind && b->padded == 1 && x->padded == 1 && geom_eq(&b->g, &A->gf) && geom_eq(&x->g, &A->gf) && x != b &&
+        x != b->lz_b && x != b->lz_x) {
+        rrA = b->lz_A; rrR = b->lz_A2; rrb = b->lz_b; rru = b->lz_x;
+        (void)vdev(rrb); (void)vdev(rru);
+        lz_before_write(b, 1);                               /* consumed below: b_c is written by the fused pass */
+        g_lzstat[5]--;
+        b->host_dirty = 0;
+    }
     (void)vdev(b);
     /* the guess is u + P u_c with the correction still deferred (VecAXPY / MatInterpolateAdd just before, src/solver.c:1540-1542):
      * a Richardson sweep on a stencil operator makes it on the fly (first post-smoothing sweep fused with the prolongation) */
@@ -1531,7 +1558,8 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
             static int pair_min_n = -1;
             if (pair_min_n < 0) { const char *e = getenv("MGPETSC_PAIR_MIN_N"); pair_min_n = e ? atoi(e) : 2047; }
             for (PetscInt it = 0; it < maxit; it++) {
-                if (it == 0 && !k->guess_nonzero) DEV(mgk_jacobi_zero_f64(G, &A->gf, dinv, k->scale, b->dev, w->dev, NULL));
+                if (it == 0 && rrA) { rr_now(rrA, rrR, rrb, rru, b, w->dev, dinv, k->scale, NULL); g_lzstat[7]++; }
+                else if (it == 0 && !k->guess_nonzero) DEV(mgk_jacobi_zero_f64(G, &A->gf, dinv, k->scale, b->dev, w->dev, NULL));
                 else if (it == 0 && addP) DEV(mgk_prolong_jacobi_f64(G, &A->gf, &addP->gc, A->coef, dinv, k->scale, b->dev, addUc->dev, x->dev, w->dev, NULL));
                 else if (A->gf.dim == 2 && maxit - it >= 2 && A->gf.nx >= pair_min_n) {
                     DEV(mgk_jacobi2_2d_f64(G, &A->gf, A->coef, dinv, k->scale, b->dev, x->dev, w->dev, NULL));
@@ -1587,7 +1615,8 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
             return 0;
         }
         for (PetscInt it = 0; it < maxit; it++) {
-            if (it == 0 && !k->guess_nonzero) DEV(mgk_jacobi_zero_rowcoef_f64(G, &A->gf, dt, k->scale, b->dev, w->dev, NULL));
+            if (it == 0 && rrA) { rr_now(rrA, rrR, rrb, rru, b, w->dev, 1.0, k->scale, dt); g_lzstat[7]++; }
+            else if (it == 0 && !k->guess_nonzero) DEV(mgk_jacobi_zero_rowcoef_f64(G, &A->gf, dt, k->scale, b->dev, w->dev, NULL));
             else if (it == 0 && addP) DEV(mgk_prolong_jacobi_rowcoef_f64(G, &A->gf, &addP->gc, A->d_ctab, dt, k->scale, b->dev, addUc->dev, x->dev, w->dev, NULL));
             else DEV(mgk_rowcoef_f64(G, &A->gf, 0, A->d_ctab, dt, k->scale, b->dev, x->dev, w->dev, NULL));
             swap_dev(x, w);

@@ -263,15 +263,17 @@ def test_lazy_temporaries_of_the_reference_loop(san, tmp_path, mesh, cycle):
         out = _refdrv(san, d, opts, {"MGPETSC_LAZY": lazy, "MGPETSC_LAZY_STATS": "1"})
         it = int(re.search(r"Number of iterations:\s+(\d+)", out).group(1))
         m = re.search(r"lazy temporaries: (\d+) residual\+restriction passes, (\d+) prolongation sweeps fused; computed after all: (\d+) residuals, "
-                      r"(\d+) prolongations, (\d+) corrections; (\d+) dropped unread", out)
+                      r"(\d+) prolongations, (\d+) corrections; (\d+) dropped unread; (\d+) zero-guess sweeps out of the restriction's pass", out)
         assert m, out[-800:]
         st = [int(x) for x in m.groups()]
         if lazy == "1":
             assert st[0] == it * (levels - 1) and st[1] == it * (levels - 1), st      # every restriction and every first post-sweep fused
             assert st[3] == 0 and st[4] == 0, st                                      # rv never computed, no correction left over
             assert st[2] <= it + 1, st                                                # only the residual whose norm closes a cycle
+            if cycle == 0:
+                assert st[6] == it * (levels - 1), st                                 # every coarse pre-smoothing starts inside the restriction's pass
         else:
-            assert st == [0] * 6
+            assert st == [0] * 7
         res[lazy] = (it, (d / "rData.dat").read_text(), (d / "uData.dat").read_text())
     assert res["1"] == res["0"]
     if cycle == 0:
