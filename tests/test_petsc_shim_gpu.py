@@ -606,6 +606,14 @@ def test_lazy_temporaries_keep_petsc_semantics(orc):
     L.MatMult(mR, r, bc)
     assert np.max(np.abs(_get(L, bc, nc) - R @ (bv - A @ xv))) <= tol
     assert np.max(np.abs(_get(L, r, nf) - (bv - A @ xv))) <= tol
+    # 2b. the restricted right-hand side is deferred as well: its fine-level operands change before it is read
+    L.MatResidual(mA, b, x, r)
+    L.MatMult(mR, r, bc)
+    L.VecScale(x, 2.0)
+    L.VecSet(b, 0.0)
+    assert np.max(np.abs(_get(L, bc, nc) - R @ (bv - A @ xv))) <= tol
+    assert np.max(np.abs(_get(L, r, nf) - (bv - A @ xv))) <= tol
+    _set(L, x, xv); _set(L, b, bv)
     # 3. deferred prolongation + deferred correction, no sweep follows: u and rv read directly
     _set(L, u, xv)
     L.MatMult(mP, uc, rv)
