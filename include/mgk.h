@@ -222,6 +222,11 @@ int  mgk_apply_add_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, cons
 int  mgk_window_add_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, int stride, const double *wtab_dev,
                         const double *xc, double *yf, void *stream);
 
+/* KSPBuildResidual + VecNorm + the first sweep of the KSPSolve that follows (src/solver.c:1545-1546,1531) in one pass over u and b (2-D):
+ * r = b - A u (stored), *sumsq_host = sum r^2, unew = u + scale*(r*dinv).  coef or (ctab, dtab: row tables, then dinv is ignored). */
+int  mgk_jacobi_sumsq_store_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale, const double *ctab, const double *dtab,
+                                const double *b, const double *u, double *unew, double *r, double *sumsq_host, void *stream);
+
 /* y = B x, B dense row-major m x n on the device: the exact coarse-grid solve of PCMG (PCLU is PETSc's default coarse solver,
  * src/solver.c:1931-1932), B = A^-1 of the coarsest grid inverted once on the host; x, y compact (unpadded) device arrays */
 int  mgk_dense_mult_f64(mgk_ctx *ctx, int m, int n, const double *B_dev, const double *x, double *y, void *stream);

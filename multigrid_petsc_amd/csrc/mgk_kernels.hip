@@ -388,6 +388,7 @@ struct StArgs {
     long crs, cms;
     int nxc, nyc, nzc;
     T *out;
+    T *out2;               // MODE_JNORM, optional: the residual b - A u of the INPUT field is stored as well (the drop-in's VecNorm pass)
     float *out32;          // MODE_RES32 / MODE_CRES32: float copy of the fp64 residual (own strides below)
     float *jz32;           // optional: the fp32 cycle's first sweep from its zero guess, scale32 * (r32 * dinv32), same strides
     float dinv32, scale32;
@@ -809,6 +810,7 @@ __global__ void __launch_bounds__(64 * WX * WY) k_stencil(const StArgs<T> a) {
                     if (MODE == MODE_CRES32) stv_stream(a.out + rowoff + x0 + (long)z * a.ms + (long)r * a.rs, uc[r]);   // the corrected u
                 } else if (MODE != MODE_RESNORM) {
                     stv_stream(a.out + rowoff + x0 + (long)z * a.ms + (long)r * a.rs, o);
+                    if (MODE == MODE_JNORM) { if (a.out2) stv_stream(a.out2 + rowoff + x0 + (long)z * a.ms + (long)r * a.rs, rsq); }
                 }
             }
         }
@@ -1102,6 +1104,23 @@ extern "C" int mgk_jacobi_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const double 
     int nblk = 0;
     int rc = jrow_ok<double>(g) ? launch_jrow<double, true>(c, g, a, 0, g->nz, S(c, stream), c->partials, c->max_partials, &nblk)
                                 : dispatch_st<MODE_JNORM>(c, g, a, S(c, stream), &nblk);
+    if (rc) return rc;
+    return finish_to_host(c, nblk, 1, S(c, stream), sumsq_host);
+}
+
+// The drop-in's pass for KSPBuildResidual + VecNorm + the first sweep of the KSPSolve that follows (src/solver.c:1545-1546,1531): one read of
+// u and b yields r = b - A u (stored), sum r^2, and unew = u + scale*(r*dinv) -- 32 B per unknown instead of 24 + 8 + 24.  2-D (the PETSc
+// surface is 2-D), constant coefficients or row tables.
+extern "C" int mgk_jacobi_sumsq_store_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale, const double *ctab, const double *dtab,
+                                          const double *b, const double *u, double *unew, double *r, double *sumsq_host, void *stream) {
+    if (!c || !g || g->dim != 2 || (!coef && !ctab) || (ctab && !dtab) || !b || !u || !unew || !r || u == unew || u == r || b == r || r == unew || b == unew || !sumsq_host)
+        return fail(MGK_EINVAL, "mgk_jacobi_sumsq_store_f64: bad arguments (2-D)");
+    StArgs<double> a; memset(&a, 0, sizeof(a));
+    a.u = u + g->org; a.b = b + g->org; a.out = unew + g->org; a.out2 = r + g->org; a.partials = c->partials;
+    if (coef) set_coef(a, g, coef);
+    a.dinv = ctab ? 1.0 : dinv; a.scale = scale; a.ctab = ctab; a.dtab = dtab;
+    int nblk = 0;
+    int rc = dispatch_st<MODE_JNORM>(c, g, a, S(c, stream), &nblk);
     if (rc) return rc;
     return finish_to_host(c, nblk, 1, S(c, stream), sumsq_host);
 }

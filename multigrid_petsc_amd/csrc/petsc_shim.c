@@ -104,8 +104,8 @@ PetscErrorCode PetscInitialize(int *argc, char ***argv, const char file[], const
 PetscErrorCode PetscFinalize(void) {
     if (getenv("MGPETSC_LAZY_STATS"))
         printf("[mgpetsc] lazy temporaries: %ld residual+restriction passes, %ld prolongation sweeps fused; computed after all: %ld residuals, "
-               "%ld prolongations, %ld corrections; %ld dropped unread; %ld zero-guess sweeps out of the restriction's pass\n",
-               g_lzstat[0], g_lzstat[1], g_lzstat[2], g_lzstat[3], g_lzstat[4], g_lzstat[5], g_lzstat[7]);
+               "%ld prolongations, %ld corrections; %ld dropped unread; %ld zero-guess sweeps out of the restriction's pass; %ld norm passes that store r and make the next sweep\n",
+               g_lzstat[0], g_lzstat[1], g_lzstat[2], g_lzstat[3], g_lzstat[4], g_lzstat[5], g_lzstat[7], g_lzstat[6]);
     if (G) { mgk_ctx_destroy(G); G = NULL; }
     for (int q = 0; q < g_nopt; q++) { free(g_opt[q].key); free(g_opt[q].val); }
     free(g_opt); g_opt = NULL; g_nopt = g_capopt = 0;
@@ -208,6 +208,8 @@ struct _p_Vec {
     int ng; mgk_geom gg[MGP_MAXG]; long goff[MGP_MAXG + 1];
     int lz;                 /* a value that has not been computed yet (lazy temporaries, below): LZ_* */
     struct _p_Mat *lz_A, *lz_A2; struct _p_Vec *lz_b, *lz_x;
+    struct _p_KSP *lz_ksp;  /* LZ_RESIDUAL made by KSPBuildResidual: the solver whose next sweep the norm pass can make (below) */
+    unsigned long ver;      /* bumped by every write to the vector's value */
     long nalloc;            /* doubles on the device */
     double *dev;
     double *host;           /* compact lexicographic mirror (VecSetValue staging / VecGetArray) */
@@ -294,11 +296,12 @@ enum { LZ_NONE = 0, LZ_RESIDUAL = 1, LZ_PROLONG = 2, LZ_ADDP = 3, LZ_RR = 4 };
 #define LZ_MAX 64
 static Vec g_lz[LZ_MAX];
 static int g_nlz = 0, g_lazy = -1;
+static unsigned long g_mat_epoch = 0;      /* bumped when any matrix changes or dies: speculative sweeps made before are void */
 static int lazy_on(void) { if (g_lazy < 0) { const char *e = getenv("MGPETSC_LAZY"); g_lazy = (e && e[0] >= '0' && e[0] <= '9') ? atoi(e) : 1; } return g_lazy; }   /* 2: b_c not deferred (measurement aid) */
 static void lz_settle(Vec v);
 static void lz_drop(Vec v) {                       /* forget v's deferred value (it is being overwritten / has been consumed) */
     if (!v->lz) return;
-    v->lz = LZ_NONE; v->lz_A = v->lz_A2 = NULL; v->lz_b = v->lz_x = NULL;
+    v->lz = LZ_NONE; v->lz_A = v->lz_A2 = NULL; v->lz_b = v->lz_x = NULL; v->lz_ksp = NULL;
     for (int q = 0; q < g_nlz; q++) if (g_lz[q] == v) { g_lz[q] = g_lz[--g_nlz]; break; }
 }
 static void lz_register(Vec v, int kind, struct _p_Mat *A, Vec b, Vec x) {
@@ -314,8 +317,10 @@ static void lz_before_write(Vec v, int full) {
         if (L != v && (L->lz_b == v || L->lz_x == v)) { lz_settle(L); q = 0; } else q++;
     }
     if (v->lz) { if (full) { g_lzstat[5]++; lz_drop(v); } else lz_settle(v); }
+    v->ver++;
 }
 static void lz_before_mat_change(struct _p_Mat *A) {
+    g_mat_epoch++;
     for (int q = 0; q < g_nlz; ) { if (g_lz[q]->lz_A == A || g_lz[q]->lz_A2 == A) { lz_settle(g_lz[q]); q = 0; } else q++; }
 }
 static double *vdev(Vec v) { if (v->lz) lz_settle(v); if (v->host_dirty) vec_upload(v); return v->dev; }
@@ -402,6 +407,7 @@ PetscErrorCode VecAXPBYPCZ(Vec z, PetscScalar a, PetscScalar b, PetscScalar c, V
     DEV(mgk_flat_axpbypcz(G, z->nalloc, a, b, c, vdev(x), vdev(y), vdev(z), NULL));
     return 0;
 }
+static int norm_of_deferred_residual(Vec r, double *ss);
 PetscErrorCode VecDot(Vec x, Vec y, PetscScalar *val) {
     need_same(x, y, "VecDot");
     DEV(mgk_flat_dot(G, x->nalloc, vdev(x), vdev(y), val, NULL));
@@ -411,6 +417,7 @@ PetscErrorCode VecTDot(Vec x, Vec y, PetscScalar *val) { return VecDot(x, y, val
 PetscErrorCode VecNorm(Vec x, NormType type, PetscReal *val) {     /* src/solver.c:1512,1518,1546 */
     if (type != NORM_2 && type != NORM_FROBENIUS) UNSUPPORTED("VecNorm with a norm other than NORM_2");
     double ss;
+    if (x->lz == LZ_RESIDUAL && x->lz_ksp && norm_of_deferred_residual(x, &ss)) { *val = sqrt(ss); return 0; }
     DEV(mgk_flat_dot(G, x->nalloc, vdev(x), vdev(x), &ss, NULL));
     *val = sqrt(ss);
     return 0;
@@ -1160,6 +1167,7 @@ struct _p_KSP {
     double rtol, atol, dtol;    /* used only by the outer Richardson of -cycle 8 (norm type != NONE) */
     PetscReal *hist; PetscInt nhist;
     int type_from_user;
+    int spec_ok; Vec spec_b, spec_x; unsigned long spec_vb, spec_vx, spec_epoch;   /* work[0] holds J(spec_x) made by the norm pass (below) */
     struct _p_PC pcobj;
 };
 
@@ -1188,7 +1196,7 @@ static int pc_type_from(const char *t) {
     exit(87);
 }
 PetscErrorCode KSPSetType(KSP k, KSPType t) { k->type = ksp_type_from(t); k->type_from_user = 1; return 0; }
-PetscErrorCode KSPSetOperators(KSP k, Mat A, Mat P) { (void)P; k->A = A; return 0; }
+PetscErrorCode KSPSetOperators(KSP k, Mat A, Mat P) { (void)P; k->A = A; k->spec_ok = 0; return 0; }
 PetscErrorCode KSPSetNormType(KSP k, KSPNormType n) { k->normtype = n; return 0; }
 PetscErrorCode KSPSetTolerances(KSP k, PetscReal rtol, PetscReal atol, PetscReal dtol, PetscInt maxits) {
     /* KSP_NORM_NONE (the smoothers): only max_it matters (src/solver.c:1473-1474); the tolerances are kept for the
@@ -1514,6 +1522,11 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
     const int pc = ksp_pc(k);
     const PetscInt maxit = k->maxits;
     k->b = b; k->x = x; k->its = 0;
+    /* the first sweep was made by the pass that evaluated the last residual norm (norm_of_deferred_residual) and nothing has touched b or x since */
+    const int spec = k->spec_ok && k->guess_nonzero && maxit >= 1 && k->type == K_RICHARDSON && k->spec_b == b && k->spec_x == x &&
+                     b->ver == k->spec_vb && x->ver == k->spec_vx && k->spec_epoch == g_mat_epoch && !x->lz && !b->lz && !x->host_dirty && !b->host_dirty &&
+                     (A->kind == MAT_STENCIL || A->kind == MAT_STENCIL_ROW);
+    k->spec_ok = 0;
     /* the right-hand side is R (b_f - A_f u_f), still deferred (MatMult(res) just before, src/solver.c:1535-1536), and the solve starts
      * from the zero guess: restriction and first sweep in one pass */
     struct _p_Mat *rrA = NULL, *rrR = NULL; Vec rrb = NULL, rru = NULL;
@@ -1558,7 +1571,8 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
             static int pair_min_n = -1;
             if (pair_min_n < 0) { const char *e = getenv("MGPETSC_PAIR_MIN_N"); pair_min_n = e ? atoi(e) : 2047; }
             for (PetscInt it = 0; it < maxit; it++) {
-                if (it == 0 && rrA) { rr_now(rrA, rrR, rrb, rru, b, w->dev, dinv, k->scale, NULL); g_lzstat[7]++; }
+                if (it == 0 && spec) { /* w = J(x) already */ }
+                else if (it == 0 && rrA) { rr_now(rrA, rrR, rrb, rru, b, w->dev, dinv, k->scale, NULL); g_lzstat[7]++; }
                 else if (it == 0 && !k->guess_nonzero) DEV(mgk_jacobi_zero_f64(G, &A->gf, dinv, k->scale, b->dev, w->dev, NULL));
                 else if (it == 0 && addP) DEV(mgk_prolong_jacobi_f64(G, &A->gf, &addP->gc, A->coef, dinv, k->scale, b->dev, addUc->dev, x->dev, w->dev, NULL));
                 else if (A->gf.dim == 2 && maxit - it >= 2 && A->gf.nx >= pair_min_n) {
@@ -1615,7 +1629,8 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
             return 0;
         }
         for (PetscInt it = 0; it < maxit; it++) {
-            if (it == 0 && rrA) { rr_now(rrA, rrR, rrb, rru, b, w->dev, 1.0, k->scale, dt); g_lzstat[7]++; }
+            if (it == 0 && spec) { /* w = J(x) already */ }
+            else if (it == 0 && rrA) { rr_now(rrA, rrR, rrb, rru, b, w->dev, 1.0, k->scale, dt); g_lzstat[7]++; }
             else if (it == 0 && !k->guess_nonzero) DEV(mgk_jacobi_zero_rowcoef_f64(G, &A->gf, dt, k->scale, b->dev, w->dev, NULL));
             else if (it == 0 && addP) DEV(mgk_prolong_jacobi_rowcoef_f64(G, &A->gf, &addP->gc, A->d_ctab, dt, k->scale, b->dev, addUc->dev, x->dev, w->dev, NULL));
             else DEV(mgk_rowcoef_f64(G, &A->gf, 0, A->d_ctab, dt, k->scale, b->dev, x->dev, w->dev, NULL));
@@ -1649,8 +1664,36 @@ PetscErrorCode KSPBuildResidual(KSP k, Vec t, Vec v, Vec *V) {
     if (!k->b || !k->x) UNSUPPORTED("KSPBuildResidual before KSPSolve");
     if (!v) UNSUPPORTED("KSPBuildResidual with v == NULL");
     MatResidual(k->A, k->b, k->x, v);
+    if (v->lz == LZ_RESIDUAL) v->lz_ksp = k;
     if (V) *V = v;
     return 0;
+}
+/* VecNorm of a residual that KSPBuildResidual deferred (src/solver.c:1545-1546), when the solver that built it is a Richardson smoother
+ * with a nonzero guess -- the reference's ksp[0], whose KSPSolve opens the next cycle (:1531) on the same u and b: ONE pass over u and b
+ * stores r, reduces sum r^2 and makes that solve's first sweep into the solver's work vector (mgk_jacobi_sumsq_store_f64; 32 B per
+ * unknown instead of 24 + 8 + 24).  KSPSolve adopts the sweep if b and u are the same vectors and have not been written since (version
+ * counters), otherwise it is ignored; r is a concrete vector afterwards. */
+static int norm_of_deferred_residual(Vec r, double *ss) {
+    KSP k = r->lz_ksp;
+    Mat A = r->lz_A;
+    Vec b = r->lz_b, u = r->lz_x;
+    if (lazy_on() != 1 || k->A != A || k->type != K_RICHARDSON || !k->guess_nonzero || k->maxits < 1 || k->pc == P_MG || k->pc == P_LU ||
+        k->normtype == KSP_NORM_UNPRECONDITIONED || (A->kind != MAT_STENCIL && A->kind != MAT_STENCIL_ROW) || A->gf.dim != 2) return 0;
+    const int pc = ksp_pc(k);
+    Vec w = ksp_work(k, 0, u);
+    (void)vdev(b); (void)vdev(u);
+    lz_before_write(r, 1);                                   /* r is computed by the pass below */
+    g_lzstat[5]--;
+    r->host_dirty = 0;
+    if (A->kind == MAT_STENCIL)
+        DEV(mgk_jacobi_sumsq_store_f64(G, &A->gf, A->coef, (pc == P_JACOBI) ? 1.0 / A->coef[2] : 1.0, k->scale, NULL, NULL, b->dev, u->dev, w->dev, r->dev, ss, NULL));
+    else {
+        mat_device_rowtabs(A);
+        DEV(mgk_jacobi_sumsq_store_f64(G, &A->gf, NULL, 1.0, k->scale, A->d_ctab, (pc == P_JACOBI) ? A->d_dtab : A->d_ones, b->dev, u->dev, w->dev, r->dev, ss, NULL));
+    }
+    k->spec_ok = 1; k->spec_b = b; k->spec_x = u; k->spec_vb = b->ver; k->spec_vx = u->ver; k->spec_epoch = g_mat_epoch;
+    g_lzstat[6]++;
+    return 1;
 }
 PetscErrorCode KSPView(KSP k, PetscViewer viewer) {               /* src/solver.c:1562 */
     (void)viewer;

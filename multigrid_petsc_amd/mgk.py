@@ -52,6 +52,10 @@ def _sigs(L):
         "mgk_jacobi2_2d_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp, vp]),
         "mgk_jacobi2_2d_rowcoef_f64": (i, [vp, G, vp, vp, d, vp, vp, vp, vp]),
         "mgk_jacobi_sumsq_rowcoef_f64": (i, [vp, G, vp, vp, d, vp, vp, vp, C.POINTER(d), vp]),
+        "mgk_jacobi_sumsq_store_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp, vp, vp, vp, C.POINTER(d), vp]),
+        "mgk_apply_add_f64": (i, [vp, G, c_dp, vp, vp, vp]),
+        "mgk_window_add_f64": (i, [vp, G, G, i, vp, vp, vp, vp]),
+        "mgk_dense_mult_f64": (i, [vp, i, i, vp, vp, vp, vp]),
         "mgk_residual_sumsq_rowcoef_f64": (i, [vp, G, vp, vp, vp, C.POINTER(d), vp]),
         "mgk_prolong_jacobi_rowcoef_f64": (i, [vp, G, G, vp, vp, d, vp, vp, vp, vp, vp]),
         "mgk_residual_restrict_2d_rowcoef_f64": (i, [vp, G, G, vp, vp, vp, vp, vp, vp, d, vp]),

@@ -705,6 +705,16 @@ int mgk_jacobi_sumsq_rowcoef_f64(mgk_ctx *c, const mgk_geom *g, const double *ct
     deliver(c, sumsq_field<double>(*g, r.data(), 0, g->ny), out);
     return 0;
 }
+int mgk_jacobi_sumsq_store_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale, const double *ctab, const double *dtab,
+                               const double *b, const double *u, double *o, double *r, double *out, void *) {
+    if (!c || !g || g->dim != 2 || (!coef && !ctab) || (ctab && !dtab) || !b || !u || !o || !r || u == o || u == r || b == r || r == o || b == o || !out)
+        return fail(MGK_EINVAL, "mgk_jacobi_sumsq_store_f64");
+    if (c->capturing) return fail(MGK_EINVAL, "reduction to the host inside a capture");
+    st_op<double>(M_RESIDUAL, *g, ctab ? nullptr : coef, 1, 1, 0, 0, 0, b, u, (const double *)nullptr, r, 0, g->ny, ctab, dtab);
+    st_op<double>(M_JACOBI, *g, ctab ? nullptr : coef, ctab ? 1.0 : dinv, scale, 0, 0, 0, b, u, (const double *)nullptr, o, 0, g->ny, ctab, dtab);
+    deliver(c, sumsq_field<double>(*g, r, 0, g->ny), out);
+    return 0;
+}
 int mgk_prolong_jacobi_rowcoef_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *ctab, const double *dtab, double scale, const double *b, const double *uc, const double *u, double *o, void *) {
     if (!c || !ctab || !dtab || !b || !uc || !u || !o || u == o || !xfer_ok(gf, gc) || gf->dim != 2) return fail(MGK_EINVAL, "mgk_prolong_jacobi_rowcoef_f64");
     const mgk_geom F = *gf, Cg = *gc;

@@ -263,19 +263,23 @@ def test_lazy_temporaries_of_the_reference_loop(san, tmp_path, mesh, cycle):
         out = _refdrv(san, d, opts, {"MGPETSC_LAZY": lazy, "MGPETSC_LAZY_STATS": "1"})
         it = int(re.search(r"Number of iterations:\s+(\d+)", out).group(1))
         m = re.search(r"lazy temporaries: (\d+) residual\+restriction passes, (\d+) prolongation sweeps fused; computed after all: (\d+) residuals, "
-                      r"(\d+) prolongations, (\d+) corrections; (\d+) dropped unread; (\d+) zero-guess sweeps out of the restriction's pass", out)
+                      r"(\d+) prolongations, (\d+) corrections; (\d+) dropped unread; (\d+) zero-guess sweeps out of the restriction's pass; (\d+) norm passes", out)
         assert m, out[-800:]
         st = [int(x) for x in m.groups()]
         if lazy == "1":
             assert st[0] == it * (levels - 1) and st[1] == it * (levels - 1), st      # every restriction and every first post-sweep fused
             assert st[3] == 0 and st[4] == 0, st                                      # rv never computed, no correction left over
-            assert st[2] <= it + 1, st                                                # only the residual whose norm closes a cycle
             if cycle == 0:
                 assert st[6] == it * (levels - 1), st                                 # every coarse pre-smoothing starts inside the restriction's pass
+                assert st[7] == it and st[2] == 0, st                                 # every closing norm stores r and makes the next cycle's first sweep
+            else:
+                assert st[2] <= it + 1, st                                            # PCMG: only the outer residual whose norm is monitored
         else:
-            assert st == [0] * 7
+            assert st == [0] * 8
         res[lazy] = (it, (d / "rData.dat").read_text(), (d / "uData.dat").read_text())
-    assert res["1"] == res["0"]
+    assert res["1"][0] == res["0"][0] and res["1"][2] == res["0"][2]                  # cycle count, solution file
+    r1, r0 = (np.array(res[q][1].split(), dtype=np.float64) for q in ("1", "0"))      # (the fused norm pass sums r^2 in another order)
+    assert np.max(np.abs(r1 / r0 - 1)) <= 1e-12
     if cycle == 0:
         ref = Oracle().vcycle(2, npts, levels, 3, 3, maxiter=1000, scale=0.8, use_csr=1 if mesh else 0, mesh=mesh)
         assert res["1"][0] == ref["iters"]

@@ -956,3 +956,39 @@ def test_two_sweeps_with_the_norm_of_the_mid_iterate(mgk, orc, n):
     mgk.L.mgk_set_tuning(-1, -1)
     for p in (du, db, dout, dref):
         mgk.free(p)
+
+
+@pytest.mark.parametrize("n", [3, 7, 63, 255, 509, 1023, 2047])
+def test_norm_pass_that_stores_the_residual_and_makes_the_next_sweep(mgk, orc, n):
+    """mgk_jacobi_sumsq_store_f64 (the drop-in's KSPBuildResidual + VecNorm + first sweep of the next KSPSolve, 2-D): r is the residual
+    kernel's, unew the sweep kernel's, bit for bit; the sum is ||r||^2; ghosts and padding of both outputs stay zero; u and b untouched"""
+    rng = np.random.default_rng(9300 + n)
+    q = float((n + 1) ** 2)
+    As = [q, q, -4.0 * q, q, q]
+    dinv = 1.0 / As[2]
+    u, b = _rand(rng, n ** 2), _rand(rng, n ** 2)
+    g = mgk.geom(2, n)
+    du, db, dout, dr = mgk.to_field(g, u), mgk.to_field(g, b), mgk.field(g), mgk.field(g)
+    ss = C.c_double(0.0)
+    mgk._chk(mgk.L.mgk_jacobi_sumsq_store_f64(mgk.ctx, C.byref(g), mgk.coef(As), dinv, 0.8, None, None, db, du, dout, dr, C.byref(ss), None))
+    res = orc.residual(2, n, As, b, u)
+    assert np.array_equal(mgk.from_field(g, dr), res)
+    assert np.array_equal(mgk.from_field(g, dout), orc.jacobi(2, n, As, 0.8, b, u))
+    assert abs(ss.value - float(res @ res)) <= 1e-12 * float(res @ res)
+    for f, v in ((dr, mgk.from_field(g, dr)), (dout, mgk.from_field(g, dout))):
+        raw = mgk.raw_field(g, f)
+        assert abs(np.abs(raw).sum() - np.abs(v).sum()) <= 1e-9 * np.abs(v).sum()
+    assert np.array_equal(mgk.from_field(g, du), u) and np.array_equal(mgk.from_field(g, db), b)
+    # row tables (stretched meshes)
+    ct, dt = _rt_tables(rng, n)
+    dct, ddt = mgk.upload(ct.ravel()), mgk.upload(dt)
+    mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dout, 8 * g.total, None))
+    mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dr, 8 * g.total, None))
+    mgk._chk(mgk.L.mgk_jacobi_sumsq_store_f64(mgk.ctx, C.byref(g), None, 1.0, 0.8, dct, ddt, db, du, dout, dr, C.byref(ss), None))
+    U, B = u.reshape(n, n), b.reshape(n, n)
+    rr = B - _rt_apply(ct, U)
+    assert np.array_equal(mgk.from_field(g, dr).reshape(n, n), rr)
+    assert np.array_equal(mgk.from_field(g, dout).reshape(n, n), _rt_jacobi(ct, B, U, 0.8))
+    assert abs(ss.value - float((rr * rr).sum())) <= 1e-12 * float((rr * rr).sum())
+    for p in (du, db, dout, dr, dct, ddt):
+        mgk.free(p)
