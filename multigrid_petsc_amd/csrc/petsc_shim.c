@@ -28,7 +28,7 @@
 /* ------------------------------------------------------------------ */
 static mgk_ctx *G = NULL;
 static int g_notice_pc = 0;
-static long g_lzstat[8];     /* lazy temporaries: [0] residual+restriction fused, [1] prolongation fused into a sweep, [2..4] deferred values that were
+static long g_lzstat[9];     /* lazy temporaries: [0] residual+restriction fused, [1] prolongation fused into a sweep, [2..4] deferred values that were
                               * computed after all (residual, prolongation, correction), [5] deferred values overwritten unread */
 
 static void die(const char *what) {
@@ -104,8 +104,8 @@ PetscErrorCode PetscInitialize(int *argc, char ***argv, const char file[], const
 PetscErrorCode PetscFinalize(void) {
     if (getenv("MGPETSC_LAZY_STATS"))
         printf("[mgpetsc] lazy temporaries: %ld residual+restriction passes, %ld prolongation sweeps fused; computed after all: %ld residuals, "
-               "%ld prolongations, %ld corrections; %ld dropped unread; %ld zero-guess sweeps out of the restriction's pass; %ld norm passes that store r and make the next sweep\n",
-               g_lzstat[0], g_lzstat[1], g_lzstat[2], g_lzstat[3], g_lzstat[4], g_lzstat[5], g_lzstat[7], g_lzstat[6]);
+               "%ld prolongations, %ld corrections; %ld dropped unread; %ld zero-guess sweeps out of the restriction's pass; %ld norm passes that store r and make the next sweep, %ld of those sweeps adopted\n",
+               g_lzstat[0], g_lzstat[1], g_lzstat[2], g_lzstat[3], g_lzstat[4], g_lzstat[5], g_lzstat[7], g_lzstat[6], g_lzstat[8]);
     if (G) { mgk_ctx_destroy(G); G = NULL; }
     for (int q = 0; q < g_nopt; q++) { free(g_opt[q].key); free(g_opt[q].val); }
     free(g_opt); g_opt = NULL; g_nopt = g_capopt = 0;
@@ -1527,6 +1527,7 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
                      b->ver == k->spec_vb && x->ver == k->spec_vx && k->spec_epoch == g_mat_epoch && !x->lz && !b->lz && !x->host_dirty && !b->host_dirty &&
                      (A->kind == MAT_STENCIL || A->kind == MAT_STENCIL_ROW);
     k->spec_ok = 0;
+    if (spec) g_lzstat[8]++;
     /* the right-hand side is R (b_f - A_f u_f), still deferred (MatMult(res) just before, src/solver.c:1535-1536), and the solve starts
      * from the zero guess: restriction and first sweep in one pass */
     struct _p_Mat *rrA = NULL, *rrR = NULL; Vec rrb = NULL, rru = NULL;

@@ -644,3 +644,58 @@ def test_lazy_temporaries_keep_petsc_semantics(orc):
         L.VecDestroy(C.byref(v))
     for m in (mA, mP, mR):
         L.MatDestroy(C.byref(m))
+
+
+def test_speculative_sweep_of_the_norm_pass_is_adopted_only_when_nothing_changed(orc):
+    """KSPBuildResidual + VecNorm on a Richardson smoother with a nonzero guess also make the first sweep of the next KSPSolve (DESIGN.md 8b
+    N2).  That sweep must be dropped when u or b is written between the norm and the solve, and adopted otherwise -- either way the
+    iterate is what sweep-by-sweep execution gives."""
+    L = _shim()
+    L.PetscInitialize(None, None, None, None)
+    L.PetscOptionsSetValue(None, b"-pc_type", b"jacobi")
+    L.PetscOptionsSetValue(None, b"-ksp_richardson_scale", b"0.8")
+    L.VecScale.argtypes = [C.c_void_p, C.c_double]
+    npts = 33
+    A = _dense(orc, "A", npts, 0)
+    mA = _assemble(L, A)
+    n = A.shape[0]
+    d = 1.0 / np.diag(A)
+    rng = np.random.default_rng(11)
+    uv, bv = rng.standard_normal(n), rng.standard_normal(n)
+    u, b, r = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    L.MatCreateVecs(mA, C.byref(u), C.byref(b))
+    L.VecDuplicate(u, C.byref(r))
+    k = C.c_void_p()
+    L.KSPCreate(1, C.byref(k))
+    L.KSPSetType(k, b"richardson"); L.KSPSetOperators(k, mA, mA); L.KSPSetNormType(k, 0)
+    L.KSPSetTolerances(k, 1e-7, -2.0, -2.0, 2)
+    L.KSPSetFromOptions(k)
+    L.KSPSetInitialGuessNonzero(k, 1)
+    V, val = C.c_void_p(), C.c_double()
+
+    def sweeps(x, rhs, m):
+        for _ in range(m):
+            x = x + 0.8 * (d * (rhs - A @ x))
+        return x
+
+    tol = 1e-12 * max(np.abs(uv).max(), 1.0) * 100
+    for change in ("nothing", "u", "b"):
+        _set(L, u, uv); _set(L, b, bv)
+        L.KSPSolve(k, b, u)
+        x = sweeps(uv, bv, 2)
+        L.KSPBuildResidual(k, None, r, C.byref(V))
+        L.VecNorm(V, NORM_2, C.byref(val))
+        assert abs(val.value - np.linalg.norm(bv - A @ x)) <= 1e-12 * np.linalg.norm(bv - A @ x)
+        rhs = bv
+        if change == "u":
+            L.VecScale(u, 0.5); x = 0.5 * x
+        if change == "b":
+            L.VecScale(b, 2.0); rhs = 2.0 * bv
+        L.KSPSolve(k, b, u)
+        x2 = sweeps(x, rhs, 2)
+        assert np.max(np.abs(_get(L, u, n) - x2)) <= tol, change
+        assert np.max(np.abs(_get(L, r, n) - (bv - A @ sweeps(uv, bv, 2)))) <= tol * np.abs(A).max(), change     # r was stored by the norm pass
+    L.KSPDestroy(C.byref(k))
+    for v in (u, b, r):
+        L.VecDestroy(C.byref(v))
+    L.MatDestroy(C.byref(mA))
