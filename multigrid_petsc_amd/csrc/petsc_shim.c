@@ -296,7 +296,7 @@ enum { LZ_NONE = 0, LZ_RESIDUAL = 1, LZ_PROLONG = 2, LZ_ADDP = 3, LZ_RR = 4 };
 #define LZ_MAX 64
 static Vec g_lz[LZ_MAX];
 static int g_nlz = 0, g_lazy = -1;
-static unsigned long g_mat_epoch = 0;      /* bumped when any matrix changes or dies: speculative sweeps made before are void */
+static unsigned long g_mat_epoch = 0;      /* bumped when any matrix changes or dies and when any vector dies: speculative sweeps made before are void */
 static int lazy_on(void) { if (g_lazy < 0) { const char *e = getenv("MGPETSC_LAZY"); g_lazy = (e && e[0] >= '0' && e[0] <= '9') ? atoi(e) : 1; } return g_lazy; }   /* 2: b_c not deferred (measurement aid) */
 static void lz_settle(Vec v);
 static void lz_drop(Vec v) {                       /* forget v's deferred value (it is being overwritten / has been consumed) */
@@ -339,6 +339,7 @@ PetscErrorCode VecDuplicate(Vec v, Vec *nv) { *nv = v->padded == 2 ? vec_newg(v-
 PetscErrorCode VecDestroy(Vec *v) {
     if (!v || !*v) return 0;
     lz_before_write(*v, 1);                                  /* deferred vectors that read *v are computed now */
+    g_mat_epoch++;                                           /* a speculative sweep that names *v is void (the address may be reused) */
     if (G) mgk_free(G, (*v)->dev);
     free((*v)->host); free(*v); *v = NULL;
     return 0;
@@ -1722,6 +1723,7 @@ PetscErrorCode KSPView(KSP k, PetscViewer viewer) {               /* src/solver.
 }
 PetscErrorCode KSPDestroy(KSP *pk) {
     if (!pk || !*pk) return 0;
+    for (int q = 0; q < g_nlz; q++) if (g_lz[q]->lz_ksp == *pk) g_lz[q]->lz_ksp = NULL;      /* deferred residuals no longer name this solver */
     for (int q = 0; q < 3; q++) if ((*pk)->work[q]) VecDestroy(&(*pk)->work[q]);
     pcmg *mg = (*pk)->pcobj.mg;
     if (mg) {
