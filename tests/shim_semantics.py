@@ -1,0 +1,209 @@
+"""PETSc semantics of the drop-in's lazy temporaries in call orders the reference's loop does not use.  Shared by the GPU
+tier (the real libmgpetsc.so) and the CPU tier (petsc_shim.c over tests/mock_mgk.cpp, built by tests/test_shim_semantics_cpu.py): the
+functions take the ctypes library `L` with its argument types set (`type_shim`)."""
+import ctypes as C
+
+import numpy as np
+
+ADD, INSERT, FINAL, NORM_2 = 2, 1, 0, 1
+
+
+def type_shim(L):
+    vp, i, d = C.c_void_p, C.c_int, C.c_double
+    L.PetscInitialize.argtypes = [vp, vp, C.c_char_p, C.c_char_p]
+    L.PetscOptionsSetValue.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.MatCreateAIJ.argtypes = [i, i, i, i, i, i, vp, i, vp, C.POINTER(vp)]
+    L.MatSetValue.argtypes = [vp, i, i, d, i]
+    L.MatAssemblyBegin.argtypes = [vp, i]
+    L.MatAssemblyEnd.argtypes = [vp, i]
+    L.MatCreateVecs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.MatMult.argtypes = [vp, vp, vp]
+    L.MatResidual.argtypes = [vp, vp, vp, vp]
+    L.MatDestroy.argtypes = [C.POINTER(vp)]
+    L.VecSetValue.argtypes = [vp, i, d, i]
+    L.VecAssemblyBegin.argtypes = [vp]
+    L.VecAssemblyEnd.argtypes = [vp]
+    L.VecDuplicate.argtypes = [vp, C.POINTER(vp)]
+    L.VecSet.argtypes = [vp, d]
+    L.VecCopy.argtypes = [vp, vp]
+    L.VecScale.argtypes = [vp, d]
+    L.VecAXPY.argtypes = [vp, d, vp]
+    L.VecNorm.argtypes = [vp, i, C.POINTER(d)]
+    L.VecGetArray.argtypes = [vp, C.POINTER(C.POINTER(d))]
+    L.VecRestoreArray.argtypes = [vp, C.POINTER(C.POINTER(d))]
+    L.VecDestroy.argtypes = [C.POINTER(vp)]
+    L.KSPCreate.argtypes = [i, C.POINTER(vp)]
+    L.KSPSetType.argtypes = [vp, C.c_char_p]
+    L.KSPSetOperators.argtypes = [vp, vp, vp]
+    L.KSPSetNormType.argtypes = [vp, i]
+    L.KSPSetTolerances.argtypes = [vp, d, d, d, i]
+    L.KSPSetFromOptions.argtypes = [vp]
+    L.KSPSetInitialGuessNonzero.argtypes = [vp, i]
+    L.KSPSolve.argtypes = [vp, vp, vp]
+    L.KSPBuildResidual.argtypes = [vp, vp, vp, C.POINTER(vp)]
+    L.KSPDestroy.argtypes = [C.POINTER(vp)]
+    return L
+
+
+def _dense(orc, which, npts, l):
+    m = orc.build(which, 2, npts, l)
+    rows = orc.csr_rows(m)
+    nr, nc = orc.L.mgo_csr_nrows(m), orc.L.mgo_csr_ncols(m)
+    d = np.zeros((nr, nc))
+    for r, (cols, vals) in enumerate(rows):
+        d[r, list(cols)] = vals
+    return d
+
+
+
+def _assemble(L, M):
+    m = C.c_void_p()
+    L.MatCreateAIJ(1, M.shape[0], M.shape[1], -1, -1, 30, None, 0, None, C.byref(m))
+    for r, c in zip(*np.nonzero(M)):
+        L.MatSetValue(m, int(r), int(c), float(M[r, c]), ADD)
+    L.MatAssemblyBegin(m, FINAL)
+    L.MatAssemblyEnd(m, FINAL)
+    return m
+
+
+
+def _set(L, v, a):
+    for q, val in enumerate(a):
+        L.VecSetValue(v, q, float(val), INSERT)
+    L.VecAssemblyBegin(v)
+    L.VecAssemblyEnd(v)
+
+
+
+def _get(L, v, n):
+    p = C.POINTER(C.c_double)()
+    L.VecGetArray(v, C.byref(p))
+    a = np.ctypeslib.as_array(p, shape=(n,)).copy()
+    L.VecRestoreArray(v, C.byref(p))
+    return a
+
+
+
+
+def lazy_temporaries_keep_petsc_semantics(L, orc):
+    """the deferred residual / prolongation / correction vectors of the drop-in in call orders the reference's loop does
+    NOT use: a deferred vector read later, an operand changed or destroyed before the deferred vector is read, a correction that no sweep
+    follows -- every value must be what call-by-call execution gives"""
+    L.PetscInitialize(None, None, None, None)
+    npts = 33
+    A, P, R = _dense(orc, "A", npts, 0), _dense(orc, "P", npts, 0), _dense(orc, "R", npts, 0)
+    mA, mP, mR = _assemble(L, A), _assemble(L, P), _assemble(L, R)
+    nf, nc = A.shape[0], P.shape[1]
+    rng = np.random.default_rng(3)
+    xv, bv, ucv = rng.standard_normal(nf), rng.standard_normal(nf), rng.standard_normal(nc)
+    x, b, r, rv, u = (C.c_void_p() for _ in range(5))
+    uc, bc = C.c_void_p(), C.c_void_p()
+    L.MatCreateVecs(mA, C.byref(x), C.byref(b))
+    for v in (r, rv, u):
+        L.VecDuplicate(x, C.byref(v))
+    L.MatCreateVecs(mR, None, C.byref(bc))
+    L.MatCreateVecs(mP, C.byref(uc), None)
+    tol = 1e-12 * np.abs(A).max() * 10
+    _set(L, x, xv); _set(L, b, bv); _set(L, uc, ucv)
+    # 1. a deferred residual whose operand changes before it is read: the OLD x counts
+    L.MatResidual(mA, b, x, r)
+    L.VecScale(x, 2.0)
+    assert np.max(np.abs(_get(L, r, nf) - (bv - A @ xv))) <= tol
+    assert np.max(np.abs(_get(L, x, nf) - 2.0 * xv)) == 0.0
+    # 2. deferred residual consumed by the restriction AND read afterwards
+    _set(L, x, xv)
+    L.MatResidual(mA, b, x, r)
+    L.MatMult(mR, r, bc)
+    assert np.max(np.abs(_get(L, bc, nc) - R @ (bv - A @ xv))) <= tol
+    assert np.max(np.abs(_get(L, r, nf) - (bv - A @ xv))) <= tol
+    # 2b. the restricted right-hand side is deferred as well: its fine-level operands change before it is read
+    L.MatResidual(mA, b, x, r)
+    L.MatMult(mR, r, bc)
+    L.VecScale(x, 2.0)
+    L.VecSet(b, 0.0)
+    assert np.max(np.abs(_get(L, bc, nc) - R @ (bv - A @ xv))) <= tol
+    assert np.max(np.abs(_get(L, r, nf) - (bv - A @ xv))) <= tol
+    _set(L, x, xv); _set(L, b, bv)
+    # 3. deferred prolongation + deferred correction, no sweep follows: u and rv read directly
+    _set(L, u, xv)
+    L.MatMult(mP, uc, rv)
+    L.VecAXPY(u, 1.0, rv)
+    assert np.max(np.abs(_get(L, u, nf) - (xv + P @ ucv))) <= 1e-13 * 10
+    assert np.max(np.abs(_get(L, rv, nf) - P @ ucv)) <= 1e-13 * 10
+    # 4. the coarse operand changes between the deferred prolongation, the deferred correction and their use
+    _set(L, u, xv)
+    L.MatMult(mP, uc, rv)
+    L.VecAXPY(u, 1.0, rv)
+    L.VecScale(uc, -3.0)                       # both deferred values were defined with the old u_c
+    assert np.max(np.abs(_get(L, u, nf) - (xv + P @ ucv))) <= 1e-13 * 10
+    assert np.max(np.abs(_get(L, rv, nf) - P @ ucv)) <= 1e-13 * 10
+    # 5. ... or is destroyed
+    _set(L, uc, ucv); _set(L, u, xv)
+    L.MatMult(mP, uc, rv)
+    L.VecAXPY(u, 1.0, rv)
+    L.VecDestroy(C.byref(uc))
+    assert np.max(np.abs(_get(L, u, nf) - (xv + P @ ucv))) <= 1e-13 * 10
+    # 6. a deferred vector that is copied, and one that is overwritten unread
+    L.MatResidual(mA, b, x, r)
+    L.VecCopy(r, rv)
+    assert np.max(np.abs(_get(L, rv, nf) - (bv - A @ xv))) <= tol
+    L.MatResidual(mA, b, x, r)
+    L.VecSet(r, 7.0)
+    assert np.all(_get(L, r, nf) == 7.0)
+    for v in (x, b, r, rv, u, bc):
+        L.VecDestroy(C.byref(v))
+    for m in (mA, mP, mR):
+        L.MatDestroy(C.byref(m))
+
+
+def speculative_sweep_is_adopted_only_when_nothing_changed(L, orc):
+    """KSPBuildResidual + VecNorm on a Richardson smoother with a nonzero guess also make the first sweep of the next KSPSolve (DESIGN.md 8b
+    N2).  That sweep must be dropped when u or b is written between the norm and the solve, and adopted otherwise -- either way the
+    iterate is what sweep-by-sweep execution gives."""
+    L.PetscInitialize(None, None, None, None)
+    L.PetscOptionsSetValue(None, b"-pc_type", b"jacobi")
+    L.PetscOptionsSetValue(None, b"-ksp_richardson_scale", b"0.8")
+    npts = 33
+    A = _dense(orc, "A", npts, 0)
+    mA = _assemble(L, A)
+    n = A.shape[0]
+    d = 1.0 / np.diag(A)
+    rng = np.random.default_rng(11)
+    uv, bv = rng.standard_normal(n), rng.standard_normal(n)
+    u, b, r = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    L.MatCreateVecs(mA, C.byref(u), C.byref(b))
+    L.VecDuplicate(u, C.byref(r))
+    k = C.c_void_p()
+    L.KSPCreate(1, C.byref(k))
+    L.KSPSetType(k, b"richardson"); L.KSPSetOperators(k, mA, mA); L.KSPSetNormType(k, 0)
+    L.KSPSetTolerances(k, 1e-7, -2.0, -2.0, 2)
+    L.KSPSetFromOptions(k)
+    L.KSPSetInitialGuessNonzero(k, 1)
+    V, val = C.c_void_p(), C.c_double()
+
+    def sweeps(x, rhs, m):
+        for _ in range(m):
+            x = x + 0.8 * (d * (rhs - A @ x))
+        return x
+
+    tol = 1e-12 * max(np.abs(uv).max(), 1.0) * 100
+    for change in ("nothing", "u", "b"):
+        _set(L, u, uv); _set(L, b, bv)
+        L.KSPSolve(k, b, u)
+        x = sweeps(uv, bv, 2)
+        L.KSPBuildResidual(k, None, r, C.byref(V))
+        L.VecNorm(V, NORM_2, C.byref(val))
+        assert abs(val.value - np.linalg.norm(bv - A @ x)) <= 1e-12 * np.linalg.norm(bv - A @ x)
+        rhs = bv
+        if change == "u":
+            L.VecScale(u, 0.5); x = 0.5 * x
+        if change == "b":
+            L.VecScale(b, 2.0); rhs = 2.0 * bv
+        L.KSPSolve(k, b, u)
+        x2 = sweeps(x, rhs, 2)
+        assert np.max(np.abs(_get(L, u, n) - x2)) <= tol, change
+        assert np.max(np.abs(_get(L, r, n) - (bv - A @ sweeps(uv, bv, 2)))) <= tol * np.abs(A).max(), change     # r was stored by the norm pass
+    L.KSPDestroy(C.byref(k))
+    for v in (u, b, r):
+        L.VecDestroy(C.byref(v))
+    L.MatDestroy(C.byref(mA))

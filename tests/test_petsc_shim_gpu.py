@@ -572,130 +572,11 @@ def test_level_operator_of_several_grids_runs_on_the_stencil_and_transfer_kernel
 
 
 def test_lazy_temporaries_keep_petsc_semantics(orc):
-    """the deferred residual / prolongation / correction vectors of the drop-in in call orders the reference's loop does
-    NOT use: a deferred vector read later, an operand changed or destroyed before the deferred vector is read, a correction that no sweep
-    follows -- every value must be what call-by-call execution gives"""
-    L = _shim()
-    L.PetscInitialize(None, None, None, None)
-    L.MatResidual.argtypes = [C.c_void_p] * 4
-    L.VecCopy.argtypes = [C.c_void_p] * 2
-    L.VecScale.argtypes = [C.c_void_p, C.c_double]
-    npts = 33
-    A, P, R = _dense(orc, "A", npts, 0), _dense(orc, "P", npts, 0), _dense(orc, "R", npts, 0)
-    mA, mP, mR = _assemble(L, A), _assemble(L, P), _assemble(L, R)
-    nf, nc = A.shape[0], P.shape[1]
-    rng = np.random.default_rng(3)
-    xv, bv, ucv = rng.standard_normal(nf), rng.standard_normal(nf), rng.standard_normal(nc)
-    x, b, r, rv, u = (C.c_void_p() for _ in range(5))
-    uc, bc = C.c_void_p(), C.c_void_p()
-    L.MatCreateVecs(mA, C.byref(x), C.byref(b))
-    for v in (r, rv, u):
-        L.VecDuplicate(x, C.byref(v))
-    L.MatCreateVecs(mR, None, C.byref(bc))
-    L.MatCreateVecs(mP, C.byref(uc), None)
-    tol = 1e-12 * np.abs(A).max() * 10
-    _set(L, x, xv); _set(L, b, bv); _set(L, uc, ucv)
-    # 1. a deferred residual whose operand changes before it is read: the OLD x counts
-    L.MatResidual(mA, b, x, r)
-    L.VecScale(x, 2.0)
-    assert np.max(np.abs(_get(L, r, nf) - (bv - A @ xv))) <= tol
-    assert np.max(np.abs(_get(L, x, nf) - 2.0 * xv)) == 0.0
-    # 2. deferred residual consumed by the restriction AND read afterwards
-    _set(L, x, xv)
-    L.MatResidual(mA, b, x, r)
-    L.MatMult(mR, r, bc)
-    assert np.max(np.abs(_get(L, bc, nc) - R @ (bv - A @ xv))) <= tol
-    assert np.max(np.abs(_get(L, r, nf) - (bv - A @ xv))) <= tol
-    # 2b. the restricted right-hand side is deferred as well: its fine-level operands change before it is read
-    L.MatResidual(mA, b, x, r)
-    L.MatMult(mR, r, bc)
-    L.VecScale(x, 2.0)
-    L.VecSet(b, 0.0)
-    assert np.max(np.abs(_get(L, bc, nc) - R @ (bv - A @ xv))) <= tol
-    assert np.max(np.abs(_get(L, r, nf) - (bv - A @ xv))) <= tol
-    _set(L, x, xv); _set(L, b, bv)
-    # 3. deferred prolongation + deferred correction, no sweep follows: u and rv read directly
-    _set(L, u, xv)
-    L.MatMult(mP, uc, rv)
-    L.VecAXPY(u, 1.0, rv)
-    assert np.max(np.abs(_get(L, u, nf) - (xv + P @ ucv))) <= 1e-13 * 10
-    assert np.max(np.abs(_get(L, rv, nf) - P @ ucv)) <= 1e-13 * 10
-    # 4. the coarse operand changes between the deferred prolongation, the deferred correction and their use
-    _set(L, u, xv)
-    L.MatMult(mP, uc, rv)
-    L.VecAXPY(u, 1.0, rv)
-    L.VecScale(uc, -3.0)                       # both deferred values were defined with the old u_c
-    assert np.max(np.abs(_get(L, u, nf) - (xv + P @ ucv))) <= 1e-13 * 10
-    assert np.max(np.abs(_get(L, rv, nf) - P @ ucv)) <= 1e-13 * 10
-    # 5. ... or is destroyed
-    _set(L, uc, ucv); _set(L, u, xv)
-    L.MatMult(mP, uc, rv)
-    L.VecAXPY(u, 1.0, rv)
-    L.VecDestroy(C.byref(uc))
-    assert np.max(np.abs(_get(L, u, nf) - (xv + P @ ucv))) <= 1e-13 * 10
-    # 6. a deferred vector that is copied, and one that is overwritten unread
-    L.MatResidual(mA, b, x, r)
-    L.VecCopy(r, rv)
-    assert np.max(np.abs(_get(L, rv, nf) - (bv - A @ xv))) <= tol
-    L.MatResidual(mA, b, x, r)
-    L.VecSet(r, 7.0)
-    assert np.all(_get(L, r, nf) == 7.0)
-    for v in (x, b, r, rv, u, bc):
-        L.VecDestroy(C.byref(v))
-    for m in (mA, mP, mR):
-        L.MatDestroy(C.byref(m))
+    """see tests/shim_semantics.py (shared with the CPU tier, which runs it over the host-memory mock of the kernel ABI)"""
+    from shim_semantics import lazy_temporaries_keep_petsc_semantics, type_shim
+    lazy_temporaries_keep_petsc_semantics(type_shim(_shim()), orc)
 
 
 def test_speculative_sweep_of_the_norm_pass_is_adopted_only_when_nothing_changed(orc):
-    """KSPBuildResidual + VecNorm on a Richardson smoother with a nonzero guess also make the first sweep of the next KSPSolve (DESIGN.md 8b
-    N2).  That sweep must be dropped when u or b is written between the norm and the solve, and adopted otherwise -- either way the
-    iterate is what sweep-by-sweep execution gives."""
-    L = _shim()
-    L.PetscInitialize(None, None, None, None)
-    L.PetscOptionsSetValue(None, b"-pc_type", b"jacobi")
-    L.PetscOptionsSetValue(None, b"-ksp_richardson_scale", b"0.8")
-    L.VecScale.argtypes = [C.c_void_p, C.c_double]
-    npts = 33
-    A = _dense(orc, "A", npts, 0)
-    mA = _assemble(L, A)
-    n = A.shape[0]
-    d = 1.0 / np.diag(A)
-    rng = np.random.default_rng(11)
-    uv, bv = rng.standard_normal(n), rng.standard_normal(n)
-    u, b, r = C.c_void_p(), C.c_void_p(), C.c_void_p()
-    L.MatCreateVecs(mA, C.byref(u), C.byref(b))
-    L.VecDuplicate(u, C.byref(r))
-    k = C.c_void_p()
-    L.KSPCreate(1, C.byref(k))
-    L.KSPSetType(k, b"richardson"); L.KSPSetOperators(k, mA, mA); L.KSPSetNormType(k, 0)
-    L.KSPSetTolerances(k, 1e-7, -2.0, -2.0, 2)
-    L.KSPSetFromOptions(k)
-    L.KSPSetInitialGuessNonzero(k, 1)
-    V, val = C.c_void_p(), C.c_double()
-
-    def sweeps(x, rhs, m):
-        for _ in range(m):
-            x = x + 0.8 * (d * (rhs - A @ x))
-        return x
-
-    tol = 1e-12 * max(np.abs(uv).max(), 1.0) * 100
-    for change in ("nothing", "u", "b"):
-        _set(L, u, uv); _set(L, b, bv)
-        L.KSPSolve(k, b, u)
-        x = sweeps(uv, bv, 2)
-        L.KSPBuildResidual(k, None, r, C.byref(V))
-        L.VecNorm(V, NORM_2, C.byref(val))
-        assert abs(val.value - np.linalg.norm(bv - A @ x)) <= 1e-12 * np.linalg.norm(bv - A @ x)
-        rhs = bv
-        if change == "u":
-            L.VecScale(u, 0.5); x = 0.5 * x
-        if change == "b":
-            L.VecScale(b, 2.0); rhs = 2.0 * bv
-        L.KSPSolve(k, b, u)
-        x2 = sweeps(x, rhs, 2)
-        assert np.max(np.abs(_get(L, u, n) - x2)) <= tol, change
-        assert np.max(np.abs(_get(L, r, n) - (bv - A @ sweeps(uv, bv, 2)))) <= tol * np.abs(A).max(), change     # r was stored by the norm pass
-    L.KSPDestroy(C.byref(k))
-    for v in (u, b, r):
-        L.VecDestroy(C.byref(v))
-    L.MatDestroy(C.byref(mA))
+    from shim_semantics import speculative_sweep_is_adopted_only_when_nothing_changed, type_shim
+    speculative_sweep_is_adopted_only_when_nothing_changed(type_shim(_shim()), orc)

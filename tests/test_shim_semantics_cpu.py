@@ -1,0 +1,51 @@
+"""CPU tier: the PETSc-surface drop-in's host logic (petsc_shim.c) linked against the host-memory mock of the kernel ABI
+(tests/mock_mgk.cpp) as a shared library and driven through ctypes -- the lazy temporaries in call orders the reference's loop does not
+use, and the adoption rule of the speculative sweep (tests/shim_semantics.py; the same functions run on the GPU tier over the real
+libmgpetsc.so).  Test infrastructure: nothing under multigrid_petsc_amd/ links the mock."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from oracle import Oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "_san")
+
+
+@pytest.fixture(scope="module")
+def mock_shim():
+    if shutil.which("gcc") is None or shutil.which("g++") is None:
+        pytest.skip("no host compiler")
+    os.makedirs(OUT, exist_ok=True)
+    inc = "-I" + os.path.join(ROOT, "include")
+    so = os.path.join(OUT, "libmgpetsc_mock.so")
+    objs = []
+    for cc, std, src, obj in (("g++", "-std=c++17", os.path.join(ROOT, "tests", "mock_mgk.cpp"), "mock_mgk_pic.o"),
+                              ("gcc", "-std=c99", os.path.join(ROOT, "multigrid_petsc_amd", "csrc", "petsc_shim.c"), "petsc_shim_pic.o")):
+        o = os.path.join(OUT, obj)
+        p = subprocess.run([cc, std, "-O1", "-g", "-fPIC", "-ffp-contract=off", "-D_POSIX_C_SOURCE=200809L", inc, "-c", src, "-o", o],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert p.returncode == 0, p.stdout[-3000:]
+        objs.append(o)
+    p = subprocess.run(["g++", "-shared", "-o", so] + objs + ["-lm", "-lpthread"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0, p.stdout[-3000:]
+    from shim_semantics import type_shim
+    return type_shim(C.CDLL(so))
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return Oracle()
+
+
+def test_lazy_temporaries_keep_petsc_semantics_on_the_mock(mock_shim, orc):
+    from shim_semantics import lazy_temporaries_keep_petsc_semantics
+    lazy_temporaries_keep_petsc_semantics(mock_shim, orc)
+
+
+def test_speculative_sweep_adoption_rule_on_the_mock(mock_shim, orc):
+    from shim_semantics import speculative_sweep_is_adopted_only_when_nothing_changed
+    speculative_sweep_is_adopted_only_when_nothing_changed(mock_shim, orc)
