@@ -207,3 +207,13 @@ def speculative_sweep_is_adopted_only_when_nothing_changed(L, orc):
     for v in (u, b, r):
         L.VecDestroy(C.byref(v))
     L.MatDestroy(C.byref(mA))
+
+
+if __name__ == "__main__":      # python tests/shim_semantics.py <shared library> <function name>: one check in a process of its own
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle import Oracle
+    lib = type_shim(C.CDLL(sys.argv[1], mode=os.RTLD_LOCAL))
+    {"lazy": lazy_temporaries_keep_petsc_semantics, "spec": speculative_sweep_is_adopted_only_when_nothing_changed}[sys.argv[2]](lib, Oracle())
+    print("SEMANTICS_OK", sys.argv[2])
