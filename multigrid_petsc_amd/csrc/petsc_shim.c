@@ -1368,12 +1368,18 @@ static void mg_setup(KSP k) {
 static void mg_cycle(pcmg *mg, int i, Vec b, Vec x) {       /* PCMGMCycle_Private, one cycle per level */
     KSP s = mg->smooth[i];
     if (i == 0) { KSPSolve(s, b, x); return; }            /* coarse solve (zero initial guess) */
-    KSPSolve(s, b, x);                                      /* pre-smoothing */
+    {   /* pre-smoothing: x is the zero vector on entry (the caller's x_i = 0), so the solve runs with the zero-guess flag -- the same
+         * values (0 + s*((b - 0)*dinv) is the zero-guess sweep bit for bit) without the zero fill and without reading x, and the first
+         * sweep can come out of the restriction's pass */
+        const int g = s->guess_nonzero;
+        s->guess_nonzero = 0;
+        KSPSolve(s, b, x);
+        s->guess_nonzero = g;
+    }
     MatResidual(s->A, b, x, mg->r[i]);
-    MatMult(mg->restr[i], mg->r[i], mg->b[i - 1]);          /* MatRestrict */
+    MatMult(mg->restr[i], mg->r[i], mg->b[i - 1]);          /* MatRestrict; x_{i-1} = 0 is implied by the zero-guess solve below */
     if (mg->r[i]->lz) { g_lzstat[5]++; lz_drop(mg->r[i]); }  /* PCMG's residual work vector (PCMGSetR): consumed by the fused restriction, its
                                                               * contents after the cycle are unspecified -- not computed when x changes below */
-    VecSet(mg->x[i - 1], 0.0);
     mg_cycle(mg, i - 1, mg->b[i - 1], mg->x[i - 1]);
     MatMultAdd(mg->interp[i], mg->x[i - 1], x, x);          /* MatInterpolateAdd */
     KSPSolve(s, b, x);                                      /* post-smoothing */
@@ -1400,8 +1406,8 @@ static PetscErrorCode ksp_solve_mg(KSP k, Vec b, Vec x) {
     if (ttol < k->atol) ttol = k->atol;
     const int top = mg->levels - 1;
     while (k->its < k->maxits && rn > ttol && !(rn >= k->dtol * rn0) && rn == rn) {
-        VecSet(z, 0.0);
-        mg_cycle(mg, top, r, z);                                                /* z = M^{-1} r */
+        if (top == 0) VecSet(z, 0.0);
+        mg_cycle(mg, top, r, z);                                                /* z = M^{-1} r (from z = 0: zero-guess solves) */
         VecAXPY(x, k->scale, z);
         MatResidual(A, b, x, r);
         VecNorm(r, NORM_2, &rn);
