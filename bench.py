@@ -225,6 +225,32 @@ def run_config(dim, npts, precision, steps, warmup, device):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD job (`python -m torch.distributed.run`, one rank per
+    GPU, rendezvous on 127.0.0.1) and relay its output and exit code.  This process has not touched HIP (nothing imported so far
+    does) and never will: it only waits -- no exec of, or from, a process that holds the GPU."""
+    import socket
+    import subprocess
+    try:
+        import torch.distributed.run  # noqa: F401  (importing the launcher module initialises no device)
+    except Exception as e:  # noqa: BLE001
+        print(f"bench.py --gpus {n}: torch.distributed.run is not importable ({e}); launch one rank per GPU yourself "
+              "(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment)", file=sys.stderr, flush=True)
+        return 2
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")          # (the launcher would set it with a warning)
+    print(f"[bench] --gpus {n} without a launcher: starting {' '.join(cmd[1:9])} ...", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode          # stdout / stderr are inherited: rank 0's JSON line passes straight through
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,6 +268,9 @@ def main():
     ap.add_argument("--cpu-cycles", type=int, default=120)
     ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -299,6 +328,7 @@ def main():
                 comm = rccl_comm(rank, world, local_rank, dist)
             except Exception as e:          # noqa: BLE001
                 why = f"communicator: {e}"
+                print(f"[bench rank {rank}] {why}", file=sys.stderr, flush=True)
             up = all_ok(comm is not None)
             if up:
                 # first-run gate: rank-coded planes through every hook of the transport, checked on every rank, before
@@ -312,6 +342,8 @@ def main():
                         m.close()
                 except Exception as e:      # noqa: BLE001
                     ok, why = False, f"self-test: {e}"
+                if not ok:      # said BEFORE the agreement below: if that collective never completes, the first mismatch is on record
+                    print(f"[bench rank {rank}] transport self-test FAILED: {why}", file=sys.stderr, flush=True)
                 up = all_ok(ok)
             if not up:
                 print(f"[bench rank {rank}] RCCL transport unusable ({why or 'another rank failed'})", file=sys.stderr, flush=True)
@@ -391,6 +423,8 @@ def main():
                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "launches": pair_n, "avg_launch_ms": t_ms, "algorithmic_bytes_per_launch": comp,
                     "traffic": tj.get("jacobi2_hbm_bytes_per_launch") if (world == 1 and args.npts == 1025 and args.precision == "fp64") else None,
+                    "traffic_source": "profiles/traffic.json: rocprofv3 PMC passes (FETCH_SIZE x2, WRITE_SIZE) of an earlier run of this kernel, "
+                                      f"{tj.get('round', 'round 2')}; a constant, NOT measured in this run",
                     "per_sweep_equivalent": {"bytes_per_launch": 2 * comp, "GB/s": 2 * ach,
                                              "note": f"SURVEY 8(d3) accounting: {bytes_per_dof:g} B per unknown and SWEEP, two sweeps per launch"}}
         else:
@@ -427,6 +461,7 @@ def main():
                                      "model": "bytes one cycle of THIS implementation must move (fused passes; DESIGN.md section 4)"}
             out["history"] = check_history(f"{args.dim}d_{args.npts}_{args.precision}", rn)
     s.close()
+    failures = []
     if rank == 0:
         if world == 1 and pair_n and args.dim == 3 and args.precision == "fp64":
             try:     # the plain one-sweep kernel beside it (north_star: >= 70 % of 8 TB/s on the fp64 smoother sweep)
@@ -460,11 +495,24 @@ def main():
             except Exception as e:   # the baseline is reporting only; never fail the GPU line for it
                 out["cpu_baseline"] = {"value": None, "error": str(e)}
         print(json.dumps(out), flush=True)
+        # the line is printed whatever happened; a configuration that crashed or a residual history that left the committed one makes
+        # the run FAIL (exit 5) -- only the cpu_baseline leg is reporting-only
+        for c_ in out.get("configs", []):
+            if "error" in c_:
+                failures.append(f"{c_.get('baseline_config')}: {c_['error']}")
+            elif c_.get("history") is not None and not c_["history"]["ok"]:
+                failures.append(f"{c_.get('baseline_config')}: residual history deviates from tests/golden/bench_history.json ({c_['history']})")
+        if out.get("history") is not None and not out["history"]["ok"]:
+            failures.append(f"headline: residual history deviates from tests/golden/bench_history.json ({out['history']})")
     if comm is not None:
         comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if failures:
+        for f_ in failures:
+            print(f"[bench] FAILED: {f_}", file=sys.stderr, flush=True)
+        raise SystemExit(5)
 
 
 if __name__ == "__main__":

@@ -63,13 +63,17 @@ mg_comm *mg_comm_phantom_create(int rank, int nranks, double lat_us, double link
 
 /* First-run gate of a transport: rank-coded planes through halo / halo_n / allgather_planes, known sums through both
  * all-reduce forms, everything read back and compared on every rank.  0, or MGK_ECOMM with mg_comm_last_error() naming the
- * first mismatch.  Collective: every rank of the communicator must call it. */
+ * first mismatch.  Collective: every rank of the communicator must call it -- and every rank RETURNS from it: a rank that
+ * sees a mismatch or a failing hook keeps taking part in the remaining collectives of the fixed sequence and reports at the
+ * end, so that a fault on one rank never leaves its peers inside a send/recv (they return 0 if what THEY saw was right). */
 int  mg_comm_selftest(mg_comm *c, mgk_ctx *ctx);
 
 /* loopback: create the shared state once, then one handle per rank-thread */
 void    *mg_comm_loopback_shared_create(int nranks);
 void     mg_comm_loopback_shared_destroy(void *shared);
 mg_comm *mg_comm_loopback_create(void *shared, int rank);
+/* test aid: rank `rank` (>= 1) receives a wrong plane as its lo ghost from now on (-1: off) -- what the gate must catch */
+void     mg_comm_loopback_inject_fault(void *shared, int rank);
 
 const char *mg_comm_last_error(void);
 void mg_comm_destroy(mg_comm *c);       /* calls c->destroy */

@@ -9,8 +9,10 @@
  * symbols the reference references, with PETSc's C signatures.
  *
  * Scope.  Fully implemented on the GPU: everything `-cycle 0` (MultigridVcycle, src/solver.c:1414-1575)
- * touches.  Objects of the other (research) cycles link; those that need machinery outside the hot path
- * (PCMG, MatMatMult, index sets / sub-vectors) abort with a clear message when called.
+ * touches, `-cycle 8` (MultigridPetscPCMG, src/solver.c:1884-1989: PCMG with richardson / chebyshev / preonly level
+ * solvers, jacobi / none / lu preconditioners, exact coarse solve) and `-cycle 1` (MultigridIcycle, src/solver.c:1991-2060).
+ * Objects of the other (research) cycles link; those that need machinery outside these paths (MatMatMult, index sets /
+ * sub-vectors, KSP monitors) abort with a clear message when called.
  *
  * Type constraints the reference imposes: PetscInt is a 32-bit int (int range[2] is
  * passed to VecGetOwnershipRange, src/solver.c:568,588), PetscScalar == PetscReal == double

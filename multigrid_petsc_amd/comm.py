@@ -25,6 +25,7 @@ def _lib():
     L.mg_comm_loopback_shared_destroy.argtypes = [C.c_void_p]
     L.mg_comm_loopback_create.restype = C.c_void_p
     L.mg_comm_loopback_create.argtypes = [C.c_void_p, C.c_int]
+    L.mg_comm_loopback_inject_fault.argtypes = [C.c_void_p, C.c_int]
     L.mg_comm_last_error.restype = C.c_char_p
     L.mg_comm_destroy.argtypes = [C.c_void_p]
     L.mg_comm_halo.restype = C.c_int
@@ -120,6 +121,10 @@ class LoopbackWorld:
             if e is not None:
                 raise e
         return results
+
+    def inject_fault(self, rank):
+        """test aid: from now on `rank` (>= 1) receives a wrong plane as its lo ghost (-1: off)"""
+        _lib().mg_comm_loopback_inject_fault(self.shared, rank)
 
     def close(self):
         if self.shared:

@@ -84,6 +84,9 @@ static int rccl_load(void) {
     return 0;
 }
 #define NCK(call) do { int rc_ = (call); if (rc_) return cfail(MGK_ECOMM, #call, g_rccl.GetErrorString(rc_)); } while (0)
+/* inside ncclGroupStart .. ncclGroupEnd: a failing call closes the group before returning, so that the communicator is not left
+ * inside an open group (every later call on it would be queued into that group and never issued) */
+#define NCKG(call) do { int rc_ = (call); if (rc_) { cfail(MGK_ECOMM, #call, g_rccl.GetErrorString(rc_)); g_rccl.GroupEnd(); return MGK_ECOMM; } } while (0)
 
 typedef struct rccl_impl {
     nccl_comm_t comm;
@@ -124,12 +127,12 @@ static int rccl_halo_n(mg_comm *c, mgk_ctx *ctx, int nf, void *const *fields, co
         const size_t cnt = (size_t)g->plane, pb = (size_t)esz * (size_t)g->plane;  /* elements / bytes per padded plane */
         char *f = (char *)fields[q];
         if (c->rank > 0) {
-            NCK(g_rccl.Send(f + pb, cnt, dt, c->rank - 1, im->comm, s));                       /* first interior plane */
-            NCK(g_rccl.Recv(f, cnt, dt, c->rank - 1, im->comm, s));                            /* lo ghost */
+            NCKG(g_rccl.Send(f + pb, cnt, dt, c->rank - 1, im->comm, s));                       /* first interior plane */
+            NCKG(g_rccl.Recv(f, cnt, dt, c->rank - 1, im->comm, s));                            /* lo ghost */
         }
         if (c->rank < c->nranks - 1) {
-            NCK(g_rccl.Send(f + (size_t)g->nz * pb, cnt, dt, c->rank + 1, im->comm, s));       /* last interior plane */
-            NCK(g_rccl.Recv(f + (size_t)(g->nz + 1) * pb, cnt, dt, c->rank + 1, im->comm, s)); /* hi ghost */
+            NCKG(g_rccl.Send(f + (size_t)g->nz * pb, cnt, dt, c->rank + 1, im->comm, s));       /* last interior plane */
+            NCKG(g_rccl.Recv(f + (size_t)(g->nz + 1) * pb, cnt, dt, c->rank + 1, im->comm, s)); /* hi ghost */
         }
     }
     NCK(g_rccl.GroupEnd());
@@ -157,8 +160,8 @@ static int rccl_allgather_planes(mg_comm *c, mgk_ctx *ctx, void *field, const mg
     for (int r = 0; r < c->nranks; r++) {
         if (r == me) continue;
         const size_t cnt = (size_t)(zstart[r + 1] - zstart[r]) * (size_t)gf->plane;
-        if (mycnt) NCK(g_rccl.Send(mine, mycnt, dt, r, im->comm, s));
-        if (cnt) NCK(g_rccl.Recv(f + (size_t)(zstart[r] + 1) * pb, cnt, dt, r, im->comm, s));
+        if (mycnt) NCKG(g_rccl.Send(mine, mycnt, dt, r, im->comm, s));
+        if (cnt) NCKG(g_rccl.Recv(f + (size_t)(zstart[r] + 1) * pb, cnt, dt, r, im->comm, s));
     }
     NCK(g_rccl.GroupEnd());
     return 0;
@@ -173,8 +176,8 @@ int mg_comm_rccl_self_sendrecv(mg_comm *c, mgk_ctx *ctx, const void *src, void *
     CK(mgk_stream_wait(ctx, s, mgk_stream_compute(ctx)));        /* src was filled on the compute stream */
     const int dt = (esz == 8) ? NCCL_FLOAT64 : NCCL_FLOAT32;
     NCK(g_rccl.GroupStart());
-    NCK(g_rccl.Send(src, (size_t)count, dt, c->rank, im->comm, s));
-    NCK(g_rccl.Recv(dst, (size_t)count, dt, c->rank, im->comm, s));
+    NCKG(g_rccl.Send(src, (size_t)count, dt, c->rank, im->comm, s));
+    NCKG(g_rccl.Recv(dst, (size_t)count, dt, c->rank, im->comm, s));
     NCK(g_rccl.GroupEnd());
     CK(mgk_sync(ctx, s));
     return 0;
@@ -188,8 +191,8 @@ int mg_comm_rccl_self_sendrecv_async(mg_comm *c, mgk_ctx *ctx, const void *src, 
     void *s = mgk_stream_comm(ctx);
     const int dt = (esz == 8) ? NCCL_FLOAT64 : NCCL_FLOAT32;
     NCK(g_rccl.GroupStart());
-    NCK(g_rccl.Send(src, (size_t)count, dt, c->rank, im->comm, s));
-    NCK(g_rccl.Recv(dst, (size_t)count, dt, c->rank, im->comm, s));
+    NCKG(g_rccl.Send(src, (size_t)count, dt, c->rank, im->comm, s));
+    NCKG(g_rccl.Recv(dst, (size_t)count, dt, c->rank, im->comm, s));
     NCK(g_rccl.GroupEnd());
     return 0;
 }
@@ -260,12 +263,19 @@ mg_comm *mg_comm_rccl_create(int rank, int nranks, const void *id, int device) {
 /* ================================================================== */
 /* loopback: ranks = threads of one process sharing one GPU            */
 /* ================================================================== */
+#define LOOP_MAXF 8
 typedef struct loop_shared {
     int nranks;
     pthread_barrier_t bar;
     void **field;             /* posted field pointer per rank */
     int *nz;                  /* posted local plane count per rank */
     double *red;              /* nranks x 64 */
+    /* grouped exchange (halo_n): what every rank posted for the group it is in */
+    int *gnf, *gesz;          /* per rank: number of fields, element size */
+    void **gfield;            /* nranks x LOOP_MAXF */
+    int *gnz;                 /* nranks x LOOP_MAXF */
+    long *gplane;             /* nranks x LOOP_MAXF */
+    int fault_rank;           /* test aid (mg_comm_loopback_inject_fault): this rank receives a WRONG plane as its lo ghost; -1: none */
 } loop_shared;
 
 typedef struct loop_impl { loop_shared *sh; } loop_impl;
@@ -277,13 +287,23 @@ void *mg_comm_loopback_shared_create(int nranks) {
     sh->field = (void **)calloc((size_t)nranks, sizeof(void *));
     sh->nz = (int *)calloc((size_t)nranks, sizeof(int));
     sh->red = (double *)calloc((size_t)nranks * 64, sizeof(double));
+    sh->gnf = (int *)calloc((size_t)nranks, sizeof(int));
+    sh->gesz = (int *)calloc((size_t)nranks, sizeof(int));
+    sh->gfield = (void **)calloc((size_t)nranks * LOOP_MAXF, sizeof(void *));
+    sh->gnz = (int *)calloc((size_t)nranks * LOOP_MAXF, sizeof(int));
+    sh->gplane = (long *)calloc((size_t)nranks * LOOP_MAXF, sizeof(long));
+    sh->fault_rank = -1;
     return sh;
 }
+/* test aid: from now on rank `rank` (>= 1) gets the lo neighbour's FIRST plane instead of its last one as lo ghost -- a transport that
+ * delivers a wrong plane, for the self-test gate to catch (-1 switches it off) */
+void mg_comm_loopback_inject_fault(void *p, int rank) { if (p) ((loop_shared *)p)->fault_rank = rank; }
 void mg_comm_loopback_shared_destroy(void *p) {
     loop_shared *sh = (loop_shared *)p;
     if (!sh) return;
     pthread_barrier_destroy(&sh->bar);
-    free(sh->field); free(sh->nz); free(sh->red); free(sh);
+    free(sh->field); free(sh->nz); free(sh->red);
+    free(sh->gnf); free(sh->gesz); free(sh->gfield); free(sh->gnz); free(sh->gplane); free(sh);
 }
 
 static int loop_halo(mg_comm *c, mgk_ctx *ctx, void *field, const mgk_geom *g, int esz, void *stream) {
@@ -294,13 +314,64 @@ static int loop_halo(mg_comm *c, mgk_ctx *ctx, void *field, const mgk_geom *g, i
     pthread_barrier_wait(&sh->bar);
     const size_t pb = (size_t)esz * (size_t)g->plane;
     char *f = (char *)field;
-    if (c->rank > 0)
-        CK(mgk_d2d(ctx, f, (char *)sh->field[c->rank - 1] + (size_t)sh->nz[c->rank - 1] * pb, pb, s));
-    if (c->rank < c->nranks - 1)
-        CK(mgk_d2d(ctx, f + (size_t)(g->nz + 1) * pb, (char *)sh->field[c->rank + 1] + pb, pb, s));
-    CK(mgk_sync(ctx, s));
+    int rc = 0;                                   /* (an error must not skip the closing barrier: the other ranks wait there) */
+    if (c->rank > 0) {
+        const int src_plane = (sh->fault_rank == c->rank) ? 1 : sh->nz[c->rank - 1];
+        rc = mgk_d2d(ctx, f, (char *)sh->field[c->rank - 1] + (size_t)src_plane * pb, pb, s);
+    }
+    if (!rc && c->rank < c->nranks - 1)
+        rc = mgk_d2d(ctx, f + (size_t)(g->nz + 1) * pb, (char *)sh->field[c->rank + 1] + pb, pb, s);
+    if (!rc) rc = mgk_sync(ctx, s);
     pthread_barrier_wait(&sh->bar);               /* nobody overwrites a plane a neighbour still reads */
-    return 0;
+    return rc ? cfail(rc, "loopback halo", mgk_last_error()) : 0;
+}
+
+/* The grouped exchange.  Every rank posts what it believes the group to be -- number of fields, element size, plane size of every
+ * field -- and compares it with its neighbours' posts before a byte moves: on a real transport a rank whose u_ghost_ok / b_ghost_ok /
+ * bfar_ok flags differ from its neighbour's would send nf planes into nf' receives (a hang, or planes landing in the wrong field);
+ * here that is an error every slab test would show. */
+static int loop_halo_n(mg_comm *c, mgk_ctx *ctx, int nf, void *const *fields, const mgk_geom *const *geoms, int esz, void *stream) {
+    loop_shared *sh = ((loop_impl *)c->impl)->sh;
+    if (c->nranks == 1 || nf < 1) return 0;
+    if (nf > LOOP_MAXF) return cfail(MGK_EINVAL, "loopback halo_n", "more fields than LOOP_MAXF");
+    void *s = stream_of(ctx, stream);
+    int rc = mgk_sync(ctx, s);
+    const int me = c->rank;
+    sh->gnf[me] = nf; sh->gesz[me] = esz;
+    for (int q = 0; q < nf; q++) {
+        sh->gfield[me * LOOP_MAXF + q] = fields[q];
+        sh->gnz[me * LOOP_MAXF + q] = geoms[q]->nz;
+        sh->gplane[me * LOOP_MAXF + q] = geoms[q]->plane;
+    }
+    pthread_barrier_wait(&sh->bar);
+    for (int nb = me - 1; nb <= me + 1 && !rc; nb += 2) {
+        if (nb < 0 || nb >= c->nranks) continue;
+        if (sh->gnf[nb] != nf || sh->gesz[nb] != esz) {
+            char d[160];
+            snprintf(d, sizeof(d), "rank %d groups %d field(s) of %d bytes, its neighbour %d groups %d of %d", me, nf, esz, nb, sh->gnf[nb], sh->gesz[nb]);
+            rc = cfail(MGK_ECOMM, "loopback halo_n: neighbours disagree about the group", d);
+            break;
+        }
+        for (int q = 0; q < nf; q++)
+            if (sh->gplane[nb * LOOP_MAXF + q] != geoms[q]->plane) {
+                rc = cfail(MGK_ECOMM, "loopback halo_n", "neighbours disagree about the plane size of a field of the group");
+                break;
+            }
+    }
+    for (int q = 0; q < nf && !rc; q++) {
+        const size_t pb = (size_t)esz * (size_t)geoms[q]->plane;
+        char *f = (char *)fields[q];
+        if (me > 0) {
+            const int src_plane = (sh->fault_rank == me) ? 1 : sh->gnz[(me - 1) * LOOP_MAXF + q];
+            rc = mgk_d2d(ctx, f, (char *)sh->gfield[(me - 1) * LOOP_MAXF + q] + (size_t)src_plane * pb, pb, s);
+        }
+        if (!rc && me < c->nranks - 1)
+            rc = mgk_d2d(ctx, f + (size_t)(geoms[q]->nz + 1) * pb, (char *)sh->gfield[(me + 1) * LOOP_MAXF + q] + pb, pb, s);
+        if (rc) cfail(rc, "loopback halo_n", mgk_last_error());
+    }
+    if (!rc) { rc = mgk_sync(ctx, s); if (rc) cfail(rc, "loopback halo_n", mgk_last_error()); }
+    pthread_barrier_wait(&sh->bar);
+    return rc;
 }
 
 static int loop_allgather_planes(mg_comm *c, mgk_ctx *ctx, void *field, const mgk_geom *gf, const int *zstart, int esz, void *stream) {
@@ -367,7 +438,7 @@ mg_comm *mg_comm_loopback_create(void *shared, int rank) {
     c->rank = rank; c->nranks = sh->nranks; c->impl = im;
     c->halo = loop_halo; c->allgather_planes = loop_allgather_planes;
     c->allreduce_sum = loop_allreduce_sum; c->barrier = loop_barrier; c->destroy = loop_destroy;
-    c->allreduce_sum_dev = loop_allreduce_sum_dev;
+    c->allreduce_sum_dev = loop_allreduce_sum_dev; c->halo_n = loop_halo_n;
     return c;
 }
 
@@ -466,104 +537,145 @@ static int st_fail(const char *what, int rank, double got, double want) {
 /* plane p (0 .. nz+1, ghosts included) of a field whose owner is `rank`, field number q */
 static double st_code(int rank, int q, int p) { return 1000.0 * (rank + 1) + 100.0 * q + p; }
 
+/* Collective-safe on failure: the gate exists for the run in which something IS wrong, so a rank that sees a wrong
+ * plane, a wrong sum or a failing hook must not leave the sequence -- its peers would sit in the matching send/recv for ever.  Every
+ * buffer is set up before the first collective and the ranks agree on that through ONE all-reduce of a status word; from then on
+ * every rank makes the same fixed sequence of collectives whatever it observes, records the FIRST failure (code + text) and returns
+ * it at the end. */
 int mg_comm_selftest(mg_comm *c, mgk_ctx *ctx) {
     if (!c || !ctx) return cfail(MGK_EINVAL, "mg_comm_selftest", "null argument");
     snprintf(g_cerr, sizeof(g_cerr), "ok");
     const int P = c->nranks, me = c->rank;
     void *cs = mgk_stream_compute(ctx), *ms = mgk_stream_comm(ctx);
-    int rc = 0;
-    /* ---- halo (one field) and halo_n (two fields of different plane counts), fp64 and fp32 ---- */
-    for (int esz = 8; esz >= 4 && !rc; esz -= 4) {
-        mgk_geom g[2];
-        if (esz == 8) { mgk_geom_init(&g[0], 3, 15, 7, 3); mgk_geom_init(&g[1], 3, 15, 7, 2); }
-        else { mgk_geom_init_f32(&g[0], 3, 15, 7, 3); mgk_geom_init_f32(&g[1], 3, 15, 7, 2); }
-        void *d[2] = {NULL, NULL};
-        char *h[2] = {NULL, NULL};
-        for (int q = 0; q < 2 && !rc; q++) {
-            const size_t bytes = (size_t)esz * (size_t)g[q].total;
-            h[q] = (char *)calloc(1, bytes);
-            rc = mgk_malloc(ctx, &d[q], bytes);
-            if (rc || !h[q]) { rc = rc ? rc : MGK_EINVAL; break; }
-            for (int p = 0; p <= g[q].nz + 1; p++)
-                for (long e = 0; e < g[q].plane; e++) {
-                    const double v = (p == 0 || p == g[q].nz + 1) ? -1.0 : st_code(me, q, p);
-                    if (esz == 8) ((double *)h[q])[(long)p * g[q].plane + e] = v; else ((float *)h[q])[(long)p * g[q].plane + e] = (float)v;
+    int first = 0;
+    char first_err[sizeof(g_cerr)] = "";
+#define NOTE(code, what) do { if (!first) { first = (code); if (!strncmp(g_cerr, "ok", 2)) cfail((code), (what), mgk_last_error()); \
+                                            snprintf(first_err, sizeof(first_err), "%s", g_cerr); } } while (0)
+    /* ---- setup (local): halo fields (two of different plane counts) in fp64 and fp32, the all-gather level, the reduce slot ---- */
+    mgk_geom g[2][2], gg;
+    void *d[2][2] = {{NULL, NULL}, {NULL, NULL}}, *dgat = NULL, *dred = NULL;
+    char *h[2][2] = {{NULL, NULL}, {NULL, NULL}};
+    double *hgat = NULL;
+    int *zs = NULL;
+    int bad = 0;
+    mgk_geom_init(&g[0][0], 3, 15, 7, 3); mgk_geom_init(&g[0][1], 3, 15, 7, 2);
+    mgk_geom_init_f32(&g[1][0], 3, 15, 7, 3); mgk_geom_init_f32(&g[1][1], 3, 15, 7, 2);
+    mgk_geom_init(&gg, 3, 7, 7, 2 * P);
+    for (int t = 0; t < 2 && !bad; t++) {
+        const int esz = t ? 4 : 8;
+        for (int q = 0; q < 2 && !bad; q++) {
+            const size_t bytes = (size_t)esz * (size_t)g[t][q].total;
+            h[t][q] = (char *)calloc(1, bytes);
+            if (!h[t][q] || mgk_malloc(ctx, &d[t][q], bytes)) { bad = 1; break; }
+            for (int p = 0; p <= g[t][q].nz + 1; p++)
+                for (long e = 0; e < g[t][q].plane; e++) {
+                    const double v = (p == 0 || p == g[t][q].nz + 1) ? -1.0 : st_code(me, q, p);
+                    if (esz == 8) ((double *)h[t][q])[(long)p * g[t][q].plane + e] = v; else ((float *)h[t][q])[(long)p * g[t][q].plane + e] = (float)v;
                 }
-            rc = mgk_h2d(ctx, d[q], h[q], bytes);
+            if (mgk_h2d(ctx, d[t][q], h[t][q], bytes)) bad = 1;
         }
-        for (int pass = 0; pass < 2 && !rc; pass++) {        /* pass 0: halo on field 0; pass 1: halo_n on both */
-            rc = mgk_stream_wait(ctx, ms, cs);
-            if (!rc && pass == 0) rc = c->halo(c, ctx, d[0], &g[0], esz, ms);
-            if (!rc && pass == 1) {
-                void *const ff[2] = {d[0], d[1]};
-                const mgk_geom *const gg[2] = {&g[0], &g[1]};
-                rc = mg_comm_halo_n(c, ctx, 2, ff, gg, esz, ms);
+    }
+    zs = (int *)calloc((size_t)P + 1, sizeof(int));
+    hgat = (double *)calloc((size_t)gg.total, sizeof(double));
+    if (!bad && (!zs || !hgat || mgk_malloc(ctx, &dgat, sizeof(double) * (size_t)gg.total) || mgk_malloc(ctx, &dred, 2 * sizeof(double)))) bad = 1;
+    if (!bad) {
+        for (int r = 0; r <= P; r++) zs[r] = 2 * r;      /* rank r produces planes [2r, 2r+2) of a level with 2P planes */
+        for (int p = zs[me]; p < zs[me + 1]; p++)
+            for (long e = 0; e < gg.plane; e++) hgat[(long)(p + 1) * gg.plane + e] = st_code(me, 7, p);
+        double v[2] = {(double)(me + 1), 0.25};
+        if (mgk_h2d(ctx, dgat, hgat, sizeof(double) * (size_t)gg.total) || mgk_h2d(ctx, dred, v, sizeof(v))) bad = 1;
+    }
+    /* ---- agreement: did the setup succeed everywhere?  (the first collective; every rank enters it) ---- */
+    {
+        double st = bad ? 1.0 : 0.0;
+        int rc = c->allreduce_sum(c, ctx, &st, 1, NULL);
+        if (rc) NOTE(rc, "mg_comm_selftest: all-reduce of the setup status");
+        else if (st != 0.0) {
+            char dd[96];
+            snprintf(dd, sizeof(dd), "buffers could not be set up on %g rank(s)%s", st, bad ? " (this one among them)" : "");
+            first = cfail(MGK_ECOMM, "mg_comm_selftest", dd);
+            snprintf(first_err, sizeof(first_err), "%s", g_cerr);
+        }
+        if (first) goto done;               /* nothing was exchanged yet, and every rank takes this exit together (or the transport's
+                                             * own all-reduce is broken, in which case nothing can be agreed on at all) */
+    }
+    /* ---- halo (one field) and halo_n (two fields of different plane counts), fp64 then fp32 ---- */
+    for (int t = 0; t < 2; t++) {
+        const int esz = t ? 4 : 8;
+        for (int pass = 0; pass < 2; pass++) {               /* pass 0: halo on field 0; pass 1: halo_n on both */
+            int rc = mgk_stream_wait(ctx, ms, cs);
+            if (rc) NOTE(rc, "mg_comm_selftest: stream wait");
+            if (pass == 0) rc = c->halo(c, ctx, d[t][0], &g[t][0], esz, ms);
+            else {
+                void *const ff[2] = {d[t][0], d[t][1]};
+                const mgk_geom *const gq[2] = {&g[t][0], &g[t][1]};
+                rc = mg_comm_halo_n(c, ctx, 2, ff, gq, esz, ms);
             }
-            if (!rc) rc = mgk_stream_wait(ctx, cs, ms);
-            for (int q = 0; q < (pass ? 2 : 1) && !rc; q++) {
-                const size_t bytes = (size_t)esz * (size_t)g[q].total;
-                rc = mgk_d2h(ctx, h[q], d[q], bytes);
-                for (int p = 0; p <= g[q].nz + 1 && !rc; p++) {
+            if (rc) NOTE(rc, pass ? "mg_comm_selftest: halo_n" : "mg_comm_selftest: halo");
+            rc = mgk_stream_wait(ctx, cs, ms);
+            if (rc) NOTE(rc, "mg_comm_selftest: stream wait");
+            for (int q = 0; q < (pass ? 2 : 1); q++) {
+                const size_t bytes = (size_t)esz * (size_t)g[t][q].total;
+                rc = mgk_d2h(ctx, h[t][q], d[t][q], bytes);
+                if (rc) { NOTE(rc, "mg_comm_selftest: read-back"); continue; }
+                for (int p = 0; p <= g[t][q].nz + 1; p++) {
                     double want = st_code(me, q, p);
-                    if (p == 0) want = me > 0 ? st_code(me - 1, q, g[q].nz) : -1.0;
-                    if (p == g[q].nz + 1) want = me < P - 1 ? st_code(me + 1, q, 1) : -1.0;
-                    for (long e = 0; e < g[q].plane && !rc; e += (g[q].plane - 1 > 0 ? g[q].plane - 1 : 1)) {   /* first and last element */
-                        const double got = esz == 8 ? ((double *)h[q])[(long)p * g[q].plane + e] : (double)((float *)h[q])[(long)p * g[q].plane + e];
-                        if (got != want) rc = st_fail(pass ? "halo_n plane" : "halo plane", me, got, want);
+                    if (p == 0) want = me > 0 ? st_code(me - 1, q, g[t][q].nz) : -1.0;
+                    if (p == g[t][q].nz + 1) want = me < P - 1 ? st_code(me + 1, q, 1) : -1.0;
+                    for (long e = 0; e < g[t][q].plane; e += (g[t][q].plane - 1 > 0 ? g[t][q].plane - 1 : 1)) {   /* first and last element */
+                        const double got = esz == 8 ? ((double *)h[t][q])[(long)p * g[t][q].plane + e] : (double)((float *)h[t][q])[(long)p * g[t][q].plane + e];
+                        if (got != want && !first) { first = st_fail(pass ? "halo_n plane" : "halo plane", me, got, want); snprintf(first_err, sizeof(first_err), "%s", g_cerr); }
                     }
                 }
             }
         }
-        for (int q = 0; q < 2; q++) { if (d[q]) mgk_free(ctx, d[q]); free(h[q]); }
-        if (rc && !strncmp(g_cerr, "ok", 2)) cfail(rc, "mg_comm_selftest: halo", mgk_last_error());
     }
-    /* ---- all-gather of planes: rank r produces planes [2r, 2r+2) of a level with 2P planes ---- */
-    if (!rc) {
-        mgk_geom g;
-        mgk_geom_init(&g, 3, 7, 7, 2 * P);
-        int *zs = (int *)calloc((size_t)P + 1, sizeof(int));
-        double *h = (double *)calloc((size_t)g.total, sizeof(double));
-        void *d = NULL;
-        rc = mgk_malloc(ctx, &d, sizeof(double) * (size_t)g.total);
-        if (!zs || !h) rc = rc ? rc : MGK_EINVAL;
-        if (!rc) {
-            for (int r = 0; r <= P; r++) zs[r] = 2 * r;
-            for (int p = zs[me]; p < zs[me + 1]; p++)
-                for (long e = 0; e < g.plane; e++) h[(long)(p + 1) * g.plane + e] = st_code(me, 7, p);
-            rc = mgk_h2d(ctx, d, h, sizeof(double) * (size_t)g.total);
-        }
-        if (!rc) rc = mgk_stream_wait(ctx, ms, cs);
-        if (!rc) rc = c->allgather_planes(c, ctx, d, &g, zs, 8, ms);
-        if (!rc) rc = mgk_stream_wait(ctx, cs, ms);
-        if (!rc) rc = mgk_d2h(ctx, h, d, sizeof(double) * (size_t)g.total);
+    /* ---- all-gather of planes ---- */
+    {
+        int rc = mgk_stream_wait(ctx, ms, cs);
+        if (rc) NOTE(rc, "mg_comm_selftest: stream wait");
+        rc = c->allgather_planes(c, ctx, dgat, &gg, zs, 8, ms);
+        if (rc) NOTE(rc, "mg_comm_selftest: allgather_planes");
+        rc = mgk_stream_wait(ctx, cs, ms);
+        if (rc) NOTE(rc, "mg_comm_selftest: stream wait");
+        rc = mgk_d2h(ctx, hgat, dgat, sizeof(double) * (size_t)gg.total);
+        if (rc) NOTE(rc, "mg_comm_selftest: read-back");
         for (int r = 0; r < P && !rc; r++)
-            for (int p = zs[r]; p < zs[r + 1] && !rc; p++) {
-                const double got = h[(long)(p + 1) * g.plane + g.plane - 1], want = st_code(r, 7, p);
-                if (got != want) rc = st_fail("all-gathered plane", me, got, want);
+            for (int p = zs[r]; p < zs[r + 1]; p++) {
+                const double got = hgat[(long)(p + 1) * gg.plane + gg.plane - 1], want = st_code(r, 7, p);
+                if (got != want && !first) { first = st_fail("all-gathered plane", me, got, want); snprintf(first_err, sizeof(first_err), "%s", g_cerr); }
             }
-        if (d) mgk_free(ctx, d);
-        free(zs); free(h);
     }
     /* ---- all-reduce: host form and device form ---- */
-    if (!rc) {
+    {
         double v[3] = {(double)(me + 1), 1.0, 0.5};
-        rc = c->allreduce_sum(c, ctx, v, 3, NULL);
+        int rc = c->allreduce_sum(c, ctx, v, 3, NULL);
+        if (rc) NOTE(rc, "mg_comm_selftest: allreduce_sum");
         const double want[3] = {0.5 * P * (P + 1), (double)P, 0.5 * P};
-        for (int q = 0; q < 3 && !rc; q++) if (v[q] != want[q]) rc = st_fail("all-reduce (host values)", me, v[q], want[q]);
+        for (int q = 0; q < 3 && !rc; q++)
+            if (v[q] != want[q] && !first) { first = st_fail("all-reduce (host values)", me, v[q], want[q]); snprintf(first_err, sizeof(first_err), "%s", g_cerr); }
     }
-    if (!rc && c->allreduce_sum_dev) {
-        double v[2] = {(double)(me + 1), 0.25};
-        void *d = NULL;
-        rc = mgk_malloc(ctx, &d, sizeof(v));
-        if (!rc) rc = mgk_h2d(ctx, d, v, sizeof(v));
-        if (!rc) rc = mgk_stream_wait(ctx, ms, cs);
-        if (!rc) rc = c->allreduce_sum_dev(c, ctx, (double *)d, 2, ms);
-        if (!rc) rc = mgk_stream_wait(ctx, cs, ms);
-        if (!rc) rc = mgk_d2h(ctx, v, d, sizeof(v));
+    if (c->allreduce_sum_dev) {
+        double v[2] = {0.0, 0.0};
+        int rc = mgk_stream_wait(ctx, ms, cs);
+        if (rc) NOTE(rc, "mg_comm_selftest: stream wait");
+        rc = c->allreduce_sum_dev(c, ctx, (double *)dred, 2, ms);
+        if (rc) NOTE(rc, "mg_comm_selftest: allreduce_sum_dev");
+        rc = mgk_stream_wait(ctx, cs, ms);
+        if (rc) NOTE(rc, "mg_comm_selftest: stream wait");
+        rc = mgk_d2h(ctx, v, dred, sizeof(v));
+        if (rc) NOTE(rc, "mg_comm_selftest: read-back");
         const double want[2] = {0.5 * P * (P + 1), 0.25 * P};
-        for (int q = 0; q < 2 && !rc; q++) if (v[q] != want[q]) rc = st_fail("all-reduce (device values)", me, v[q], want[q]);
-        if (d) mgk_free(ctx, d);
+        for (int q = 0; q < 2 && !rc; q++)
+            if (v[q] != want[q] && !first) { first = st_fail("all-reduce (device values)", me, v[q], want[q]); snprintf(first_err, sizeof(first_err), "%s", g_cerr); }
     }
-    if (rc && !strncmp(g_cerr, "ok", 2)) cfail(rc, "mg_comm_selftest", mgk_last_error());
-    return rc;
+done:
+#undef NOTE
+    for (int t = 0; t < 2; t++) for (int q = 0; q < 2; q++) { if (d[t][q]) mgk_free(ctx, d[t][q]); free(h[t][q]); }
+    if (dgat) mgk_free(ctx, dgat);
+    if (dred) mgk_free(ctx, dred);
+    free(zs); free(hgat);
+    if (first) snprintf(g_cerr, sizeof(g_cerr), "%s", first_err);
+    else snprintf(g_cerr, sizeof(g_cerr), "ok");
+    return first;
 }

@@ -1196,9 +1196,11 @@ static int pc_type_from(const char *t) {
     fprintf(stderr, "[mgpetsc] FATAL: -pc_type %s is not provided by this drop-in (available: jacobi, none, lu on <= 1024 unknowns)\n", t);
     exit(87);
 }
-PetscErrorCode KSPSetType(KSP k, KSPType t) { k->type = ksp_type_from(t); k->type_from_user = 1; return 0; }
+/* (every setter that changes what a sweep IS drops the speculative first sweep the last norm pass may have left in work[0]: it was made
+ * with the old scale / preconditioner / type -- ADVICE round 2) */
+PetscErrorCode KSPSetType(KSP k, KSPType t) { k->type = ksp_type_from(t); k->type_from_user = 1; k->spec_ok = 0; return 0; }
 PetscErrorCode KSPSetOperators(KSP k, Mat A, Mat P) { (void)P; k->A = A; k->spec_ok = 0; return 0; }
-PetscErrorCode KSPSetNormType(KSP k, KSPNormType n) { k->normtype = n; return 0; }
+PetscErrorCode KSPSetNormType(KSP k, KSPNormType n) { k->normtype = n; k->spec_ok = 0; return 0; }
 PetscErrorCode KSPSetTolerances(KSP k, PetscReal rtol, PetscReal atol, PetscReal dtol, PetscInt maxits) {
     /* KSP_NORM_NONE (the smoothers): only max_it matters (src/solver.c:1473-1474); the tolerances are kept for the
      * outer Richardson of -cycle 8 (src/solver.c:1924) */
@@ -1208,8 +1210,8 @@ PetscErrorCode KSPSetTolerances(KSP k, PetscReal rtol, PetscReal atol, PetscReal
     if (maxits != PETSC_DEFAULT) k->maxits = maxits;
     return 0;
 }
-PetscErrorCode KSPRichardsonSetScale(KSP k, PetscReal s) { k->scale = s; return 0; }
-PetscErrorCode KSPChebyshevSetEigenvalues(KSP k, PetscReal emax, PetscReal emin) { k->emax = emax; k->emin = emin; return 0; }
+PetscErrorCode KSPRichardsonSetScale(KSP k, PetscReal s) { k->scale = s; k->spec_ok = 0; return 0; }
+PetscErrorCode KSPChebyshevSetEigenvalues(KSP k, PetscReal emax, PetscReal emin) { k->emax = emax; k->emin = emin; k->spec_ok = 0; return 0; }
 PetscErrorCode PetscObjectSetOptionsPrefix(void *obj, const char prefix[]) {
     KSP k = (KSP)obj;           /* the reference only prefixes KSPs (src/solver.c:1624,1634,1643) */
     snprintf(k->prefix, sizeof(k->prefix), "%s", prefix ? prefix : "");
@@ -1222,6 +1224,7 @@ static const char *kopt(KSP k, const char *name) {
 }
 PetscErrorCode KSPSetFromOptions(KSP k) {                         /* src/solver.c:1476,1492,1509 */
     const char *v;
+    k->spec_ok = 0;
     if ((v = kopt(k, "ksp_type")) && v[0]) { k->type = ksp_type_from(v); k->type_from_user = 1; }
     if ((v = kopt(k, "pc_type")) && v[0]) k->pc = pc_type_from(v);
     if ((v = kopt(k, "ksp_richardson_scale")) && v[0]) k->scale = strtod(v, NULL);
@@ -1236,9 +1239,10 @@ PetscErrorCode KSPSetFromOptions(KSP k) {                         /* src/solver.
         for (int i = 0; i < k->pcobj.mg->levels; i++) KSPSetFromOptions(k->pcobj.mg->smooth[i]);
     return 0;
 }
-PetscErrorCode KSPSetInitialGuessNonzero(KSP k, PetscBool f) { k->guess_nonzero = (f == PETSC_TRUE); return 0; }
+PetscErrorCode KSPSetInitialGuessNonzero(KSP k, PetscBool f) { k->guess_nonzero = (f == PETSC_TRUE); k->spec_ok = 0; return 0; }
 PetscErrorCode KSPGetPC(KSP k, PC *pc) { *pc = &k->pcobj; return 0; }
 PetscErrorCode PCSetType(PC pc, PCType t) {
+    pc->ksp->spec_ok = 0;
     if (!strcmp(t, PCMG)) { pc->ksp->pc = P_MG; return 0; }
     pc->ksp->pc = pc_type_from(t);
     return 0;
@@ -1255,11 +1259,13 @@ PetscErrorCode KSPMonitorSet(KSP k, PetscErrorCode (*m)(KSP, PetscInt, PetscReal
  * Multiplicative V-cycle, one cycle per application, the textbook PCMG recursion:
  *   x_L = 0;  level i > 0:  smooth(b_i, x_i);  r_i = b_i - A_i x_i;  b_{i-1} = R_i r_i;  x_{i-1} = 0;  recurse;
  *                           x_i += P_i x_{i-1};  smooth(b_i, x_i);       level 0:  coarse solve(b_0, x_0)
- * Level solvers are ordinary KSPs of this shim (richardson / chebyshev + jacobi / none, KSP_NORM_NONE, max_it sweeps)
- * configured through -mg_levels_* and -mg_coarse_*.  PETSc's defaults (chebyshev+SOR with estimated eigenvalues on the
- * levels, LU on the coarsest grid) are not provided: without options the level solvers fall back, with a note, to
- * richardson + jacobi, 2 sweeps.  The PETSc version is unpinned and PCMG's internals are version dependent:
- * parity of this path is pinned only against the oracle's restatement of the recursion above (oracle/mgo.c, mgo_pcmg). */
+ * Level solvers are ordinary KSPs of this shim (richardson / chebyshev / preonly + jacobi / none / lu, KSP_NORM_NONE, max_it
+ * sweeps) configured through -mg_levels_* and -mg_coarse_*.  The COARSE solve defaults to PETSc's own default, preonly + LU: an
+ * exact solve with the dense inverse of the coarsest operator (mg_setup, ksp_solve_direct; <= 1024 unknowns).  PETSc's default
+ * LEVEL smoother (chebyshev + SOR with eigenvalues estimated by GMRES) is not provided: without -mg_levels_* options the level
+ * solvers fall back, with a note, to richardson + jacobi, 2 sweeps.  The PETSc version is unpinned and PCMG's internals are
+ * version dependent: parity of this path is pinned only against the oracle's restatement of the recursion above (oracle/mgo.c,
+ * mgo_pcmg) and a dense numpy restatement with an exact coarse solve (tests/test_petsc_shim_gpu.py). */
 static pcmg *need_mg(PC pc, const char *who) {
     if (pc->ksp->pc != P_MG || !pc->mg) { fprintf(stderr, "[mgpetsc] FATAL: %s before PCSetType(PCMG) + PCMGSetLevels\n", who); exit(86); }
     return pc->mg;
@@ -1491,12 +1497,8 @@ static void mat_device_inverse(Mat A) {
     free(inv);
     A->inv_stale = 0;
 }
-static PetscErrorCode ksp_solve_direct(KSP k, Vec b, Vec x) {
-    Mat A = k->A;
-    if (A->m != A->n) UNSUPPORTED("PCLU on a rectangular operator");
-    if (A->m > MGP_LU_MAX) UNSUPPORTED("PCLU on more than 1024 unknowns (it is meant for PCMG's coarsest grid: use more levels)");
-    need_same(b, x, "KSPSolve");
-    if (b->padded == 2 || b == x) UNSUPPORTED("PCLU on a several-grid level operator / in place");
+/* x = A^-1 b with the dense inverse (x is overwritten) */
+static void direct_apply(Mat A, Vec b, Vec x) {
     mat_device_inverse(A);
     const double *bd = vdev(b);
     lz_before_write(x, 1);
@@ -1506,7 +1508,35 @@ static PetscErrorCode ksp_solve_direct(KSP k, Vec b, Vec x) {
         DEV(mgk_dense_mult_f64(G, A->m, A->m, A->d_inv, A->d_c1, A->d_c2, NULL));
         DEV(mgk_pack_f64(G, &x->g, A->d_c2, x->dev, NULL));
     } else DEV(mgk_dense_mult_f64(G, A->m, A->m, A->d_inv, bd, x->dev, NULL));
-    k->b = b; k->x = x; k->its = 1;
+}
+/* -pc_type lu.  With an exact preconditioner B = A^-1:
+ *   preonly, and every Krylov method PETSc would default to (exact after one step): x = A^-1 b;
+ *   richardson, scale 1, max_it >= 1: x_1 = x_0 + 1 * A^-1 (b - A x_0) = A^-1 b whatever the guess: the same;
+ *   richardson, scale s != 1 (or max_it = 0): x_{k+1} = x_k + s A^-1 (b - A x_k) = (1 - s) x_k + s y with y = A^-1 b, i.e. after
+ *     m = max_it steps  x_m = (1 - s)^m x_0 + (1 - (1 - s)^m) y  (x_0 = 0 without KSPSetInitialGuessNonzero) -- NOT an exact solve,
+ *     and PETSc would not make it one (it used to be returned as exact, silently);
+ *   chebyshev + lu: not provided. */
+static PetscErrorCode ksp_solve_direct(KSP k, Vec b, Vec x) {
+    Mat A = k->A;
+    if (A->m != A->n) UNSUPPORTED("PCLU on a rectangular operator");
+    if (A->m > MGP_LU_MAX) UNSUPPORTED("PCLU on more than 1024 unknowns (it is meant for PCMG's coarsest grid: use more levels)");
+    need_same(b, x, "KSPSolve");
+    if (b->padded == 2 || b == x) UNSUPPORTED("PCLU on a several-grid level operator / in place");
+    if (k->type == K_CHEBYSHEV) UNSUPPORTED("-ksp_type chebyshev with -pc_type lu (use preonly or richardson)");
+    k->b = b; k->x = x;
+    if (k->type == K_RICHARDSON && (k->scale != 1.0 || k->maxits < 1)) {
+        Vec y = NULL;
+        VecDuplicate(x, &y);
+        direct_apply(A, b, y);
+        const double c = pow(1.0 - k->scale, (double)k->maxits);        /* weight of the initial guess after max_it damped steps */
+        if (k->guess_nonzero) VecScale(x, c); else VecSet(x, 0.0);
+        VecAXPY(x, 1.0 - c, y);
+        VecDestroy(&y);
+        k->its = k->maxits;
+        return 0;
+    }
+    direct_apply(A, b, x);
+    k->its = 1;
     return 0;
 }
 
@@ -1515,7 +1545,7 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
     Mat A = k->A;
     if (!A || !A->assembled) UNSUPPORTED("KSPSolve without assembled operators");
     if (k->pc == P_MG) return ksp_solve_mg(k, b, x);
-    if (k->pc == P_LU) return ksp_solve_direct(k, b, x);            /* an exact solve whatever the Krylov type */
+    if (k->pc == P_LU) return ksp_solve_direct(k, b, x);            /* exact for preonly / richardson scale 1; damped otherwise */
     if (k->normtype == KSP_NORM_UNPRECONDITIONED) return ksp_solve_monitored(k, b, x);
     if (k->type == K_OTHER) UNSUPPORTED("KSPSolve with a Krylov type other than richardson/chebyshev/preonly");
     if (k->type == K_PREONLY) {                                     /* x = B b: one undamped Richardson step from the zero guess */

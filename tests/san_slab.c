@@ -44,8 +44,44 @@ static void *work(void *p) {
     return NULL;
 }
 
+/* the first-run gate with a transport that delivers ONE wrong plane (rank `bad` gets a wrong lo ghost): every rank must come back
+ * from mg_comm_selftest -- nobody left inside a collective --, the rank that saw the wrong plane with MGK_ECOMM and its message,
+ * the others with 0 */
+typedef struct { int rank; void *shared; int rc; char msg[512]; } fjob;
+static void *fault_work(void *p) {
+    fjob *j = (fjob *)p;
+    mg_comm *cm = mg_comm_loopback_create(j->shared, j->rank);
+    mgk_ctx *ctx = NULL;
+    j->rc = -1;
+    if (!cm || mgk_ctx_create(&ctx, 0)) return NULL;
+    j->rc = mg_comm_selftest(cm, ctx);
+    snprintf(j->msg, sizeof(j->msg), "%s", mg_comm_last_error());
+    mgk_ctx_destroy(ctx);
+    mg_comm_destroy(cm);
+    return NULL;
+}
+static int fault_run(int P, int bad_rank) {
+    fjob *js = (fjob *)calloc((size_t)P, sizeof(fjob));
+    pthread_t *th = (pthread_t *)calloc((size_t)P, sizeof(pthread_t));
+    void *shared = mg_comm_loopback_shared_create(P);
+    mg_comm_loopback_inject_fault(shared, bad_rank);
+    for (int r = 0; r < P; r++) { js[r].rank = r; js[r].shared = shared; pthread_create(&th[r], NULL, fault_work, &js[r]); }
+    int bad = 0;
+    for (int r = 0; r < P; r++) {
+        pthread_join(th[r], NULL);
+        const int want = (r == bad_rank) ? MGK_ECOMM : 0;
+        if (js[r].rc != want) { fprintf(stderr, "fault run: rank %d returned %d (%s), expected %d\n", r, js[r].rc, js[r].msg, want); bad = 1; }
+        if (r == bad_rank && !strstr(js[r].msg, "halo plane")) { fprintf(stderr, "fault run: rank %d does not name the first mismatch: %s\n", r, js[r].msg); bad = 1; }
+    }
+    mg_comm_loopback_shared_destroy(shared);
+    free(js); free(th);
+    printf("SAN_FAULT_%s P=%d bad_rank=%d\n", bad ? "FAILED" : "OK", P, bad_rank);
+    return bad;
+}
+
 int main(int argc, char **argv) {
-    if (argc < 5) { fprintf(stderr, "usage: san_slab P npts levels dist_min_n [mixed]\n"); return 2; }
+    if (argc == 4 && !strcmp(argv[1], "fault")) return fault_run(atoi(argv[2]), atoi(argv[3]));
+    if (argc < 5) { fprintf(stderr, "usage: san_slab P npts levels dist_min_n [mixed] | san_slab fault P bad_rank\n"); return 2; }
     const int P = atoi(argv[1]);
     job base; memset(&base, 0, sizeof(base));
     base.npts = atoi(argv[2]); base.levels = atoi(argv[3]); base.dmin = atoi(argv[4]); base.mixed = argc > 5 && !strcmp(argv[5], "mixed");

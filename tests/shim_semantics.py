@@ -42,6 +42,7 @@ def type_shim(L):
     L.KSPSolve.argtypes = [vp, vp, vp]
     L.KSPBuildResidual.argtypes = [vp, vp, vp, C.POINTER(vp)]
     L.KSPDestroy.argtypes = [C.POINTER(vp)]
+    L.KSPRichardsonSetScale.argtypes = [vp, d]
     return L
 
 
@@ -181,30 +182,81 @@ def speculative_sweep_is_adopted_only_when_nothing_changed(L, orc):
     L.KSPSetInitialGuessNonzero(k, 1)
     V, val = C.c_void_p(), C.c_double()
 
-    def sweeps(x, rhs, m):
+    def sweeps(x, rhs, m, s=0.8):
         for _ in range(m):
-            x = x + 0.8 * (d * (rhs - A @ x))
+            x = x + s * (d * (rhs - A @ x))
         return x
 
     tol = 1e-12 * max(np.abs(uv).max(), 1.0) * 100
-    for change in ("nothing", "u", "b"):
+    # "scale" / "options": a PARAMETER of the solver changes between the norm and the solve: the sweep the norm pass made
+    # with the old scale must be dropped, both sweeps of the next solve use the new one
+    for change in ("nothing", "u", "b", "scale", "options"):
         _set(L, u, uv); _set(L, b, bv)
         L.KSPSolve(k, b, u)
         x = sweeps(uv, bv, 2)
         L.KSPBuildResidual(k, None, r, C.byref(V))
         L.VecNorm(V, NORM_2, C.byref(val))
         assert abs(val.value - np.linalg.norm(bv - A @ x)) <= 1e-12 * np.linalg.norm(bv - A @ x)
-        rhs = bv
+        rhs, s2 = bv, 0.8
         if change == "u":
             L.VecScale(u, 0.5); x = 0.5 * x
         if change == "b":
             L.VecScale(b, 2.0); rhs = 2.0 * bv
+        if change == "scale":
+            L.KSPRichardsonSetScale(k, 0.5); s2 = 0.5
+        if change == "options":
+            L.PetscOptionsSetValue(None, b"-ksp_richardson_scale", b"0.6")
+            L.KSPSetFromOptions(k); s2 = 0.6
         L.KSPSolve(k, b, u)
-        x2 = sweeps(x, rhs, 2)
+        x2 = sweeps(x, rhs, 2, s2)
+        if change in ("scale", "options"):          # back to the scale of the other rounds
+            L.PetscOptionsSetValue(None, b"-ksp_richardson_scale", b"0.8")
+            L.KSPRichardsonSetScale(k, 0.8)
         assert np.max(np.abs(_get(L, u, n) - x2)) <= tol, change
         assert np.max(np.abs(_get(L, r, n) - (bv - A @ sweeps(uv, bv, 2)))) <= tol * np.abs(A).max(), change     # r was stored by the norm pass
     L.KSPDestroy(C.byref(k))
     for v in (u, b, r):
+        L.VecDestroy(C.byref(v))
+    L.MatDestroy(C.byref(mA))
+
+
+def richardson_with_lu_is_damped_not_exact(L, orc):
+    """-pc_type lu (the dense inverse of a small operator): preonly and richardson with scale 1 return A^-1 b whatever the guess;
+    richardson with scale s != 1 makes max_it DAMPED steps x <- (1 - s) x + s A^-1 b, as PETSc would (it used to come
+    back as the exact solution, silently)."""
+    L.PetscInitialize(None, None, None, None)
+    L.PetscOptionsSetValue(None, b"-pc_type", b"lu")
+    A = _dense(orc, "A", 17, 0)
+    mA = _assemble(L, A)
+    n = A.shape[0]
+    rng = np.random.default_rng(5)
+    bv, x0 = rng.standard_normal(n), rng.standard_normal(n)
+    y = np.linalg.solve(A, bv)
+    u, b = C.c_void_p(), C.c_void_p()
+    L.MatCreateVecs(mA, C.byref(u), C.byref(b))
+    _set(L, b, bv)
+    tol = 1e-10 * np.abs(y).max()
+    for ktype, scale, maxit, guess in ((b"preonly", 1.0, 1, 0), (b"richardson", 1.0, 2, 1), (b"richardson", 1.0, 1, 0),
+                                       (b"richardson", 0.5, 3, 0), (b"richardson", 0.5, 3, 1), (b"richardson", 1.3, 2, 1), (b"richardson", 0.7, 0, 1)):
+        k = C.c_void_p()
+        L.KSPCreate(1, C.byref(k))
+        L.KSPSetType(k, ktype); L.KSPSetOperators(k, mA, mA); L.KSPSetNormType(k, 0)
+        L.KSPSetTolerances(k, 1e-7, -2.0, -2.0, maxit)
+        L.KSPSetFromOptions(k)
+        L.KSPRichardsonSetScale(k, scale)
+        L.KSPSetInitialGuessNonzero(k, guess)
+        _set(L, u, x0)
+        L.KSPSolve(k, b, u)
+        x = x0.copy() if guess else np.zeros(n)
+        if ktype == b"preonly":
+            x = y
+        else:
+            for _ in range(maxit):
+                x = (1.0 - scale) * x + scale * y
+        got = _get(L, u, n)
+        assert np.max(np.abs(got - x)) <= tol, (ktype, scale, maxit, guess, np.max(np.abs(got - x)))
+        L.KSPDestroy(C.byref(k))
+    for v in (u, b):
         L.VecDestroy(C.byref(v))
     L.MatDestroy(C.byref(mA))
 
@@ -215,5 +267,6 @@ if __name__ == "__main__":      # python tests/shim_semantics.py <shared library
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from oracle import Oracle
     lib = type_shim(C.CDLL(sys.argv[1], mode=os.RTLD_LOCAL))
-    {"lazy": lazy_temporaries_keep_petsc_semantics, "spec": speculative_sweep_is_adopted_only_when_nothing_changed}[sys.argv[2]](lib, Oracle())
+    {"lazy": lazy_temporaries_keep_petsc_semantics, "spec": speculative_sweep_is_adopted_only_when_nothing_changed,
+     "lu": richardson_with_lu_is_damped_not_exact}[sys.argv[2]](lib, Oracle())
     print("SEMANTICS_OK", sys.argv[2])

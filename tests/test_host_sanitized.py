@@ -147,6 +147,15 @@ def test_slab_ranks_under_sanitizers(san, tmp_path, P, npts, levels, dmin, extra
         assert m and int(m.group(3)) > 0 and int(m.group(4)) > 0, out[-400:]
 
 
+@pytest.mark.parametrize("P,bad", [(2, 1), (3, 1), (8, 5)])
+def test_selftest_gate_returns_on_every_rank_when_one_plane_is_wrong(san, tmp_path, P, bad):
+    """mg_comm_selftest must be collective-safe on FAILURE.  The loopback transport is told to hand rank `bad` a wrong
+    lo ghost plane; every rank-thread must return from the gate (a rank that left the fixed sequence early would leave the others in
+    a barrier: this test would time out), the bad rank with MGK_ECOMM and the first mismatch named, the others with 0."""
+    out = _run(san["slab"], ["fault", str(P), str(bad)], tmp_path)
+    assert f"SAN_FAULT_OK P={P} bad_rank={bad}" in out
+
+
 # objects the REFERENCE's own code never releases (SURVEY 3.3: rv[0] is duplicated twice, src/solver.c:1460 and :1515; the PCMG and
 # I-cycle drivers keep their work vectors): leaks of the caller, not of the drop-in -- everything else still counts
 REF_LEAKS = "leak:MultigridVcycle\nleak:MultigridPetscPCMG\nleak:MultigridIcycle\nleak:SetUpSolver\nleak:SetUpPostProcess\n"

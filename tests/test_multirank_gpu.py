@@ -189,6 +189,25 @@ def test_bench_two_processes_host_staged_transport(tmp_path):
     assert abs(j2["residual_reduction_per_cycle"] - j1["residual_reduction_per_cycle"]) <= 1e-12
 
 
+@pytest.mark.timeout(900)
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` exactly as the driver types it for N = 1 -- NO `-m torch.distributed.run` in front: bench.py starts the
+    launcher itself as a child process (the parent never touches HIP), and ONE JSON line with n_gpus = 2 comes back through it, exit
+    code 0.  Both ranks share GPU 0 here (host-staged transport: RCCL refuses two ranks on one device)."""
+    import json
+    env = dict(os.environ, MG_BENCH_DEVICE="0", MG_BENCH_TRANSPORT="host", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--npts", "129",
+                        "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=800)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["transport"] == "host" and j["transport_fallback"] is False
+    assert j["value"] > 0 and j["scaling"] == "strong"
+
+
 @pytest.mark.timeout(300)
 def test_fixed_count_cycling_defers_the_norms_on_slabs():
     """mg_solver_cycles (bench.py's loop): the per-cycle sums of squares stay on the device and are all-reduced once at the
@@ -257,6 +276,35 @@ def test_transport_selftest_on_loopback_ranks(P):
         assert all(world.run(fn))
     finally:
         world.close()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("P,bad", [(2, 1), (8, 3)])
+def test_transport_selftest_returns_on_every_rank_when_a_plane_is_wrong(P, bad):
+    """the gate is collective-safe on FAILURE: with a transport that hands rank `bad` a wrong lo ghost plane every rank returns from
+    mg_comm_selftest (none is left inside a collective -- this test would time out), `bad` with the first mismatch named, the rest 0"""
+    from multigrid_petsc_amd.comm import LoopbackWorld, _lib
+    from multigrid_petsc_amd.mgk import Mgk
+    world = LoopbackWorld(P)
+    world.inject_fault(bad)
+
+    def fn(rank, comm):
+        m = Mgk(0)
+        try:
+            rc = _lib().mg_comm_selftest(comm, m.ctx)
+            return rc, _lib().mg_comm_last_error().decode()
+        finally:
+            m.close()
+
+    try:
+        res = world.run(fn)
+    finally:
+        world.close()
+    for r, (rc, msg) in enumerate(res):
+        if r == bad:
+            assert rc != 0 and "halo plane" in msg and f"rank {bad}" in msg, (rc, msg)
+        else:
+            assert rc == 0, (r, rc, msg)
 
 
 @pytest.mark.timeout(120)

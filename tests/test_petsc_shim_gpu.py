@@ -580,3 +580,13 @@ def test_lazy_temporaries_keep_petsc_semantics(orc):
 def test_speculative_sweep_of_the_norm_pass_is_adopted_only_when_nothing_changed(orc):
     from shim_semantics import speculative_sweep_is_adopted_only_when_nothing_changed, type_shim
     speculative_sweep_is_adopted_only_when_nothing_changed(type_shim(_shim()), orc)
+
+
+def test_richardson_with_lu_is_damped_not_exact():
+    """a process of its own (it changes -pc_type in the options database): see tests/shim_semantics.py"""
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "multigrid_petsc_amd", "libmgpetsc.so")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "shim_semantics.py"), lib, "lu"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and "SEMANTICS_OK lu" in p.stdout, (p.returncode, p.stdout[-3000:])

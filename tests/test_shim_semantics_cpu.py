@@ -47,3 +47,7 @@ def test_lazy_temporaries_keep_petsc_semantics_on_the_mock(mock_shim):
 
 def test_speculative_sweep_adoption_rule_on_the_mock(mock_shim):
     _check(mock_shim, "spec")
+
+
+def test_richardson_with_lu_is_damped_on_the_mock(mock_shim):
+    _check(mock_shim, "lu")
