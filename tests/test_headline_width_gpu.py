@@ -255,4 +255,5 @@ def test_headline_cycles_equal_the_oracle_cycles(orc):
     del u
     eo = orc.error_norms(3, 1025, ref["u"])
     assert same, "solution after two cycles differs from the oracle's"
-    assert e[0] == eo[0] and abs(e[1] - eo[1]) <= 1e-12 * eo[1] and abs(e[2] - eo[2]) <= 1e-12 * eo[2]
+    # (the three GetError sums over 1.07e9 points: the max is exact, the sums differ in summation order only -- 9e-12 observed)
+    assert e[0] == eo[0] and abs(e[1] - eo[1]) <= 1e-10 * eo[1] and abs(e[2] - eo[2]) <= 1e-10 * eo[2]
