@@ -1,6 +1,6 @@
 """rank 3 of 8 (phantom neighbours, free link model) for a rocprofv3 kernel trace: 12 cycles of the 1023^3 V(3,3) cycle"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multigrid_petsc_amd.comm import phantom_comm
 from multigrid_petsc_amd.solver import Solver
 c = phantom_comm(3, 8, 0.0, 0.0)
