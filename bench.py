@@ -52,6 +52,41 @@ def cpu_baseline(args):
                       f"{levels} levels, {cycles} cycles, solve loop only ({r['seconds']:.2f} s)"}
 
 
+def cpu_reference_loop(threads, npts=2049):
+    """the reference's OWN V-cycle loop (src/solver.c:1526-1553, unmodified objects of /root/reference/src/*.c) on the
+    host cores, over a PETSc-equivalent CPU data path -- assembled CSR SpMV + Jacobi + BLAS-1 (MGPETSC_NO_RECOGNITION=1: the matrices
+    the reference assembles are applied as matrices) -- timed by the reference's own `Solver walltime` window.  The binary
+    (build/refdriver/poisson_cpu, made by __graft_entry__.build() where the reference tree exists) links the drop-in's host logic with
+    a host-memory OpenMP backend of the kernel ABI; it is a bench-only artefact, PETSc itself being unavailable offline: kind "port".
+    2-D, the family of BASELINE config 2, at a bounded npts."""
+    import re
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "build", "refdriver", "poisson_cpu")
+    if not os.path.exists(exe):
+        return {"value": None, "error": "build/refdriver/poisson_cpu is not built (it needs the reference tree at build time)"}
+    levels = 0
+    while (npts - 1) % (2 ** levels) == 0 and (npts - 1) // (2 ** levels) - 1 >= 1:
+        levels += 1
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "poisson.in"), "w") as f:
+            f.write(f"-npts {npts}\n-mesh 0\n-iter 1000\n-grids {levels}\n-levels {levels}\n-cycle 0\n-map 2\n-v 3,3\n-moreNorm 0\n"
+                    "-pc_type jacobi\n-ksp_richardson_scale 0.8\n")
+        env = dict(os.environ, MGPETSC_NO_RECOGNITION="1", OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close")
+        p = subprocess.run([exe], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    m, it = re.search(r"Solver walltime:\s+(\S+)", p.stdout), re.search(r"Number of iterations:\s+(\d+)", p.stdout)
+    if p.returncode != 0 or not m or not it:
+        return {"value": None, "error": f"poisson_cpu rc={p.returncode}: {p.stdout[-300:]}"}
+    wall, cycles = float(m.group(1)), int(it.group(1))
+    dof = sum((3 if l == levels - 1 else 6) * float((npts - 1) // (2 ** l) - 1) ** 2 for l in range(levels))
+    return {"value": dof * cycles / wall, "unit": "DOF-updates/s", "cores": threads, "kind": "port",
+            "ms_per_cycle": 1e3 * wall / cycles,
+            "sample": f"the reference's unmodified driver (src/solver.c:1526-1553 loop, its own Solver walltime {wall:.2f} s) over the drop-in's "
+                      f"host logic + host CSR backend (assembled AIJ SpMV, Jacobi, BLAS-1; OpenMP), 2-D npts={npts} ({npts - 2}^2), "
+                      f"{levels} levels, V(3,3), solved to 1e-7 in {cycles} cycles; PETSc itself is unavailable offline"}
+
+
 def stream_ceiling(device, n_doubles):
     """Measured HBM ceiling on this box: STREAM triad a = b + s*c over arrays of the fine field's
     size, 24 B per element like a Jacobi sweep, HIP-event timed; best of a few launch shapes."""
@@ -488,6 +523,11 @@ def main():
                 except Exception as e:   # reporting only
                     c_ = {"error": str(e)}
                 c_["baseline_config"] = name
+                if name == "config2" and not args.no_cpu_baseline:
+                    try:     # the CPU column of the one configuration the reference itself can run (reporting only)
+                        c_["cpu_baseline"] = cpu_reference_loop(args.cpu_threads)
+                    except Exception as e:   # noqa: BLE001
+                        c_["cpu_baseline"] = {"value": None, "error": str(e)}
                 out["configs"].append(c_)
         if not args.no_cpu_baseline and world == 1:
             try:

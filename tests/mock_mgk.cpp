@@ -767,7 +767,9 @@ int mgk_error_sums_f64(mgk_ctx *c, const mgk_geom *g, const double *u, const dou
     e3[0] = m; e3[1] = s1; e3[2] = s2;
     return 0;
 }
-#define FLAT(NAME, ARGS, BODY) int NAME ARGS { if (!c) return fail(MGK_EINVAL, #NAME); return run(c, [=] { for (long q = 0; q < n; q++) { BODY; } }); }
+// (the _Pragma lines: no-ops in the test builds; bench.py's CPU baseline artefact build/refdriver/poisson_cpu is this file compiled -O3 -fopenmp --
+// the CSR / BLAS-1 data path of the reference's PETSc on the host cores)
+#define FLAT(NAME, ARGS, BODY) int NAME ARGS { if (!c) return fail(MGK_EINVAL, #NAME); return run(c, [=] { _Pragma("omp parallel for schedule(static)") for (long q = 0; q < n; q++) { BODY; } }); }
 FLAT(mgk_flat_axpy, (mgk_ctx *c, long n, double a, const double *x, double *y, void *), y[q] = y[q] + a * x[q])
 FLAT(mgk_flat_aypx, (mgk_ctx *c, long n, double a, const double *x, double *y, void *), y[q] = x[q] + a * y[q])
 FLAT(mgk_flat_axpbypcz, (mgk_ctx *c, long n, double a, double b, double g, const double *x, const double *y, double *z, void *), z[q] = (a * x[q] + b * y[q]) + g * z[q])
@@ -776,7 +778,9 @@ FLAT(mgk_flat_scale, (mgk_ctx *c, long n, double a, double *z, void *), z[q] = a
 FLAT(mgk_flat_pointwise_mult, (mgk_ctx *c, long n, const double *x, const double *y, double *z, void *), z[q] = x[q] * y[q])
 int mgk_flat_dot(mgk_ctx *c, long n, const double *x, const double *y, double *out, void *) {
     if (!c || !x || !y || !out) return fail(MGK_EINVAL, "mgk_flat_dot");
-    long double s = 0; for (long q = 0; q < n; q++) s += (long double)x[q] * y[q];
+    long double s = 0;
+    _Pragma("omp parallel for schedule(static) reduction(+:s)")
+    for (long q = 0; q < n; q++) s += (long double)x[q] * y[q];
     deliver(c, (double)s, out);
     return 0;
 }
@@ -789,6 +793,7 @@ int mgk_csr_mult_f64(mgk_ctx *c, long nrows, const long *rowptr, const int *col,
                      const double *addto, int row_n, long row_pitch, long row_org, void *) {
     if (!c || !rowptr || !col || !val || !x || !y) return fail(MGK_EINVAL, "mgk_csr_mult_f64");
     return run(c, [=] {
+        _Pragma("omp parallel for schedule(static)")
         for (long r = 0; r < nrows; r++) {
             double sum = 0.0;
             for (long q = rowptr[r]; q < rowptr[r + 1]; q++) sum += val[q] * x[col[q]];
