@@ -185,7 +185,10 @@ def cycle_compulsory_bytes(dim, npts, levels, precision):
             # sweep 25, two sweeps 24 = 99 at level 0 (115 - 24 without the norm pass below it: 91); levels >= 127^2 without pairs:
             # zero-guess sweep from the restriction above (1), one sweep 24, sweep + residual + restriction 26, prolongation sweep 25,
             # two sweeps 48 = 124; below that the kernel-per-operation count
-            per = (99.0 if l == 0 else 91.0) if n >= 2047 else (124.0 if n >= 127 else 172.0)
+            # round 3 (fuse bit 13): THREE sweeps per pass on every level with kernels of its own (n >= 127): norm + three pre-smoothing
+            # sweeps 24 (below level 0: the three from the zero guess over b alone, 16), residual + restriction 16 + 2, prolongation + three
+            # post-smoothing sweeps 25: 67 at level 0, 59 below; the LDS tail (n <= 63): the per-operation count
+            per = (67.0 if l == 0 else 59.0) if n >= 127 else 172.0
         if precision == "mixed":
             # fp32 inner cycle: half the fp64 bytes of a level that starts from the zero guess, with the three-sweep pass where the level
             # sweeps in pairs (n >= 255); level 0 adds the fp64 outer pass (u += e, r = b - A u -> fp32: 8 + 4 + 8 read, 8 + 4 written)
@@ -246,7 +249,8 @@ def run_config(dim, npts, precision, steps, warmup, device):
            "ms_per_cycle": 1e3 * el / steps, "dof_updates_per_s": s.dof_updates_per_cycle * steps / el, "steps": steps, "warmup": warmup}
     if pair_n:
         t = pair_ms / pair_n
-        out["dominant_kernel"] = {"kernel": "two fine-level sweeps in one pass", "avg_launch_ms": t, "launches": pair_n,
+        out["dominant_kernel"] = {"kernel": "three fine-level sweeps (+ norm) in one pass" if dim == 2 else "two fine-level sweeps in one pass",
+                                  "avg_launch_ms": t, "launches": pair_n,
                                   "achieved_GBs": 3 * esz * N0 / (t * 1e-3) / 1e9, "frac": 3 * esz * N0 / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
     elif one_n:
         t = one_ms / one_n

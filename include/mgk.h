@@ -417,6 +417,26 @@ int  mgk_correct_residual_f64_f32_jz(mgk_ctx *ctx, const mgk_geom *g, const mgk_
 int  mgk_pack_f32(mgk_ctx *ctx, const mgk_geom *g32, const double *compact_dev, float *padded_dev, void *stream);
 int  mgk_unpack_f32(mgk_ctx *ctx, const mgk_geom *g32, const float *padded_dev, double *compact_dev, void *stream);
 
+/* ---- round 3: THREE sweeps per pass, 2-D (independent-wave kernels, any vertex-centred 2-D grid) ----
+ * KSPSolve with max_it = 3 (src/solver.c:1531, :1536, :1542) in ONE pass over the level instead of a sweep + a two-sweep pass:
+ *   mgk_jacobi3_2d_f64          unew = J(J(J(u)))                                                                    24 B / unknown
+ *   mgk_jacobi3_2d_sumsq_f64    ... and *sumsq_host = || b - A u ||^2 of the INPUT field: the norm that closes cycle k (:1545-1546)
+ *                               and all three pre-smoothing sweeps of cycle k+1 (:1531); unew is adopted only if a cycle follows
+ *   mgk_jacobi3_2d_zero_f64     from the zero guess (:1536): the first sweep is scale * (b * dinv), u is not read         16 B
+ *   mgk_prolong_jacobi3_2d_f64  unew = J(J(J(u + P uc))): MatMult(pro) + VecAXPY + the three post-smoothing sweeps (:1540-1542)  25 B
+ * coef / dinv: the level's five constants {(i-1), W, C, E, (i+1)} and 1 / diag; or ctab / dtab != NULL: per-row tables (stretched
+ * meshes, as the *_rowcoef_* entry points; coef may then be NULL).  Every stage is the arithmetic of mgk_jacobi_f64: the results
+ * equal three separate sweeps bit for bit. */
+int  mgk_jacobi3_2d_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale, const double *ctab, const double *dtab,
+                        const double *b, const double *u, double *unew, void *stream);
+int  mgk_jacobi3_2d_sumsq_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale, const double *ctab, const double *dtab,
+                              const double *b, const double *u, double *unew, double *sumsq_host, void *stream);
+int  mgk_jacobi3_2d_zero_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale, const double *ctab, const double *dtab,
+                             const double *b, double *unew, void *stream);
+int  mgk_prolong_jacobi3_2d_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
+                                const double *ctab, const double *dtab, const double *b, const double *uc, const double *u, double *unew,
+                                void *stream);
+
 /* tuning knob for the marching stencil kernel (profiling only): <=0 keeps the built-in choice */
 void mgk_set_tuning(int variant, int zchunk);
 

@@ -56,7 +56,10 @@ typedef struct mg_config {
                          * sweeps (mgk_prolong_jacobi2_f64); the third sweep is the first stage of the two-sweep pass that evaluates the
                          * norm (mgk_jacobi2_sumsq_mid_f64): 91 B per fine unknown and cycle.  The iterate the norm belongs to is not
                          * stored; when the iteration stops one more sweep materialises it;
-                         * default (-1): bits 0-5 and 8-12 on */
+                         * bit 13 (2-D, fp64, Richardson, uniform and stretched meshes): THREE sweeps per pass (mgk_jacobi3_2d_*): pre-smoothing
+                         * from the zero guess in one pass over b, post-smoothing in one pass with the prolongation, and the norm pass of
+                         * bit 3 makes all three pre-smoothing sweeps of the next cycle: three passes over a level per V(3,3) cycle;
+                         * default (-1): bits 0-5 and 8-13 on */
     int overlap;        /* nranks > 1: halo of sweep k on the comm stream while sweep k's interior runs; default on (-1) */
     int graph;          /* replay the launch-bound coarse levels as one captured HIP graph; default on (-1) */
     int pair_min_n;     /* levels with n >= pair_min_n run their sweeps two per pass (fuse bit 5); <=0: default 255 (3-D), 2047 (2-D) */

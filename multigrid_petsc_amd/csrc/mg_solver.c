@@ -378,7 +378,7 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
         const int n0 = mg_grid_n(cfg->npts, 0);
         s->cfg.dist_min_n = n0 < 255 ? n0 : 255;
     }
-    if (s->cfg.fuse < 0) s->cfg.fuse = 63 | 256 | 512 | 1024 | 2048 | 4096;
+    if (s->cfg.fuse < 0) s->cfg.fuse = 63 | 256 | 512 | 1024 | 2048 | 4096 | 8192;
     if (s->cfg.pair_min_n <= 0) s->cfg.pair_min_n = (cfg->dim == 3) ? 255 : 2047;   /* where a two-sweep pass beats two sweeps
                                                                                       * (255^3: 0.107 ms against 2 x 0.063) */
     if (s->cfg.mesh) s->cfg.fuse &= ~(16 | 128);   /* row-dependent coefficients (2-D, fp64): the same fused cycle on the row-table forms of the kernels */
@@ -741,8 +741,16 @@ static int srr_ok(const mg_solver *s, int P, int l) {
 /* fuse bit 11: a pre-smoothing KSPSolve of >= 3 sweeps from the zero guess starts with ONE pass that makes three of them and reads b alone
  * (mgk_jacobi2_zero_*): whole 3-D levels that sweep in pairs, fp32 up to 1023^3, fp64 up to 511^3.  The producers of such a level's
  * right-hand side then do not write its zero-guess sweep (fuse bit 8). */
+/* fuse bit 13 (2-D, fp64, Richardson; uniform and stretched meshes): THREE sweeps per pass on every level the cycle launches kernels for
+ * (mgk_jacobi3_2d_*): a KSPSolve of >= 3 sweeps from the zero guess starts with one pass over b (16 B), the post-smoothing is ONE pass with
+ * the prolongation (25 B), and the norm that closes a cycle makes all three pre-smoothing sweeps of the next one (24 B): with the fused
+ * residual + restriction (18 B) a V(3,3) cycle makes three passes over a level, 67 B on the fine level and 59 B below, instead of four. */
+static int j3_2d_ok(const mg_solver *s, int P, int l, int maxit) {
+    return (s->cfg.fuse & 8192) && s->cfg.dim == 2 && P == 0 && s->cfg.ksp_type == MG_KSP_RICHARDSON && maxit >= 3 && !s->L[l].distributed;
+}
 static int triple_ok(const mg_solver *s, int P, int l, int maxit) {
     const mg_level *L = &s->L[l];
+    if (j3_2d_ok(s, P, l, maxit)) return 1;
     if (!(s->cfg.fuse & 2048) || !(s->cfg.fuse & 32) || s->cfg.ksp_type != MG_KSP_RICHARDSON || s->cfg.dim != 3 || s->cfg.mesh) return 0;
     if (maxit < 3 || L->distributed || L->n < s->cfg.pair_min_n || L->n + 1 > 1024) return 0;
     return P == 0 ? mgk_jacobi2_zero_ok_f64(&L->f[0].g) : mgk_jacobi2_zero_ok_f32(&L->f[1].g);
@@ -779,6 +787,22 @@ static int smooth(mg_solver *s, int P, int l, int maxit, int pre) {
     if (maxit < 1 || F->guess_nonzero) F->jz_ready = 0;
     const int mesh = s->cfg.mesh != 0;                   /* -mesh 1/2 (2-D, fp64, one GPU): the row-table forms of the same kernels */
     for (int it = it0; it < maxit; it++) {
+        if (it == 0 && !F->jz_ready && j3_2d_ok(s, P, l, maxit)) {
+            /* 2-D: sweeps 1-3 in one pass -- over b alone from the zero guess, over u and b otherwise (level 0 of a cycle that has no
+             * speculative sweeps to adopt).  The result goes to tmp and is swapped in: ONE swap in every case (zero guess, plain, adopted
+             * norm pass above), like the one pass of the post-smoothing (prolong_smooth) -- the same even count in every cycle, so the
+             * pointers the coarse-level graph recorded stay valid */
+            if (!F->guess_nonzero)
+                CHK(mgk_jacobi3_2d_zero_f64(s->ctx, &F->g, mesh ? NULL : L->coef, mesh ? 1.0 : L->dinv, s->cfg.scale, mesh ? L->ctab : NULL,
+                                            mesh ? L->dtab : NULL, (const double *)F->b, (double *)F->tmp, NULL));
+            else
+                CHK(mgk_jacobi3_2d_f64(s->ctx, &F->g, mesh ? NULL : L->coef, mesh ? 1.0 : L->dinv, s->cfg.scale, mesh ? L->ctab : NULL,
+                                       mesh ? L->dtab : NULL, (const double *)F->b, (const double *)F->u, (double *)F->tmp, NULL));
+            swap_ptr(&F->u, &F->tmp);
+            F->u_ghost_ok = 0; F->u_ghost_pending = 0;
+            it += 2;
+            continue;
+        }
         if (it == 0 && !F->guess_nonzero && !F->jz_ready && triple_ok(s, P, l, maxit)) {
             /* sweeps 1-3 from the zero guess in one pass over b; u is not an input, so the result lands in u itself: no swap (the
              * two swaps of the zero-guess sweep and the pair it replaces cancel, the pointers the coarse-level graph holds stay valid) */
@@ -1007,6 +1031,15 @@ static int prolong_smooth(mg_solver *s, int P, int l) {
     if (!(s->cfg.fuse & 2) || s->cfg.ksp_type != MG_KSP_RICHARDSON || v0 < 1) {
         CHK(prolong_from(s, P, l));
         return smooth(s, P, l, v0, 0);
+    }
+    if (j3_2d_ok(s, P, l, v0)) {
+        /* 2-D: the prolongation, the correction and the first THREE post-smoothing sweeps in one pass */
+        const int mesh = s->cfg.mesh != 0;
+        CHK(mgk_prolong_jacobi3_2d_f64(s->ctx, &F->g, &Cq->g, mesh ? NULL : Lf->coef, mesh ? 1.0 : Lf->dinv, s->cfg.scale, mesh ? Lf->ctab : NULL,
+                                       mesh ? Lf->dtab : NULL, (const double *)F->b, (const double *)Cq->u, (const double *)F->u, (double *)F->tmp, NULL));
+        swap_ptr(&F->u, &F->tmp);
+        F->u_ghost_ok = 0; F->u_ghost_pending = 0;
+        return v0 > 3 ? smooth(s, P, l, v0 - 3, 0) : 0;
     }
     if (l == 0 && pjp_ok(s, P)) {
         /* the prolongation and the first TWO post-smoothing sweeps in one pass; the third one is made by the pass that evaluates the
@@ -1259,7 +1292,7 @@ gathered:
          * zero-guess sweep when that level is smoothed by its own launches */
         mg_fset *Cq = &s->L[l].f[P];
         const int sweeps = (l == levels - 1) ? v[1] : v[0];
-        const int jz = (s->cfg.fuse & 256) && !no_jz && s->cfg.ksp_type == MG_KSP_RICHARDSON && sweeps >= 1 && !Cq->guess_nonzero;
+        const int jz = (s->cfg.fuse & 256) && !no_jz && s->cfg.ksp_type == MG_KSP_RICHARDSON && sweeps >= 1 && !Cq->guess_nonzero && !triple_ok(s, P, l, sweeps);
         if (s->cfg.mesh) CHK(mgk_residual_restrict_2d_rowcoef_f64(s->ctx, &Lf->f[P].g, &Cq->g, Lf->ctab, (const double *)Lf->f[P].b,
                                                                   (const double *)Lf->f[P].u, (double *)Cq->b, jz ? (double *)Cq->tmp : NULL,
                                                                   s->L[l].dtab, s->cfg.scale, NULL));
@@ -1426,6 +1459,19 @@ static int vcycle_once(mg_solver *s) {
              * a cycle from the recording cycle's count, and the recorded restriction reads level 0's buffers) */
             const int two = (s->cfg.fuse & 1024) && (s->cfg.fuse & 32) && !L->distributed &&
                             s->cfg.v[0] >= 2 && L->n >= s->cfg.pair_min_n && s->lgraph != 1 && (s->cfg.dim == 2 || mgk_jacobi2_sumsq_ok_f64(&F->g));
+            if (j3_2d_ok(s, 0, 0, s->cfg.v[0])) {
+                /* 2-D: ... and ALL THREE pre-smoothing sweeps of the next cycle */
+                const int mesh = s->cfg.mesh != 0;
+                s->prof_kind = 1;
+                void *t = prof_begin(s, 0);
+                s->prof_kind = 0;
+                int rc2 = mgk_jacobi3_2d_sumsq_f64(s->ctx, &F->g, mesh ? NULL : L->coef, mesh ? 1.0 : L->dinv, s->cfg.scale, mesh ? L->ctab : NULL,
+                                                   mesh ? L->dtab : NULL, (const double *)F->b, (const double *)F->u, (double *)F->tmp, &ss, NULL);
+                prof_end(s, t);
+                CHK(rc2);
+                s->spec_valid = 3;
+                goto norm_done;
+            }
             if (s->cfg.mesh && two) CHK(mgk_jacobi2_2d_sumsq_rowcoef_f64(s->ctx, &F->g, L->ctab, L->dtab, s->cfg.scale, (const double *)F->b,
                                                                          (const double *)F->u, (double *)F->tmp, &ss, NULL));
             else if (s->cfg.mesh) CHK(mgk_jacobi_sumsq_rowcoef_f64(s->ctx, &F->g, L->ctab, L->dtab, s->cfg.scale, (const double *)F->b,

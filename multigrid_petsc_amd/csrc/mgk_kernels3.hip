@@ -1,0 +1,268 @@
+// mgk_kernels3.hip -- round 3: three-sweep passes (2-D independent-wave forms; 3-D forms below).  Same build flags as mgk_kernels.hip
+// (-O3 -ffp-contract=off, gfx950 only); shares mgk_dev.hpp with it.
+#include "mgk_dev.hpp"
+
+// ------------------------------------------------------------------------------------------
+// Round 3: THREE Richardson+Jacobi sweeps in one pass, 2-D (src/solver.c:1531 / :1536 / :1542 with max_it = 3):
+//     plain      unew = J(J(J(u)))                               24 B per unknown instead of 24 + 24 (sweep + two-sweep pass)
+//     NORM       ... and || b - A u ||^2 of the INPUT field (the first stage forms that residual anyway): closes cycle k (:1545-1546) and
+//                makes ALL pre-smoothing sweeps of cycle k+1 (:1531); adopted only if a next cycle runs
+//     ZG         from the zero guess: the first sweep is pointwise, u1 = scale * (b * dinv); u is not read: 8 + 8 B (:1536 on a coarse level)
+//     PRO        unew = J(J(J(u + P uc))): prolongation, correction and ALL post-smoothing sweeps (:1540-1542): 25 B
+// With these a V(3,3) cycle makes three passes over a level -- (N + S1 S2 S3)(R)(P + S1' S2' S3') = 24 + 18 + 25 = 67 B on the fine
+// level, (J3 from b)(R)(P + 3 sweeps) = 16 + 18 + 25 = 59 B below -- instead of four (99 / 91 B).
+// Structure of k_pj2d / k_rr2d: every WAVE is independent (no LDS, no barrier).  Lane l holds the column pair x0 = 2 (60 tx + l - 2);
+// x neighbours come by whole-wavefront DPP shifts.  A pair is two columns but a stage consumes ONE column of halo, so three stages
+// need two halo lanes a side: stage 1 is right on the columns c0+1 .. c0+126 of the wave's 128, stage 2 on c0+2 .. c0+125, stage 3 on
+// c0+3 .. c0+124: lanes 2 .. 61 store (120 of 128 columns; the tiles overlap by four lanes).  The wave marches along y with the rows
+// t+1 .. t+3 of u, t .. t+2 of the first sweep and t-1 .. t+1 of the second in registers: at step t it makes the first sweep of row
+// t+2, the second of row t+1, the third of row t.  A chunk [y0, y1) starts four steps early (first sweeps only, then first and
+// second: wave-uniform branches) so that its three-row windows are filled; the rows it recomputes come from L2.
+// Every stage evaluates the expression of k_stencil<MODE_JACOBI> (ascending-column sum, no FMA) and forces the positions outside
+// the grid to zero (the homogeneous Dirichlet ring every sweep sees): the result equals three separate sweeps bit for bit.
+// Stretched meshes: per-row coefficient tables (ctab / dtab) instead of the launch constants, as in the other 2-D kernels.
+// ------------------------------------------------------------------------------------------
+struct J3dArgs {
+    const double *u, *b, *uc;
+    double *out;
+    int nx, ny, nxc, nyc;
+    long rs, crs;
+    int ntx, yc, nwaves;
+    double a0, a2, a3, a4, a6, dinv, scale;
+    const double *ctab, *dtab;
+    double *partials;               // NORM: one partial of || b - A u ||^2 per wave
+};
+// YC = 0: a chunk of a.yc rows per wave, marching with the next row in flight (the big levels: long streams).
+// YC > 0 (even): a chunk of exactly YC rows, EVERY load of the chunk issued before the first sweep and the marching loop fully unrolled
+// (the levels that fit the caches, 127^2 .. 1023^2: they are short of waves, not of bandwidth -- a wave that waits for one row per
+// step spends 0.7 us per step; with all its rows requested at once it pays the latency once).
+template <bool PRO, bool ZG, bool NORM, bool TAB, int YC>
+__global__ void __launch_bounds__(256) k_jacobi3_2d(const J3dArgs a) {
+    using VT = V16<double>;
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tx = wid % a.ntx, cy = wid / a.ntx;
+    const int yc = YC > 0 ? YC : a.yc;
+    const int y0 = cy * yc, y1 = min(y0 + yc, a.ny);
+    if (y0 >= y1) { if (NORM && lane == 0) a.partials[wid] = 0.0; return; }      // whole wave
+    const int pidx = tx * 60 + lane - 2;                      // pair index (= coarse column of the pair's odd fine column)
+    const int x0 = 2 * pidx;
+    const bool xin = (x0 >= 0 && x0 < a.nx);
+    const bool lastvec = (x0 + 2 > a.nx);
+    const bool store = (lane >= 2 && lane <= 61 && xin);
+    const int xc = min(max(x0, 0), a.nx - 1);
+    const double *__restrict__ up_ = a.u + xc;
+    const double *__restrict__ bp_ = a.b + xc;
+    const double *__restrict__ cp_ = PRO ? a.uc + min(max(pidx, -1), a.nxc) : nullptr;
+    double *__restrict__ op_ = a.out + x0;
+    const VT Z = v16_zero<double>();
+    // a row of a field as it counts for a sweep: zero outside the grid (rows -1 / ny and everything beyond, columns < 0 and >= nx)
+    auto fix = [&](VT v, int y) -> VT {
+        if (!xin || y < 0 || y >= a.ny) { v.v[0] = 0.0; v.v[1] = 0.0; }
+        if (lastvec) v.v[1] = 0.0;
+        return v;
+    };
+    auto ldraw = [&](int y) -> VT { return *reinterpret_cast<const VT *>(up_ + (long)min(max(y, -1), a.ny) * a.rs); };
+    auto ldbraw = [&](int y) -> VT { return ldv_stream(bp_ + (long)min(max(y, 0), a.ny - 1) * a.rs, true); };
+    auto ldc = [&](int ic) -> double { return PRO ? cp_[(long)min(max(ic, -1), a.nyc) * a.crs] : 0.0; };
+    auto pA = [&](int y) { return (y & 1) ? (y - 1) >> 1 : (y >> 1) - 1; };
+    auto pB = [&](int y) { return (y & 1) ? (y - 1) >> 1 : (y >> 1); };
+    // u + P uc on row y (k_pj2d: terms in the order of the prolongation's row, weights w = wi * wj as there)
+    auto correct = [&](VT v, int y, double cA, double cB) -> VT {
+        if (PRO) {
+            const bool two = ((y & 1) == 0);
+            const double wi = two ? 0.5 : 1.0;
+            const double wh = wi * 0.5, w1 = wi * 1.0;
+            const double mA = lane_up<true>(cA), mB = lane_up<true>(cB);
+            double s0 = 0.0, s1 = 0.0;
+            s0 += wh * mA; s0 += wh * cA; s1 += w1 * cA;
+            if (two) { s0 += wh * mB; s0 += wh * cB; s1 += w1 * cB; }
+            v.v[0] = v.v[0] + s0; v.v[1] = v.v[1] + s1;
+        }
+        return fix(v, y);
+    };
+    // coefficients of grid row y: the launch constants, or row y of the tables (stretched meshes; wave-uniform scalar loads)
+#define J3_COEFS(y)                                                                                                   \
+    double k0 = a.a0, k2 = a.a2, k3 = a.a3, k4 = a.a4, k6 = a.a6, kd = a.dinv;                                        \
+    if (TAB) { const int yy_ = min(max((y), 0), a.ny - 1); const double *cr_ = a.ctab + 5 * (long)yy_;                \
+                  k0 = cr_[0]; k2 = cr_[1]; k3 = cr_[2]; k4 = cr_[3]; k6 = cr_[4]; kd = a.dtab[yy_]; }
+    // one sweep of row y from the rows lo / c / hi of the previous iterate
+    double nacc = 0.0;
+    auto sweep = [&](const VT &lo, const VT &c, const VT &hi, const VT &bb, int y, bool norm) -> VT {
+        J3_COEFS(y)
+        const double Wv = lane_up<true>(c.v[1]), Ev = lane_dn<true>(c.v[0]);
+        VT o;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const double wv = (e == 0) ? Wv : c.v[0];
+            const double ev = (e == 1) ? Ev : c.v[1];
+            double s = k0 * lo.v[e];
+            s = s + k2 * wv;
+            s = s + k3 * c.v[e];
+            s = s + k4 * ev;
+            s = s + k6 * hi.v[e];
+            const double res = bb.v[e] - s;
+            const double zz = res * kd;
+            o.v[e] = c.v[e] + a.scale * zz;
+            if (NORM && norm) nacc += (store && y >= y0 && y < y1 && !(lastvec && e == 1)) ? res * res : 0.0;     // the points this wave owns
+        }
+        return fix(o, y);
+    };
+    auto sweep0 = [&](const VT &bb, int y) -> VT {            // first sweep from the zero guess (k_jacobi_zero)
+        J3_COEFS(y)
+        (void)k0; (void)k2; (void)k3; (void)k4; (void)k6;
+        VT o;
+#pragma unroll
+        for (int e = 0; e < 2; e++) { const double zz = bb.v[e] * kd; o.v[e] = a.scale * zz; }
+        return fix(o, y);
+    };
+    // one marching step: first sweep of row t+2 (from the corrected u rows ua, ub and the raw row ur = row t+3 with its parents), second
+    // sweep of row t+1, third sweep of row t
+    VT ua = Z, ub = Z;
+    VT b2 = Z, b1 = Z, b0 = Z;                                // b of the rows t+2, t+1, t
+    VT p0 = Z, p1 = Z;                                        // first sweep: rows t, t+1
+    VT q0 = Z, q1 = Z;                                        // second sweep: rows t-1, t
+    auto step = [&](int t, const VT &ur, double cA, double cB, const VT &bnext) {
+        VT p2;
+        if (ZG) p2 = sweep0(b2, t + 2);
+        else {
+            const VT uc = correct(ur, t + 3, cA, cB);
+            p2 = sweep(ua, ub, uc, b2, t + 2, true);
+            ua = ub; ub = uc;
+        }
+        if (t >= y0 - 2) {                                    // wave-uniform
+            const VT q2 = sweep(p0, p1, p2, b1, t + 1, false);
+            if (t >= y0 && t < y1) {
+                const VT o = sweep(q0, q1, q2, b0, t, false);
+                if (store) stv_stream(op_ + (long)t * a.rs, o);
+            }
+            q0 = q1; q1 = q2;
+        }
+        p0 = p1; p1 = p2;
+        b0 = b1; b1 = b2; b2 = fix(bnext, t + 3);
+    };
+    const int t0 = y0 - 4;
+    if constexpr (YC > 0) {
+        // rows t0+1 .. t0+YC+6 of u, t0+2 .. t0+YC+6 of b, and the coarse rows that are their parents: requested together
+        constexpr int NU = YC + 6, NC = NU / 2 + 2;
+        VT U[NU], B[NU];
+        double Cc[NC];
+        const int c0 = pA(t0 + 1);                            // first coarse row needed
+#pragma unroll
+        for (int q = 0; q < NU; q++) { if (!ZG) U[q] = ldraw(t0 + 1 + q); B[q] = ldbraw(t0 + 1 + q); }
+#pragma unroll
+        for (int q = 0; q < NC; q++) Cc[q] = ldc(c0 + q);
+        // t0 = cy * YC - 4 is even, so the parents of row t0 + k are the coarse rows c0 + (k - 1) / 2 (k odd) or c0 + k / 2 - 1 and
+        // c0 + k / 2 (k even) with c0 = t0 / 2: every index below is a compile-time constant once the loop is unrolled
+        if (!ZG) {
+            ua = correct(U[0], t0 + 1, Cc[0], Cc[0]);
+            ub = correct(U[1], t0 + 2, Cc[0], Cc[1]);
+        }
+        b2 = fix(B[1], t0 + 2);
+#pragma unroll
+        for (int sidx = 0; sidx < YC + 4; sidx++) {
+            constexpr int dummy = 0; (void)dummy;
+            const int k = sidx + 3;                           // the raw row of this step is row t0 + k
+            const int ia = (k & 1) ? (k - 1) / 2 : k / 2 - 1;
+            const int ib = (k & 1) ? (k - 1) / 2 : k / 2;
+            step(t0 + sidx, ZG ? Z : U[sidx + 2], Cc[ia], Cc[ib], B[sidx + 2]);
+        }
+    } else {
+        VT ur = Z;
+        double cA = 0.0, cB = 0.0;
+        if (!ZG) {
+            ua = correct(ldraw(t0 + 1), t0 + 1, ldc(pA(t0 + 1)), ldc(pB(t0 + 1)));
+            ub = correct(ldraw(t0 + 2), t0 + 2, ldc(pA(t0 + 2)), ldc(pB(t0 + 2)));
+            ur = ldraw(t0 + 3);
+            cA = ldc(pA(t0 + 3)); cB = ldc(pB(t0 + 3));
+        }
+        b2 = fix(ldbraw(t0 + 2), t0 + 2);
+        VT bn = ldbraw(t0 + 3);
+        for (int t = t0; t < y1; t++) {
+            // loads consumed in the next step
+            VT ur2 = Z;
+            double cA2 = 0.0, cB2 = 0.0;
+            if (!ZG) { ur2 = ldraw(t + 4); cA2 = ldc(pA(t + 4)); cB2 = ldc(pB(t + 4)); }
+            const VT bn2 = ldbraw(t + 4);
+            step(t, ur, cA, cB, bn);
+            ur = ur2; cA = cA2; cB = cB2; bn = bn2;
+        }
+    }
+    if (NORM) {
+        const double sw = wave_sum(nacc);
+        if (lane == 0) a.partials[wid] = sw;
+    }
+#undef J3_COEFS
+}
+// shapes: any 2-D grid (nx odd, as everywhere)
+template <bool PRO, bool ZG, bool NORM>
+static int jacobi3_2d(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gc, const double *coef, double dinv, double scale, const double *ctab, const double *dtab,
+                      const double *b, const double *uc, const double *u, double *unew, void *stream, int *norm_parts) {
+    if (!c || !g || g->dim != 2 || (!coef && !ctab) || (ctab && !dtab) || !b || !unew || (!ZG && (!u || u == unew)) || b == unew)
+        return fail(MGK_EINVAL, "mgk_jacobi3_2d: bad arguments (2-D)");
+    J3dArgs a; memset(&a, 0, sizeof(a));
+    a.u = ZG ? nullptr : u + g->org; a.b = b + g->org; a.out = unew + g->org;
+    a.nx = g->nx; a.ny = g->ny; a.rs = g->pitch;
+    if (PRO) {
+        if (!gc || !uc || gc->dim != 2 || g->nx != 2 * gc->nx + 1 || g->ny != 2 * gc->ny + 1) return fail(MGK_EINVAL, "mgk_prolong_jacobi3_2d: coarse grid does not match");
+        a.uc = uc + gc->org; a.nxc = gc->nx; a.nyc = gc->ny; a.crs = gc->pitch;
+    }
+    if (coef) { a.a0 = coef[0]; a.a2 = coef[1]; a.a3 = coef[2]; a.a4 = coef[3]; a.a6 = coef[4]; }
+    a.dinv = dinv; a.scale = scale; a.ctab = ctab; a.dtab = dtab;
+    a.ntx = ((g->nx + 1) / 2 + 59) / 60;                      // pairs 0 .. (nx-1)/2
+    // levels that fit the caches (rows of <= 1024): short chunks with every load up front (they lack waves, not bandwidth); the big
+    // levels: ~4096 waves (16 per CU) marching over long chunks -- a chunk pays four warm-up steps (two sweep-equivalents) and re-reads
+    // six rows.  Tuning variants 50 / 51 / 52 force the marching form / chunks of 4 / chunks of 8 rows.
+    int ycs = (g->nx + 1 <= 1024) ? 4 : 0;
+    if (g_variant == 50) ycs = 0; else if (g_variant == 51) ycs = 4; else if (g_variant == 52) ycs = 8;
+    if (g_zchunk > 0 && g_variant != 51 && g_variant != 52) ycs = 0;      // an explicit chunk length: the marching form
+    long nch = (4096 + a.ntx - 1) / a.ntx;
+    if (g_zchunk > 0) nch = (g->ny + g_zchunk - 1) / g_zchunk;
+    int yc = (int)((g->ny + nch - 1) / nch);
+    if (yc < 12 && g_zchunk <= 0) yc = 12;
+    if (yc > g->ny) yc = g->ny;
+    if (ycs) yc = ycs;
+    long waves = (long)a.ntx * ((g->ny + yc - 1) / yc);
+    if (NORM && ((waves + 3) / 4) * 4 > c->max_partials) {    // one partial per wave: longer chunks where that would overflow the slots
+        if (ycs) { ycs = 0; }
+        const long maxch = c->max_partials / a.ntx - 1;
+        if (maxch < 1) return fail(MGK_EINVAL, "mgk_jacobi3_2d_sumsq_f64: more waves than partial slots");
+        yc = (int)((g->ny + maxch - 1) / maxch);
+        waves = (long)a.ntx * ((g->ny + yc - 1) / yc);
+    }
+    a.yc = yc;
+    const unsigned nblk = (unsigned)((waves + 3) / 4);
+    a.nwaves = (int)waves;
+    if (NORM) {
+        if (!norm_parts || 4L * nblk > c->max_partials) return fail(MGK_EINVAL, "mgk_jacobi3_2d_sumsq_f64: more waves than partial slots");
+        a.partials = c->partials;
+        *norm_parts = (int)(4 * nblk);
+    }
+    hipStream_t st = S(c, stream);
+#define J3_LAUNCH(TABV, YCV) hipLaunchKernelGGL((k_jacobi3_2d<PRO, ZG, NORM, TABV, YCV>), dim3(nblk), dim3(256), 0, st, a)
+    if (ctab) { if (ycs == 4) J3_LAUNCH(true, 4); else if (ycs == 8) J3_LAUNCH(true, 8); else J3_LAUNCH(true, 0); }
+    else { if (ycs == 4) J3_LAUNCH(false, 4); else if (ycs == 8) J3_LAUNCH(false, 8); else J3_LAUNCH(false, 0); }
+#undef J3_LAUNCH
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int mgk_jacobi3_2d_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale, const double *ctab, const double *dtab,
+                                  const double *b, const double *u, double *unew, void *stream) {
+    return jacobi3_2d<false, false, false>(c, g, nullptr, coef, dinv, scale, ctab, dtab, b, nullptr, u, unew, stream, nullptr);
+}
+extern "C" int mgk_jacobi3_2d_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale, const double *ctab, const double *dtab,
+                                        const double *b, const double *u, double *unew, double *sumsq_host, void *stream) {
+    if (!sumsq_host) return fail(MGK_EINVAL, "mgk_jacobi3_2d_sumsq_f64: bad arguments");
+    int nparts = 0;
+    int rc = jacobi3_2d<false, false, true>(c, g, nullptr, coef, dinv, scale, ctab, dtab, b, nullptr, u, unew, stream, &nparts);
+    if (rc) return rc;
+    return finish_to_host(c, nparts, 1, S(c, stream), sumsq_host);
+}
+extern "C" int mgk_jacobi3_2d_zero_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale, const double *ctab, const double *dtab,
+                                       const double *b, double *unew, void *stream) {
+    return jacobi3_2d<false, true, false>(c, g, nullptr, coef, dinv, scale, ctab, dtab, b, nullptr, nullptr, unew, stream, nullptr);
+}
+extern "C" int mgk_prolong_jacobi3_2d_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
+                                          const double *ctab, const double *dtab, const double *b, const double *uc, const double *u, double *unew, void *stream) {
+    return jacobi3_2d<true, false, false>(c, gf, gc, coef, dinv, scale, ctab, dtab, b, uc, u, unew, stream, nullptr);
+}

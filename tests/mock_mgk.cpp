@@ -731,6 +731,48 @@ int mgk_residual_restrict_2d_rowcoef_f64(mgk_ctx *c, const mgk_geom *gf, const m
     });
 }
 
+// round 3: three sweeps per pass (2-D): compositions of the single sweep
+static void j3_sweeps(const mgk_geom &G, const double *coef, double dinv, double scale, const double *ctab, const double *dtab, const double *b,
+                      const double *first, double *o, int nsweeps) {
+    // `nsweeps` sweeps starting from the field `first` (not modified), the last one into o
+    std::vector<double> w1(G.total, 0.0), w2(G.total, 0.0);
+    const double *src = first;
+    for (int q = 0; q < nsweeps; q++) {
+        double *dst = (q == nsweeps - 1) ? o : (q & 1 ? w2.data() : w1.data());
+        st_op<double>(M_JACOBI, G, ctab ? nullptr : coef, ctab ? 1.0 : dinv, scale, 0, 0, 0, b, src, (const double *)nullptr, dst, 0, G.ny, ctab, dtab);
+        src = dst;
+    }
+}
+int mgk_jacobi3_2d_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale, const double *ctab, const double *dtab, const double *b, const double *u, double *o, void *) {
+    if (!c || !g || g->dim != 2 || (!coef && !ctab) || (ctab && !dtab) || !b || !u || !o || u == o || b == o) return fail(MGK_EINVAL, "mgk_jacobi3_2d_f64");
+    const mgk_geom G = *g; std::vector<double> k(7, 0.0); if (coef) k.assign(coef, coef + 7);
+    return run(c, [=] { j3_sweeps(G, k.data(), dinv, scale, ctab, dtab, b, u, o, 3); });
+}
+int mgk_jacobi3_2d_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale, const double *ctab, const double *dtab, const double *b, const double *u, double *o, double *out, void *) {
+    if (!c || !g || g->dim != 2 || (!coef && !ctab) || (ctab && !dtab) || !b || !u || !o || u == o || b == o || !out) return fail(MGK_EINVAL, "mgk_jacobi3_2d_sumsq_f64");
+    if (c->capturing) return fail(MGK_EINVAL, "reduction to the host inside a capture");
+    std::vector<double> r(g->total, 0.0);
+    st_op<double>(M_RESIDUAL, *g, ctab ? nullptr : coef, 1, 1, 0, 0, 0, b, u, (const double *)nullptr, r.data(), 0, g->ny, ctab, (const double *)nullptr);
+    j3_sweeps(*g, coef, dinv, scale, ctab, dtab, b, u, o, 3);
+    deliver(c, sumsq_field<double>(*g, r.data(), 0, g->ny), out);
+    return 0;
+}
+int mgk_jacobi3_2d_zero_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale, const double *ctab, const double *dtab, const double *b, double *o, void *) {
+    if (!c || !g || g->dim != 2 || (!coef && !ctab) || (ctab && !dtab) || !b || !o || b == o) return fail(MGK_EINVAL, "mgk_jacobi3_2d_zero_f64");
+    const mgk_geom G = *g; std::vector<double> k(7, 0.0); if (coef) k.assign(coef, coef + 7);
+    return run(c, [=] {
+        std::vector<double> z(G.total, 0.0);
+        for (int i = 0; i < G.ny; i++) for (int j = 0; j < G.nx; j++) { const double zx = at(b, G, 0, i, j) * (dtab ? dtab[i] : dinv); at(z.data(), G, 0, i, j) = scale * zx; }
+        j3_sweeps(G, k.data(), dinv, scale, ctab, dtab, b, z.data(), o, 2);
+    });
+}
+int mgk_prolong_jacobi3_2d_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale, const double *ctab, const double *dtab,
+                               const double *b, const double *uc, const double *u, double *o, void *) {
+    if (!c || (!coef && !ctab) || (ctab && !dtab) || !b || !uc || !u || !o || u == o || b == o || !xfer_ok(gf, gc) || gf->dim != 2) return fail(MGK_EINVAL, "mgk_prolong_jacobi3_2d_f64");
+    const mgk_geom F = *gf, Cg = *gc; std::vector<double> k(7, 0.0); if (coef) k.assign(coef, coef + 7);
+    return run(c, [=] { std::vector<double> t = corrected<double>(F, Cg, uc, u); j3_sweeps(F, k.data(), dinv, scale, ctab, dtab, b, t.data(), o, 3); });
+}
+
 int mgk_pack_f64(mgk_ctx *c, const mgk_geom *g, const double *compact, double *padded, void *) {
     if (!c || !g || !compact || !padded) return fail(MGK_EINVAL, "mgk_pack_f64");
     const mgk_geom G = *g;
