@@ -431,6 +431,10 @@ int  mgk_jacobi3_2d_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, dou
                         const double *b, const double *u, double *unew, void *stream);
 int  mgk_jacobi3_2d_sumsq_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale, const double *ctab, const double *dtab,
                               const double *b, const double *u, double *unew, double *sumsq_host, void *stream);
+/* ... and r = b - A u of the input field is also stored (8 B more): KSPBuildResidual + VecNorm + the next KSPSolve's three sweeps of the
+ * PETSc-surface drop-in (the three-sweep form of mgk_jacobi_sumsq_store_f64) */
+int  mgk_jacobi3_2d_sumsq_store_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale, const double *ctab,
+                                    const double *dtab, const double *b, const double *u, double *unew, double *r, double *sumsq_host, void *stream);
 int  mgk_jacobi3_2d_zero_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale, const double *ctab, const double *dtab,
                              const double *b, double *unew, void *stream);
 int  mgk_prolong_jacobi3_2d_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,

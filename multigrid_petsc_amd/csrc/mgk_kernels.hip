@@ -5253,9 +5253,15 @@ static int residual_restrict_2d(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *
     int ycc = (int)((gc->ny + nch - 1) / nch);
     if (ycc < 4) ycc = 4;
     if (ycc > gc->ny) ycc = gc->ny;
+    // round 3: the levels that fit the caches (rows of <= 1024) lack waves, not bandwidth: chunks of TWO coarse rows whose seven fine rows
+    // of u (and five of b) are all requested before the first residual (PD = 5: the register ring holds the whole chunk), as the short
+    // form of k_jacobi3_2d.  Tuning variants 55 / 56 force the marching / the short form.
+    const bool shortf = (g_variant == 56) || (g_variant != 55 && g_zchunk <= 0 && gf->nx + 1 <= 1024);
+    if (shortf) ycc = gc->ny < 2 ? gc->ny : 2;
     a.ycc = ycc;
     const long waves = (long)a.ntx * ((gc->ny + ycc - 1) / ycc);
-    hipLaunchKernelGGL((k_rr2d<2>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, S(c, stream), a);
+    if (shortf) hipLaunchKernelGGL((k_rr2d<5>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, S(c, stream), a);
+    else hipLaunchKernelGGL((k_rr2d<2>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, S(c, stream), a);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -27,10 +27,11 @@ struct J3dArgs {
     double *out;
     int nx, ny, nxc, nyc;
     long rs, crs;
-    int ntx, yc, nwaves;
+    int ntx, yc, nwaves, xcd;
     double a0, a2, a3, a4, a6, dinv, scale;
     const double *ctab, *dtab;
     double *partials;               // NORM: one partial of || b - A u ||^2 per wave
+    double *rout;                   // NORM, optional: b - A u of the input field is also STORED (the drop-in's KSPBuildResidual + VecNorm)
 };
 // YC = 0: a chunk of a.yc rows per wave, marching with the next row in flight (the big levels: long streams).
 // YC > 0 (even): a chunk of exactly YC rows, EVERY load of the chunk issued before the first sweep and the marching loop fully unrolled
@@ -40,7 +41,11 @@ template <bool PRO, bool ZG, bool NORM, bool TAB, int YC>
 __global__ void __launch_bounds__(256) k_jacobi3_2d(const J3dArgs a) {
     using VT = V16<double>;
     const int lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // workgroups are dealt round-robin over the 8 XCDs: give every XCD a CONTIGUOUS range of wave tiles, so that the rows and columns
+    // neighbouring tiles share are re-read from the L2 they were first brought into (the grid is padded to a multiple of 8 blocks)
+    int bid = blockIdx.x;
+    if (a.xcd) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int wid = bid * 4 + (threadIdx.x >> 6);
     const int tx = wid % a.ntx, cy = wid / a.ntx;
     const int yc = YC > 0 ? YC : a.yc;
     const int y0 = cy * yc, y1 = min(y0 + yc, a.ny);
@@ -91,7 +96,7 @@ __global__ void __launch_bounds__(256) k_jacobi3_2d(const J3dArgs a) {
     auto sweep = [&](const VT &lo, const VT &c, const VT &hi, const VT &bb, int y, bool norm) -> VT {
         J3_COEFS(y)
         const double Wv = lane_up<true>(c.v[1]), Ev = lane_dn<true>(c.v[0]);
-        VT o;
+        VT o, rr;
 #pragma unroll
         for (int e = 0; e < 2; e++) {
             const double wv = (e == 0) ? Wv : c.v[0];
@@ -104,8 +109,10 @@ __global__ void __launch_bounds__(256) k_jacobi3_2d(const J3dArgs a) {
             const double res = bb.v[e] - s;
             const double zz = res * kd;
             o.v[e] = c.v[e] + a.scale * zz;
+            rr.v[e] = (lastvec && e == 1) ? 0.0 : res;
             if (NORM && norm) nacc += (store && y >= y0 && y < y1 && !(lastvec && e == 1)) ? res * res : 0.0;     // the points this wave owns
         }
+        if (NORM && norm && a.rout && store && y >= y0 && y < y1) stv_stream(a.rout + (long)y * a.rs + x0, rr);
         return fix(o, y);
     };
     auto sweep0 = [&](const VT &bb, int y) -> VT {            // first sweep from the zero guess (k_jacobi_zero)
@@ -197,7 +204,7 @@ __global__ void __launch_bounds__(256) k_jacobi3_2d(const J3dArgs a) {
 // shapes: any 2-D grid (nx odd, as everywhere)
 template <bool PRO, bool ZG, bool NORM>
 static int jacobi3_2d(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gc, const double *coef, double dinv, double scale, const double *ctab, const double *dtab,
-                      const double *b, const double *uc, const double *u, double *unew, void *stream, int *norm_parts) {
+                      const double *b, const double *uc, const double *u, double *unew, void *stream, int *norm_parts, double *rout = nullptr) {
     if (!c || !g || g->dim != 2 || (!coef && !ctab) || (ctab && !dtab) || !b || !unew || (!ZG && (!u || u == unew)) || b == unew)
         return fail(MGK_EINVAL, "mgk_jacobi3_2d: bad arguments (2-D)");
     J3dArgs a; memset(&a, 0, sizeof(a));
@@ -209,6 +216,7 @@ static int jacobi3_2d(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gc, const d
     }
     if (coef) { a.a0 = coef[0]; a.a2 = coef[1]; a.a3 = coef[2]; a.a4 = coef[3]; a.a6 = coef[4]; }
     a.dinv = dinv; a.scale = scale; a.ctab = ctab; a.dtab = dtab;
+    if (rout) { if (!NORM || rout == unew || rout == u || rout == b) return fail(MGK_EINVAL, "mgk_jacobi3_2d_sumsq_store_f64: bad arguments"); a.rout = rout + g->org; }
     a.ntx = ((g->nx + 1) / 2 + 59) / 60;                      // pairs 0 .. (nx-1)/2
     // levels that fit the caches (rows of <= 1024): short chunks with every load up front (they lack waves, not bandwidth); the big
     // levels: ~4096 waves (16 per CU) marching over long chunks -- a chunk pays four warm-up steps (two sweep-equivalents) and re-reads
@@ -223,7 +231,7 @@ static int jacobi3_2d(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gc, const d
     if (yc > g->ny) yc = g->ny;
     if (ycs) yc = ycs;
     long waves = (long)a.ntx * ((g->ny + yc - 1) / yc);
-    if (NORM && ((waves + 3) / 4) * 4 > c->max_partials) {    // one partial per wave: longer chunks where that would overflow the slots
+    if (NORM && ((waves + 3) / 4 + 7) * 4 > c->max_partials) {    // one partial per wave: longer chunks where that would overflow the slots
         if (ycs) { ycs = 0; }
         const long maxch = c->max_partials / a.ntx - 1;
         if (maxch < 1) return fail(MGK_EINVAL, "mgk_jacobi3_2d_sumsq_f64: more waves than partial slots");
@@ -231,7 +239,11 @@ static int jacobi3_2d(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gc, const d
         waves = (long)a.ntx * ((g->ny + yc - 1) / yc);
     }
     a.yc = yc;
-    const unsigned nblk = (unsigned)((waves + 3) / 4);
+    unsigned nblk = (unsigned)((waves + 3) / 4);
+    // XCD-aware tile order where it paid (MI355X, HIP events): the short-chunk form (1023^2: 10.5 -> 9.3 us) and the marching form from
+    // 4095^2 on (69 -> 66 us); at 2047^2 the dispatch order was quicker (23.6 against 25.3 us).  53 / 54 force dispatch / XCD order
+    a.xcd = (g_variant == 54) || (g_variant != 53 && nblk >= 64 && (ycs != 0 || g->nx >= 4095));
+    if (a.xcd) nblk = (nblk + 7u) & ~7u;
     a.nwaves = (int)waves;
     if (NORM) {
         if (!norm_parts || 4L * nblk > c->max_partials) return fail(MGK_EINVAL, "mgk_jacobi3_2d_sumsq_f64: more waves than partial slots");
@@ -255,6 +267,14 @@ extern "C" int mgk_jacobi3_2d_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const dou
     if (!sumsq_host) return fail(MGK_EINVAL, "mgk_jacobi3_2d_sumsq_f64: bad arguments");
     int nparts = 0;
     int rc = jacobi3_2d<false, false, true>(c, g, nullptr, coef, dinv, scale, ctab, dtab, b, nullptr, u, unew, stream, &nparts);
+    if (rc) return rc;
+    return finish_to_host(c, nparts, 1, S(c, stream), sumsq_host);
+}
+extern "C" int mgk_jacobi3_2d_sumsq_store_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale, const double *ctab, const double *dtab,
+                                              const double *b, const double *u, double *unew, double *r, double *sumsq_host, void *stream) {
+    if (!sumsq_host || !r) return fail(MGK_EINVAL, "mgk_jacobi3_2d_sumsq_store_f64: bad arguments");
+    int nparts = 0;
+    int rc = jacobi3_2d<false, false, true>(c, g, nullptr, coef, dinv, scale, ctab, dtab, b, nullptr, u, unew, stream, &nparts, r);
     if (rc) return rc;
     return finish_to_host(c, nparts, 1, S(c, stream), sumsq_host);
 }

@@ -1169,6 +1169,7 @@ struct _p_KSP {
     PetscReal *hist; PetscInt nhist;
     int type_from_user;
     int spec_ok; Vec spec_b, spec_x; unsigned long spec_vb, spec_vx, spec_epoch;   /* work[0] holds J(spec_x) made by the norm pass (below) */
+    int spec_n;                 /* ... how many sweeps that pass made: 1, or 3 (2-D, round 3: mgk_jacobi3_2d_sumsq_store_f64) */
     struct _p_PC pcobj;
 };
 
@@ -1540,6 +1541,15 @@ static PetscErrorCode ksp_solve_direct(KSP k, Vec b, Vec x) {
     return 0;
 }
 
+/* round 3: Richardson solves of >= 3 sweeps on 2-D stencil operators start with ONE pass that makes three of them (mgk_jacobi3_2d_*): over b
+ * alone from the zero guess, with the prolongation when the guess is u + P u_c still deferred, with the residual norm when the solve opens
+ * the next cycle.  MGPETSC_J3=0 keeps the round-2 sequence (first sweep fused with its producer, the others one or two per pass). */
+static int j3_on(void) {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MGPETSC_J3"); v = (e && *e) ? atoi(e) : 1; }
+    return v;
+}
+
 /* KSPSolve, KSP_NORM_NONE: exactly max_it iterations (src/solver.c:1531,1536,1542) */
 PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
     Mat A = k->A;
@@ -1560,7 +1570,7 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
     const PetscInt maxit = k->maxits;
     k->b = b; k->x = x; k->its = 0;
     /* the first sweep was made by the pass that evaluated the last residual norm (norm_of_deferred_residual) and nothing has touched b or x since */
-    const int spec = k->spec_ok && k->guess_nonzero && maxit >= 1 && k->type == K_RICHARDSON && k->spec_b == b && k->spec_x == x &&
+    const int spec = k->spec_ok && k->guess_nonzero && maxit >= k->spec_n && k->type == K_RICHARDSON && k->spec_b == b && k->spec_x == x &&
                      b->ver == k->spec_vb && x->ver == k->spec_vx && k->spec_epoch == g_mat_epoch && !x->lz && !b->lz && !x->host_dirty && !b->host_dirty &&
                      (A->kind == MAT_STENCIL || A->kind == MAT_STENCIL_ROW);
     k->spec_ok = 0;
@@ -1608,8 +1618,17 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
              * (MGPETSC_PAIR_MIN_N overrides the threshold; bit-identical either way) */
             static int pair_min_n = -1;
             if (pair_min_n < 0) { const char *e = getenv("MGPETSC_PAIR_MIN_N"); pair_min_n = e ? atoi(e) : 2047; }
+            const int j3 = j3_on() && A->gf.dim == 2 && maxit >= 3;
             for (PetscInt it = 0; it < maxit; it++) {
-                if (it == 0 && spec) { /* w = J(x) already */ }
+                if (it == 0 && spec) { if (k->spec_n == 3) it += 2; /* w = J(x) / J(J(J(x))) already */ }
+                else if (it == 0 && j3) {
+                    /* sweeps 1-3 in one pass; a deferred restriction is made first (without the zero-guess sweep it could emit) */
+                    if (rrA) { rr_now(rrA, rrR, rrb, rru, b, NULL, dinv, k->scale, NULL); g_lzstat[7]++; }
+                    if (rrA || !k->guess_nonzero) DEV(mgk_jacobi3_2d_zero_f64(G, &A->gf, A->coef, dinv, k->scale, NULL, NULL, b->dev, w->dev, NULL));
+                    else if (addP) DEV(mgk_prolong_jacobi3_2d_f64(G, &A->gf, &addP->gc, A->coef, dinv, k->scale, NULL, NULL, b->dev, addUc->dev, x->dev, w->dev, NULL));
+                    else DEV(mgk_jacobi3_2d_f64(G, &A->gf, A->coef, dinv, k->scale, NULL, NULL, b->dev, x->dev, w->dev, NULL));
+                    it += 2;
+                }
                 else if (it == 0 && rrA) { rr_now(rrA, rrR, rrb, rru, b, w->dev, dinv, k->scale, NULL); g_lzstat[7]++; }
                 else if (it == 0 && !k->guess_nonzero) DEV(mgk_jacobi_zero_f64(G, &A->gf, dinv, k->scale, b->dev, w->dev, NULL));
                 else if (it == 0 && addP) DEV(mgk_prolong_jacobi_f64(G, &A->gf, &addP->gc, A->coef, dinv, k->scale, b->dev, addUc->dev, x->dev, w->dev, NULL));
@@ -1666,8 +1685,16 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
             k->its = maxit;
             return 0;
         }
+        const int j3 = j3_on() && A->gf.dim == 2 && maxit >= 3;
         for (PetscInt it = 0; it < maxit; it++) {
-            if (it == 0 && spec) { /* w = J(x) already */ }
+            if (it == 0 && spec) { if (k->spec_n == 3) it += 2; /* w = J(x) / J(J(J(x))) already */ }
+            else if (it == 0 && j3) {
+                if (rrA) { rr_now(rrA, rrR, rrb, rru, b, NULL, 1.0, k->scale, dt); g_lzstat[7]++; }
+                if (rrA || !k->guess_nonzero) DEV(mgk_jacobi3_2d_zero_f64(G, &A->gf, NULL, 1.0, k->scale, A->d_ctab, dt, b->dev, w->dev, NULL));
+                else if (addP) DEV(mgk_prolong_jacobi3_2d_f64(G, &A->gf, &addP->gc, NULL, 1.0, k->scale, A->d_ctab, dt, b->dev, addUc->dev, x->dev, w->dev, NULL));
+                else DEV(mgk_jacobi3_2d_f64(G, &A->gf, NULL, 1.0, k->scale, A->d_ctab, dt, b->dev, x->dev, w->dev, NULL));
+                it += 2;
+            }
             else if (it == 0 && rrA) { rr_now(rrA, rrR, rrb, rru, b, w->dev, 1.0, k->scale, dt); g_lzstat[7]++; }
             else if (it == 0 && !k->guess_nonzero) DEV(mgk_jacobi_zero_rowcoef_f64(G, &A->gf, dt, k->scale, b->dev, w->dev, NULL));
             else if (it == 0 && addP) DEV(mgk_prolong_jacobi_rowcoef_f64(G, &A->gf, &addP->gc, A->d_ctab, dt, k->scale, b->dev, addUc->dev, x->dev, w->dev, NULL));
@@ -1723,12 +1750,18 @@ static int norm_of_deferred_residual(Vec r, double *ss) {
     lz_before_write(r, 1);                                   /* r is computed by the pass below */
     g_lzstat[5]--;
     r->host_dirty = 0;
-    if (A->kind == MAT_STENCIL)
-        DEV(mgk_jacobi_sumsq_store_f64(G, &A->gf, A->coef, (pc == P_JACOBI) ? 1.0 / A->coef[2] : 1.0, k->scale, NULL, NULL, b->dev, u->dev, w->dev, r->dev, ss, NULL));
-    else {
+    const int three = j3_on() && k->maxits >= 3;            /* ... ALL of the next solve's first three sweeps (round 3) */
+    if (A->kind == MAT_STENCIL) {
+        const double dinv = (pc == P_JACOBI) ? 1.0 / A->coef[2] : 1.0;
+        if (three) DEV(mgk_jacobi3_2d_sumsq_store_f64(G, &A->gf, A->coef, dinv, k->scale, NULL, NULL, b->dev, u->dev, w->dev, r->dev, ss, NULL));
+        else DEV(mgk_jacobi_sumsq_store_f64(G, &A->gf, A->coef, dinv, k->scale, NULL, NULL, b->dev, u->dev, w->dev, r->dev, ss, NULL));
+    } else {
         mat_device_rowtabs(A);
-        DEV(mgk_jacobi_sumsq_store_f64(G, &A->gf, NULL, 1.0, k->scale, A->d_ctab, (pc == P_JACOBI) ? A->d_dtab : A->d_ones, b->dev, u->dev, w->dev, r->dev, ss, NULL));
+        const double *dt = (pc == P_JACOBI) ? A->d_dtab : A->d_ones;
+        if (three) DEV(mgk_jacobi3_2d_sumsq_store_f64(G, &A->gf, NULL, 1.0, k->scale, A->d_ctab, dt, b->dev, u->dev, w->dev, r->dev, ss, NULL));
+        else DEV(mgk_jacobi_sumsq_store_f64(G, &A->gf, NULL, 1.0, k->scale, A->d_ctab, dt, b->dev, u->dev, w->dev, r->dev, ss, NULL));
     }
+    k->spec_n = three ? 3 : 1;
     k->spec_ok = 1; k->spec_b = b; k->spec_x = u; k->spec_vb = b->ver; k->spec_vx = u->ver; k->spec_epoch = g_mat_epoch;
     g_lzstat[6]++;
     return 1;

@@ -121,6 +121,7 @@ def _sigs(L):
         "mgk_jacobi3_2d_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp, vp, vp, vp]),
         "mgk_jacobi3_2d_sumsq_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp, vp, vp, C.POINTER(d), vp]),
         "mgk_jacobi3_2d_zero_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp, vp, vp]),
+        "mgk_jacobi3_2d_sumsq_store_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp, vp, vp, vp, C.POINTER(d), vp]),
         "mgk_prolong_jacobi3_2d_f64": (i, [vp, G, G, c_dp, d, d, vp, vp, vp, vp, vp, vp, vp]),
         "mgk_sweep_residual_restrict_2d_f64": (i, [vp, G, G, c_dp, d, d, vp, vp, vp, vp, vp, d, d, vp]),
         "mgk_jacobi2_sumsq_slab_f64": (i, [vp, G, G, c_dp, d, d, vp, vp, vp, vp, i, i, i, i, i, C.POINTER(i), vp]),

@@ -757,6 +757,14 @@ int mgk_jacobi3_2d_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, 
     deliver(c, sumsq_field<double>(*g, r.data(), 0, g->ny), out);
     return 0;
 }
+int mgk_jacobi3_2d_sumsq_store_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale, const double *ctab, const double *dtab, const double *b, const double *u, double *o, double *r, double *out, void *) {
+    if (!c || !g || g->dim != 2 || (!coef && !ctab) || (ctab && !dtab) || !b || !u || !o || !r || u == o || b == o || r == o || r == u || r == b || !out) return fail(MGK_EINVAL, "mgk_jacobi3_2d_sumsq_store_f64");
+    if (c->capturing) return fail(MGK_EINVAL, "reduction to the host inside a capture");
+    st_op<double>(M_RESIDUAL, *g, ctab ? nullptr : coef, 1, 1, 0, 0, 0, b, u, (const double *)nullptr, r, 0, g->ny, ctab, (const double *)nullptr);
+    j3_sweeps(*g, coef, dinv, scale, ctab, dtab, b, u, o, 3);
+    deliver(c, sumsq_field<double>(*g, r, 0, g->ny), out);
+    return 0;
+}
 int mgk_jacobi3_2d_zero_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale, const double *ctab, const double *dtab, const double *b, double *o, void *) {
     if (!c || !g || g->dim != 2 || (!coef && !ctab) || (ctab && !dtab) || !b || !o || b == o) return fail(MGK_EINVAL, "mgk_jacobi3_2d_zero_f64");
     const mgk_geom G = *g; std::vector<double> k(7, 0.0); if (coef) k.assign(coef, coef + 7);

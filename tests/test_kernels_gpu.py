@@ -523,12 +523,12 @@ def test_fused_residual_restrict_2d_bit_exact(mgk, orc, nf):
     du, db, dbc, duc0 = mgk.to_field(gf, u), mgk.to_field(gf, b), mgk.field(gc), mgk.field(gc)
     want = orc.restrict(2, nf, orc.residual(2, nf, As, b, u))
     dinv_c = 1.0 / Ac[2]
-    for zc in (-1, 5, 64):
-        mgk.L.mgk_set_tuning(-1, zc)
+    for var, zc in ((-1, -1), (-1, 5), (-1, 64), (55, -1), (56, -1)):          # 55 / 56: the marching / the short-chunk form forced (round 3)
+        mgk.L.mgk_set_tuning(var, zc)
         mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dbc, 8 * gc.total, None))
         mgk._chk(mgk.L.mgk_residual_restrict_2d_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), db, du, dbc, duc0, dinv_c, 0.8, None))
         got = mgk.from_field(gc, dbc)
-        assert np.array_equal(got, want), f"zc={zc} max diff {np.abs(got - want).max()}"
+        assert np.array_equal(got, want), f"variant={var} zc={zc} max diff {np.abs(got - want).max()}"
         assert np.array_equal(mgk.from_field(gc, duc0), 0.8 * (want * dinv_c))
         raw = mgk.raw_field(gc, dbc)
         assert abs(np.abs(raw).sum() - np.abs(got).sum()) <= 1e-9 * max(np.abs(got).sum(), 1e-300)

@@ -135,3 +135,36 @@ def test_three_sweeps_2d_on_row_tables(mgk, orc, n):
     L.mgk_set_tuning(-1, -1)
     for p in (du, db, dout, dct, ddt):
         mgk.free(p)
+
+
+@pytest.mark.parametrize("n", [7, 255, 1023, 2047])
+def test_three_sweeps_with_stored_residual_2d(mgk, orc, n):
+    """mgk_jacobi3_2d_sumsq_store_f64 (the drop-in's KSPBuildResidual + VecNorm + the next KSPSolve's three sweeps): r is the residual
+    kernel's, unew three sweeps, bit for bit; the sum is ||r||^2; ghosts and padding of both outputs stay zero"""
+    rng = np.random.default_rng(34000 + n)
+    q = float((n + 1) ** 2)
+    As = [q, q, -4.0 * q, q, q]
+    dinv = 1.0 / As[2]
+    u, b = rng.uniform(-1, 1, n * n), rng.uniform(-1, 1, n * n)
+    g = mgk.geom(2, n)
+    du, db, dout, dr = mgk.to_field(g, u), mgk.to_field(g, b), mgk.field(g), mgk.field(g)
+    res = orc.residual(2, n, As, b, u)
+    j3 = u
+    for _ in range(3):
+        j3 = orc.jacobi(2, n, As, 0.8, b, j3)
+    ss = C.c_double()
+    for var in (-1, 50, 51, 52):
+        mgk.L.mgk_set_tuning(var, -1)
+        for f in (dout, dr):
+            mgk._chk(mgk.L.mgk_memset0(mgk.ctx, f, 8 * g.total, None))
+        mgk._chk(mgk.L.mgk_jacobi3_2d_sumsq_store_f64(mgk.ctx, C.byref(g), mgk.coef(As), dinv, 0.8, None, None, db, du, dout, dr, C.byref(ss), None))
+        assert np.array_equal(mgk.from_field(g, dr), res), f"variant={var}: stored residual"
+        assert np.array_equal(mgk.from_field(g, dout), j3), f"variant={var}: three sweeps"
+        assert abs(ss.value - orc.sumsq(res)) <= 1e-13 * orc.sumsq(res)
+        for f, v in ((dr, res), (dout, j3)):
+            raw = mgk.raw_field(g, f)
+            assert abs(np.abs(raw).sum() - np.abs(v).sum()) <= 1e-9 * np.abs(v).sum()
+    mgk.L.mgk_set_tuning(-1, -1)
+    assert mgk.L.mgk_jacobi3_2d_sumsq_store_f64(mgk.ctx, C.byref(g), mgk.coef(As), dinv, 0.8, None, None, db, du, dout, dout, C.byref(ss), None) != 0
+    for p in (du, db, dout, dr):
+        mgk.free(p)

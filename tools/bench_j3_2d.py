@@ -41,8 +41,9 @@ for n in [int(x) for x in sys.argv[1:]] or [4095, 2047, 1023, 511, 255, 127]:
         ("THREE from zero", 16, lambda: L.mgk_jacobi3_2d_zero_f64(m.ctx, G, coef, dinv, 0.8, None, None, b, o, None)),
         ("prolong + sweep", 25, lambda: L.mgk_prolong_jacobi_f64(m.ctx, G, GC, coef, dinv, 0.8, b, uc, u, o, None)),
         ("prolong + THREE", 25, lambda: L.mgk_prolong_jacobi3_2d_f64(m.ctx, G, GC, coef, dinv, 0.8, None, None, b, uc, u, o, None)),
+        ("residual+restrict THREE", 18, lambda: L.mgk_residual_restrict_2d_f64(m.ctx, G, GC, coef, b, u, uc, None, 0.0, 0.0, None)),
     ]
-    for var, zc in ((-1, -1), (50, -1), (51, -1), (52, -1), (50, 24)):
+    for var, zc in ((-1, -1), (55, -1), (56, -1)):
         L.mgk_set_tuning(var, zc)
         for name, byts, fn in rows:
             if (var, zc) != (-1, -1) and "THREE" not in name:
