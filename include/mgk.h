@@ -441,6 +441,13 @@ int  mgk_prolong_jacobi3_2d_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom
                                 const double *ctab, const double *dtab, const double *b, const double *uc, const double *u, double *unew,
                                 void *stream);
 
+/* the same in 3-D (whole grids, any vertex-centred shape): unew = J(J(J(u))) [and *sumsq_host = || b - A u ||^2 of the input field] in one
+ * pass, 24 B per unknown.  Independent waves, one per SIMD (up to 512 registers per lane), 120 x 4 point columns per wave marching along z. */
+int  mgk_jacobi3_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale,
+                     const double *b, const double *u, double *unew, void *stream);
+int  mgk_jacobi3_sumsq_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale,
+                           const double *b, const double *u, double *unew, double *sumsq_host, void *stream);
+
 /* tuning knob for the marching stencil kernel (profiling only): <=0 keeps the built-in choice */
 void mgk_set_tuning(int variant, int zchunk);
 

@@ -1,6 +1,7 @@
 // mgk_kernels3.hip -- round 3: three-sweep passes (2-D independent-wave forms; 3-D forms below).  Same build flags as mgk_kernels.hip
 // (-O3 -ffp-contract=off, gfx950 only); shares mgk_dev.hpp with it.
 #include "mgk_dev.hpp"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------
 // Round 3: THREE Richardson+Jacobi sweeps in one pass, 2-D (src/solver.c:1531 / :1536 / :1542 with max_it = 3):
@@ -285,4 +286,252 @@ extern "C" int mgk_jacobi3_2d_zero_f64(mgk_ctx *c, const mgk_geom *g, const doub
 extern "C" int mgk_prolong_jacobi3_2d_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const double *coef, double dinv, double scale,
                                           const double *ctab, const double *dtab, const double *b, const double *uc, const double *u, double *unew, void *stream) {
     return jacobi3_2d<true, false, false>(c, gf, gc, coef, dinv, scale, ctab, dtab, b, uc, u, unew, stream, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------
+// THREE sweeps in one pass, 3-D (prototype of DESIGN.md section 10.2): independent waves as above, one wave per SIMD so that a lane may
+// hold up to 512 registers (VGPR + AGPR).  A wave owns 120 of its 128 columns (two halo lanes a side) x TY rows and marches along z;
+// the lane keeps, for its column pair: u on TY+6 rows of the planes t+1 .. t+3 (+ the plane in flight), the first sweep on TY+4 rows of
+// the planes t .. t+2, the second sweep on TY+2 rows of the planes t-1 .. t+1, and b of the three planes the stages work on.  y
+// neighbours are the lane's own registers, x neighbours DPP shifts, z neighbours the other planes: no LDS, no barrier.  At step t:
+// first sweep of plane t+2, second sweep of plane t+1, third sweep of plane t (stored).  The halo rows are recomputed by the
+// neighbouring tiles: (TY+4 + TY+2 + TY) / TY row-sweeps per three output sweeps.
+// ------------------------------------------------------------------------------------------
+struct J33Args {
+    const double *u, *b;
+    double *out;
+    int nx, ny, nz;
+    long rs, ms;
+    int ntx, nty, ntz, zc, xcd;
+    double a0, a1, a2, a3, a4, a5, a6, dinv, scale;
+    double *partials;
+};
+template <int TY, bool NORM, int g_form>
+__global__ void __launch_bounds__(256, 1) k_jacobi3_3d(const J33Args a) {
+    constexpr int R0 = TY + 6, R1 = TY + 4, R2 = TY + 2;
+    using VT = V16<double>;
+    const int lane = threadIdx.x & 63;
+    int bid = blockIdx.x;
+    if (a.xcd) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    // everything derived from the wave's number is wave-uniform: keep it on the scalar unit (row / plane offsets in SGPRs)
+    const int wid = bid * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tx = wid % a.ntx, ty = (wid / a.ntx) % a.nty, tz = wid / (a.ntx * a.nty);
+    const int z0 = tz * a.zc, z1 = min(z0 + a.zc, a.nz);
+    if (tz >= a.ntz || z0 >= z1) { if (NORM && lane == 0) a.partials[wid] = 0.0; return; }
+    const int yb = ty * TY;
+    const int x0 = 2 * (tx * 60 + lane - 2);
+    const bool xin = (x0 >= 0 && x0 < a.nx);
+    const bool lastvec = (x0 + 2 > a.nx);
+    const bool store = (lane >= 2 && lane <= 61 && xin);
+    // lanes left / right of the grid read the zero padding of the row (columns -4, -2 / nx + 1: the pitch leaves room, mgk_geom_init):
+    // with the zero ghost rows and planes of a whole grid no loaded value needs a select
+    const unsigned lo = (unsigned)(8 * min(x0, a.nx + 1));    // byte offset of the lane's pair in its row (may be negative: -32, -16)
+    const char *__restrict__ ub_ = reinterpret_cast<const char *>(a.u);
+    const char *__restrict__ bb_ = reinterpret_cast<const char *>(a.b);
+    char *__restrict__ ob_ = reinterpret_cast<char *>(a.out);
+    const long loff = (long)(int)lo;
+    const VT Z = v16_zero<double>();
+    // wave-uniform row offsets in bytes (rows outside -1 .. ny are clamped to the zero ghost rows; b has no ghost data: clamped into the grid,
+    // the sweeps of rows outside the grid are discarded)
+    long uro[R0], bro[R1];
+#pragma unroll
+    for (int r = 0; r < R0; r++) uro[r] = 8 * (long)min(max(yb - 3 + r, -1), a.ny) * a.rs;
+#pragma unroll
+    for (int q = 0; q < R1; q++) bro[q] = 8 * (long)min(max(yb - 2 + q, 0), a.ny - 1) * a.rs;
+    bool rowok[R1];                                           // rows yb-2 .. yb+TY+1 inside the grid (wave-uniform)
+#pragma unroll
+    for (int q = 0; q < R1; q++) rowok[q] = (yb - 2 + q >= 0 && yb - 2 + q < a.ny);
+    double nacc = 0.0;
+    // positions outside the grid count as zero for the next sweep.  Bit masks, not selects: a select on a condition with wave-uniform
+    // parts becomes an exec-mask region per value (30 branch regions in the first build: the sweeps of different rows could not be
+    // interleaved any more, and with one wave per SIMD nothing else covers the latency of a dependent chain)
+    const unsigned long long Mx0 = xin ? ~0ull : 0ull, Mx1 = (xin && !lastvec) ? ~0ull : 0ull;
+    auto andm = [](double v, unsigned long long m) -> double { return __longlong_as_double((long long)((unsigned long long)__double_as_longlong(v) & m)); };
+    // one sweep of a lane vector; mu: all ones if the row and the plane are inside the grid (wave-uniform), else zero
+    auto jac = [&](const VT &dn, const VT &sv, const VT &c, const VT &nv, const VT &upv, const VT &bb, unsigned long long mu, bool own, bool norm) -> VT {
+        const double Wv = lane_up<true>(c.v[1]), Ev = lane_dn<true>(c.v[0]);
+        VT o;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const double wv = (e == 0) ? Wv : c.v[0];
+            const double ev = (e == 1) ? Ev : c.v[1];
+            double s = a.a0 * dn.v[e];
+            s = s + a.a1 * sv.v[e];
+            s = s + a.a2 * wv;
+            s = s + a.a3 * c.v[e];
+            s = s + a.a4 * ev;
+            s = s + a.a5 * nv.v[e];
+            s = s + a.a6 * upv.v[e];
+            const double res = bb.v[e] - s;
+            const double zz = res * a.dinv;
+            const double val = c.v[e] + a.scale * zz;
+            const unsigned long long m = (e == 0 ? Mx0 : Mx1) & mu;
+            o.v[e] = andm(val, m);
+            if (NORM && norm) { const double rm = andm(res, (own && store) ? m : 0ull); nacc += rm * rm; }
+        }
+        return o;
+    };
+    auto ldplane = [&](VT (&P)[R0], int z) {
+        const char *pz = ub_ + 8 * (long)min(max(z, -1), a.nz) * a.ms + loff;
+#pragma unroll
+        for (int r = 0; r < R0; r++) P[r] = *reinterpret_cast<const VT *>(pz + uro[r]);
+    };
+    auto ldb = [&](VT (&P)[R1], int z) {
+        const char *pz = bb_ + 8 * (long)min(max(z, 0), a.nz - 1) * a.ms + loff;
+#pragma unroll
+        for (int q = 0; q < R1; q++) P[q] = ldv_stream(reinterpret_cast<const double *>(pz + bro[q]), true);
+    };
+    // one sweep of NR rows at once, TERM BY TERM over all rows (the same per-point expression and order as jac): 2 NR independent
+    // accumulators, so that a wave that is alone on its SIMD never waits for the previous add of the same chain.
+    // rows: C has NR + 2 rows (row q + 1 is the centre of output row q); dn / up / bb start at their offsets o_dn / o_up / o_b
+#define J33_STAGE(NR, OUT, DN, o_dn, C, UP, o_up, BB, o_b, MASK, ...)                                            \
+    {                                                                                                                  \
+        double s_[NR][2], w_[NR], e_[NR];                                                                              \
+        _Pragma("unroll") for (int q = 0; q < NR; q++) { w_[q] = lane_up<true>(C[q + 1].v[1]); e_[q] = lane_dn<true>(C[q + 1].v[0]); } \
+        _Pragma("unroll") for (int q = 0; q < NR; q++) { s_[q][0] = a.a0 * DN[q + o_dn].v[0]; s_[q][1] = a.a0 * DN[q + o_dn].v[1]; } \
+        _Pragma("unroll") for (int q = 0; q < NR; q++) { s_[q][0] = s_[q][0] + a.a1 * C[q].v[0]; s_[q][1] = s_[q][1] + a.a1 * C[q].v[1]; } \
+        _Pragma("unroll") for (int q = 0; q < NR; q++) { s_[q][0] = s_[q][0] + a.a2 * w_[q]; s_[q][1] = s_[q][1] + a.a2 * C[q + 1].v[0]; } \
+        _Pragma("unroll") for (int q = 0; q < NR; q++) { s_[q][0] = s_[q][0] + a.a3 * C[q + 1].v[0]; s_[q][1] = s_[q][1] + a.a3 * C[q + 1].v[1]; } \
+        _Pragma("unroll") for (int q = 0; q < NR; q++) { s_[q][0] = s_[q][0] + a.a4 * C[q + 1].v[1]; s_[q][1] = s_[q][1] + a.a4 * e_[q]; } \
+        _Pragma("unroll") for (int q = 0; q < NR; q++) { s_[q][0] = s_[q][0] + a.a5 * C[q + 2].v[0]; s_[q][1] = s_[q][1] + a.a5 * C[q + 2].v[1]; } \
+        _Pragma("unroll") for (int q = 0; q < NR; q++) { s_[q][0] = s_[q][0] + a.a6 * UP[q + o_up].v[0]; s_[q][1] = s_[q][1] + a.a6 * UP[q + o_up].v[1]; } \
+        _Pragma("unroll") for (int q = 0; q < NR; q++) {                                                               \
+            const double r0_ = BB[q + o_b].v[0] - s_[q][0], r1_ = BB[q + o_b].v[1] - s_[q][1];                          \
+            const double z0_ = r0_ * a.dinv, z1_ = r1_ * a.dinv;                                                       \
+            const double v0_ = C[q + 1].v[0] + a.scale * z0_, v1_ = C[q + 1].v[1] + a.scale * z1_;                     \
+            const unsigned long long mu_ = MASK;                                                                       \
+            OUT[q].v[0] = andm(v0_, Mx0 & mu_); OUT[q].v[1] = andm(v1_, Mx1 & mu_);                                   \
+            __VA_ARGS__                                                                                                \
+        }                                                                                                              \
+    }
+    unsigned long long rowm[R1];                              // all ones for the rows yb-2 .. yb+TY+1 that lie inside the grid
+#pragma unroll
+    for (int q = 0; q < R1; q++) rowm[q] = rowok[q] ? ~0ull : 0ull;
+    const int t0 = z0 - 4;
+    // rings of three planes, indexed by the step's phase (t - t0) mod 3 -- the marching loop is unrolled by three, every index below is a
+    // compile-time constant, and no plane is ever copied except the two that arrive from memory (they land in Un / Bn: a full step of
+    // latency tolerance, then 18 register-pair moves)
+    VT U[3][R0], Un[R0];                                      // u:            planes t+1, t+2, t+3 in the slots PH, PH+1, PH+2 (mod 3)
+    VT P[3][R1];                                              // first sweep:  planes t, t+1, (new) t+2
+    VT Q[3][R2];                                              // second sweep: planes t-1, t, (new) t+1
+    VT B[3][R1], Bn[R1];                                      // b:            planes t, t+1, t+2
+    ldplane(U[0], t0 + 1); ldplane(U[1], t0 + 2); ldplane(U[2], t0 + 3);
+    ldb(B[2], t0 + 2);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int q = 0; q < R1; q++) { P[k][q] = Z; if (k < 2) B[k][q] = Z; }
+#pragma unroll
+        for (int q = 0; q < R2; q++) Q[k][q] = Z;
+    }
+    auto step = [&](auto phc, int t) {
+        constexpr int PH = decltype(phc)::value, S0 = PH % 3, S1 = (PH + 1) % 3, S2 = (PH + 2) % 3;
+        ldplane(Un, t + 4);
+        ldb(Bn, t + 3);
+        const unsigned long long z2m = (t + 2 >= 0 && t + 2 < a.nz) ? ~0ull : 0ull, z1m = (t + 1 >= 0 && t + 1 < a.nz) ? ~0ull : 0ull;
+        const bool z2own = (t + 2 >= z0 && t + 2 < z1);
+        // first sweep of plane t+2 (rows yb-2 .. yb+TY+1) into the slot the dead plane t-1 held
+        if (g_form == 0) {
+#pragma unroll
+        for (int q = 0; q < R1; q++)
+            P[S2][q] = jac(U[S0][q + 1], U[S1][q], U[S1][q + 1], U[S1][q + 2], U[S2][q + 1], B[S2][q], rowm[q] & z2m, z2own && q >= 2 && q < 2 + TY, true);
+        if (t >= z0 - 2) {
+            // second sweep of plane t+1 (rows yb-1 .. yb+TY)
+#pragma unroll
+            for (int q = 0; q < R2; q++)
+                Q[S2][q] = jac(P[S0][q + 1], P[S1][q], P[S1][q + 1], P[S1][q + 2], P[S2][q + 1], B[S1][q + 1], rowm[q + 1] & z1m, false, false);
+            if (t >= z0) {
+                // third sweep of plane t (rows yb .. yb+TY-1)
+#pragma unroll
+                for (int j = 0; j < TY; j++) {
+                    const VT o = jac(Q[S0][j + 1], Q[S1][j], Q[S1][j + 1], Q[S1][j + 2], Q[S2][j + 1], B[S0][j + 2], ~0ull, false, false);
+                    if (store && rowok[j + 2]) stv_stream(reinterpret_cast<double *>(ob_ + 8 * ((long)t * a.ms + (long)(yb + j) * a.rs) + loff), o);
+                }
+            }
+        }
+        } else {
+        J33_STAGE(R1, P[S2], U[S0], 1, U[S1], U[S2], 1, B[S2], 0, (rowm[q] & z2m),
+                  if (NORM) { const unsigned long long mn_ = (z2own && q >= 2 && q < 2 + TY && store) ? mu_ : 0ull;
+                              const double n0_ = andm(r0_, Mx0 & mn_), n1_ = andm(r1_, Mx1 & mn_); nacc += n0_ * n0_; nacc += n1_ * n1_; })
+        if (t >= z0 - 2) {
+            J33_STAGE(R2, Q[S2], P[S0], 1, P[S1], P[S2], 1, B[S1], 1, (rowm[q + 1] & z1m), ;)
+            if (t >= z0) {
+                VT O[TY];
+                J33_STAGE(TY, O, Q[S0], 1, Q[S1], Q[S2], 1, B[S0], 2, (~0ull), ;)
+#pragma unroll
+                for (int j = 0; j < TY; j++)
+                    if (store && rowok[j + 2]) stv_stream(reinterpret_cast<double *>(ob_ + 8 * ((long)t * a.ms + (long)(yb + j) * a.rs) + loff), O[j]);
+            }
+        }
+        }
+        // the planes requested at the top of the step are first touched here: a whole step of latency tolerance
+#pragma unroll
+        for (int r = 0; r < R0; r++) U[S0][r] = Un[r];         // plane t+4 takes the place of plane t+1 (dead since the first sweep)
+#pragma unroll
+        for (int q = 0; q < R1; q++) B[S0][q] = Bn[q];         // b of plane t+3 takes the place of b of plane t
+    };
+    for (int t = t0; t < z1; t += 3) {
+        step(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < z1) step(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < z1) step(std::integral_constant<int, 2>{}, t + 2);
+    }
+    if (NORM) {
+        const double sw = wave_sum(nacc);
+        if (lane == 0) a.partials[wid] = sw;
+    }
+#undef J33_STAGE
+}
+template <int TY, bool NORM>
+static int jacobi3_3d_launch(mgk_ctx *c, J33Args &a, const mgk_geom *g, int *norm_parts, void *stream) {
+    a.ntx = ((g->nx + 1) / 2 + 59) / 60;
+    a.nty = (g->ny + TY - 1) / TY;
+    // one wave per SIMD: 1024 run at a time; cut z so that the wave tiles are a whole number of rounds (>= 4), chunks of >= 32 planes
+    const long per = (long)a.ntx * a.nty;
+    int ntz = 1;
+    if (g_zchunk > 0) ntz = (g->nz + g_zchunk - 1) / g_zchunk;
+    else { while (per * ntz < 4096 && g->nz / (ntz + 1) >= 32) ntz++; }
+    if (NORM) while (ntz > 1 && per * ntz + 32 > c->max_partials) ntz--;      // one partial per wave
+    a.zc = (g->nz + ntz - 1) / ntz;
+    a.ntz = (g->nz + a.zc - 1) / a.zc;
+    const long waves = per * a.ntz;
+    unsigned nblk = (unsigned)((waves + 3) / 4);
+    a.xcd = (g_variant != 53 && nblk >= 64) ? 1 : 0;
+    if (a.xcd) nblk = (nblk + 7u) & ~7u;
+    if (NORM) {
+        if (!norm_parts || 4L * nblk > c->max_partials) return fail(MGK_EINVAL, "mgk_jacobi3_sumsq_f64: more waves than partial slots");
+        a.partials = c->partials;
+        *norm_parts = (int)(4 * nblk);
+    }
+    if (g_variant == 64) hipLaunchKernelGGL((k_jacobi3_3d<TY, NORM, 0>), dim3(nblk), dim3(256), 0, S(c, stream), a);      // row by row (64)
+    else hipLaunchKernelGGL((k_jacobi3_3d<TY, NORM, 1>), dim3(nblk), dim3(256), 0, S(c, stream), a);                       // term by term over the rows
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+template <bool NORM>
+static int jacobi3_3d(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale, const double *b, const double *u, double *unew,
+                      void *stream, int *norm_parts) {
+    if (!c || !g || g->dim != 3 || !coef || !b || !u || !unew || u == unew || b == unew) return fail(MGK_EINVAL, "mgk_jacobi3_f64: bad arguments (3-D)");
+    J33Args a; memset(&a, 0, sizeof(a));
+    a.u = u + g->org; a.b = b + g->org; a.out = unew + g->org;
+    a.nx = g->nx; a.ny = g->ny; a.nz = g->nz; a.rs = g->pitch; a.ms = g->plane;
+    a.a0 = coef[0]; a.a1 = coef[1]; a.a2 = coef[2]; a.a3 = coef[3]; a.a4 = coef[4]; a.a5 = coef[5]; a.a6 = coef[6];
+    a.dinv = dinv; a.scale = scale;
+    // rows per wave tile: 4 (480-498 registers per lane, none in scratch); with the norm 3 (456): the 4-row form would spill 28-38 registers
+    // to scratch.  Tuning variants 62 / 63 force 2 / 3 rows
+    const int ty = (g_variant == 62) ? 2 : (g_variant == 63 || NORM) ? 3 : 4;
+    if (ty == 2) return jacobi3_3d_launch<2, NORM>(c, a, g, norm_parts, stream);
+    if (ty == 3) return jacobi3_3d_launch<3, NORM>(c, a, g, norm_parts, stream);
+    return jacobi3_3d_launch<4, NORM>(c, a, g, norm_parts, stream);
+}
+extern "C" int mgk_jacobi3_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
+                               const double *b, const double *u, double *unew, void *stream) {
+    return jacobi3_3d<false>(c, g, coef, dinv, scale, b, u, unew, stream, nullptr);
+}
+extern "C" int mgk_jacobi3_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale,
+                                     const double *b, const double *u, double *unew, double *sumsq_host, void *stream) {
+    if (!sumsq_host) return fail(MGK_EINVAL, "mgk_jacobi3_sumsq_f64: bad arguments");
+    int nparts = 0;
+    int rc = jacobi3_3d<true>(c, g, coef, dinv, scale, b, u, unew, stream, &nparts);
+    if (rc) return rc;
+    return finish_to_host(c, nparts, 1, S(c, stream), sumsq_host);
 }

@@ -118,6 +118,8 @@ def _sigs(L):
         "mgk_jacobi2_zero_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp]),
         "mgk_jacobi2_zero_f32": (i, [vp, G, c_dp, d, d, vp, vp, vp]),
         "mgk_jacobi2_2d_sumsq_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp, C.POINTER(d), vp]),
+        "mgk_jacobi3_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp, vp]),
+        "mgk_jacobi3_sumsq_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp, C.POINTER(d), vp]),
         "mgk_jacobi3_2d_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp, vp, vp, vp]),
         "mgk_jacobi3_2d_sumsq_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp, vp, vp, C.POINTER(d), vp]),
         "mgk_jacobi3_2d_zero_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp, vp, vp]),

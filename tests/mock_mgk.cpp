@@ -743,6 +743,26 @@ static void j3_sweeps(const mgk_geom &G, const double *coef, double dinv, double
         src = dst;
     }
 }
+int mgk_jacobi3_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale, const double *b, const double *u, double *o, void *) {
+    if (!c || !g || g->dim != 3 || !coef || !b || !u || !o || u == o || b == o) return fail(MGK_EINVAL, "mgk_jacobi3_f64");
+    const mgk_geom G = *g; std::vector<double> k(coef, coef + 7);
+    return run(c, [=] {
+        std::vector<double> w1(G.total, 0.0), w2(G.total, 0.0);
+        st_op<double>(M_JACOBI, G, k.data(), dinv, scale, 0, 0, 0, b, u, (const double *)nullptr, w1.data(), 0, G.nz);
+        st_op<double>(M_JACOBI, G, k.data(), dinv, scale, 0, 0, 0, b, w1.data(), (const double *)nullptr, w2.data(), 0, G.nz);
+        st_op<double>(M_JACOBI, G, k.data(), dinv, scale, 0, 0, 0, b, w2.data(), (const double *)nullptr, o, 0, G.nz);
+    });
+}
+int mgk_jacobi3_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale, const double *b, const double *u, double *o, double *out, void *s) {
+    if (!c || !g || g->dim != 3 || !coef || !b || !u || !o || u == o || b == o || !out) return fail(MGK_EINVAL, "mgk_jacobi3_sumsq_f64");
+    if (c->capturing) return fail(MGK_EINVAL, "reduction to the host inside a capture");
+    std::vector<double> r(g->total, 0.0);
+    st_op<double>(M_RESIDUAL, *g, coef, 1, 1, 0, 0, 0, b, u, (const double *)nullptr, r.data(), 0, g->nz);
+    int rc = mgk_jacobi3_f64(c, g, coef, dinv, scale, b, u, o, s);
+    if (rc) return rc;
+    deliver(c, sumsq_field<double>(*g, r.data(), 0, g->nz), out);
+    return 0;
+}
 int mgk_jacobi3_2d_f64(mgk_ctx *c, const mgk_geom *g, const double *coef, double dinv, double scale, const double *ctab, const double *dtab, const double *b, const double *u, double *o, void *) {
     if (!c || !g || g->dim != 2 || (!coef && !ctab) || (ctab && !dtab) || !b || !u || !o || u == o || b == o) return fail(MGK_EINVAL, "mgk_jacobi3_2d_f64");
     const mgk_geom G = *g; std::vector<double> k(7, 0.0); if (coef) k.assign(coef, coef + 7);

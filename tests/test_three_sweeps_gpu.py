@@ -168,3 +168,48 @@ def test_three_sweeps_with_stored_residual_2d(mgk, orc, n):
     assert mgk.L.mgk_jacobi3_2d_sumsq_store_f64(mgk.ctx, C.byref(g), mgk.coef(As), dinv, 0.8, None, None, db, du, dout, dout, C.byref(ss), None) != 0
     for p in (du, db, dout, dr):
         mgk.free(p)
+
+
+# ---- 3-D ----
+@pytest.mark.parametrize("nx,ny,nz", [(1, 1, 1), (3, 3, 3), (7, 7, 7), (31, 31, 31), (63, 63, 63), (119, 9, 11), (121, 5, 7), (127, 127, 127),
+                                      (239, 13, 9), (255, 255, 33), (511, 31, 17), (1023, 1023, 9), (1023, 21, 40)])
+def test_three_sweeps_3d_bit_exact(mgk, orc, nx, ny, nz):
+    """mgk_jacobi3_f64 / _sumsq_f64 == three sweeps of the oracle (cubes) / of mgk_jacobi_f64, itself pinned to the oracle (boxes: the
+    oracle's stencil operators want nx = ny), bit for bit; tile heights 2 / 3 / 4 and several z chunkings"""
+    rng = np.random.default_rng(35000 + nx + 7 * ny + 13 * nz)
+    q = float((nx + 1) ** 2)
+    As = [q, q, q, -6.0 * q, q, q, q]
+    dinv = 1.0 / As[3]
+    N = nx * ny * nz
+    u, b = rng.uniform(-1, 1, N), rng.uniform(-1, 1, N)
+    g = mgk.geom(3, nx, ny, nz)
+    du, db, dout, d1, d2 = mgk.to_field(g, u), mgk.to_field(g, b), mgk.field(g), mgk.field(g), mgk.field(g)
+    L, coef = mgk.L, mgk.coef(As)
+    if nx == ny:
+        J = lambda x: orc.jacobi(3, nx, As, 0.8, b, x, nz=nz)
+        want = J(J(J(u)))
+        r0 = orc.residual(3, nx, As, b, u, nz=nz)
+    else:
+        mgk._chk(L.mgk_jacobi_f64(mgk.ctx, C.byref(g), coef, dinv, 0.8, db, du, d1, None))
+        mgk._chk(L.mgk_jacobi_f64(mgk.ctx, C.byref(g), coef, dinv, 0.8, db, d1, d2, None))
+        mgk._chk(L.mgk_jacobi_f64(mgk.ctx, C.byref(g), coef, dinv, 0.8, db, d2, d1, None))
+        want = mgk.from_field(g, d1)
+        mgk._chk(L.mgk_residual_f64(mgk.ctx, C.byref(g), coef, db, du, d2, None))
+        r0 = mgk.from_field(g, d2)
+    ss = C.c_double()
+    for var, zc in ((-1, -1), (62, -1), (63, -1), (64, -1), (-1, 1), (-1, 5), (63, 7), (53, 16)):      # 64: the row-by-row form
+        L.mgk_set_tuning(var, zc)
+        mgk._chk(L.mgk_memset0(mgk.ctx, dout, 8 * g.total, None))
+        mgk._chk(L.mgk_jacobi3_f64(mgk.ctx, C.byref(g), coef, dinv, 0.8, db, du, dout, None))
+        got = mgk.from_field(g, dout)
+        assert np.array_equal(got, want), f"variant={var} zc={zc}: max diff {np.abs(got - want).max()}"
+        raw = mgk.raw_field(g, dout)
+        assert abs(np.abs(raw).sum() - np.abs(got).sum()) <= 1e-9 * max(np.abs(got).sum(), 1e-300)
+        mgk._chk(L.mgk_memset0(mgk.ctx, dout, 8 * g.total, None))
+        mgk._chk(L.mgk_jacobi3_sumsq_f64(mgk.ctx, C.byref(g), coef, dinv, 0.8, db, du, dout, C.byref(ss), None))
+        assert np.array_equal(mgk.from_field(g, dout), want), f"variant={var} zc={zc}: with the norm"
+        assert abs(ss.value - orc.sumsq(r0)) <= 1e-13 * orc.sumsq(r0)
+    L.mgk_set_tuning(-1, -1)
+    assert np.array_equal(mgk.from_field(g, du), u)
+    for p in (du, db, dout, d1, d2):
+        mgk.free(p)
