@@ -351,7 +351,7 @@ def main():
         from multigrid_petsc_amd.comm import rccl_comm, HostStagedComm, selftest
         from multigrid_petsc_amd.mgk import Mgk
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        requested = os.environ.get("MG_BENCH_TRANSPORT", "rccl")       # rccl (default) | host
+        requested = os.environ.get("MG_BENCH_TRANSPORT", "rccl")       # rccl (default) | peer | host
         transport = requested
 
         def all_ok(ok):                     # every rank takes the same decision: MIN over ranks of a status flag
@@ -393,6 +393,39 @@ def main():
                     raise SystemExit(3)
                 # the run continues on the host-staged (gloo) transport so that the job still yields a correct line, but the
                 # line says so at top level ("transport_fallback": true): it is NOT an RCCL/xGMI number
+                transport, transport_fallback = "host", True
+        if transport == "peer":
+            # IPC-mapped mailboxes + flag words, plane copies by the copy engines (include/mg_comm.h); the same first-run gate as RCCL
+            from multigrid_petsc_amd.comm import peer_comm
+            why = ""
+            try:
+                m = Mgk(local_rank)
+                g0, g2 = m.geom(args.dim, args.npts - 2), m.geom(args.dim, min(args.npts - 2, 255))
+                m.close()
+                comm = peer_comm(rank, world, local_rank, dist, 8 * g0.plane, 5, 8 * g2.total)
+            except Exception as e:          # noqa: BLE001
+                why = f"communicator: {e}"
+                print(f"[bench rank {rank}] {why}", file=sys.stderr, flush=True)
+            up = all_ok(comm is not None)
+            if up:
+                ok = True
+                try:
+                    m = Mgk(local_rank)
+                    try:
+                        selftest(comm.handle, m.ctx)
+                    finally:
+                        m.close()
+                except Exception as e:      # noqa: BLE001
+                    ok, why = False, f"self-test: {e}"
+                    print(f"[bench rank {rank}] transport self-test FAILED: {why}", file=sys.stderr, flush=True)
+                up = all_ok(ok)
+            if not up:
+                print(f"[bench rank {rank}] peer transport unusable ({why or 'another rank failed'})", file=sys.stderr, flush=True)
+                if comm is not None:
+                    comm.close()
+                    comm = None
+                if os.environ.get("MG_BENCH_ALLOW_FALLBACK", "1") != "1":
+                    raise SystemExit(3)
                 transport, transport_fallback = "host", True
         if transport == "host":
             comm = HostStagedComm(rank, world, dist)

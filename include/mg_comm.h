@@ -14,6 +14,7 @@
  *             any other stream fails with MGK_EINVAL.
  *   loopback  all ranks are threads of ONE process sharing one GPU (device-to-device copies and
  *             a pthread barrier): exercises every line of the slab logic on a single-GPU box
+ *   peer      (round 3) IPC-mapped mailboxes + flag words: plane copies by the copy engines, sequenced by one-wave flag kernels; see below
  *   phantom   ONE rank of an N-rank run alone on a GPU: ghost planes are filled by device copies of
  *             the rank's own boundary planes and every exchange holds its stream for
  *             latency + bytes / link bandwidth (mgk_delay_us): times one rank's share of the
@@ -60,6 +61,20 @@ int  mg_comm_rccl_self_sendrecv_async(mg_comm *c, mgk_ctx *ctx, const void *src,
 /* phantom: rank `rank` of `nranks` alone on its GPU (measurement aid, see above).  lat_us: latency of one exchange,
  * link_gbs: one-directional bandwidth of one link; an exchange holds its stream for lat_us + bytes_per_direction/link_gbs */
 mg_comm *mg_comm_phantom_create(int rank, int nranks, double lat_us, double link_gbs);
+
+/* peer (round 3): every rank owns a mailbox, a gather box and a block of flag words in fine-grained device memory, exported with hipIpc*
+ * and mapped by its neighbours; a halo is a peer copy of the boundary planes into the neighbour's mailbox (copy engines between devices: no
+ * workgroup), sequenced by ONE-wave flag kernels -- nothing that has to find a free CU beside the one-block-per-CU marching kernels, which
+ * is what a send/recv kernel must.  All-reduce: 8-byte stores into every rank's slot block, summed in rank order.
+ * At most MGK_PEER_MAX (16) ranks of ONE node.  plane_bytes_max / fields_max: largest plane and most fields of one grouped exchange;
+ * gather_bytes: (nz + 2) planes of the largest level that is all-gathered.  blob_out receives this rank's MG_PEER_BLOB_BYTES of handles;
+ * the launcher all-gathers the blobs of all ranks (rank order) and passes them to mg_comm_peer_connect on every rank.
+ * Every rank must issue the same sequence of exchanges.  MG_PEER_TIMEOUT_S (default 60): a flag that does not arrive in time makes the
+ * next host-synchronising hook (allreduce_sum, barrier) fail with MGK_ECOMM instead of hanging the stream.
+ * Tested with two and three PROCESSES sharing one GPU (IPC handles of the same device); its bandwidth over xGMI is unmeasured. */
+#define MG_PEER_BLOB_BYTES (3 * MGK_IPC_HANDLE_BYTES)
+mg_comm *mg_comm_peer_create(int rank, int nranks, int device, size_t plane_bytes_max, int fields_max, size_t gather_bytes, void *blob_out);
+int      mg_comm_peer_connect(mg_comm *c, const void *all_blobs);
 
 /* First-run gate of a transport: rank-coded planes through halo / halo_n / allgather_planes, known sums through both
  * all-reduce forms, everything read back and compared on every rank.  0, or MGK_ECOMM with mg_comm_last_error() naming the

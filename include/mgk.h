@@ -448,6 +448,28 @@ int  mgk_jacobi3_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double
 int  mgk_jacobi3_sumsq_f64(mgk_ctx *ctx, const mgk_geom *g, const double *coef, double dinv, double scale,
                            const double *b, const double *u, double *unew, double *sumsq_host, void *stream);
 
+/* ---- round 3: primitives of the peer halo transport (mg_comm_peer_*, include/mg_comm.h) ----
+ * mgk_ipc_alloc: `bytes` of FINE-GRAINED device memory (zeroed; not cached in L2, so that a neighbour's writes over xGMI are what the next
+ * load sees) and its 64-byte inter-process handle; mgk_ipc_open maps another process's allocation (any device of the node) into this
+ * one; mgk_peer_copy: copy between two device allocations that may live on different GPUs, queued on `stream` (between devices the
+ * runtime uses the copy engines: no workgroup).  mgk_flag_set / mgk_flag_wait: ONE-wave kernels that store `value` into a (possibly
+ * remote) 8-byte flag word with system-scope release / wait until the local flag word is >= value (acquire; after timeout_s they set
+ * *status_u32 (fine-grained or pinned memory) to 1 and return, so that a stream never hangs).  mgk_peer_allreduce: in-place sum of n <= 64
+ * device doubles over `nranks` <= MGK_PEER_MAX processes through per-rank slot blocks (2 x nranks x 65 x 8 bytes) in fine-grained memory,
+ * peer_blocks[r] = rank r's block as mapped here; summed in rank order: the same bits on every rank; one wave. */
+#define MGK_IPC_HANDLE_BYTES 64
+#define MGK_PEER_MAX 16
+int  mgk_ipc_alloc(mgk_ctx *ctx, size_t bytes, void **ptr, void *handle64);
+int  mgk_ipc_open(mgk_ctx *ctx, const void *handle64, void **ptr);
+int  mgk_ipc_close(mgk_ctx *ctx, void *ptr);
+int  mgk_peer_copy(mgk_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream);
+int  mgk_flags_set(mgk_ctx *ctx, void *const *flags, int n, unsigned long long value, void *stream);                 /* n <= MGK_PEER_MAX words, one launch */
+int  mgk_flags_wait(mgk_ctx *ctx, void *const *flags, int n, unsigned long long value, double timeout_s, void *status_u32, void *stream);
+int  mgk_flag_set(mgk_ctx *ctx, void *flag, unsigned long long value, void *stream);
+int  mgk_flag_wait(mgk_ctx *ctx, const void *flag, unsigned long long value, double timeout_s, void *status_u32, void *stream);
+int  mgk_peer_allreduce(mgk_ctx *ctx, void *const *peer_blocks, int nranks, int me, unsigned long long seq, double *vals_dev, int n,
+                        double timeout_s, void *status_u32, void *stream);
+
 /* tuning knob for the marching stencil kernel (profiling only): <=0 keeps the built-in choice */
 void mgk_set_tuning(int variant, int zchunk);
 

@@ -34,6 +34,10 @@ def _lib():
     L.mg_comm_allreduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.mg_comm_phantom_create.restype = C.c_void_p
     L.mg_comm_phantom_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double]
+    L.mg_comm_peer_create.restype = C.c_void_p
+    L.mg_comm_peer_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p]
+    L.mg_comm_peer_connect.restype = C.c_int
+    L.mg_comm_peer_connect.argtypes = [C.c_void_p, C.c_void_p]
     L.mg_comm_selftest.restype = C.c_int
     L.mg_comm_selftest.argtypes = [C.c_void_p, C.c_void_p]
     L._comm_sigs = True
@@ -89,6 +93,43 @@ def rccl_comm(rank, world, device, dist=None, uid=None):
         if status != "ok":
             raise RuntimeError("rank 0 could not create the RCCL unique id: " + str(uid))
     return Comm(_lib().mg_comm_rccl_create(rank, world, uid, device))
+
+
+PEER_BLOB_BYTES = 192
+
+
+def peer_comm(rank, world, device, dist, plane_bytes_max, fields_max=5, gather_bytes=None):
+    """The peer transport (include/mg_comm.h: IPC-mapped mailboxes + flag words, copy-engine plane copies): every rank creates its
+    mailbox / flag block / gather box and publishes the 192 bytes of IPC handles; `dist` (an initialised torch.distributed module, any
+    backend) all-gathers the blobs; then every rank maps its peers.  Collective-safe like rccl_comm: a rank that could not create its
+    side still takes part in the all-gather (with an error marker), and every rank raises."""
+    L = _lib()
+    blob = C.create_string_buffer(PEER_BLOB_BYTES)
+    h = L.mg_comm_peer_create(rank, world, device, int(plane_bytes_max), int(fields_max), int(gather_bytes or plane_bytes_max), blob)
+    mine = ("ok", blob.raw) if h else ("error", L.mg_comm_last_error().decode())
+    allb = [None] * world
+    if world > 1:
+        dist.all_gather_object(allb, mine)
+    else:
+        allb = [mine]
+    bad = [(r, b[1]) for r, b in enumerate(allb) if b[0] != "ok"]
+    if bad:
+        if h:
+            L.mg_comm_destroy(C.c_void_p(h))
+        raise RuntimeError("peer transport: " + "; ".join(f"rank {r}: {m}" for r, m in bad))
+    comm = Comm(h)
+    joined = b"".join(b[1] for b in allb)
+    rc = L.mg_comm_peer_connect(comm.handle, joined)
+    ok = [None] * world
+    if world > 1:
+        dist.all_gather_object(ok, rc)
+    else:
+        ok = [rc]
+    if any(ok):
+        msg = L.mg_comm_last_error().decode()
+        comm.close()
+        raise RuntimeError(f"peer transport: mapping the peers' memory failed on rank(s) {[r for r, v in enumerate(ok) if v]}: {msg}")
+    return comm
 
 
 class LoopbackWorld:

@@ -527,6 +527,230 @@ mg_comm *mg_comm_phantom_create(int rank, int nranks, double lat_us, double link
 }
 
 /* ================================================================== */
+/* peer: IPC-mapped mailboxes + flag words, copy-engine plane copies   */
+/* ================================================================== */
+/* (round 3)  One process per GPU.  Every rank owns, in fine-grained device memory (mgk_ipc_alloc):
+ *   a MAILBOX  [from_lo | from_hi], each `nfmax` slots of `pmax` bytes: where its neighbours drop their boundary planes;
+ *   a GATHER BOX of `gbytes`: where all ranks drop their planes of a level that becomes replicated;
+ *   a FLAG BLOCK of 8-byte words: 0/1 data from lo/hi has landed (exchange number), 2/3 lo/hi has drained what I sent (free to overwrite),
+ *   4+r gather data of rank r has landed, 20+r rank r has drained the gather box I wrote into, 64.. the all-reduce slots.
+ * A halo exchange number k, all on the caller's stream (the comm stream of the solver's context):
+ *   wait (one wave) until both neighbours acknowledged exchange k-1  ->  peer copies of my boundary planes into THEIR mailboxes
+ *   (mgk_peer_copy: between devices the copy engines move the planes -- no workgroup, nothing to squeeze in beside the marching
+ *   kernels)  ->  one wave stores k into their "landed" words  ->  one wave waits for k in my own "landed" words  ->  copies
+ *   mailbox -> ghost planes  ->  one wave stores k into their "drained" words.
+ * The flag kernels use a handful of registers: a wave slot is free beside the one-block-per-CU marching kernels, where RCCL's send/recv
+ * kernel finds none.  Every rank must issue the same sequence of exchanges (the solver does).  A wait that does
+ * not see its number within `timeout_s` raises the status word; the next host-synchronising hook returns MGK_ECOMM.
+ * Bootstrap: mg_comm_peer_create returns the rank's 192-byte blob of IPC handles; the launcher all-gathers the blobs (bench.py: gloo)
+ * and hands all of them to mg_comm_peer_connect. */
+#define PEER_W_LANDED 0
+#define PEER_W_DRAINED 2
+#define PEER_W_GLANDED 4
+#define PEER_W_GDRAINED 20
+#define PEER_W_RED 64
+#define PEER_FLAG_WORDS (PEER_W_RED + 2 * MGK_PEER_MAX * 65)
+typedef struct peer_impl {
+    mgk_ctx *ctx;                         /* owner of the allocations */
+    int device, nfmax, connected;
+    size_t pmax, gbytes;
+    char *mbox, *gbox;                    /* mine */
+    unsigned long long *flags;            /* mine */
+    char *nb_mbox[2];                     /* lo / hi neighbour's mailbox as mapped here */
+    char *all_gbox[MGK_PEER_MAX];
+    unsigned long long *all_flags[MGK_PEER_MAX];
+    unsigned long long seq_halo, seq_gather, seq_red;
+    unsigned int *status;                 /* pinned host word: a flag wait timed out */
+    double *red_dev;                      /* 64 doubles (device) */
+    double *red_pin;                      /* 64 doubles (pinned host) */
+    double timeout_s;
+} peer_impl;
+
+static int peer_check(mg_comm *c, const char *where) {
+    peer_impl *im = (peer_impl *)c->impl;
+    if (im->status && *im->status) return cfail(MGK_ECOMM, where, "a flag wait of the peer transport timed out (a neighbour never signalled)");
+    return 0;
+}
+static int peer_halo_n(mg_comm *c, mgk_ctx *ctx, int nf, void *const *fields, const mgk_geom *const *geoms, int esz, void *stream) {
+    peer_impl *im = (peer_impl *)c->impl;
+    if (c->nranks == 1 || nf < 1) return 0;
+    if (!im->connected) return cfail(MGK_EINVAL, "peer halo", "mg_comm_peer_connect has not been called");
+    if (nf > im->nfmax) return cfail(MGK_EINVAL, "peer halo", "more fields in one exchange than the mailbox has slots");
+    for (int q = 0; q < nf; q++)
+        if ((size_t)esz * (size_t)geoms[q]->plane > im->pmax) return cfail(MGK_EINVAL, "peer halo", "a plane is larger than a mailbox slot");
+    void *s = stream_of(ctx, stream);
+    const int me = c->rank, lo = me > 0, hi = me < c->nranks - 1;
+    const unsigned long long k = ++im->seq_halo;
+    const size_t box = (size_t)im->nfmax * im->pmax;                /* from_lo box at 0, from_hi box at `box` */
+    void *w[2];
+    int nw = 0;
+    /* 1. the neighbours have drained what exchange k-1 put into their mailboxes */
+    if (lo) w[nw++] = im->flags + PEER_W_DRAINED + 0;
+    if (hi) w[nw++] = im->flags + PEER_W_DRAINED + 1;
+    CK(mgk_flags_wait(ctx, w, nw, k - 1, im->timeout_s, im->status, s));
+    /* 2. my boundary planes into their mailboxes: I am the HI neighbour of rank-1 and the LO neighbour of rank+1 */
+    for (int q = 0; q < nf; q++) {
+        const size_t pb = (size_t)esz * (size_t)geoms[q]->plane;
+        char *f = (char *)fields[q];
+        if (lo) CK(mgk_peer_copy(ctx, im->nb_mbox[0] + box + (size_t)q * im->pmax, f + pb, pb, s));
+        if (hi) CK(mgk_peer_copy(ctx, im->nb_mbox[1] + (size_t)q * im->pmax, f + (size_t)geoms[q]->nz * pb, pb, s));
+    }
+    /* 3. tell them */
+    nw = 0;
+    if (lo) w[nw++] = im->all_flags[me - 1] + PEER_W_LANDED + 1;
+    if (hi) w[nw++] = im->all_flags[me + 1] + PEER_W_LANDED + 0;
+    CK(mgk_flags_set(ctx, w, nw, k, s));
+    /* 4. theirs have landed in mine */
+    nw = 0;
+    if (lo) w[nw++] = im->flags + PEER_W_LANDED + 0;
+    if (hi) w[nw++] = im->flags + PEER_W_LANDED + 1;
+    CK(mgk_flags_wait(ctx, w, nw, k, im->timeout_s, im->status, s));
+    /* 5. mailbox -> ghost planes */
+    for (int q = 0; q < nf; q++) {
+        const size_t pb = (size_t)esz * (size_t)geoms[q]->plane;
+        char *f = (char *)fields[q];
+        if (lo) CK(mgk_d2d(ctx, f, im->mbox + (size_t)q * im->pmax, pb, s));
+        if (hi) CK(mgk_d2d(ctx, f + (size_t)(geoms[q]->nz + 1) * pb, im->mbox + box + (size_t)q * im->pmax, pb, s));
+    }
+    /* 6. drained: they may overwrite */
+    nw = 0;
+    if (lo) w[nw++] = im->all_flags[me - 1] + PEER_W_DRAINED + 1;
+    if (hi) w[nw++] = im->all_flags[me + 1] + PEER_W_DRAINED + 0;
+    CK(mgk_flags_set(ctx, w, nw, k, s));
+    return 0;
+}
+static int peer_halo(mg_comm *c, mgk_ctx *ctx, void *field, const mgk_geom *g, int esz, void *stream) {
+    void *const f[1] = {field};
+    const mgk_geom *const gg[1] = {g};
+    return peer_halo_n(c, ctx, 1, f, gg, esz, stream);
+}
+static int peer_allgather_planes(mg_comm *c, mgk_ctx *ctx, void *field, const mgk_geom *gf, const int *zstart, int esz, void *stream) {
+    peer_impl *im = (peer_impl *)c->impl;
+    if (c->nranks == 1) return 0;
+    if (!im->connected) return cfail(MGK_EINVAL, "peer allgather", "mg_comm_peer_connect has not been called");
+    const size_t pb = (size_t)esz * (size_t)gf->plane;
+    if ((size_t)(gf->nz + 2) * pb > im->gbytes) return cfail(MGK_EINVAL, "peer allgather", "the level is larger than the gather box");
+    void *s = stream_of(ctx, stream);
+    const int me = c->rank, P = c->nranks;
+    const unsigned long long k = ++im->seq_gather;
+    void *w[MGK_PEER_MAX];
+    int nw = 0;
+    for (int r = 0; r < P; r++) if (r != me) w[nw++] = im->flags + PEER_W_GDRAINED + r;
+    CK(mgk_flags_wait(ctx, w, nw, k - 1, im->timeout_s, im->status, s));
+    const size_t off = (size_t)(zstart[me] + 1) * pb, mine = (size_t)(zstart[me + 1] - zstart[me]) * pb;
+    for (int r = 0; r < P; r++) if (r != me && mine) CK(mgk_peer_copy(ctx, im->all_gbox[r] + off, (char *)field + off, mine, s));
+    nw = 0;
+    for (int r = 0; r < P; r++) if (r != me) w[nw++] = im->all_flags[r] + PEER_W_GLANDED + me;
+    CK(mgk_flags_set(ctx, w, nw, k, s));
+    nw = 0;
+    for (int r = 0; r < P; r++) if (r != me) w[nw++] = im->flags + PEER_W_GLANDED + r;
+    CK(mgk_flags_wait(ctx, w, nw, k, im->timeout_s, im->status, s));
+    for (int r = 0; r < P; r++) {
+        if (r == me) continue;
+        const size_t o = (size_t)(zstart[r] + 1) * pb, n = (size_t)(zstart[r + 1] - zstart[r]) * pb;
+        if (n) CK(mgk_d2d(ctx, (char *)field + o, im->gbox + o, n, s));
+    }
+    nw = 0;
+    for (int r = 0; r < P; r++) if (r != me) w[nw++] = im->all_flags[r] + PEER_W_GDRAINED + me;
+    CK(mgk_flags_set(ctx, w, nw, k, s));
+    return 0;
+}
+static int peer_allreduce_sum_dev(mg_comm *c, mgk_ctx *ctx, double *dvals, int n, void *stream) {
+    peer_impl *im = (peer_impl *)c->impl;
+    if (n < 1) return 0;
+    if (!im->connected && c->nranks > 1) return cfail(MGK_EINVAL, "peer allreduce", "mg_comm_peer_connect has not been called");
+    void *s = stream_of(ctx, stream);
+    void *blocks[MGK_PEER_MAX];
+    for (int r = 0; r < c->nranks; r++) blocks[r] = im->all_flags[r] + PEER_W_RED;
+    for (int q = 0; q < n; q += 64)
+        CK(mgk_peer_allreduce(ctx, blocks, c->nranks, c->rank, ++im->seq_red, dvals + q, n - q < 64 ? n - q : 64, im->timeout_s, im->status, s));
+    return 0;
+}
+static int peer_allreduce_sum(mg_comm *c, mgk_ctx *ctx, double *vals, int n, void *stream) {
+    peer_impl *im = (peer_impl *)c->impl;
+    if (n > 64) return cfail(MGK_EINVAL, "allreduce_sum", "at most 64 values");
+    void *s = stream ? stream : mgk_stream_comm(ctx);
+    CK(mgk_stream_wait(ctx, s, mgk_stream_compute(ctx)));
+    memcpy(im->red_pin, vals, sizeof(double) * (size_t)n);
+    CK(mgk_h2d_async(ctx, im->red_dev, im->red_pin, sizeof(double) * (size_t)n, s));
+    int rc = peer_allreduce_sum_dev(c, ctx, im->red_dev, n, s);
+    if (rc) return rc;
+    CK(mgk_d2h_async(ctx, im->red_pin, im->red_dev, sizeof(double) * (size_t)n, s));
+    CK(mgk_sync(ctx, s));
+    memcpy(vals, im->red_pin, sizeof(double) * (size_t)n);
+    return peer_check(c, "peer allreduce_sum");
+}
+static int peer_barrier(mg_comm *c, mgk_ctx *ctx) {
+    double z = 0.0;
+    return peer_allreduce_sum(c, ctx, &z, 1, NULL);
+}
+static void peer_destroy(mg_comm *c) {
+    if (!c) return;
+    peer_impl *im = (peer_impl *)c->impl;
+    if (im) {
+        for (int q = 0; q < 2; q++) if (im->nb_mbox[q]) mgk_ipc_close(im->ctx, im->nb_mbox[q]);
+        for (int r = 0; r < c->nranks; r++) {
+            if (r == c->rank) continue;
+            if (im->all_gbox[r]) mgk_ipc_close(im->ctx, im->all_gbox[r]);
+            if (im->all_flags[r]) mgk_ipc_close(im->ctx, im->all_flags[r]);
+        }
+        if (im->mbox) mgk_free(im->ctx, im->mbox);
+        if (im->gbox) mgk_free(im->ctx, im->gbox);
+        if (im->flags) mgk_free(im->ctx, im->flags);
+        if (im->red_dev) mgk_free(im->ctx, im->red_dev);
+        if (im->red_pin) mgk_host_free(im->ctx, im->red_pin);
+        if (im->status) mgk_host_free(im->ctx, im->status);
+        if (im->ctx) mgk_ctx_destroy(im->ctx);
+        free(im);
+    }
+    free(c);
+}
+mg_comm *mg_comm_peer_create(int rank, int nranks, int device, size_t plane_bytes_max, int fields_max, size_t gather_bytes, void *blob_out) {
+    if (nranks < 1 || nranks > MGK_PEER_MAX || rank < 0 || rank >= nranks || !plane_bytes_max || fields_max < 1 || !gather_bytes || !blob_out) {
+        cfail(MGK_EINVAL, "mg_comm_peer_create", "bad arguments (at most 16 ranks)");
+        return NULL;
+    }
+    peer_impl *im = (peer_impl *)calloc(1, sizeof(peer_impl));
+    mg_comm *c = (mg_comm *)calloc(1, sizeof(mg_comm));
+    if (!im || !c) { free(im); free(c); cfail(MGK_EINVAL, "mg_comm_peer_create", "out of host memory"); return NULL; }
+    c->rank = rank; c->nranks = nranks; c->impl = im;
+    im->device = device; im->nfmax = fields_max;
+    im->pmax = (plane_bytes_max + 255) & ~(size_t)255; im->gbytes = gather_bytes;
+    { const char *e = getenv("MG_PEER_TIMEOUT_S"); im->timeout_s = (e && atof(e) > 0.0) ? atof(e) : 60.0; }
+    char *blob = (char *)blob_out;
+    void *p = NULL;
+    int rc = mgk_ctx_create(&im->ctx, device);
+    if (!rc) { rc = mgk_ipc_alloc(im->ctx, 2 * (size_t)fields_max * im->pmax, &p, blob); im->mbox = (char *)p; }
+    if (!rc) { rc = mgk_ipc_alloc(im->ctx, sizeof(unsigned long long) * PEER_FLAG_WORDS, &p, blob + MGK_IPC_HANDLE_BYTES); im->flags = (unsigned long long *)p; }
+    if (!rc) { rc = mgk_ipc_alloc(im->ctx, gather_bytes, &p, blob + 2 * MGK_IPC_HANDLE_BYTES); im->gbox = (char *)p; }
+    if (!rc) { rc = mgk_malloc(im->ctx, &p, 64 * sizeof(double)); im->red_dev = (double *)p; }
+    if (!rc) { rc = mgk_host_alloc(im->ctx, &p, 64 * sizeof(double)); im->red_pin = (double *)p; }
+    if (!rc) { rc = mgk_host_alloc(im->ctx, &p, 64); im->status = (unsigned int *)p; if (!rc) *im->status = 0; }
+    if (rc) { cfail(rc, "mg_comm_peer_create", mgk_last_error()); peer_destroy(c); return NULL; }
+    im->all_flags[rank] = im->flags; im->all_gbox[rank] = im->gbox;
+    c->halo = peer_halo; c->halo_n = peer_halo_n; c->allgather_planes = peer_allgather_planes;
+    c->allreduce_sum = peer_allreduce_sum; c->allreduce_sum_dev = peer_allreduce_sum_dev; c->barrier = peer_barrier; c->destroy = peer_destroy;
+    if (nranks == 1) im->connected = 1;
+    return c;
+}
+int mg_comm_peer_connect(mg_comm *c, const void *all_blobs) {
+    if (!c || c->halo != peer_halo || !all_blobs) return cfail(MGK_EINVAL, "mg_comm_peer_connect", "not a peer communicator");
+    peer_impl *im = (peer_impl *)c->impl;
+    if (im->connected) return 0;
+    const char *b = (const char *)all_blobs;
+    for (int r = 0; r < c->nranks; r++) {
+        if (r == c->rank) continue;
+        const char *br = b + (size_t)r * MG_PEER_BLOB_BYTES;
+        void *p = NULL;
+        CK(mgk_ipc_open(im->ctx, br + MGK_IPC_HANDLE_BYTES, &p)); im->all_flags[r] = (unsigned long long *)p;
+        CK(mgk_ipc_open(im->ctx, br + 2 * MGK_IPC_HANDLE_BYTES, &p)); im->all_gbox[r] = (char *)p;
+        if (r == c->rank - 1 || r == c->rank + 1) { CK(mgk_ipc_open(im->ctx, br, &p)); im->nb_mbox[r == c->rank - 1 ? 0 : 1] = (char *)p; }
+    }
+    im->connected = 1;
+    return 0;
+}
+
+/* ================================================================== */
 /* self-test of a transport (collective)                               */
 /* ================================================================== */
 static int st_fail(const char *what, int rank, double got, double want) {

@@ -535,3 +535,126 @@ extern "C" int mgk_jacobi3_sumsq_f64(mgk_ctx *c, const mgk_geom *g, const double
     if (rc) return rc;
     return finish_to_host(c, nparts, 1, S(c, stream), sumsq_host);
 }
+
+// ------------------------------------------------------------------------------------------
+// Round 3: primitives of the PEER halo transport (include/mg_comm.h, csrc/mg_comm.c: mg_comm_peer_*).  One process per GPU; every rank
+// allocates a mailbox and a block of flag words in FINE-GRAINED device memory (not cached in L2: what a neighbour writes over xGMI is what the
+// next load sees), exports them with hipIpc*, and maps its neighbours'.  An exchange is: peer copies of the boundary planes into the
+// neighbour's mailbox (hipMemcpyAsync between devices: the copy engines, no workgroup), a ONE-WAVE kernel that stores the exchange's
+// sequence number into the neighbour's flag word, a one-wave kernel that waits for the neighbour's number in the own flag word, copies
+// mailbox -> ghost planes.  The two flag kernels use ~10 registers: they find a slot beside the one-block-per-CU marching kernels (which
+// leave 32 VGPRs per SIMD), where RCCL's send/recv kernel does not.
+// ------------------------------------------------------------------------------------------
+extern "C" int mgk_ipc_alloc(mgk_ctx *c, size_t bytes, void **ptr, void *handle64) {
+    if (!c || !ptr || !handle64 || !bytes) return fail(MGK_EINVAL, "mgk_ipc_alloc: bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocFinegrained));
+    HIPCHK(hipMemsetAsync(*ptr, 0, bytes, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    hipIpcMemHandle_t h;
+    HIPCHK(hipIpcGetMemHandle(&h, *ptr));
+    static_assert(sizeof(h) == MGK_IPC_HANDLE_BYTES, "handle size");
+    memcpy(handle64, &h, sizeof(h));
+    return 0;
+}
+extern "C" int mgk_ipc_open(mgk_ctx *c, const void *handle64, void **ptr) {
+    if (!c || !ptr || !handle64) return fail(MGK_EINVAL, "mgk_ipc_open: bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, sizeof(h));
+    HIPCHK(hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return 0;
+}
+extern "C" int mgk_ipc_close(mgk_ctx *c, void *ptr) { (void)c; if (ptr) HIPCHK(hipIpcCloseMemHandle(ptr)); return 0; }
+// copy between two device allocations that may live on different GPUs (peer copy: copy engines), queued on `stream`
+extern "C" int mgk_peer_copy(mgk_ctx *c, void *dst, const void *src, size_t bytes, void *stream) {
+    if (!c || !dst || !src) return fail(MGK_EINVAL, "mgk_peer_copy: bad arguments");
+    if (bytes) HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, S(c, stream)));
+    return 0;
+}
+struct FlagArgs { unsigned long long *flag[MGK_PEER_MAX]; int n; unsigned long long value, ticks; unsigned int *status; };
+__global__ void __launch_bounds__(64) k_flag_set(const FlagArgs a) {
+    if ((int)threadIdx.x < a.n) __hip_atomic_store(a.flag[threadIdx.x], a.value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// waits until every *flag[q] >= value; gives up after `ticks` of the 100 MHz clock and reports in *status (every lane reaches the exit)
+__global__ void __launch_bounds__(64) k_flag_wait(const FlagArgs a) {
+    if ((int)threadIdx.x >= a.n) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(a.flag[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.value) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > a.ticks) { __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+static int flag_args(FlagArgs &a, void *const *flags, int n, unsigned long long value) {
+    memset(&a, 0, sizeof(a));
+    if (!flags || n < 1 || n > MGK_PEER_MAX) return 1;
+    for (int q = 0; q < n; q++) { if (!flags[q]) return 1; a.flag[q] = (unsigned long long *)flags[q]; }
+    a.n = n; a.value = value;
+    return 0;
+}
+extern "C" int mgk_flags_set(mgk_ctx *c, void *const *flags, int n, unsigned long long value, void *stream) {
+    FlagArgs a;
+    if (!c || flag_args(a, flags, n, value)) return fail(MGK_EINVAL, "mgk_flags_set: bad arguments");
+    hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(64), 0, S(c, stream), a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int mgk_flags_wait(mgk_ctx *c, void *const *flags, int n, unsigned long long value, double timeout_s, void *status_u32, void *stream) {
+    FlagArgs a;
+    if (!c || !status_u32 || !(timeout_s > 0.0) || flag_args(a, flags, n, value)) return fail(MGK_EINVAL, "mgk_flags_wait: bad arguments");
+    a.ticks = (unsigned long long)(timeout_s * 1.0e8); a.status = (unsigned int *)status_u32;
+    hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, S(c, stream), a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int mgk_flag_set(mgk_ctx *c, void *flag, unsigned long long value, void *stream) { void *f[1] = {flag}; return mgk_flags_set(c, f, 1, value, stream); }
+extern "C" int mgk_flag_wait(mgk_ctx *c, const void *flag, unsigned long long value, double timeout_s, void *status_u32, void *stream) {
+    void *f[1] = {const_cast<void *>(flag)};
+    return mgk_flags_wait(c, f, 1, value, timeout_s, status_u32, stream);
+}
+// all-reduce (sum) of n <= 64 doubles between `nranks` processes through their fine-grained slot blocks: rank me stores its values and the
+// sequence number into slot `me` of EVERY rank's block (peers[r]: that rank's block as mapped here; one 8-byte store per value),
+// waits until all slots of its own block carry the number, and sums them in rank order -- the same bits on every rank.
+// Block layout: two buffers (parity of the sequence number: a rank may be one all-reduce ahead of a peer that still sums the last one,
+// never two) of nranks slots [seq, v0 .. v63] (65 x 8 bytes each).  One wave.
+struct ARArgs { unsigned long long *peers[MGK_PEER_MAX]; int nranks, me, n; unsigned long long seq, ticks; double *vals; unsigned int *status; };
+__global__ void __launch_bounds__(64) k_peer_allreduce(const ARArgs a) {
+    const int lane = threadIdx.x;
+    const int buf = (int)(a.seq & 1ull);
+    const double mine = lane < a.n ? a.vals[lane] : 0.0;
+    for (int r = 0; r < a.nranks; r++) {
+        unsigned long long *slot = a.peers[r] + 65 * (buf * a.nranks + a.me);
+        if (lane < a.n) __hip_atomic_store(reinterpret_cast<double *>(slot + 1 + lane), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __builtin_amdgcn_s_waitcnt(0);
+    if (lane == 0) for (int r = 0; r < a.nranks; r++) __hip_atomic_store(a.peers[r] + 65 * (buf * a.nranks + a.me), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long *own = a.peers[a.me] + 65 * buf * a.nranks;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    bool ok = true;
+    if (lane < a.nranks) {
+        while (__hip_atomic_load(own + 65 * lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > a.ticks) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    if (!ok) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // every lane's poll has ended (one wave: the loop above is a divergent region that reconverges here)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    if (lane < a.n) {
+        double s = 0.0;
+        for (int r = 0; r < a.nranks; r++) s += __hip_atomic_load(reinterpret_cast<const double *>(own + 65 * r + 1 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        a.vals[lane] = s;
+    }
+}
+extern "C" int mgk_peer_allreduce(mgk_ctx *c, void *const *peer_blocks, int nranks, int me, unsigned long long seq, double *vals_dev, int n,
+                                  double timeout_s, void *status_u32, void *stream) {
+    if (!c || !peer_blocks || nranks < 1 || nranks > MGK_PEER_MAX || me < 0 || me >= nranks || !vals_dev || n < 1 || n > 64 || !status_u32)
+        return fail(MGK_EINVAL, "mgk_peer_allreduce: bad arguments");
+    ARArgs a; memset(&a, 0, sizeof(a));
+    for (int r = 0; r < nranks; r++) { if (!peer_blocks[r]) return fail(MGK_EINVAL, "mgk_peer_allreduce: unmapped peer"); a.peers[r] = (unsigned long long *)peer_blocks[r]; }
+    a.nranks = nranks; a.me = me; a.n = n; a.seq = seq; a.ticks = (unsigned long long)(timeout_s * 1.0e8); a.vals = vals_dev; a.status = (unsigned int *)status_u32;
+    hipLaunchKernelGGL(k_peer_allreduce, dim3(1), dim3(64), 0, S(c, stream), a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}

@@ -12,6 +12,8 @@
 #include <cstring>
 #include <functional>
 #include <vector>
+#include <sched.h>
+#include <time.h>
 #include "mgk.h"
 
 struct mgk_ctx {
@@ -729,6 +731,59 @@ int mgk_residual_restrict_2d_rowcoef_f64(mgk_ctx *c, const mgk_geom *gf, const m
         restrict_fw<double>(F, Cg, r.data(), bc, 0, 1);
         if (uc0) for (int i = 0; i < Cg.ny; i++) for (int j = 0; j < Cg.nx; j++) { const double zq = at(bc, Cg, 0, i, j) * dtab_c[i]; at(uc0, Cg, 0, i, j) = scale_c * zq; }
     });
+}
+
+// round 3: primitives of the peer transport, in host memory: a "handle" is the pointer itself (ranks are threads of one process), flag words
+// are atomics, waits spin (yielding) until the other rank-thread has stored the number or the timeout passes
+int mgk_ipc_alloc(mgk_ctx *c, size_t bytes, void **ptr, void *handle64) {
+    if (!c || !ptr || !handle64 || !bytes) return fail(MGK_EINVAL, "mgk_ipc_alloc");
+    *ptr = calloc(1, bytes);
+    if (!*ptr) return fail(MGK_EINVAL, "mgk_ipc_alloc: out of memory");
+    memset(handle64, 0, MGK_IPC_HANDLE_BYTES);
+    memcpy(handle64, ptr, sizeof(void *));
+    return 0;
+}
+int mgk_ipc_open(mgk_ctx *c, const void *handle64, void **ptr) { if (!c || !handle64 || !ptr) return fail(MGK_EINVAL, "mgk_ipc_open"); memcpy(ptr, handle64, sizeof(void *)); return 0; }
+int mgk_ipc_close(mgk_ctx *, void *) { return 0; }
+int mgk_peer_copy(mgk_ctx *c, void *d, const void *s, size_t n, void *) { if (!c || !d || !s) return fail(MGK_EINVAL, "mgk_peer_copy"); memcpy(d, s, n); return 0; }
+int mgk_flags_set(mgk_ctx *c, void *const *flags, int n, unsigned long long value, void *) {
+    if (!c || !flags || n < 1 || n > MGK_PEER_MAX) return fail(MGK_EINVAL, "mgk_flags_set");
+    for (int q = 0; q < n; q++) __atomic_store_n((unsigned long long *)flags[q], value, __ATOMIC_RELEASE);
+    return 0;
+}
+static bool mock_wait(const unsigned long long *f, unsigned long long value, double timeout_s) {
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    while (__atomic_load_n(f, __ATOMIC_ACQUIRE) < value) {
+        sched_yield();
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) > timeout_s) return false;
+    }
+    return true;
+}
+int mgk_flags_wait(mgk_ctx *c, void *const *flags, int n, unsigned long long value, double timeout_s, void *status, void *) {
+    if (!c || !flags || n < 1 || n > MGK_PEER_MAX || !status || !(timeout_s > 0.0)) return fail(MGK_EINVAL, "mgk_flags_wait");
+    for (int q = 0; q < n; q++) if (!mock_wait((const unsigned long long *)flags[q], value, timeout_s)) __atomic_store_n((unsigned int *)status, 1u, __ATOMIC_RELAXED);
+    return 0;
+}
+int mgk_flag_set(mgk_ctx *c, void *flag, unsigned long long value, void *s) { void *f[1] = {flag}; return mgk_flags_set(c, f, 1, value, s); }
+int mgk_flag_wait(mgk_ctx *c, const void *flag, unsigned long long value, double timeout_s, void *status, void *s) { void *f[1] = {const_cast<void *>(flag)}; return mgk_flags_wait(c, f, 1, value, timeout_s, status, s); }
+int mgk_peer_allreduce(mgk_ctx *c, void *const *blocks, int nranks, int me, unsigned long long seq, double *vals, int n, double timeout_s, void *status, void *) {
+    if (!c || !blocks || nranks < 1 || nranks > MGK_PEER_MAX || me < 0 || me >= nranks || !vals || n < 1 || n > 64 || !status) return fail(MGK_EINVAL, "mgk_peer_allreduce");
+    const int buf = (int)(seq & 1ull);
+    for (int r = 0; r < nranks; r++) {
+        unsigned long long *slot = (unsigned long long *)blocks[r] + 65 * (buf * nranks + me);
+        memcpy(slot + 1, vals, sizeof(double) * (size_t)n);
+        __atomic_store_n(slot, seq, __ATOMIC_RELEASE);
+    }
+    const unsigned long long *own = (const unsigned long long *)blocks[me] + 65 * buf * nranks;
+    for (int r = 0; r < nranks; r++) if (!mock_wait(own + 65 * r, seq, timeout_s)) __atomic_store_n((unsigned int *)status, 1u, __ATOMIC_RELAXED);
+    for (int q = 0; q < n; q++) {
+        double s = 0.0;
+        for (int r = 0; r < nranks; r++) { double v; memcpy(&v, own + 65 * r + 1 + q, sizeof(double)); s += v; }
+        vals[q] = s;
+    }
+    return 0;
 }
 
 // round 3: three sweeps per pass (2-D): compositions of the single sweep

@@ -10,7 +10,8 @@
 #include "mgsolve.h"
 #include "mg_comm.h"
 
-typedef struct { int rank, P, npts, levels, dmin, mixed, rc; void *shared; double *u; long n; int it; } job;
+typedef struct { pthread_barrier_t bar; char blobs[MGK_PEER_MAX][MG_PEER_BLOB_BYTES]; } peer_boot;      /* the launcher's all-gather of the handle blobs */
+typedef struct { int rank, P, npts, levels, dmin, mixed, rc; void *shared; double *u; long n; int it; peer_boot *boot; } job;
 
 static void cfg(mg_config *c, const job *j, int rank, int P) {
     mg_config_default(c);
@@ -20,7 +21,15 @@ static void cfg(mg_config *c, const job *j, int rank, int P) {
 }
 static void *work(void *p) {
     job *j = (job *)p;
-    mg_comm *cm = j->P > 1 ? mg_comm_loopback_create(j->shared, j->rank) : NULL;
+    mg_comm *cm = NULL;
+    if (j->P > 1 && j->boot) {
+        /* the peer transport (mailboxes + flag words): planes of the finest level, 5 fields per exchange, gather box for the whole 3-D level */
+        mgk_geom g0; mgk_geom_init(&g0, 3, j->npts - 2, j->npts - 2, j->npts - 2);
+        cm = mg_comm_peer_create(j->rank, j->P, 0, sizeof(double) * (size_t)g0.plane, 5, sizeof(double) * (size_t)g0.total, j->boot->blobs[j->rank]);
+        pthread_barrier_wait(&j->boot->bar);
+        if (!cm || mg_comm_peer_connect(cm, j->boot->blobs)) { fprintf(stderr, "peer: %s\n", mg_comm_last_error()); return NULL; }
+        pthread_barrier_wait(&j->boot->bar);
+    } else if (j->P > 1) cm = mg_comm_loopback_create(j->shared, j->rank);
     mg_config c; cfg(&c, j, j->rank, j->P);
     mg_solver *s = NULL;
     j->rc = 1;
@@ -81,17 +90,20 @@ static int fault_run(int P, int bad_rank) {
 
 int main(int argc, char **argv) {
     if (argc == 4 && !strcmp(argv[1], "fault")) return fault_run(atoi(argv[2]), atoi(argv[3]));
-    if (argc < 5) { fprintf(stderr, "usage: san_slab P npts levels dist_min_n [mixed] | san_slab fault P bad_rank\n"); return 2; }
+    if (argc < 5) { fprintf(stderr, "usage: san_slab P npts levels dist_min_n [mixed|peer] | san_slab fault P bad_rank\n"); return 2; }
     const int P = atoi(argv[1]);
     job base; memset(&base, 0, sizeof(base));
     base.npts = atoi(argv[2]); base.levels = atoi(argv[3]); base.dmin = atoi(argv[4]); base.mixed = argc > 5 && !strcmp(argv[5], "mixed");
+    const int use_peer = argc > 5 && !strcmp(argv[5], "peer");        /* the ranks talk through the peer transport instead of loopback */
     job one = base; one.P = 1;
     work(&one);
     if (one.rc) return 1;
     job *js = (job *)calloc((size_t)P, sizeof(job));
     pthread_t *th = (pthread_t *)calloc((size_t)P, sizeof(pthread_t));
     void *shared = mg_comm_loopback_shared_create(P);
-    for (int r = 0; r < P; r++) { js[r] = base; js[r].rank = r; js[r].P = P; js[r].shared = shared; pthread_create(&th[r], NULL, work, &js[r]); }
+    peer_boot *boot = NULL;
+    if (use_peer) { boot = (peer_boot *)calloc(1, sizeof(peer_boot)); pthread_barrier_init(&boot->bar, NULL, (unsigned)P); }
+    for (int r = 0; r < P; r++) { js[r] = base; js[r].rank = r; js[r].P = P; js[r].shared = shared; js[r].boot = boot; pthread_create(&th[r], NULL, work, &js[r]); }
     long off = 0; int bad = 0;
     for (int r = 0; r < P; r++) {
         pthread_join(th[r], NULL);
@@ -110,6 +122,7 @@ int main(int argc, char **argv) {
     if (s) mg_solver_destroy(s);
     if (ph) mg_comm_destroy(ph);
     free(one.u); free(js); free(th);
-    printf("SAN_SLAB_%s P=%d cycles=%d\n", bad ? "FAILED" : "OK", P, one.it);
+    if (boot) { pthread_barrier_destroy(&boot->bar); free(boot); }
+    printf("SAN_SLAB_%s P=%d cycles=%d%s\n", bad ? "FAILED" : "OK", P, one.it, use_peer ? " transport=peer" : "");
     return bad;
 }

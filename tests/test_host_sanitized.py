@@ -147,6 +147,15 @@ def test_slab_ranks_under_sanitizers(san, tmp_path, P, npts, levels, dmin, extra
         assert m and int(m.group(3)) > 0 and int(m.group(4)) > 0, out[-400:]
 
 
+@pytest.mark.parametrize("P,npts,levels,dmin", [(2, 33, 4, 15), (3, 33, 4, 15), (8, 65, 4, 31)])
+def test_slab_ranks_over_the_peer_transport_under_sanitizers(san, tmp_path, P, npts, levels, dmin):
+    """the peer transport's host logic (csrc/mg_comm.c: mailbox slots, flag words and their sequence numbers, gather box, all-reduce slots)
+    with ranks as threads over the mock's host-memory primitives: transport self-test on every rank, then the slab solve equal to the
+    single rank bit for bit, under ASan / UBSan"""
+    out = _run(san["slab"], [str(P), str(npts), str(levels), str(dmin), "peer"], tmp_path)
+    assert f"SAN_SLAB_OK P={P}" in out and "transport=peer" in out
+
+
 @pytest.mark.parametrize("P,bad", [(2, 1), (3, 1), (8, 5)])
 def test_selftest_gate_returns_on_every_rank_when_one_plane_is_wrong(san, tmp_path, P, bad):
     """mg_comm_selftest must be collective-safe on FAILURE.  The loopback transport is told to hand rank `bad` a wrong

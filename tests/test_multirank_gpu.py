@@ -163,6 +163,45 @@ def test_rccl_two_ranks_on_one_gpu_if_allowed():
         assert p.returncode == 0 and "SELFTEST_OK" in o and "PAIR_OK" in o, o
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,npts,levels,dmin", [(2, 65, 5, 15), (3, 65, 5, 15)])
+def test_peer_transport_between_processes_on_one_gpu(tmp_path, world, npts, levels, dmin):
+    """The peer transport (round 3: IPC-mapped mailboxes + flag words, one-wave flag kernels, plane copies by the runtime) between real
+    PROCESSES that share GPU 0: hipIpc handles of fine-grained memory, cross-process flag words, the first-run gate, then the slab solve --
+    iteration count and history of every rank equal the single rank's, the concatenated slabs equal its solution bit for bit, and the
+    fixed-count loop with device all-reduces gives the same history.  (Between GPUs only the copies differ: copy engines over xGMI --
+    unmeasured here.)"""
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = str(sk.getsockname()[1])
+    sk.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MG_PEER_TIMEOUT_S="30")
+    script = os.path.join(ROOT, "tests", "peer_pair.py")
+    procs = [subprocess.Popen([sys.executable, script, str(r), str(world), port, str(npts), str(levels), str(dmin), str(tmp_path)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=400)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            o, _ = p.communicate()
+            o += "\n[timeout]"
+        outs.append(o)
+    for p, o in zip(procs, outs):
+        assert "[timeout]" not in o and p.returncode == 0 and "SELFTEST_OK" in o and "PAIR_OK" in o, o[-3000:]
+    it1, rn1, u1, e1 = _solve_single(npts, levels, 6.0 / 7.0, 60)
+    parts = [np.load(tmp_path / f"peer_rank{r}.npz") for r in range(world)]
+    for p in parts:
+        assert int(p["it"]) == it1
+        assert np.abs(p["rn"] / rn1 - 1).max() <= 1e-12
+        assert np.abs(p["rn3"] / rn1[:4] - 1).max() <= 1e-12
+        assert np.array_equal(p["e"], parts[0]["e"])
+    assert np.array_equal(np.concatenate([p["u"] for p in parts]), u1)
+
+
 @pytest.mark.timeout(900)
 def test_bench_two_processes_host_staged_transport(tmp_path):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), here with both
@@ -206,6 +245,28 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["transport"] == "host" and j["transport_fallback"] is False
     assert j["value"] > 0 and j["scaling"] == "strong"
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_processes_peer_transport():
+    """`MG_BENCH_TRANSPORT=peer python bench.py --gpus 2` (self-launched ranks, both on GPU 0): the peer transport passes the first-run
+    gate and carries the run -- one JSON line, transport "peer", no fallback, the residual reduction of the single-process run"""
+    import json
+    env = dict(os.environ, MG_BENCH_DEVICE="0", MG_BENCH_TRANSPORT="peer", MG_BENCH_ALLOW_FALLBACK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", MG_PEER_TIMEOUT_S="30")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    bench = os.path.join(ROOT, "bench.py")
+    common = ["--steps", "4", "--warmup", "1", "--npts", "129", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, bench, "--gpus", "1"] + common, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    j1 = json.loads(one.stdout.strip().splitlines()[-1])
+    two = subprocess.run([sys.executable, bench, "--gpus", "2"] + common, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=800)
+    assert two.returncode == 0, (two.stdout[-1500:], two.stderr[-3000:])
+    lines = [l for l in two.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j2 = json.loads(lines[0])
+    assert j2["n_gpus"] == 2 and j2["transport"] == "peer" and j2["transport_fallback"] is False
+    assert abs(j2["residual_reduction_per_cycle"] - j1["residual_reduction_per_cycle"]) <= 1e-12
 
 
 @pytest.mark.timeout(300)
