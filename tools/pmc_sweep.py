@@ -37,5 +37,11 @@ for _ in range(2):
     # round 2: last pre-smoothing sweep + residual + restriction (+ coarse first sweep) in one pass; two sweeps + norm
     m._chk(L.mgk_sweep_residual_restrict_f64(m.ctx, C.byref(g), C.byref(gc), coef, dinv, 6.0 / 7.0, b, u, out, bc, uc, dinv, 6.0 / 7.0, None))
     m._chk(L.mgk_jacobi2_sumsq_f64(m.ctx, C.byref(g), coef, dinv, 6.0 / 7.0, b, u, out, C.byref(ss), None))
+    # end of round 2 / round 3: the passes of the 91-byte fine level (prolongation + two sweeps, two sweeps + norm of the mid iterate, residual
+    # + restriction + coarse zero-guess sweep) and the three-sweep prototype
+    m._chk(L.mgk_prolong_jacobi2_f64(m.ctx, C.byref(g), C.byref(gc), coef, dinv, 6.0 / 7.0, b, uc, u, out, None))
+    m._chk(L.mgk_jacobi2_sumsq_mid_f64(m.ctx, C.byref(g), coef, dinv, 6.0 / 7.0, b, u, out, C.byref(ss), None))
+    m._chk(L.mgk_residual_restrict_jz_f64(m.ctx, C.byref(g), C.byref(gc), coef, b, u, bc, uc, dinv, 6.0 / 7.0, None))
+    m._chk(L.mgk_jacobi3_f64(m.ctx, C.byref(g), coef, dinv, 6.0 / 7.0, b, u, out, None))
 m.sync()
 m.close()
