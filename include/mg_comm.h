@@ -22,6 +22,7 @@
  */
 #ifndef MG_COMM_H
 #define MG_COMM_H
+#include <stddef.h>
 #include "mgk.h"
 #ifdef __cplusplus
 extern "C" {
@@ -47,6 +48,13 @@ typedef struct mg_comm {
     int (*halo_n)(struct mg_comm *c, mgk_ctx *ctx, int nf, void *const *fields, const mgk_geom *const *geoms, int esz, void *stream);
     /* in-place sum over ranks of n DEVICE doubles, queued on `stream`: no host synchronisation */
     int (*allreduce_sum_dev)(struct mg_comm *c, mgk_ctx *ctx, double *dvals, int n, void *stream);
+    /* (round 3) the general neighbour exchange, ONE group of n slots: slot q sends `bytes[q]` bytes from send_lo[q] to the rank below
+     * (which receives them at ITS recv_hi[q]) and from send_hi[q] to the rank above (its recv_lo[q]); a NULL send_lo[q] / recv_hi[q] pair
+     * (or send_hi / recv_lo) means the slot carries nothing in that direction -- the same on every rank.  halo_n is the special case
+     * send = first / last interior plane, recv = ghost planes; with this hook the solver sends the neighbours' second and third planes
+     * straight from the field instead of staging them in the far fields first. */
+    int (*exchange)(struct mg_comm *c, mgk_ctx *ctx, int n, const void *const *send_lo, const void *const *send_hi,
+                    void *const *recv_lo, void *const *recv_hi, const size_t *bytes, void *stream);
 } mg_comm;
 
 #define MG_RCCL_ID_BYTES 128

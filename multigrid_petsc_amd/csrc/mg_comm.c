@@ -138,6 +138,30 @@ static int rccl_halo_n(mg_comm *c, mgk_ctx *ctx, int nf, void *const *fields, co
     NCK(g_rccl.GroupEnd());
     return 0;
 }
+/* the general form: any plane-sized pieces, one group */
+static int rccl_exchange(mg_comm *c, mgk_ctx *ctx, int n, const void *const *send_lo, const void *const *send_hi,
+                         void *const *recv_lo, void *const *recv_hi, const size_t *bytes, void *stream) {
+    rccl_impl *im = (rccl_impl *)c->impl;
+    if (c->nranks == 1 || n < 1) return 0;
+    void *s = NULL;
+    int rc = rccl_stream(ctx, stream, &s);
+    if (rc) return rc;
+    for (int q = 0; q < n; q++) if (bytes[q] % 4) return cfail(MGK_EINVAL, "rccl exchange", "piece size is not a multiple of 4 bytes");
+    NCK(g_rccl.GroupStart());
+    for (int q = 0; q < n; q++) {
+        const size_t cnt = bytes[q] / 4;                          /* as 32-bit words: the bytes are what matters */
+        if (c->rank > 0) {
+            if (send_lo[q]) NCKG(g_rccl.Send(send_lo[q], cnt, NCCL_FLOAT32, c->rank - 1, im->comm, s));
+            if (recv_lo[q]) NCKG(g_rccl.Recv(recv_lo[q], cnt, NCCL_FLOAT32, c->rank - 1, im->comm, s));
+        }
+        if (c->rank < c->nranks - 1) {
+            if (send_hi[q]) NCKG(g_rccl.Send(send_hi[q], cnt, NCCL_FLOAT32, c->rank + 1, im->comm, s));
+            if (recv_hi[q]) NCKG(g_rccl.Recv(recv_hi[q], cnt, NCCL_FLOAT32, c->rank + 1, im->comm, s));
+        }
+    }
+    NCK(g_rccl.GroupEnd());
+    return 0;
+}
 static int rccl_halo(mg_comm *c, mgk_ctx *ctx, void *field, const mgk_geom *g, int esz, void *stream) {
     void *const f[1] = {field};
     const mgk_geom *const gg[1] = {g};
@@ -256,7 +280,7 @@ mg_comm *mg_comm_rccl_create(int rank, int nranks, const void *id, int device) {
     c->rank = rank; c->nranks = nranks; c->impl = im;
     c->halo = rccl_halo; c->allgather_planes = rccl_allgather_planes;
     c->allreduce_sum = rccl_allreduce_sum; c->barrier = rccl_barrier; c->destroy = rccl_destroy;
-    c->halo_n = rccl_halo_n; c->allreduce_sum_dev = rccl_allreduce_sum_dev;
+    c->halo_n = rccl_halo_n; c->allreduce_sum_dev = rccl_allreduce_sum_dev; c->exchange = rccl_exchange;
     return c;
 }
 
@@ -275,6 +299,8 @@ typedef struct loop_shared {
     void **gfield;            /* nranks x LOOP_MAXF */
     int *gnz;                 /* nranks x LOOP_MAXF */
     long *gplane;             /* nranks x LOOP_MAXF */
+    const void **xs_lo, **xs_hi;  /* general exchange: posted send pointers, nranks x LOOP_MAXF */
+    int *xr_lo, *xr_hi;       /* ... and whether the rank receives in that slot / direction */
     int fault_rank;           /* test aid (mg_comm_loopback_inject_fault): this rank receives a WRONG plane as its lo ghost; -1: none */
 } loop_shared;
 
@@ -292,6 +318,8 @@ void *mg_comm_loopback_shared_create(int nranks) {
     sh->gfield = (void **)calloc((size_t)nranks * LOOP_MAXF, sizeof(void *));
     sh->gnz = (int *)calloc((size_t)nranks * LOOP_MAXF, sizeof(int));
     sh->gplane = (long *)calloc((size_t)nranks * LOOP_MAXF, sizeof(long));
+    sh->xs_lo = (const void **)calloc((size_t)nranks * LOOP_MAXF, sizeof(void *)); sh->xs_hi = (const void **)calloc((size_t)nranks * LOOP_MAXF, sizeof(void *));
+    sh->xr_lo = (int *)calloc((size_t)nranks * LOOP_MAXF, sizeof(int)); sh->xr_hi = (int *)calloc((size_t)nranks * LOOP_MAXF, sizeof(int));
     sh->fault_rank = -1;
     return sh;
 }
@@ -303,7 +331,8 @@ void mg_comm_loopback_shared_destroy(void *p) {
     if (!sh) return;
     pthread_barrier_destroy(&sh->bar);
     free(sh->field); free(sh->nz); free(sh->red);
-    free(sh->gnf); free(sh->gesz); free(sh->gfield); free(sh->gnz); free(sh->gplane); free(sh);
+    free(sh->gnf); free(sh->gesz); free(sh->gfield); free(sh->gnz); free(sh->gplane);
+    free((void *)sh->xs_lo); free((void *)sh->xs_hi); free(sh->xr_lo); free(sh->xr_hi); free(sh);
 }
 
 static int loop_halo(mg_comm *c, mgk_ctx *ctx, void *field, const mgk_geom *g, int esz, void *stream) {
@@ -374,6 +403,43 @@ static int loop_halo_n(mg_comm *c, mgk_ctx *ctx, int nf, void *const *fields, co
     return rc;
 }
 
+/* the general exchange: every rank posts its send pointers and what it expects to receive; a slot that one neighbour sends and the other does
+ * not receive (or the other way round) is an error -- on a real transport it would be a hang */
+static int loop_exchange(mg_comm *c, mgk_ctx *ctx, int n, const void *const *send_lo, const void *const *send_hi,
+                         void *const *recv_lo, void *const *recv_hi, const size_t *bytes, void *stream) {
+    loop_shared *sh = ((loop_impl *)c->impl)->sh;
+    if (c->nranks == 1 || n < 1) return 0;
+    if (n > LOOP_MAXF) return cfail(MGK_EINVAL, "loopback exchange", "more slots than LOOP_MAXF");
+    void *s = stream_of(ctx, stream);
+    int rc = mgk_sync(ctx, s);
+    const int me = c->rank;
+    sh->gnf[me] = n;
+    for (int q = 0; q < n; q++) {
+        sh->xs_lo[me * LOOP_MAXF + q] = send_lo[q]; sh->xs_hi[me * LOOP_MAXF + q] = send_hi[q];
+        sh->xr_lo[me * LOOP_MAXF + q] = recv_lo[q] != NULL; sh->xr_hi[me * LOOP_MAXF + q] = recv_hi[q] != NULL;
+        sh->gplane[me * LOOP_MAXF + q] = (long)bytes[q];
+    }
+    pthread_barrier_wait(&sh->bar);
+    for (int q = 0; q < n && !rc; q++) {
+        if (me > 0) {
+            const int nb = me - 1;
+            if (sh->gnf[nb] != n || sh->gplane[nb * LOOP_MAXF + q] != (long)bytes[q] || (sh->xs_hi[nb * LOOP_MAXF + q] != NULL) != (recv_lo[q] != NULL) ||
+                (send_lo[q] != NULL) != (sh->xr_hi[nb * LOOP_MAXF + q] != 0)) { rc = cfail(MGK_ECOMM, "loopback exchange", "neighbours disagree about a slot of the group"); break; }
+            if (recv_lo[q]) rc = mgk_d2d(ctx, recv_lo[q], sh->xs_hi[nb * LOOP_MAXF + q], bytes[q], s);
+        }
+        if (!rc && me < c->nranks - 1) {
+            const int nb = me + 1;
+            if (sh->gnf[nb] != n || sh->gplane[nb * LOOP_MAXF + q] != (long)bytes[q] || (sh->xs_lo[nb * LOOP_MAXF + q] != NULL) != (recv_hi[q] != NULL) ||
+                (send_hi[q] != NULL) != (sh->xr_lo[nb * LOOP_MAXF + q] != 0)) { rc = cfail(MGK_ECOMM, "loopback exchange", "neighbours disagree about a slot of the group"); break; }
+            if (recv_hi[q]) rc = mgk_d2d(ctx, recv_hi[q], sh->xs_lo[nb * LOOP_MAXF + q], bytes[q], s);
+        }
+        if (rc && strncmp(g_cerr, "loopback", 8)) cfail(rc, "loopback exchange", mgk_last_error());
+    }
+    if (!rc) { rc = mgk_sync(ctx, s); if (rc) cfail(rc, "loopback exchange", mgk_last_error()); }
+    pthread_barrier_wait(&sh->bar);
+    return rc;
+}
+
 static int loop_allgather_planes(mg_comm *c, mgk_ctx *ctx, void *field, const mgk_geom *gf, const int *zstart, int esz, void *stream) {
     loop_shared *sh = ((loop_impl *)c->impl)->sh;
     void *s = stream_of(ctx, stream);
@@ -438,7 +504,7 @@ mg_comm *mg_comm_loopback_create(void *shared, int rank) {
     c->rank = rank; c->nranks = sh->nranks; c->impl = im;
     c->halo = loop_halo; c->allgather_planes = loop_allgather_planes;
     c->allreduce_sum = loop_allreduce_sum; c->barrier = loop_barrier; c->destroy = loop_destroy;
-    c->allreduce_sum_dev = loop_allreduce_sum_dev; c->halo_n = loop_halo_n;
+    c->allreduce_sum_dev = loop_allreduce_sum_dev; c->halo_n = loop_halo_n; c->exchange = loop_exchange;
     return c;
 }
 
@@ -468,6 +534,20 @@ static int phantom_halo_n(mg_comm *c, mgk_ctx *ctx, int nf, void *const *fields,
         char *f = (char *)fields[q];
         if (c->rank > 0) CK(mgk_paced_copy(ctx, f, f + pb, pb, 0.0, 32, s));
         if (c->rank < c->nranks - 1) CK(mgk_paced_copy(ctx, f + (size_t)(g->nz + 1) * pb, f + (size_t)g->nz * pb, pb, 0.0, 32, s));
+    }
+    return 0;
+}
+static int phantom_exchange(mg_comm *c, mgk_ctx *ctx, int n, const void *const *send_lo, const void *const *send_hi,
+                            void *const *recv_lo, void *const *recv_hi, const size_t *bytes, void *stream) {
+    if (c->nranks == 1 || n < 1) return 0;
+    void *s = stream_of(ctx, stream);
+    double most = 0.0, tlo = 0.0, thi = 0.0;
+    for (int q = 0; q < n; q++) { if (send_lo[q]) tlo += (double)bytes[q]; if (send_hi[q]) thi += (double)bytes[q]; }
+    most = tlo > thi ? tlo : thi;                               /* lo and hi travel over different links at the same time */
+    CK(phantom_hold(c, ctx, most, s));
+    for (int q = 0; q < n; q++) {                               /* what arrives: a copy of what I send the other way (defined values, same bytes written) */
+        if (c->rank > 0 && recv_lo[q]) CK(mgk_paced_copy(ctx, recv_lo[q], send_lo[q] ? send_lo[q] : send_hi[q], bytes[q], 0.0, 32, s));
+        if (c->rank < c->nranks - 1 && recv_hi[q]) CK(mgk_paced_copy(ctx, recv_hi[q], send_hi[q] ? send_hi[q] : send_lo[q], bytes[q], 0.0, 32, s));
     }
     return 0;
 }
@@ -522,7 +602,7 @@ mg_comm *mg_comm_phantom_create(int rank, int nranks, double lat_us, double link
     c->rank = rank; c->nranks = nranks; c->impl = im;
     c->halo = phantom_halo; c->allgather_planes = phantom_allgather_planes;
     c->allreduce_sum = phantom_allreduce_sum; c->barrier = phantom_barrier; c->destroy = phantom_destroy;
-    c->halo_n = phantom_halo_n; c->allreduce_sum_dev = phantom_allreduce_sum_dev;
+    c->halo_n = phantom_halo_n; c->allreduce_sum_dev = phantom_allreduce_sum_dev; c->exchange = phantom_exchange;
     return c;
 }
 
@@ -571,13 +651,13 @@ static int peer_check(mg_comm *c, const char *where) {
     if (im->status && *im->status) return cfail(MGK_ECOMM, where, "a flag wait of the peer transport timed out (a neighbour never signalled)");
     return 0;
 }
-static int peer_halo_n(mg_comm *c, mgk_ctx *ctx, int nf, void *const *fields, const mgk_geom *const *geoms, int esz, void *stream) {
+static int peer_exchange(mg_comm *c, mgk_ctx *ctx, int n, const void *const *send_lo, const void *const *send_hi,
+                         void *const *recv_lo, void *const *recv_hi, const size_t *bytes, void *stream) {
     peer_impl *im = (peer_impl *)c->impl;
-    if (c->nranks == 1 || nf < 1) return 0;
-    if (!im->connected) return cfail(MGK_EINVAL, "peer halo", "mg_comm_peer_connect has not been called");
-    if (nf > im->nfmax) return cfail(MGK_EINVAL, "peer halo", "more fields in one exchange than the mailbox has slots");
-    for (int q = 0; q < nf; q++)
-        if ((size_t)esz * (size_t)geoms[q]->plane > im->pmax) return cfail(MGK_EINVAL, "peer halo", "a plane is larger than a mailbox slot");
+    if (c->nranks == 1 || n < 1) return 0;
+    if (!im->connected) return cfail(MGK_EINVAL, "peer exchange", "mg_comm_peer_connect has not been called");
+    if (n > im->nfmax) return cfail(MGK_EINVAL, "peer exchange", "more slots in one exchange than the mailbox has");
+    for (int q = 0; q < n; q++) if (bytes[q] > im->pmax) return cfail(MGK_EINVAL, "peer exchange", "a piece is larger than a mailbox slot");
     void *s = stream_of(ctx, stream);
     const int me = c->rank, lo = me > 0, hi = me < c->nranks - 1;
     const unsigned long long k = ++im->seq_halo;
@@ -588,12 +668,10 @@ static int peer_halo_n(mg_comm *c, mgk_ctx *ctx, int nf, void *const *fields, co
     if (lo) w[nw++] = im->flags + PEER_W_DRAINED + 0;
     if (hi) w[nw++] = im->flags + PEER_W_DRAINED + 1;
     CK(mgk_flags_wait(ctx, w, nw, k - 1, im->timeout_s, im->status, s));
-    /* 2. my boundary planes into their mailboxes: I am the HI neighbour of rank-1 and the LO neighbour of rank+1 */
-    for (int q = 0; q < nf; q++) {
-        const size_t pb = (size_t)esz * (size_t)geoms[q]->plane;
-        char *f = (char *)fields[q];
-        if (lo) CK(mgk_peer_copy(ctx, im->nb_mbox[0] + box + (size_t)q * im->pmax, f + pb, pb, s));
-        if (hi) CK(mgk_peer_copy(ctx, im->nb_mbox[1] + (size_t)q * im->pmax, f + (size_t)geoms[q]->nz * pb, pb, s));
+    /* 2. my pieces into their mailboxes: I am the HI neighbour of rank-1 and the LO neighbour of rank+1 */
+    for (int q = 0; q < n; q++) {
+        if (lo && send_lo[q]) CK(mgk_peer_copy(ctx, im->nb_mbox[0] + box + (size_t)q * im->pmax, send_lo[q], bytes[q], s));
+        if (hi && send_hi[q]) CK(mgk_peer_copy(ctx, im->nb_mbox[1] + (size_t)q * im->pmax, send_hi[q], bytes[q], s));
     }
     /* 3. tell them */
     nw = 0;
@@ -605,12 +683,10 @@ static int peer_halo_n(mg_comm *c, mgk_ctx *ctx, int nf, void *const *fields, co
     if (lo) w[nw++] = im->flags + PEER_W_LANDED + 0;
     if (hi) w[nw++] = im->flags + PEER_W_LANDED + 1;
     CK(mgk_flags_wait(ctx, w, nw, k, im->timeout_s, im->status, s));
-    /* 5. mailbox -> ghost planes */
-    for (int q = 0; q < nf; q++) {
-        const size_t pb = (size_t)esz * (size_t)geoms[q]->plane;
-        char *f = (char *)fields[q];
-        if (lo) CK(mgk_d2d(ctx, f, im->mbox + (size_t)q * im->pmax, pb, s));
-        if (hi) CK(mgk_d2d(ctx, f + (size_t)(geoms[q]->nz + 1) * pb, im->mbox + box + (size_t)q * im->pmax, pb, s));
+    /* 5. mailbox -> where the pieces belong */
+    for (int q = 0; q < n; q++) {
+        if (lo && recv_lo[q]) CK(mgk_d2d(ctx, recv_lo[q], im->mbox + (size_t)q * im->pmax, bytes[q], s));
+        if (hi && recv_hi[q]) CK(mgk_d2d(ctx, recv_hi[q], im->mbox + box + (size_t)q * im->pmax, bytes[q], s));
     }
     /* 6. drained: they may overwrite */
     nw = 0;
@@ -618,6 +694,19 @@ static int peer_halo_n(mg_comm *c, mgk_ctx *ctx, int nf, void *const *fields, co
     if (hi) w[nw++] = im->all_flags[me + 1] + PEER_W_DRAINED + 0;
     CK(mgk_flags_set(ctx, w, nw, k, s));
     return 0;
+}
+static int peer_halo_n(mg_comm *c, mgk_ctx *ctx, int nf, void *const *fields, const mgk_geom *const *geoms, int esz, void *stream) {
+    if (c->nranks == 1 || nf < 1) return 0;
+    if (nf > MGK_PEER_MAX) return cfail(MGK_EINVAL, "peer halo", "too many fields in one exchange");
+    const void *slo[MGK_PEER_MAX], *shi[MGK_PEER_MAX];
+    void *rlo[MGK_PEER_MAX], *rhi[MGK_PEER_MAX];
+    size_t nb[MGK_PEER_MAX];
+    for (int q = 0; q < nf; q++) {
+        const size_t pb = (size_t)esz * (size_t)geoms[q]->plane;
+        char *f = (char *)fields[q];
+        slo[q] = f + pb; shi[q] = f + (size_t)geoms[q]->nz * pb; rlo[q] = f; rhi[q] = f + (size_t)(geoms[q]->nz + 1) * pb; nb[q] = pb;
+    }
+    return peer_exchange(c, ctx, nf, slo, shi, rlo, rhi, nb, stream);
 }
 static int peer_halo(mg_comm *c, mgk_ctx *ctx, void *field, const mgk_geom *g, int esz, void *stream) {
     void *const f[1] = {field};
@@ -728,7 +817,7 @@ mg_comm *mg_comm_peer_create(int rank, int nranks, int device, size_t plane_byte
     if (!rc) { rc = mgk_host_alloc(im->ctx, &p, 64); im->status = (unsigned int *)p; if (!rc) *im->status = 0; }
     if (rc) { cfail(rc, "mg_comm_peer_create", mgk_last_error()); peer_destroy(c); return NULL; }
     im->all_flags[rank] = im->flags; im->all_gbox[rank] = im->gbox;
-    c->halo = peer_halo; c->halo_n = peer_halo_n; c->allgather_planes = peer_allgather_planes;
+    c->halo = peer_halo; c->halo_n = peer_halo_n; c->exchange = peer_exchange; c->allgather_planes = peer_allgather_planes;
     c->allreduce_sum = peer_allreduce_sum; c->allreduce_sum_dev = peer_allreduce_sum_dev; c->barrier = peer_barrier; c->destroy = peer_destroy;
     if (nranks == 1) im->connected = 1;
     return c;
@@ -852,6 +941,34 @@ int mg_comm_selftest(mg_comm *c, mgk_ctx *ctx) {
                     }
                 }
             }
+        }
+    }
+    /* ---- the general exchange (optional hook): planes sent from INSIDE a field, one slot that travels downwards only ---- */
+    if (c->exchange) {
+        const mgk_geom *ga = &g[0][0], *gb = &g[0][1];                 /* fp64, nz = 3 and nz = 2, same plane size */
+        const size_t pb = sizeof(double) * (size_t)ga->plane;
+        char *fa = (char *)d[0][0], *fb = (char *)d[0][1];
+        const void *slo[2] = {fa + 2 * pb, fa + 3 * pb}, *shi[2] = {fa + 2 * pb, NULL};
+        void *rlo[2] = {fb, NULL}, *rhi[2] = {fb + (size_t)(gb->nz + 1) * pb, fa + (size_t)(ga->nz + 1) * pb};
+        const size_t nb[2] = {pb, pb};
+        int rc = mgk_stream_wait(ctx, ms, cs);
+        if (rc) NOTE(rc, "mg_comm_selftest: stream wait");
+        rc = c->exchange(c, ctx, 2, slo, shi, rlo, rhi, nb, ms);
+        if (rc) NOTE(rc, "mg_comm_selftest: exchange");
+        rc = mgk_stream_wait(ctx, cs, ms);
+        if (rc) NOTE(rc, "mg_comm_selftest: stream wait");
+        for (int q = 0; q < 2; q++) {
+            rc = mgk_d2h(ctx, h[0][q], d[0][q], sizeof(double) * (size_t)g[0][q].total);
+            if (rc) NOTE(rc, "mg_comm_selftest: read-back");
+        }
+        if (!rc) {
+            const double *ha = (const double *)h[0][0], *hb = (const double *)h[0][1];
+            const double got[3] = {hb[0], hb[(long)(gb->nz + 1) * gb->plane + gb->plane - 1], ha[(long)(ga->nz + 1) * ga->plane]};
+            /* b's lo ghost: plane 2 of the lower neighbour's field a; b's hi ghost: plane 2 of the upper neighbour's; a's hi ghost: its plane 3.
+             * Without a neighbour the ghost keeps what the halo tests left there (-1) */
+            const double want[3] = {me > 0 ? st_code(me - 1, 0, 2) : -1.0, me < P - 1 ? st_code(me + 1, 0, 2) : -1.0, me < P - 1 ? st_code(me + 1, 0, 3) : -1.0};
+            for (int q = 0; q < 3; q++)
+                if (got[q] != want[q] && !first) { first = st_fail("exchanged plane", me, got[q], want[q]); snprintf(first_err, sizeof(first_err), "%s", g_cerr); }
         }
     }
     /* ---- all-gather of planes ---- */

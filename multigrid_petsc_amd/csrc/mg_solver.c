@@ -679,6 +679,52 @@ int mg_solver_profile_read(mg_solver *s, double *total_ms, int *launches) {
 }
 static void swap_ptr(void **a, void **b) { void *t = *a; *a = *b; *b = t; }
 
+/* ONE grouped exchange of a pass on a z-slab (one latency): u's ghost planes unless valid / travelling, b's ghost planes once per right-hand
+ * side, the neighbours' SECOND planes of u (far), and -- for the sweep inside the restriction -- the upper neighbour's THIRD plane of u (far2)
+ * and SECOND plane of b (bfar, once per right-hand side).  With a transport that can send any plane (mg_comm.exchange: rccl, peer, loopback,
+ * phantom) the planes 1, nz-2, 2 of u and 1 of b leave from where they are; otherwise (host-staged) they are first copied into the interior
+ * planes of the far fields, whose ordinary halo then carries them (round 2: 20 plane copies per cycle on the compute stream).
+ * Queued on the comm stream behind everything the compute stream holds so far. */
+static int group_exchange(mg_solver *s, int P, mg_fset *F, int with_far2) {
+    const mg_ops *O = &OPS[P];
+    const size_t pb = (size_t)O->esz * (size_t)F->g.plane;
+    const int nz = F->g.nz;
+    void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
+    const int want_u = !F->u_ghost_pending && !F->u_ghost_ok, want_b = !F->b_ghost_ok, want_bfar = with_far2 && !F->bfar_ok;
+    char *u = (char *)F->u, *b = (char *)F->b, *far = (char *)F->far, *far2 = (char *)F->far2, *bfar = (char *)F->bfar;
+    if (s->comm->exchange) {
+        const void *slo[5], *shi[5];
+        void *rlo[5], *rhi[5];
+        size_t nb[5];
+        int n = 0;
+#define SLOT(a, b_, c, d) do { slo[n] = (a); shi[n] = (b_); rlo[n] = (c); rhi[n] = (d); nb[n++] = pb; } while (0)
+        if (want_u) SLOT(u + pb, u + (size_t)nz * pb, u, u + (size_t)(nz + 1) * pb);
+        if (want_b) SLOT(b + pb, b + (size_t)nz * pb, b, b + (size_t)(nz + 1) * pb);
+        SLOT(u + 2 * pb, u + (size_t)(nz - 1) * pb, far, far + 3 * pb);                 /* my planes 1 / nz-2 -> their far hi / lo ghost */
+        if (with_far2) SLOT(u + 3 * pb, NULL, NULL, far2 + 3 * pb);                     /* my plane 2 -> the lower neighbour's far2 hi ghost */
+        if (want_bfar) SLOT(b + 2 * pb, NULL, NULL, bfar + 3 * pb);                     /* my plane 1 of b */
+#undef SLOT
+        CHK(mgk_stream_wait(s->ctx, ms, cs));
+        CHK(s->comm->exchange(s->comm, s->ctx, n, slo, shi, rlo, rhi, nb, ms));
+        return 0;
+    }
+    CHK(mgk_d2d(s->ctx, far + pb, u + 2 * pb, pb, cs));                                 /* my plane 1 */
+    CHK(mgk_d2d(s->ctx, far + 2 * pb, u + (size_t)(nz - 1) * pb, pb, cs));              /* my plane nz-2 */
+    if (with_far2) CHK(mgk_d2d(s->ctx, far2 + pb, u + 3 * pb, pb, cs));                 /* my plane 2 */
+    if (want_bfar) CHK(mgk_d2d(s->ctx, bfar + pb, b + 2 * pb, pb, cs));                 /* my plane 1 of b */
+    CHK(mgk_stream_wait(s->ctx, ms, cs));
+    void *ff[5];
+    const mgk_geom *gg[5];
+    int nf = 0;
+    if (want_u) { ff[nf] = F->u; gg[nf++] = &F->g; }
+    if (want_b) { ff[nf] = F->b; gg[nf++] = &F->g; }
+    ff[nf] = F->far; gg[nf++] = &F->gfar;
+    if (with_far2) { ff[nf] = F->far2; gg[nf++] = &F->gfar; }
+    if (want_bfar) { ff[nf] = F->bfar; gg[nf++] = &F->gfar; }
+    CHK(mg_comm_halo_n(s->comm, s->ctx, nf, ff, gg, O->esz, ms));
+    return 0;
+}
+
 /* KSPSolve(ksp[l], b[l], u[l]) with KSPCHEBYSHEV (fp64 only), classic three-term recurrence (oracle/mgo.c) */
 static int smooth_chebyshev(mg_solver *s, int l, int maxit) {
     mg_level *L = &s->L[l];
@@ -826,22 +872,10 @@ static int smooth(mg_solver *s, int P, int l, int maxit, int pre) {
             if (L->distributed) {
                 /* slab: the second sweep of my first / last plane needs the first sweep of the neighbour's last / first plane,
                  * i.e. TWO of its planes of u (one is the regular ghost plane) and its b on that plane */
-                const size_t pb = (size_t)O->esz * (size_t)F->g.plane;
                 const int nz = F->g.nz, lo = s->cfg.rank > 0, hi = s->cfg.rank < s->cfg.nranks - 1;
                 void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
-                CHK(mgk_d2d(s->ctx, (char *)F->far + pb, (char *)F->u + 2 * pb, pb, NULL));                       /* my plane 1 */
-                CHK(mgk_d2d(s->ctx, (char *)F->far + 2 * pb, (char *)F->u + (size_t)(nz - 1) * pb, pb, NULL));   /* my plane nz-2 */
-                /* all exchanges of this pass on the comm stream ... */
-                CHK(mgk_stream_wait(s->ctx, ms, cs));
-                {   /* ONE grouped exchange (one latency): the far planes, u's ghosts unless valid / travelling, b's ghosts once */
-                    void *ff[3];
-                    const mgk_geom *gg[3];
-                    int nf = 0;
-                    if (!F->u_ghost_pending && !F->u_ghost_ok) { ff[nf] = F->u; gg[nf++] = &F->g; }
-                    if (!F->b_ghost_ok) { ff[nf] = F->b; gg[nf++] = &F->g; }
-                    ff[nf] = F->far; gg[nf++] = &F->gfar;
-                    CHK(mg_comm_halo_n(s->comm, s->ctx, nf, ff, gg, O->esz, ms));
-                }
+                /* all exchanges of this pass on the comm stream: ONE group (the far planes, u's ghosts unless valid / travelling, b's once) ... */
+                CHK(group_exchange(s, P, F, 0));
                 /* ... while the planes 2 .. nz-3, which need no ghost data, are already being swept */
                 if (s->cfg.overlap && L->nz_min >= 6) {
                     s->prof_kind = 1;                       /* timed: the interior planes 2 .. nz-3 of the slab */
@@ -1142,24 +1176,8 @@ static int descend_restrict(mg_solver *s, int P, int l, int no_jz) {
             gc.nz = c1 - c0;
             bc = (char *)Cq->b + (size_t)O->esz * (size_t)c0 * (size_t)Cq->g.plane;
         }
-        const size_t pb = (size_t)O->esz * (size_t)F->g.plane;
-        const int nz = F->g.nz, nzc = gc.nz;
-        CHK(mgk_d2d(s->ctx, (char *)F->far + pb, (char *)F->u + 2 * pb, pb, cs));                       /* my plane 1 */
-        CHK(mgk_d2d(s->ctx, (char *)F->far + 2 * pb, (char *)F->u + (size_t)(nz - 1) * pb, pb, cs));   /* my plane nz-2 */
-        CHK(mgk_d2d(s->ctx, (char *)F->far2 + pb, (char *)F->u + 3 * pb, pb, cs));                      /* my plane 2 */
-        if (!F->bfar_ok) CHK(mgk_d2d(s->ctx, (char *)F->bfar + pb, (char *)F->b + 2 * pb, pb, cs));     /* my plane 1 of b */
-        CHK(mgk_stream_wait(s->ctx, ms, cs));
-        {
-            void *ff[5];
-            const mgk_geom *gg[5];
-            int nf = 0;
-            if (!F->u_ghost_pending && !F->u_ghost_ok) { ff[nf] = F->u; gg[nf++] = &F->g; }
-            if (!F->b_ghost_ok) { ff[nf] = F->b; gg[nf++] = &F->g; }
-            ff[nf] = F->far; gg[nf++] = &F->gfar;
-            ff[nf] = F->far2; gg[nf++] = &F->gfar;
-            if (!F->bfar_ok) { ff[nf] = F->bfar; gg[nf++] = &F->gfar; }
-            CHK(mg_comm_halo_n(s->comm, s->ctx, nf, ff, gg, O->esz, ms));
-        }
+        const int nzc = gc.nz;
+        CHK(group_exchange(s, P, F, 1));
         /* coarse planes 1 .. nzc-3 read the fine planes 0 .. nz-2 of u only */
         const int split = s->cfg.overlap && nzc >= 5 && Lf->nz_min >= 10;
 #define SRRS(k0, k1) mgk_sweep_residual_restrict_slab_f64(s->ctx, &F->g, &gc, &F->gfar, Lf->coef, Lf->dinv, s->cfg.scale, (const double *)F->b, \
@@ -1234,20 +1252,8 @@ static int descend_restrict(mg_solver *s, int P, int l, int no_jz) {
             /* ONE exchange: with u's and b's ghost planes and the neighbours' second planes of u (the far field of the two-sweep
              * passes) every rank evaluates the residual of the plane above its slab itself and completes its last coarse plane.
              * The exchange travels while the coarse planes that read no ghost plane are restricted. */
-            const size_t pb = (size_t)O->esz * (size_t)F->g.plane;
-            const int nz = F->g.nz, nzc = gc.nz, hi = !last;
-            CHK(mgk_d2d(s->ctx, (char *)F->far + pb, (char *)F->u + 2 * pb, pb, cs));                       /* my plane 1 */
-            CHK(mgk_d2d(s->ctx, (char *)F->far + 2 * pb, (char *)F->u + (size_t)(nz - 1) * pb, pb, cs));   /* my plane nz-2 */
-            CHK(mgk_stream_wait(s->ctx, ms, cs));
-            {
-                void *ff[3];
-                const mgk_geom *gg[3];
-                int nf = 0;
-                if (!F->u_ghost_pending && !F->u_ghost_ok) { ff[nf] = F->u; gg[nf++] = &F->g; }
-                if (!F->b_ghost_ok) { ff[nf] = F->b; gg[nf++] = &F->g; }
-                ff[nf] = F->far; gg[nf++] = &F->gfar;
-                CHK(mg_comm_halo_n(s->comm, s->ctx, nf, ff, gg, O->esz, ms));
-            }
+            const int nzc = gc.nz, hi = !last;
+            CHK(group_exchange(s, P, F, 0));
             const int split = s->cfg.overlap && nzc >= 3 && Lf->nz_min >= 6;
             if (split) CHK(O->residual_restrict_slab(s->ctx, &F->g, &gc, &F->gfar, Lf->coef, F->b, F->u, F->far, hi, bc, 1, nzc - 1, cs));
             CHK(mgk_stream_wait(s->ctx, cs, ms));
@@ -1404,22 +1410,10 @@ static int vcycle_once(mg_solver *s) {
             s->cfg.v[0] >= 2 && L->n >= s->cfg.pair_min_n && L->n + 1 <= 1024 && s->lgraph != 1 && mgk_jacobi2_sumsq_ok_f64(&F->g)) {
             /* slab: the norm and the first TWO sweeps of the next cycle in one pass (the two-sweep slab pass with the norm of its
              * input's residual): the planes 2 .. nz-3 while the grouped exchange (u's ghosts, b's once, the far planes) travels */
-            const size_t pb = sizeof(double) * (size_t)F->g.plane;
             const int nz = F->g.nz, lo = s->cfg.rank > 0, hi = s->cfg.rank < s->cfg.nranks - 1;
             void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
             int n1 = 0, n2 = 0, n3 = 0;
-            CHK(mgk_d2d(s->ctx, (char *)F->far + pb, (char *)F->u + 2 * pb, pb, cs));
-            CHK(mgk_d2d(s->ctx, (char *)F->far + 2 * pb, (char *)F->u + (size_t)(nz - 1) * pb, pb, cs));
-            CHK(mgk_stream_wait(s->ctx, ms, cs));
-            {
-                void *ff[3];
-                const mgk_geom *gg[3];
-                int nf = 0;
-                if (!F->u_ghost_pending && !F->u_ghost_ok) { ff[nf] = F->u; gg[nf++] = &F->g; }
-                if (!F->b_ghost_ok) { ff[nf] = F->b; gg[nf++] = &F->g; }
-                ff[nf] = F->far; gg[nf++] = &F->gfar;
-                CHK(mg_comm_halo_n(s->comm, s->ctx, nf, ff, gg, 8, ms));
-            }
+            CHK(group_exchange(s, 0, F, 0));
 #define J2N(z0, z1, off, np) mgk_jacobi2_sumsq_slab_f64(s->ctx, &F->g, &F->gfar, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u, \
                                 (double *)F->tmp, (const double *)F->far, lo, hi, z0, z1, off, np, cs)
             const int split = s->cfg.overlap && nz >= 6;
