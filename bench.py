@@ -198,9 +198,20 @@ def cycle_compulsory_bytes(dim, npts, levels, precision):
     return tot
 
 
+def survey_cycle_bytes(dim, N0, seconds_per_cycle):
+    """SURVEY 8(d3)'s per-OPERATION count for one V(3,3) cycle, [48 nu + 2 (16 + 8 / 2^d)] 2^d / (2^d - 1) + 16 bytes per fine unknown (219 B in 3-D,
+    256 B in 2-D): what the cycle would move one kernel per PETSc call; the rate it implies may exceed the HBM peak -- that is what fusing and
+    temporal blocking buy"""
+    per = (48.0 * 3 + 2 * (16.0 + 8.0 / 2 ** dim)) * 2 ** dim / (2 ** dim - 1) + 16.0
+    gbs = per * N0 / seconds_per_cycle / 1e9
+    return {"bytes_per_fine_unknown": per, "GB/s": gbs, "of_peak": gbs / HBM_PEAK_GBS}
+
+
 def golden_history(key):
     """normalised residual histories rnorm[i]/rnorm[0] of the bench configurations (tests/golden/bench_history.json, made by
-    tools/make_bench_golden.py on an MI355X with the kernel-per-operation cycle, fuse=0); None when the file has no entry"""
+    tools/make_bench_golden.py on an MI355X with THIS implementation's kernel-per-operation cycle, fuse=0: a regression guard for the
+    fused cycles, NOT parity evidence -- that is what the oracle tests are: tests/test_headline_width_gpu.py compares the 511^3 solve
+    and two cycles at 1023^3 with the CPU oracle bit for bit); None when the file has no entry"""
     path = os.path.join(ROOT, "tests", "golden", "bench_history.json")
     try:
         return json.load(open(path)).get(key)
@@ -258,7 +269,10 @@ def run_config(dim, npts, precision, steps, warmup, device):
                                   "achieved_GBs": 3 * esz * N0 / (t * 1e-3) / 1e9, "frac": 3 * esz * N0 / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
     cb = cycle_compulsory_bytes(dim, npts, levels, precision)
     gbs = cb / (el / steps) / 1e9
-    out["cycle_roofline"] = {"compulsory_bytes": cb, "GB/s": gbs, "frac": gbs / HBM_PEAK_GBS}
+    out["cycle_roofline"] = {"compulsory_bytes": cb, "GB/s": gbs, "frac": gbs / HBM_PEAK_GBS,
+                             "bytes_per_fine_unknown": cb / N0,
+                             "model": "bytes one cycle of THIS implementation must move (fused passes; fewer passes lower the bytes, not the fraction)",
+                             "survey_8d3": survey_cycle_bytes(dim, N0, el / steps)}
     out["history"] = check_history(f"{dim}d_{npts}_{precision}", s.rnorm)
     s.close()
     return out
@@ -530,7 +544,8 @@ def main():
             # the whole cycle against the bytes it cannot avoid (per-operation count of SURVEY 8(d3) beside it)
             out["cycle_roofline"] = {"compulsory_bytes": cb, "GB/s": gbs, "frac": gbs / HBM_PEAK_GBS,
                                      "bytes_per_fine_unknown": cb / float(n0) ** args.dim,
-                                     "model": "bytes one cycle of THIS implementation must move (fused passes; DESIGN.md section 4)"}
+                                     "model": "bytes one cycle of THIS implementation must move (fused passes; DESIGN.md section 4)",
+                                     "survey_8d3": survey_cycle_bytes(args.dim, float(n0) ** args.dim, elapsed / args.steps)}
             out["history"] = check_history(f"{args.dim}d_{args.npts}_{args.precision}", rn)
     s.close()
     failures = []
