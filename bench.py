@@ -373,73 +373,54 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             return int(flag[0]) == 1
 
-        if transport == "rccl":
-            # every rank makes the same sequence of control-plane collectives whatever fails where: rccl_comm broadcasts a
-            # (status, id) pair from rank 0; then one MIN for the communicator, one MIN for the first-run gate
-            why = ""
+        def bring_up(make):
+            """communicator + first-run gate with the SAME sequence of control-plane collectives on every rank whatever fails where
+            (make() itself is collective-safe: rccl_comm / peer_comm ship a status with what they exchange); then one MIN for the
+            communicator, one MIN for the gate.  Returns the communicator, or None after saying why on stderr."""
+            c_, why = None, ""
             try:
-                comm = rccl_comm(rank, world, local_rank, dist)
+                c_ = make()
             except Exception as e:          # noqa: BLE001
                 why = f"communicator: {e}"
                 print(f"[bench rank {rank}] {why}", file=sys.stderr, flush=True)
-            up = all_ok(comm is not None)
+            up = all_ok(c_ is not None)
             if up:
-                # first-run gate: rank-coded planes through every hook of the transport, checked on every rank, before
-                # anything is timed (a wrong neighbour, plane or element type shows up here, not as a wrong residual)
+                # first-run gate: rank-coded planes through every hook of the transport, checked on every rank, before anything is timed
+                # (a wrong neighbour, plane or element type shows up here, not as a wrong residual); it returns on every rank
                 ok = True
                 try:
                     m = Mgk(local_rank)
                     try:
-                        selftest(comm.handle, m.ctx)
+                        selftest(c_.handle, m.ctx)
                     finally:
                         m.close()
                 except Exception as e:      # noqa: BLE001
                     ok, why = False, f"self-test: {e}"
-                if not ok:      # said BEFORE the agreement below: if that collective never completes, the first mismatch is on record
+                    # said BEFORE the agreement below: if that collective never completes, the first mismatch is on record
                     print(f"[bench rank {rank}] transport self-test FAILED: {why}", file=sys.stderr, flush=True)
                 up = all_ok(ok)
-            if not up:
-                print(f"[bench rank {rank}] RCCL transport unusable ({why or 'another rank failed'})", file=sys.stderr, flush=True)
-                if comm is not None:
-                    comm.close()
-                    comm = None
+            if up:
+                return c_
+            print(f"[bench rank {rank}] {'RCCL' if transport == 'rccl' else transport} transport unusable ({why or 'another rank failed'})", file=sys.stderr, flush=True)
+            if c_ is not None:
+                c_.close()
+            return None
+
+        def make_peer():
+            # IPC-mapped mailboxes + flag words, plane copies by the copy engines (include/mg_comm.h)
+            from multigrid_petsc_amd.comm import peer_comm
+            m = Mgk(local_rank)
+            g0, g2 = m.geom(args.dim, args.npts - 2), m.geom(args.dim, min(args.npts - 2, 255))
+            m.close()
+            return peer_comm(rank, world, local_rank, dist, 8 * g0.plane, 5, 8 * g2.total)
+
+        if transport in ("rccl", "peer"):
+            comm = bring_up((lambda: rccl_comm(rank, world, local_rank, dist)) if transport == "rccl" else make_peer)
+            if comm is None:
                 if os.environ.get("MG_BENCH_ALLOW_FALLBACK", "1") != "1":
                     raise SystemExit(3)
                 # the run continues on the host-staged (gloo) transport so that the job still yields a correct line, but the
                 # line says so at top level ("transport_fallback": true): it is NOT an RCCL/xGMI number
-                transport, transport_fallback = "host", True
-        if transport == "peer":
-            # IPC-mapped mailboxes + flag words, plane copies by the copy engines (include/mg_comm.h); the same first-run gate as RCCL
-            from multigrid_petsc_amd.comm import peer_comm
-            why = ""
-            try:
-                m = Mgk(local_rank)
-                g0, g2 = m.geom(args.dim, args.npts - 2), m.geom(args.dim, min(args.npts - 2, 255))
-                m.close()
-                comm = peer_comm(rank, world, local_rank, dist, 8 * g0.plane, 5, 8 * g2.total)
-            except Exception as e:          # noqa: BLE001
-                why = f"communicator: {e}"
-                print(f"[bench rank {rank}] {why}", file=sys.stderr, flush=True)
-            up = all_ok(comm is not None)
-            if up:
-                ok = True
-                try:
-                    m = Mgk(local_rank)
-                    try:
-                        selftest(comm.handle, m.ctx)
-                    finally:
-                        m.close()
-                except Exception as e:      # noqa: BLE001
-                    ok, why = False, f"self-test: {e}"
-                    print(f"[bench rank {rank}] transport self-test FAILED: {why}", file=sys.stderr, flush=True)
-                up = all_ok(ok)
-            if not up:
-                print(f"[bench rank {rank}] peer transport unusable ({why or 'another rank failed'})", file=sys.stderr, flush=True)
-                if comm is not None:
-                    comm.close()
-                    comm = None
-                if os.environ.get("MG_BENCH_ALLOW_FALLBACK", "1") != "1":
-                    raise SystemExit(3)
                 transport, transport_fallback = "host", True
         if transport == "host":
             comm = HostStagedComm(rank, world, dist)

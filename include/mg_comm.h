@@ -55,6 +55,10 @@ typedef struct mg_comm {
      * straight from the field instead of staging them in the far fields first. */
     int (*exchange)(struct mg_comm *c, mgk_ctx *ctx, int n, const void *const *send_lo, const void *const *send_hi,
                     void *const *recv_lo, void *const *recv_hi, const size_t *bytes, void *stream);
+    /* (round 3) has an asynchronous operation of this transport failed since the last call (the peer transport: a flag wait that timed
+     * out)?  0 or MGK_ECOMM.  Called by the solver wherever the host has just synchronised with the comm stream, so that a run whose
+     * exchanges did not arrive ends with an error instead of numbers computed from stale ghost planes. */
+    int (*check)(struct mg_comm *c);
 } mg_comm;
 
 #define MG_RCCL_ID_BYTES 128

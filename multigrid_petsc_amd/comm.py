@@ -195,7 +195,7 @@ class _MgComm(C.Structure):
     # halo() per field (the far planes staged in their fields first) and to the host all-reduce
     _fields_ = [("rank", C.c_int), ("nranks", C.c_int), ("impl", C.c_void_p), ("halo", _HALO),
                 ("allgather_planes", _GATHER), ("allreduce_sum", _REDUCE), ("barrier", _BARRIER), ("destroy", _DESTROY),
-                ("halo_n", C.c_void_p), ("allreduce_sum_dev", C.c_void_p), ("exchange", C.c_void_p)]
+                ("halo_n", C.c_void_p), ("allreduce_sum_dev", C.c_void_p), ("exchange", C.c_void_p), ("check", C.c_void_p)]
 
 
 class HostStagedComm:
@@ -213,7 +213,7 @@ class HostStagedComm:
         self.K.mgk_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         self.K.mgk_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         self._cb = (_HALO(self._halo), _GATHER(self._gather), _REDUCE(self._reduce), _BARRIER(self._barrier), _DESTROY(self._destroy))
-        self.struct = _MgComm(rank, world, None, *self._cb, None, None, None)
+        self.struct = _MgComm(rank, world, None, *self._cb, None, None, None, None)
         self.handle = C.c_void_p(C.addressof(self.struct))
 
     # device plane <-> host tensor

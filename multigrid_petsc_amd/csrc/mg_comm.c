@@ -695,6 +695,7 @@ static int peer_exchange(mg_comm *c, mgk_ctx *ctx, int n, const void *const *sen
     CK(mgk_flags_set(ctx, w, nw, k, s));
     return 0;
 }
+static int peer_check_hook(mg_comm *c) { return peer_check(c, "peer transport"); }
 static int peer_halo_n(mg_comm *c, mgk_ctx *ctx, int nf, void *const *fields, const mgk_geom *const *geoms, int esz, void *stream) {
     if (c->nranks == 1 || nf < 1) return 0;
     if (nf > MGK_PEER_MAX) return cfail(MGK_EINVAL, "peer halo", "too many fields in one exchange");
@@ -819,6 +820,7 @@ mg_comm *mg_comm_peer_create(int rank, int nranks, int device, size_t plane_byte
     im->all_flags[rank] = im->flags; im->all_gbox[rank] = im->gbox;
     c->halo = peer_halo; c->halo_n = peer_halo_n; c->exchange = peer_exchange; c->allgather_planes = peer_allgather_planes;
     c->allreduce_sum = peer_allreduce_sum; c->allreduce_sum_dev = peer_allreduce_sum_dev; c->barrier = peer_barrier; c->destroy = peer_destroy;
+    c->check = peer_check_hook;
     if (nranks == 1) im->connected = 1;
     return c;
 }

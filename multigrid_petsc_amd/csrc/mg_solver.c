@@ -975,6 +975,7 @@ static int reduce_slots(mg_solver *s, double *dslots, int n, double *host) {
         CHK(mgk_d2h_async(s->ctx, s->pin, dslots, sizeof(double) * (size_t)n, ms));
         CHK(mgk_sync(s->ctx, ms));
         memcpy(host, s->pin, sizeof(double) * (size_t)n);
+        if (s->comm->check) { int rcc = s->comm->check(s->comm); if (rcc) return mgfail(rcc, mg_comm_last_error()); }   /* did every exchange arrive? */
         return 0;
     }
     CHK(mgk_d2h(s->ctx, host, dslots, sizeof(double) * (size_t)n));                    /* synchronises the compute stream */
@@ -1595,7 +1596,11 @@ int mg_solver_cycles(mg_solver *s, int ncycles) {
     return 0;
 }
 
-int mg_solver_sync(mg_solver *s) { CHK(mgk_sync(s->ctx, NULL)); return 0; }
+int mg_solver_sync(mg_solver *s) {
+    CHK(mgk_sync(s->ctx, NULL));
+    if (s->comm && s->comm->check) { int rcc = s->comm->check(s->comm); if (rcc) return mgfail(rcc, mg_comm_last_error()); }
+    return 0;
+}
 int mg_solver_iterations(const mg_solver *s) { return s->iter; }
 double mg_solver_bnorm(const mg_solver *s) { return s->bnorm; }
 const double *mg_solver_rnorm(const mg_solver *s) { return s->rnorm; }

@@ -88,7 +88,49 @@ static int fault_run(int P, int bad_rank) {
     return bad;
 }
 
+/* the peer transport when a neighbour never shows up: rank 0 of 2 exchanges a halo and all-reduces; rank 1 maps the memory and then does
+ * nothing.  With MG_PEER_TIMEOUT_S = 1 rank 0 must come back from both calls within seconds and the all-reduce (a host-synchronising hook)
+ * must report MGK_ECOMM -- never a hang */
+static void *timeout_work(void *p) {
+    job *j = (job *)p;
+    mgk_geom g; mgk_geom_init(&g, 3, 15, 7, 3);
+    mg_comm *cm = mg_comm_peer_create(j->rank, 2, 0, sizeof(double) * (size_t)g.plane, 2, sizeof(double) * (size_t)g.total, j->boot->blobs[j->rank]);
+    pthread_barrier_wait(&j->boot->bar);
+    j->rc = -1;
+    if (!cm || mg_comm_peer_connect(cm, j->boot->blobs)) return NULL;
+    pthread_barrier_wait(&j->boot->bar);
+    if (j->rank == 0) {
+        mgk_ctx *ctx = NULL;
+        void *f = NULL;
+        double v = 1.0;
+        if (mgk_ctx_create(&ctx, 0) || mgk_malloc(ctx, &f, sizeof(double) * (size_t)g.total)) return NULL;
+        int r1 = cm->halo(cm, ctx, f, &g, 8, mgk_stream_comm(ctx));
+        int r2 = cm->allreduce_sum(cm, ctx, &v, 1, NULL);
+        j->rc = (r1 == 0 && r2 == MGK_ECOMM && cm->check(cm) == MGK_ECOMM) ? 0 : 100 + r2;
+        mgk_free(ctx, f);
+        mgk_ctx_destroy(ctx);
+    } else j->rc = 0;
+    pthread_barrier_wait(&j->boot->bar);                      /* rank 1 keeps its memory mapped until rank 0 is through */
+    mg_comm_destroy(cm);
+    return NULL;
+}
+static int timeout_run(void) {
+    setenv("MG_PEER_TIMEOUT_S", "1", 1);
+    peer_boot *boot = (peer_boot *)calloc(1, sizeof(peer_boot));
+    pthread_barrier_init(&boot->bar, NULL, 2);
+    job js[2]; memset(js, 0, sizeof(js));
+    pthread_t th[2];
+    for (int r = 0; r < 2; r++) { js[r].rank = r; js[r].boot = boot; pthread_create(&th[r], NULL, timeout_work, &js[r]); }
+    for (int r = 0; r < 2; r++) pthread_join(th[r], NULL);
+    const int bad = js[0].rc || js[1].rc;
+    if (bad) fprintf(stderr, "timeout run: rank 0 rc %d, rank 1 rc %d (%s)\n", js[0].rc, js[1].rc, mg_comm_last_error());
+    pthread_barrier_destroy(&boot->bar); free(boot);
+    printf("SAN_PEER_TIMEOUT_%s\n", bad ? "FAILED" : "OK");
+    return bad;
+}
+
 int main(int argc, char **argv) {
+    if (argc == 2 && !strcmp(argv[1], "peer_timeout")) return timeout_run();
     if (argc == 4 && !strcmp(argv[1], "fault")) return fault_run(atoi(argv[2]), atoi(argv[3]));
     if (argc < 5) { fprintf(stderr, "usage: san_slab P npts levels dist_min_n [mixed|peer] | san_slab fault P bad_rank\n"); return 2; }
     const int P = atoi(argv[1]);

@@ -156,6 +156,13 @@ def test_slab_ranks_over_the_peer_transport_under_sanitizers(san, tmp_path, P, n
     assert f"SAN_SLAB_OK P={P}" in out and "transport=peer" in out
 
 
+def test_peer_transport_times_out_instead_of_hanging(san, tmp_path):
+    """a neighbour that maps the memory and then never exchanges: with MG_PEER_TIMEOUT_S = 1 the flag waits give up, the calls return, and the
+    next host-synchronising hook (all-reduce) and the `check` hook report MGK_ECOMM"""
+    out = _run(san["slab"], ["peer_timeout"], tmp_path)
+    assert "SAN_PEER_TIMEOUT_OK" in out
+
+
 @pytest.mark.parametrize("P,bad", [(2, 1), (3, 1), (8, 5)])
 def test_selftest_gate_returns_on_every_rank_when_one_plane_is_wrong(san, tmp_path, P, bad):
     """mg_comm_selftest must be collective-safe on FAILURE.  The loopback transport is told to hand rank `bad` a wrong
