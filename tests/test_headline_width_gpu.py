@@ -18,7 +18,7 @@ Which instance each case covers (DESIGN.md section 5 carries the same table):
   mgk_jacobi2_sumsq_mid_f64   k_jacobi2r<double,8|4,3,2>        two sweeps + norm of the mid iterate's residual       :1542 + :1546 + :1531
   mgk_jacobi2_zero_f64        k_jacobi2<double,8|4,3,true>      three sweeps from the zero guess (level 1)            :1536
   mgk_prolong_jacobi_f64      k_pjrow<double,8|4,..>            prolongation + correction + sweep                     :1540-1542
-  mgk_prolong_jacobi2_f64     k_pj2r3<8> / k_pj2r<4>            prolongation + correction + two sweeps                :1540-1542
+  mgk_prolong_jacobi2_f64     k_pj2r3<8|4> (and k_pj2r<8|4>)    prolongation + correction + two sweeps                :1540-1542
   mgk_residual_restrict_f64 / _jz_f64   k_rrrow<double,8|4,1,*>  residual + full weighting (+ coarse zero-guess sweep) :1534-1536
   mgk_sweep_residual_restrict_f64       k_srr4b<8|4>            sweep + residual + full weighting                     :1531 + :1534-1535
 (src/solver.c lines of /root/reference.)"""
@@ -166,10 +166,13 @@ def test_transfer_passes_against_the_oracle(mgk, orc, n, nz):
         assert np.array_equal(t.get(o), pj1), f"mgk_prolong_jacobi_f64 zc={zc}"
         assert t.ghosts_clean(o)
         assert L.mgk_prolong_jacobi2_ok_f64(g, gc) == 1
-        o = t.out()
-        mgk._chk(L.mgk_prolong_jacobi2_f64(mgk.ctx, g, gc, t.coef, t.dinv, SCALE, t.db, t.duc, t.du, o, None))
-        assert np.array_equal(t.get(o), pj2), f"mgk_prolong_jacobi2_f64 zc={zc}"
-        assert t.ghosts_clean(o)
+        for var in (-1, 46):                                        # the unrolled form k_pj2r3<8|4> (default) and the copying form k_pj2r<8|4>
+            L.mgk_set_tuning(var, zc)
+            o = t.out()
+            mgk._chk(L.mgk_prolong_jacobi2_f64(mgk.ctx, g, gc, t.coef, t.dinv, SCALE, t.db, t.duc, t.du, o, None))
+            assert np.array_equal(t.get(o), pj2), f"mgk_prolong_jacobi2_f64 variant={var} zc={zc}"
+            assert t.ghosts_clean(o)
+        L.mgk_set_tuning(-1, zc)
         o = t.out()
         mgk._chk(L.mgk_prolong_add_f64(mgk.ctx, g, gc, t.duc, t.du, None))          # in place on u: restore afterwards
         assert np.array_equal(t.get(t.du), pu), "mgk_prolong_add_f64"
