@@ -2120,7 +2120,9 @@ static int jacobi2(mgk_ctx *c, const mgk_geom *g, const double *coef, double din
     // one 512-thread block per CU (LDS) for fp64 at 1023^3: 256 tiles, one chunk; blocks of <= 256 threads (fp64 511^3, fp32):
     // two per CU, 512 blocks (measured, fp64 511^3: 128 blocks 0.83 ms, 512 blocks 0.57 ms); every chunk recomputes two
     // planes of the first sweep
-    const long target = (w > 4) ? 256 : (sizeof(T) == 4 ? 1024 : 512);      // fp32 1023^3: 1024 blocks 2.72 ms, 512 blocks 2.84 ms
+    // rows of <= 2 waves (255^3, the third level of the headline): blocks of 128 threads, a chunk per SIMD is too few waves to
+    // cover the latency -- 1024 blocks of 16 planes (in the 511^3 cycle: 118 -> 88 us, zero-guess form 126 -> 81; 8 planes 104 / 89)
+    const long target = (w > 4) ? 256 : ((sizeof(T) == 4 || w <= 2) ? 1024 : 512);      // fp32 1023^3: 1024 blocks 2.72 ms, 512 blocks 2.84 ms
     long nch = (a.nty >= target) ? 1 : (target + a.nty - 1) / a.nty;
     if (g_zchunk > 0) nch = (nzr + g_zchunk - 1) / g_zchunk;
     else if (c->chunk_planes > 0 && nch < (nzr + c->chunk_planes - 1) / c->chunk_planes) nch = (nzr + c->chunk_planes - 1) / c->chunk_planes;
@@ -4639,7 +4641,8 @@ static int residual_restrict(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc,
     const int nkc = kcend - kcbeg;
     const int w = (gf->nx + 1 + 64 * VX - 1) / (64 * VX);       // waves needed for a full row
     // blocks of <= 256 threads (fp32 rows) leave room for two per CU: cut z in two (fp32 at 1023^3: 2.78 -> 1.82 ms)
-    long nch = (a.nty >= 256) ? ((w <= 4) ? 2 : 1) : (512 + a.nty - 1) / a.nty;
+    // (rows of <= 2 waves: 1024 blocks -- 255^3 inside the 511^3 cycle 73 -> 52 us)
+    long nch = (a.nty >= 256) ? ((w <= 4) ? 2 : 1) : ((w <= 2 && sizeof(T) == 8 ? 1024 : 512) + a.nty - 1) / a.nty;
     if (g_zchunk > 0) nch = (nkc + g_zchunk - 1) / g_zchunk;
     else if (c->chunk_planes > 1 && nch < (nkc + c->chunk_planes / 2 - 1) / (c->chunk_planes / 2)) nch = (nkc + c->chunk_planes / 2 - 1) / (c->chunk_planes / 2);
     int kcc = (int)((nkc + nch - 1) / nch);
@@ -4882,7 +4885,7 @@ static int prolong_jacobi(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, co
         q.zbeg = zbeg; q.zend = zend;
         q.nty = (gf->ny + 3) / 4;
         const int nzr = zend - zbeg;
-        const long target = (w > 4) ? 256 : 512;
+        const long target = (w > 4) ? 256 : (w <= 2 && sizeof(T) == 8 ? 1024 : 512);       // (255^3 inside the 511^3 cycle: 76 -> 67 us)
         long nch = (q.nty >= target) ? 1 : (target + q.nty - 1) / q.nty;
         if (g_zchunk > 0) nch = (nzr + g_zchunk - 1) / g_zchunk;
         else if (c->chunk_planes > 0 && nch < (nzr + c->chunk_planes - 1) / c->chunk_planes) nch = (nzr + c->chunk_planes - 1) / c->chunk_planes;
