@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(256) k_jacobi3_2d(const J3dArgs a) {
                 ur = ur2; cA = cA2; cB = cB2; bn = bn2;
             }
         };
-        if (a.bous && (cy & 1)) march(std::true_type{}); else march(std::false_type{});
+        if (a.bous && ((cy & 1) || a.bous == 2)) march(std::true_type{}); else march(std::false_type{});
     }
     if (NORM) {
         const double sw = wave_sum(nacc);
@@ -260,7 +260,7 @@ static int jacobi3_2d(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gc, const d
     a.nwaves = (int)waves;
     // odd chunks marched downwards (tuning variant 58 only: bit-identical, but at 4095^2 it measured 67-68 us against 64 us with every chunk
     // marching upwards -- the shared rows are served by the Infinity Cache either way)
-    a.bous = (ycs == 0 && g_variant == 58) ? 1 : 0;
+    a.bous = (ycs == 0 && g_variant == 58) ? 1 : (ycs == 0 && g_variant == 59) ? 2 : 0;      // 59: EVERY chunk downwards
     if (NORM) {
         if (!norm_parts || 4L * nblk > c->max_partials) return fail(MGK_EINVAL, "mgk_jacobi3_2d_sumsq_f64: more waves than partial slots");
         a.partials = c->partials;

@@ -38,6 +38,7 @@ for var in variants:
     for name, byts, fn in (
             ("prolong + two sweeps", 25, lambda: L.mgk_prolong_jacobi2_f64(m.ctx, G, GC, coef, dinv, 0.8, b, uc, u, o, None)),
             ("prolong + sweep", 25, lambda: L.mgk_prolong_jacobi_f64(m.ctx, G, GC, coef, dinv, 0.8, b, uc, u, o, None)),
+            ("three sweeps from zero", 16, lambda: L.mgk_jacobi2_zero_f64(m.ctx, G, coef, dinv, 0.8, b, o, None)),
             ("two sweeps", 24, lambda: L.mgk_jacobi2_f64(m.ctx, G, coef, dinv, 0.8, b, u, o, None)),
             ("residual + restriction + jz", 18, lambda: L.mgk_residual_restrict_jz_f64(m.ctx, G, GC, coef, b, u, bc, uc, dinv, 0.8, None))):
         ms = timeit(fn)
