@@ -257,6 +257,9 @@ int  mgk_tail_cycle_f64(mgk_ctx *ctx, const mgk_geom *g0, int nlev, const int *n
 int  mgk_tail_cycle_f32(mgk_ctx *ctx, const mgk_geom *g0, int nlev, const int *n, const double *coef7, const double *dinv,
                         double scale, int v0, int v1, const float *b, float *u, void *stream);
 int  mgk_tail_max_n(int dim);
+/* profiling aid: the tail kernels this thread launches deposit (s_memrealtime [100 MHz], s_memtime [shader clock]) pairs at each of their
+ * barriers into dev[0 .. 255] and the number of pairs into dev[256] (257 long longs of DEVICE memory; NULL switches it off) */
+void mgk_debug_tail_stamps(long long *dev);
 
 /* ---- K6: VecNorm(NORM_2) (src/solver.c:1512,1518,1546): returns sum of squares of the interior ---- */
 int  mgk_sumsq_f64(mgk_ctx *ctx, const mgk_geom *g, const double *x, double *sumsq_host, void *stream);

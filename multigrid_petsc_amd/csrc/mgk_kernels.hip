@@ -4951,22 +4951,47 @@ struct TailArgs {
     long rs, ms;                           // its row / plane strides
     int total;                             // elements of LDS in use
     const T *ctab[MGK_TAIL_MAXLEV], *dtab[MGK_TAIL_MAXLEV];   // optional (2-D stretched meshes): per-row coefficients / 1/diag of every tail level
+    long long *stamps;                     // profiling aid (mgk_debug_tail_stamps; null in production): lane 0 deposits s_memrealtime / s_memtime pairs at every barrier
 };
 
 template <typename T, int DIM>
 __device__ __forceinline__ int tail_idx(int m, int k, int i, int j) {      // (k,i,j) interior coordinates -> index in an (n+2)^DIM array
     return (DIM == 3) ? ((k + 1) * m + (i + 1)) * m + (j + 1) : (i + 1) * m + (j + 1);
 }
+// Every interior point (k, i, j) of an n^DIM level once, dealt over the lanes of the workgroup.  With n + 1 a power of two (every level of
+// a hierarchy with npts = 2^k + 1) the coordinates are shifts and masks of the lane number instead of two divisions and two remainders
+// by n (~70 of the ~100 vector instructions per point; round 3, under rocprofv3: k_tail<double, 3> 43 -> 33 us, <double, 2> 45 -> 42 us).
+// Which lane evaluates a point does not change its value.  What bounds the kernel (tools/tail_phases.py, stamps at every barrier): a step on
+// a tiny level costs 0.36 us (850 clocks at 2.4 GHz: scalar loads of the level's constants, LDS round trip, the dependent fp64 chain, the
+// barrier), a sweep of the largest level 1.7-2.3 us -- the instruction and LDS throughput of ONE CU for 4 points per lane (evaluating the
+// four points of a lane before storing any of them, so that their latencies overlap, changed nothing: it is throughput, not latency).
+template <int DIM, typename F>
+__device__ __forceinline__ void tail_points(int n, F &&f) {
+    const int t = threadIdx.x, B = blockDim.x;
+    const int lg = 31 - __clz(n + 1);
+    if (((n + 1) & n) == 0 && (B >> (DIM == 3 ? 2 * lg : lg)) >= 1) {
+        const int j = t & n;
+        if (DIM == 2) {
+            const int step = B >> lg;
+            if (j < n) for (int i = t >> lg; i < n; i += step) f(0, i, j);
+        } else {
+            const int i = (t >> lg) & n, step = B >> (2 * lg);
+            if (j < n && i < n) for (int k = t >> (2 * lg); k < n; k += step) f(k, i, j);
+        }
+    } else {
+        const int N = (DIM == 3) ? n * n * n : n * n;
+        for (int p = t; p < N; p += B) f((DIM == 3) ? p / (n * n) : 0, (p / n) % n, p % n);
+    }
+}
 // mode 0: out = u + scale*((b - A u)*dinv); mode 1: out = b - A u; mode 2 (zero guess): out = scale*(b*dinv)
 template <typename T, int DIM>
 __device__ void tail_stencil(int mode, int n, const T *cf_, T dinv_, T scale, const T *u, const T *b, T *out, const T *ctab = nullptr, const T *dtab = nullptr) {
-    const int m = n + 2, N = (DIM == 3) ? n * n * n : n * n, sk = m * m;
-    for (int p = threadIdx.x; p < N; p += blockDim.x) {
-        const int j = p % n, i = (p / n) % n, k = (DIM == 3) ? p / (n * n) : 0;
+    const int m = n + 2, sk = m * m;
+    tail_points<DIM>(n, [&](int k, int i, int j) {
         const int q = tail_idx<T, DIM>(m, k, i, j);
         const T *cf = (DIM == 2 && ctab) ? ctab + 5 * i : cf_;
         const T dinv = (DIM == 2 && dtab) ? dtab[i] : dinv_;
-        if (mode == 2) { const T zx = b[q] * dinv; out[q] = scale * zx; continue; }
+        if (mode == 2) { const T zx = b[q] * dinv; out[q] = scale * zx; return; }
         T t;
         if (DIM == 3) {
             t = cf[0] * u[q - sk];
@@ -4984,19 +5009,18 @@ __device__ void tail_stencil(int mode, int n, const T *cf_, T dinv_, T scale, co
             t = t + cf[4] * u[q + m];
         }
         const T res = b[q] - t;
-        if (mode == 1) { out[q] = res; continue; }
+        if (mode == 1) { out[q] = res; return; }
         const T zz = res * dinv;
         out[q] = u[q] + scale * zz;
-    }
+    });
 }
 // bc = R r (k_restrict: ascending fine index (dk, di, dj), weights w1[dk]*w2[di][dj])
 template <typename T, int DIM>
 __device__ void tail_restrict(int nf, int nc, const T *r, T *bc) {
-    const int mf = nf + 2, mc = nc + 2, N = (DIM == 3) ? nc * nc * nc : nc * nc;
+    const int mf = nf + 2, mc = nc + 2;
     const T w2[3][3] = {{(T)0.0625, (T)0.125, (T)0.0625}, {(T)0.125, (T)0.25, (T)0.125}, {(T)0.0625, (T)0.125, (T)0.0625}};
     const T w1[3] = {(T)0.25, (T)0.5, (T)0.25};
-    for (int p = threadIdx.x; p < N; p += blockDim.x) {
-        const int jc = p % nc, ic = (p / nc) % nc, kc = (DIM == 3) ? p / (nc * nc) : 0;
+    tail_points<DIM>(nc, [&](int kc, int ic, int jc) {
         T sum = (T)0;
         if (DIM == 3) {
 #pragma unroll
@@ -5018,14 +5042,14 @@ __device__ void tail_restrict(int nf, int nc, const T *r, T *bc) {
             }
         }
         bc[tail_idx<T, DIM>(mc, kc, ic, jc)] = sum;
-    }
+    });
 }
 // uf += P uc (k_prolong_add / prolong_one: parents in ascending coarse index, weight wk*(wi*wj) each)
 template <typename T, int DIM>
 __device__ void tail_prolong_add(int nf, int nc, const T *uc, T *uf) {
-    const int mf = nf + 2, mc = nc + 2, N = (DIM == 3) ? nf * nf * nf : nf * nf;
-    for (int p = threadIdx.x; p < N; p += blockDim.x) {
-        const int x = p % nf, i = (p / nf) % nf, k = (DIM == 3) ? p / (nf * nf) : 1;
+    const int mf = nf + 2, mc = nc + 2;
+    tail_points<DIM>(nf, [&](int k3, int i, int x) {
+        const int k = (DIM == 3) ? k3 : 1;
         const int iodd = i & 1, kodd = k & 1, xodd = x & 1;
         const int ic0 = iodd ? (i - 1) / 2 : i / 2 - 1, nic = iodd ? 1 : 2;
         const int kc0 = (DIM == 3) ? (kodd ? (k - 1) / 2 : k / 2 - 1) : 0, nkc = (DIM == 3) ? (kodd ? 1 : 2) : 1;
@@ -5038,15 +5062,19 @@ __device__ void tail_prolong_add(int nf, int nc, const T *uc, T *uf) {
                 for (int qj = 0; qj < njc; qj++) s += w * uc[tail_idx<T, DIM>(mc, kc0 + qk, ic0 + qi, jc0 + qj)];
         const int q = tail_idx<T, DIM>(mf, (DIM == 3) ? k : 0, i, x);
         uf[q] = uf[q] + s;
-    }
+    });
 }
 
 template <typename T, int DIM>
 __global__ void __launch_bounds__(1024) k_tail(const TailArgs<T> a) {
     __shared__ __attribute__((aligned(16))) unsigned char raw[MGK_TAIL_LDS_BYTES];
     T *lds = reinterpret_cast<T *>(raw);
+    int nstamp = 0;
+    auto stamp = [&]() { if (a.stamps && threadIdx.x == 0 && nstamp < 128) { a.stamps[2 * nstamp] = wall_clock64(); a.stamps[2 * nstamp + 1] = clock64(); nstamp++; } };
+    stamp();
     for (int q = threadIdx.x; q < a.total; q += blockDim.x) lds[q] = (T)0;        // ghost rings stay 0 (homogeneous Dirichlet)
     __syncthreads();
+    stamp();
     int cur[MGK_TAIL_MAXLEV];                     // which of A0 / A1 holds u of the level
     auto A = [&](int l, int which) -> T * { const int m = a.n[l] + 2; const int sz = (DIM == 3) ? m * m * m : m * m; return lds + a.off[l] + which * sz; };
     auto Bv = [&](int l) -> T * { return A(l, 2); };
@@ -5058,34 +5086,34 @@ __global__ void __launch_bounds__(1024) k_tail(const TailArgs<T> a) {
             b0[tail_idx<T, DIM>(m, k, i, j)] = a.b_in[(long)k * a.ms + (long)i * a.rs + j];
         }
     }
-    __syncthreads();
+    __syncthreads(); stamp();
     // KSPSolve from a zero guess, `sweeps` Richardson+Jacobi sweeps (src/solver.c:1536): the first is scale*(b*dinv)
     auto smooth0 = [&](int l, int sweeps) {
         cur[l] = 0;
         if (sweeps < 1) return;                   // KSPSolve zero-fills: A0 is still all zeros
         tail_stencil<T, DIM>(2, a.n[l], a.coef[l], a.dinv[l], a.scale, A(l, 0), Bv(l), A(l, 0), a.ctab[l], a.dtab[l]);
-        __syncthreads();
+        __syncthreads(); stamp();
         for (int it = 1; it < sweeps; it++) {
             tail_stencil<T, DIM>(0, a.n[l], a.coef[l], a.dinv[l], a.scale, A(l, cur[l]), Bv(l), A(l, cur[l] ^ 1), a.ctab[l], a.dtab[l]);
-            __syncthreads();
+            __syncthreads(); stamp();
             cur[l] ^= 1;
         }
     };
     smooth0(0, a.nlev == 1 ? a.v1 : a.v0);
     for (int l = 1; l < a.nlev; l++) {            // :1534-1537
         tail_stencil<T, DIM>(1, a.n[l - 1], a.coef[l - 1], a.dinv[l - 1], a.scale, A(l - 1, cur[l - 1]), Bv(l - 1), A(l - 1, cur[l - 1] ^ 1), a.ctab[l - 1], a.dtab[l - 1]);
-        __syncthreads();
+        __syncthreads(); stamp();
         tail_restrict<T, DIM>(a.n[l - 1], a.n[l], A(l - 1, cur[l - 1] ^ 1), Bv(l));
-        __syncthreads();
+        __syncthreads(); stamp();
         // the zero-guess sweep writes A0 of level l, which is all zeros only in the first cycle... it is overwritten in full
         smooth0(l, l == a.nlev - 1 ? a.v1 : a.v0);
     }
     for (int l = a.nlev - 2; l >= 0; l--) {       // :1540-1542
         tail_prolong_add<T, DIM>(a.n[l], a.n[l + 1], A(l + 1, cur[l + 1]), A(l, cur[l]));
-        __syncthreads();
+        __syncthreads(); stamp();
         for (int it = 0; it < a.v0; it++) {
             tail_stencil<T, DIM>(0, a.n[l], a.coef[l], a.dinv[l], a.scale, A(l, cur[l]), Bv(l), A(l, cur[l] ^ 1), a.ctab[l], a.dtab[l]);
-            __syncthreads();
+            __syncthreads(); stamp();
             cur[l] ^= 1;
         }
     }
@@ -5097,8 +5125,14 @@ __global__ void __launch_bounds__(1024) k_tail(const TailArgs<T> a) {
             a.u_out[(long)k * a.ms + (long)i * a.rs + j] = u0[tail_idx<T, DIM>(m, k, i, j)];
         }
     }
+    stamp();
+    if (a.stamps && threadIdx.x == 0) a.stamps[256] = nstamp;
 }
 
+static thread_local long long *g_tail_stamps = nullptr;
+// profiling aid: the tail kernels launched by this thread deposit (s_memrealtime, s_memtime) at each of their barriers into dev[0 .. 255]
+// and the number of pairs into dev[256] (257 long longs of device memory; null switches it off)
+extern "C" void mgk_debug_tail_stamps(long long *dev) { g_tail_stamps = dev; }
 template <typename T>
 static int tail_cycle(mgk_ctx *c, const mgk_geom *g0, int nlev, const int *n, const double *coef7, const double *dinv, double scale,
                       int v0, int v1, const T *b, T *u, void *stream, const T *const *ctab = nullptr, const T *const *dtab = nullptr) {
@@ -5122,6 +5156,7 @@ static int tail_cycle(mgk_ctx *c, const mgk_geom *g0, int nlev, const int *n, co
     if (off * (long)sizeof(T) > MGK_TAIL_LDS_BYTES) return fail(MGK_EINVAL, "mgk_tail_cycle: the levels do not fit in LDS");
     a.total = (int)off;
     a.b_in = b + g0->org; a.u_out = u + g0->org; a.rs = g0->pitch; a.ms = g0->plane;
+    a.stamps = g_tail_stamps;
     if (g0->dim == 3) hipLaunchKernelGGL((k_tail<T, 3>), dim3(1), dim3(1024), 0, S(c, stream), a);
     else hipLaunchKernelGGL((k_tail<T, 2>), dim3(1), dim3(1024), 0, S(c, stream), a);
     HIPCHK(hipGetLastError());

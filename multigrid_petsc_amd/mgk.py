@@ -135,6 +135,7 @@ def _sigs(L):
         "mgk_tail_cycle_f64": (i, [vp, G, i, C.POINTER(i), c_dp, c_dp, d, i, i, vp, vp, vp]),
         "mgk_tail_cycle_f32": (i, [vp, G, i, C.POINTER(i), c_dp, c_dp, d, i, i, vp, vp, vp]),
         "mgk_tail_max_n": (i, [i]),
+        "mgk_debug_tail_stamps": (None, [vp]),
         "mgk_jacobi_sumsq_range_f64": (i, [vp, G, c_dp, d, d, vp, vp, vp, i, i, i, C.POINTER(i), vp]),
         "mgk_partials_finish": (i, [vp, i, C.POINTER(d), vp]),
         "mgk_host_alloc": (i, [vp, C.POINTER(vp), sz]),

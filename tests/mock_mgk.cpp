@@ -103,6 +103,7 @@ void mgk_graph_destroy(mgk_ctx *, void *ge) { delete (mock_graph *)ge; }
 int mgk_defer_result(mgk_ctx *c, double *slot) { c->defer = slot; return 0; }
 void mgk_set_tuning(int, int) {}
 int mgk_tail_max_n(int dim) { return dim == 3 ? 15 : 63; }
+void mgk_debug_tail_stamps(long long *) {}
 }   // extern "C"
 
 // ---------------------------------------------------------------------------------------------

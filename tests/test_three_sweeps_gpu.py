@@ -39,8 +39,8 @@ def test_three_sweeps_2d_bit_exact(mgk, orc, n):
     ss = C.c_double()
     L, coef = mgk.L, mgk.coef(As)
     # default choice; the marching form (50) and the short-chunk forms (51: 4 rows, 52: 8 rows) forced; chunk seams everywhere
-    # (58: odd chunks marched downwards whatever the size -- the default from 4095^2 on; 57: never)
-    for var, zc in ((-1, -1), (50, -1), (51, -1), (52, -1), (-1, 1), (-1, 5), (-1, 12), (-1, 64), (58, -1), (58, 5), (58, 12), (57, -1)):
+    # (tuning variants: 58 marches the odd chunks downwards, 59 every chunk; neither is a default)
+    for var, zc in ((-1, -1), (50, -1), (51, -1), (52, -1), (-1, 1), (-1, 5), (-1, 12), (-1, 64), (58, -1), (58, 5), (58, 12), (57, -1), (59, -1), (59, 5)):
         L.mgk_set_tuning(var, zc)
         mgk._chk(L.mgk_memset0(mgk.ctx, dout, 8 * g.total, None))
         mgk._chk(L.mgk_jacobi3_2d_f64(mgk.ctx, C.byref(g), coef, dinv, 0.8, None, None, db, du, dout, None))
@@ -78,7 +78,7 @@ def test_prolongation_and_three_sweeps_2d_bit_exact(mgk, orc, nf):
     x = orc.prolong_add(2, nf, uc, u)
     for _ in range(3):
         x = orc.jacobi(2, nf, As, 0.8, b, x)
-    for var, zc in ((-1, -1), (50, -1), (51, -1), (52, -1), (-1, 1), (-1, 7), (-1, 64), (58, -1), (58, 7), (58, 12)):
+    for var, zc in ((-1, -1), (50, -1), (51, -1), (52, -1), (-1, 1), (-1, 7), (-1, 64), (58, -1), (58, 7), (58, 12), (59, 7)):
         mgk.L.mgk_set_tuning(var, zc)
         mgk._chk(mgk.L.mgk_memset0(mgk.ctx, dout, 8 * gf.total, None))
         mgk._chk(mgk.L.mgk_prolong_jacobi3_2d_f64(mgk.ctx, C.byref(gf), C.byref(gc), mgk.coef(As), dinv, 0.8, None, None, db, duc, du, dout, None))
@@ -108,7 +108,7 @@ def test_three_sweeps_2d_on_row_tables(mgk, orc, n):
     rr = b - _rt_apply(ct, u)
     ss = C.c_double()
     L = mgk.L
-    for var, zc in ((-1, -1), (50, -1), (51, -1), (52, -1), (-1, 3), (-1, 16), (58, -1), (58, 16)):
+    for var, zc in ((-1, -1), (50, -1), (51, -1), (52, -1), (-1, 3), (-1, 16), (58, -1), (58, 16), (59, 16)):
         L.mgk_set_tuning(var, zc)
         mgk._chk(L.mgk_memset0(mgk.ctx, dout, 8 * g.total, None))
         mgk._chk(L.mgk_jacobi3_2d_sumsq_f64(mgk.ctx, C.byref(g), None, 1.0, 0.8, dct, ddt, db, du, dout, C.byref(ss), None))
