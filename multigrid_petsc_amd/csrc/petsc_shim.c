@@ -28,7 +28,7 @@
 /* ------------------------------------------------------------------ */
 static mgk_ctx *G = NULL;
 static int g_notice_pc = 0;
-static long g_lzstat[9];     /* lazy temporaries: [0] residual+restriction fused, [1] prolongation fused into a sweep, [2..4] deferred values that were
+static long g_lzstat[11];    /* lazy temporaries: [0] residual+restriction fused, [1] prolongation fused into a sweep, [2..4] deferred values that were
                               * computed after all (residual, prolongation, correction), [5] deferred values overwritten unread */
 
 static void die(const char *what) {
@@ -104,8 +104,9 @@ PetscErrorCode PetscInitialize(int *argc, char ***argv, const char file[], const
 PetscErrorCode PetscFinalize(void) {
     if (getenv("MGPETSC_LAZY_STATS"))
         printf("[mgpetsc] lazy temporaries: %ld residual+restriction passes, %ld prolongation sweeps fused; computed after all: %ld residuals, "
-               "%ld prolongations, %ld corrections; %ld dropped unread; %ld zero-guess sweeps out of the restriction's pass; %ld norm passes that store r and make the next sweep, %ld of those sweeps adopted\n",
-               g_lzstat[0], g_lzstat[1], g_lzstat[2], g_lzstat[3], g_lzstat[4], g_lzstat[5], g_lzstat[7], g_lzstat[6], g_lzstat[8]);
+               "%ld prolongations, %ld corrections; %ld dropped unread; %ld zero-guess sweeps out of the restriction's pass; %ld norm passes that store r and make the next sweep, %ld of those sweeps adopted; "
+               "%ld norm passes that left r deferred, %ld of those residuals followed the old iterate into the work vector\n",
+               g_lzstat[0], g_lzstat[1], g_lzstat[2], g_lzstat[3], g_lzstat[4], g_lzstat[5], g_lzstat[7], g_lzstat[6], g_lzstat[8], g_lzstat[9], g_lzstat[10]);
     if (G) { mgk_ctx_destroy(G); G = NULL; }
     for (int q = 0; q < g_nopt; q++) { free(g_opt[q].key); free(g_opt[q].val); }
     free(g_opt); g_opt = NULL; g_nopt = g_capopt = 0;
@@ -1328,9 +1329,12 @@ static int ksp_pc(KSP k) {
     }
     return k->pc;
 }
+/* work vector q of solver k, about to be WRITTEN: a deferred residual may name it as its iterate (KSPSolve moves the dependency of a
+ * residual whose norm pass left it deferred from x to the work vector that receives x's old buffer, see there) and is computed first */
 static Vec ksp_work(KSP k, int q, Vec like) {
     if (k->work[q] && !same_layout(k->work[q], like)) VecDestroy(&k->work[q]);
     if (!k->work[q]) VecDuplicate(like, &k->work[q]);
+    else lz_before_write(k->work[q], 1);
     return k->work[q];
 }
 static void swap_dev(Vec a, Vec b) { double *t = a->dev; a->dev = b->dev; b->dev = t; }
@@ -1575,6 +1579,14 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
                      (A->kind == MAT_STENCIL || A->kind == MAT_STENCIL_ROW);
     k->spec_ok = 0;
     if (spec) g_lzstat[8]++;
+    /* the adopted sweeps are the whole solve: x and the work vector swap buffers and nothing is written.  A residual b - A x that is still
+     * deferred (its norm pass did not store it, norm_of_deferred_residual) then follows the OLD iterate into the work vector instead of being
+     * computed now; the reference overwrites it unread (src/solver.c:1534), anything else that reads it, or writes b or the work vector
+     * (ksp_work), computes it from there first */
+    const int adopt_only = spec && maxit == k->spec_n && k->work[0] && same_layout(k->work[0], x);
+    if (adopt_only)
+        for (int q = 0; q < g_nlz; q++)
+            if (g_lz[q]->lz == LZ_RESIDUAL && g_lz[q]->lz_x == x && g_lz[q] != x && g_lz[q] != k->work[0]) { g_lz[q]->lz_x = k->work[0]; g_lzstat[10]++; }
     /* the right-hand side is R (b_f - A_f u_f), still deferred (MatMult(res) just before, src/solver.c:1535-1536), and the solve starts
      * from the zero guess: restriction and first sweep in one pass */
     struct _p_Mat *rrA = NULL, *rrR = NULL; Vec rrb = NULL, rru = NULL;
@@ -1612,7 +1624,7 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
     if (A->kind == MAT_STENCIL) {
         need_vec(x, 1, &A->gf, A->n, "KSPSolve");
         const double dinv = (pc == P_JACOBI) ? 1.0 / A->coef[2] : 1.0;
-        Vec w = ksp_work(k, 0, x);
+        Vec w = adopt_only ? k->work[0] : ksp_work(k, 0, x);
         if (k->type == K_RICHARDSON) {
             /* sweeps two per pass (temporal blocking) where that beats two launches: 2-D grids of 2047^2 and more
              * (MGPETSC_PAIR_MIN_N overrides the threshold; bit-identical either way) */
@@ -1665,7 +1677,7 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
         need_vec(x, 1, &A->gf, A->n, "KSPSolve");
         mat_device_rowtabs(A);
         const double *dt = (pc == P_JACOBI) ? A->d_dtab : A->d_ones;
-        Vec w = ksp_work(k, 0, x);
+        Vec w = adopt_only ? k->work[0] : ksp_work(k, 0, x);
         if (k->type == K_CHEBYSHEV) {                       /* the recurrence of the constant-coefficient branch on the row tables */
             if (!(k->emax > k->emin && k->emin > 0.0)) UNSUPPORTED("chebyshev without -ksp_chebyshev_eigenvalues emin,emax (no eigenvalue estimation)");
             Vec w2 = ksp_work(k, 1, x);
@@ -1744,13 +1756,33 @@ static int norm_of_deferred_residual(Vec r, double *ss) {
     Vec b = r->lz_b, u = r->lz_x;
     if (lazy_on() != 1 || k->A != A || k->type != K_RICHARDSON || !k->guess_nonzero || k->maxits < 1 || k->pc == P_MG || k->pc == P_LU ||
         k->normtype == KSP_NORM_UNPRECONDITIONED || (A->kind != MAT_STENCIL && A->kind != MAT_STENCIL_ROW) || A->gf.dim != 2) return 0;
+    if (u == k->work[0] || u == k->work[1] || b == k->work[0] || b == k->work[1]) return 0;      /* (a residual that followed the old iterate into the work vector: the general way) */
     const int pc = ksp_pc(k);
     Vec w = ksp_work(k, 0, u);
     (void)vdev(b); (void)vdev(u);
+    const int three = j3_on() && k->maxits >= 3;            /* ... ALL of the next solve's first three sweeps (round 3) */
+    /* when those three sweeps ARE the next solve (max_it = 3, the reference's -v 3,3), r need not be stored either: it stays deferred, and
+     * the KSPSolve that adopts the sweeps lets it follow the old iterate into the work vector (24 B per unknown instead of 32; the
+     * reference overwrites r unread, src/solver.c:1534).  MGPETSC_KEEP_R=0 stores it as before */
+    static int keep_r = -1;
+    if (keep_r < 0) { const char *e = getenv("MGPETSC_KEEP_R"); keep_r = (e && *e) ? atoi(e) : 1; }
+    if (three && k->maxits == 3 && keep_r && r != b && r != u && r != w) {
+        if (A->kind == MAT_STENCIL) {
+            const double dinv = (pc == P_JACOBI) ? 1.0 / A->coef[2] : 1.0;
+            DEV(mgk_jacobi3_2d_sumsq_f64(G, &A->gf, A->coef, dinv, k->scale, NULL, NULL, b->dev, u->dev, w->dev, ss, NULL));
+        } else {
+            mat_device_rowtabs(A);
+            const double *dt = (pc == P_JACOBI) ? A->d_dtab : A->d_ones;
+            DEV(mgk_jacobi3_2d_sumsq_f64(G, &A->gf, NULL, 1.0, k->scale, A->d_ctab, dt, b->dev, u->dev, w->dev, ss, NULL));
+        }
+        k->spec_n = 3;
+        k->spec_ok = 1; k->spec_b = b; k->spec_x = u; k->spec_vb = b->ver; k->spec_vx = u->ver; k->spec_epoch = g_mat_epoch;
+        g_lzstat[9]++;
+        return 1;
+    }
     lz_before_write(r, 1);                                   /* r is computed by the pass below */
     g_lzstat[5]--;
     r->host_dirty = 0;
-    const int three = j3_on() && k->maxits >= 3;            /* ... ALL of the next solve's first three sweeps (round 3) */
     if (A->kind == MAT_STENCIL) {
         const double dinv = (pc == P_JACOBI) ? 1.0 / A->coef[2] : 1.0;
         if (three) DEV(mgk_jacobi3_2d_sumsq_store_f64(G, &A->gf, A->coef, dinv, k->scale, NULL, NULL, b->dev, u->dev, w->dev, r->dev, ss, NULL));

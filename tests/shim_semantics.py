@@ -220,6 +220,97 @@ def speculative_sweep_is_adopted_only_when_nothing_changed(L, orc):
     L.MatDestroy(C.byref(mA))
 
 
+def residual_left_deferred_by_the_norm_pass(L, orc):
+    """max_it = 3 (the reference's -v 3,3): the pass that evaluates || b - A u || makes ALL three sweeps of the next KSPSolve and does not
+    store r (round 3): r stays deferred, and when the solve adopts the sweeps (x and the work vector swap buffers) r's dependency follows
+    the OLD iterate into the work vector.  Whatever is done next -- r read at once, after the adopting solve, after b was rewritten, after
+    another solve reused the work vector, after the solver died, the norm asked twice -- r must be b - A (old u) and u three sweeps further."""
+    L.PetscInitialize(None, None, None, None)
+    L.PetscOptionsSetValue(None, b"-pc_type", b"jacobi")
+    L.PetscOptionsSetValue(None, b"-ksp_richardson_scale", b"0.8")
+    npts = 33
+    A = _dense(orc, "A", npts, 0)
+    mA = _assemble(L, A)
+    n = A.shape[0]
+    d = 1.0 / np.diag(A)
+    rng = np.random.default_rng(17)
+    uv, bv = rng.standard_normal(n), rng.standard_normal(n)
+
+    def sweeps(x, rhs, m, s=0.8):
+        for _ in range(m):
+            x = x + s * (d * (rhs - A @ x))
+        return x
+
+    tol = 1e-12 * max(np.abs(uv).max(), 1.0) * 100
+    rtol = tol * np.abs(A).max()
+    for case in ("reference order", "read r at once", "read r after the solve", "b rewritten after the solve", "second solve reuses the work vector",
+                 "solver destroyed", "norm twice", "norm again after the solve", "u written before the solve", "restriction of r after the solve"):
+        u, b, r = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        L.MatCreateVecs(mA, C.byref(u), C.byref(b))
+        L.VecDuplicate(u, C.byref(r))
+        k = C.c_void_p()
+        L.KSPCreate(1, C.byref(k))
+        L.KSPSetType(k, b"richardson"); L.KSPSetOperators(k, mA, mA); L.KSPSetNormType(k, 0)
+        L.KSPSetTolerances(k, 1e-7, -2.0, -2.0, 3)
+        L.KSPSetFromOptions(k)
+        L.KSPSetInitialGuessNonzero(k, 1)
+        V, val = C.c_void_p(), C.c_double()
+        _set(L, u, uv); _set(L, b, bv)
+        L.KSPSolve(k, b, u)
+        x = sweeps(uv, bv, 3)
+        r_old = bv - A @ x
+        L.KSPBuildResidual(k, None, r, C.byref(V))
+        L.VecNorm(V, NORM_2, C.byref(val))
+        assert abs(val.value - np.linalg.norm(r_old)) <= 1e-12 * np.linalg.norm(r_old), case
+        if case == "read r at once":
+            assert np.max(np.abs(_get(L, r, n) - r_old)) <= rtol, case
+        if case == "norm twice":
+            L.VecNorm(V, NORM_2, C.byref(val))
+            assert abs(val.value - np.linalg.norm(r_old)) <= 1e-12 * np.linalg.norm(r_old), case
+        if case == "u written before the solve":
+            L.VecScale(u, 0.5)
+            x = 0.5 * x
+        L.KSPSolve(k, b, u)                                  # adopts the three sweeps (except after the write to u)
+        x3 = sweeps(x, bv, 3)
+        if case == "reference order":
+            L.KSPBuildResidual(k, None, r, C.byref(V))       # r overwritten unread (src/solver.c:1534)
+            L.VecNorm(V, NORM_2, C.byref(val))
+            assert abs(val.value - np.linalg.norm(bv - A @ x3)) <= 1e-11 * np.linalg.norm(bv - A @ x3), case
+        elif case == "b rewritten after the solve":
+            L.VecSet(b, 1.0)                                 # r was defined with the old b
+            assert np.max(np.abs(_get(L, r, n) - r_old)) <= rtol, case
+            assert np.all(_get(L, b, n) == 1.0)
+        elif case == "second solve reuses the work vector":
+            L.KSPSolve(k, b, u)                              # writes the work vector that holds the old iterate
+            assert np.max(np.abs(_get(L, r, n) - r_old)) <= rtol, case
+            x3 = sweeps(x3, bv, 3)
+        elif case == "solver destroyed":
+            L.KSPDestroy(C.byref(k))
+            assert np.max(np.abs(_get(L, r, n) - r_old)) <= rtol, case
+        elif case == "norm again after the solve":
+            L.VecNorm(V, NORM_2, C.byref(val))
+            assert abs(val.value - np.linalg.norm(r_old)) <= 1e-12 * np.linalg.norm(r_old), case
+            assert np.max(np.abs(_get(L, r, n) - r_old)) <= rtol, case
+        elif case == "restriction of r after the solve":
+            Rm = _dense(orc, "R", npts, 0)
+            mR = _assemble(L, Rm)
+            bc = C.c_void_p()
+            L.MatCreateVecs(mR, None, C.byref(bc))
+            L.MatMult(mR, r, bc)
+            assert np.max(np.abs(_get(L, bc, Rm.shape[0]) - Rm @ r_old)) <= rtol, case
+            L.VecDestroy(C.byref(bc)); L.MatDestroy(C.byref(mR))
+        elif case != "u written before the solve":
+            assert np.max(np.abs(_get(L, r, n) - r_old)) <= rtol, case
+        if case == "u written before the solve":
+            assert np.max(np.abs(_get(L, r, n) - r_old)) <= rtol, case      # r belongs to u BEFORE the scaling
+        assert np.max(np.abs(_get(L, u, n) - x3)) <= tol, case
+        if k:
+            L.KSPDestroy(C.byref(k))
+        for v in (u, b, r):
+            L.VecDestroy(C.byref(v))
+    L.MatDestroy(C.byref(mA))
+
+
 def richardson_with_lu_is_damped_not_exact(L, orc):
     """-pc_type lu (the dense inverse of a small operator): preonly and richardson with scale 1 return A^-1 b whatever the guess;
     richardson with scale s != 1 makes max_it DAMPED steps x <- (1 - s) x + s A^-1 b, as PETSc would (it used to come
@@ -268,5 +359,5 @@ if __name__ == "__main__":      # python tests/shim_semantics.py <shared library
     from oracle import Oracle
     lib = type_shim(C.CDLL(sys.argv[1], mode=os.RTLD_LOCAL))
     {"lazy": lazy_temporaries_keep_petsc_semantics, "spec": speculative_sweep_is_adopted_only_when_nothing_changed,
-     "lu": richardson_with_lu_is_damped_not_exact}[sys.argv[2]](lib, Oracle())
+     "keepr": residual_left_deferred_by_the_norm_pass, "lu": richardson_with_lu_is_damped_not_exact}[sys.argv[2]](lib, Oracle())
     print("SEMANTICS_OK", sys.argv[2])

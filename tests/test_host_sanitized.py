@@ -288,7 +288,8 @@ def test_lazy_temporaries_of_the_reference_loop(san, tmp_path, mesh, cycle):
         out = _refdrv(san, d, opts, {"MGPETSC_LAZY": lazy, "MGPETSC_LAZY_STATS": "1"})
         it = int(re.search(r"Number of iterations:\s+(\d+)", out).group(1))
         m = re.search(r"lazy temporaries: (\d+) residual\+restriction passes, (\d+) prolongation sweeps fused; computed after all: (\d+) residuals, "
-                      r"(\d+) prolongations, (\d+) corrections; (\d+) dropped unread; (\d+) zero-guess sweeps out of the restriction's pass; (\d+) norm passes that store r and make the next sweep, (\d+) of those", out)
+                      r"(\d+) prolongations, (\d+) corrections; (\d+) dropped unread; (\d+) zero-guess sweeps out of the restriction's pass; (\d+) norm passes that store r and make the next sweep, (\d+) of those sweeps adopted; "
+                      r"(\d+) norm passes that left r deferred, (\d+) of those", out)
         assert m, out[-800:]
         st = [int(x) for x in m.groups()]
         if lazy == "1":
@@ -296,12 +297,13 @@ def test_lazy_temporaries_of_the_reference_loop(san, tmp_path, mesh, cycle):
             assert st[3] == 0 and st[4] == 0, st                                      # rv never computed, no correction left over
             if cycle == 0:
                 assert st[6] == it * (levels - 1), st                                 # every coarse pre-smoothing starts inside the restriction's pass
-                assert st[7] == it and st[2] == 0, st                                 # every closing norm stores r and makes the next cycle's first sweep
+                assert st[7] + st[9] == it and st[2] == 0, st                         # every closing norm makes the next cycle's first sweeps (r stored, or -- max_it = 3 -- left deferred)
                 assert st[8] == it - 1, st                                            # ... which every cycle but the first adopts
+                assert st[9] == it and st[10] == it - 1, st                           # round 3: r never stored; it follows the old iterate into the work vector and is dropped unread
             else:
                 assert st[2] <= it + 1, st                                            # PCMG: only the outer residual whose norm is monitored
         else:
-            assert st == [0] * 9
+            assert st == [0] * 11
         res[lazy] = (it, (d / "rData.dat").read_text(), (d / "uData.dat").read_text())
     assert res["1"][0] == res["0"][0] and res["1"][2] == res["0"][2]                  # cycle count, solution file
     r1, r0 = (np.array(res[q][1].split(), dtype=np.float64) for q in ("1", "0"))      # (the fused norm pass sums r^2 in another order)

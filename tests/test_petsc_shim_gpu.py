@@ -582,6 +582,12 @@ def test_speculative_sweep_of_the_norm_pass_is_adopted_only_when_nothing_changed
     speculative_sweep_is_adopted_only_when_nothing_changed(type_shim(_shim()), orc)
 
 
+def test_residual_left_deferred_by_the_norm_pass(orc):
+    """max_it = 3: the norm pass makes all three sweeps of the next solve and does NOT store r; see tests/shim_semantics.py"""
+    from shim_semantics import residual_left_deferred_by_the_norm_pass, type_shim
+    residual_left_deferred_by_the_norm_pass(type_shim(_shim()), orc)
+
+
 def test_richardson_with_lu_is_damped_not_exact():
     """a process of its own (it changes -pc_type in the options database): see tests/shim_semantics.py"""
     import subprocess

@@ -49,5 +49,9 @@ def test_speculative_sweep_adoption_rule_on_the_mock(mock_shim):
     _check(mock_shim, "spec")
 
 
+def test_residual_left_deferred_by_the_norm_pass_on_the_mock(mock_shim):
+    _check(mock_shim, "keepr")
+
+
 def test_richardson_with_lu_is_damped_on_the_mock(mock_shim):
     _check(mock_shim, "lu")
