@@ -30,6 +30,7 @@ static inline hipStream_t S(mgk_ctx *c, void *s) { return s ? (hipStream_t)s : c
 // per THREAD tuning knobs (mgk_set_tuning) and the fixed-order finish of per-block / per-wave partial sums (mgk_kernels.hip)
 extern thread_local int g_variant, g_zchunk;
 int finish_to_host(mgk_ctx *c, int nparts, int nslots, hipStream_t s, double *host_out);
+int mgk_preload_kernels3();      // forces the code object of mgk_kernels3.hip to load (mgk_ctx_create)
 
 // ------------------------------------------------------------------------------------------
 // device helpers

@@ -37,6 +37,7 @@ extern "C" int mgk_device_count(void) {
 
 extern "C" int mgk_set_device(int device) { HIPCHK(hipSetDevice(device)); return 0; }
 
+__global__ void k_finish_sum(const double *partials, int n, double *out, int slot);
 extern "C" int mgk_ctx_create(mgk_ctx **out, int device) {
     if (!out) return fail(MGK_EINVAL, "mgk_ctx_create: null out");
     int n = 0;
@@ -62,6 +63,13 @@ extern "C" int mgk_ctx_create(mgk_ctx **out, int device) {
     HIPCHK(hipHostMalloc(&c->result_host, sizeof(double) * 8, hipHostMallocDefault));
     for (int q = 0; q < 32; q++) HIPCHK(hipEventCreateWithFlags(&c->ev[q], hipEventDisableTiming));
     c->ev_next = 0;
+    {   // HIP loads a translation unit's code object at the first use of one of its kernels (~2 ms each: a third of the reference driver's
+        // whole `Solver walltime` at 4097^2 when it happened inside its first KSPSolve): both units are loaded here
+        hipFuncAttributes fa;
+        HIPCHK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_finish_sum)));
+        int rc = mgk_preload_kernels3();
+        if (rc) return rc;
+    }
     *out = c;
     return 0;
 }

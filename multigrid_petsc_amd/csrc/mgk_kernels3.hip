@@ -622,6 +622,11 @@ extern "C" int mgk_flags_wait(mgk_ctx *c, void *const *flags, int n, unsigned lo
     HIPCHK(hipGetLastError());
     return 0;
 }
+int mgk_preload_kernels3() {
+    hipFuncAttributes fa;
+    HIPCHK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_flag_set)));
+    return 0;
+}
 extern "C" int mgk_flag_set(mgk_ctx *c, void *flag, unsigned long long value, void *stream) { void *f[1] = {flag}; return mgk_flags_set(c, f, 1, value, stream); }
 extern "C" int mgk_flag_wait(mgk_ctx *c, const void *flag, unsigned long long value, double timeout_s, void *status_u32, void *stream) {
     void *f[1] = {const_cast<void *>(flag)};

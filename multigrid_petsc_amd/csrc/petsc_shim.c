@@ -28,9 +28,10 @@
 /* ------------------------------------------------------------------ */
 static mgk_ctx *G = NULL;
 static int g_notice_pc = 0;
-static long g_lzstat[11];    /* lazy temporaries: [0] residual+restriction fused, [1] prolongation fused into a sweep, [2..4] deferred values that were
+static long g_lzstat[14];    /* lazy temporaries: [0] residual+restriction fused, [1] prolongation fused into a sweep, [2..4] deferred values that were
                               * computed after all (residual, prolongation, correction), [5] deferred values overwritten unread */
 
+static void tc_shutdown(void);       /* the tail recorder's logs (below) */
 static void die(const char *what) {
     fprintf(stderr, "[mgpetsc] FATAL: %s (kernel layer: %s)\n", what, mgk_last_error());
     exit(86);
@@ -105,8 +106,11 @@ PetscErrorCode PetscFinalize(void) {
     if (getenv("MGPETSC_LAZY_STATS"))
         printf("[mgpetsc] lazy temporaries: %ld residual+restriction passes, %ld prolongation sweeps fused; computed after all: %ld residuals, "
                "%ld prolongations, %ld corrections; %ld dropped unread; %ld zero-guess sweeps out of the restriction's pass; %ld norm passes that store r and make the next sweep, %ld of those sweeps adopted; "
-               "%ld norm passes that left r deferred, %ld of those residuals followed the old iterate into the work vector\n",
-               g_lzstat[0], g_lzstat[1], g_lzstat[2], g_lzstat[3], g_lzstat[4], g_lzstat[5], g_lzstat[7], g_lzstat[6], g_lzstat[8], g_lzstat[9], g_lzstat[10]);
+               "%ld norm passes that left r deferred, %ld of those residuals followed the old iterate into the work vector; "
+               "%ld coarse sub-cycles run as ONE tail launch, %ld recordings replayed call by call, %ld times their unread intermediates were computed after all\n",
+               g_lzstat[0], g_lzstat[1], g_lzstat[2], g_lzstat[3], g_lzstat[4], g_lzstat[5], g_lzstat[7], g_lzstat[6], g_lzstat[8], g_lzstat[9], g_lzstat[10],
+               g_lzstat[11], g_lzstat[12], g_lzstat[13]);
+    tc_shutdown();
     if (G) { mgk_ctx_destroy(G); G = NULL; }
     for (int q = 0; q < g_nopt; q++) { free(g_opt[q].key); free(g_opt[q].val); }
     free(g_opt); g_opt = NULL; g_nopt = g_capopt = 0;
@@ -293,8 +297,18 @@ static void vec_download(Vec v) {        /* device -> host mirror */
  * lz_settle), ANY write to a vector first computes the deferred vectors that depend on it (lz_before_write), destroying an operand
  * likewise.  A deferred vector that is overwritten before anyone reads it is never computed -- which is what happens to r and rv in
  * the reference's loop.  MGPETSC_LAZY=0 switches the whole mechanism off (every call executes at once, as before). */
-enum { LZ_NONE = 0, LZ_RESIDUAL = 1, LZ_PROLONG = 2, LZ_ADDP = 3, LZ_RR = 4 };
-#define LZ_MAX 64
+enum { LZ_NONE = 0, LZ_RESIDUAL = 1, LZ_PROLONG = 2, LZ_ADDP = 3, LZ_RR = 4,
+       LZ_TAIL = 5 };      /* written by a recorded (not yet executed) coarse sub-cycle, or an unread intermediate of one that ran as ONE tail launch (below: tail capture) */
+#define LZ_MAX 128
+static void tc_settle(Vec v);                      /* a LZ_TAIL value is needed: the recording is replayed / the intermediates are computed */
+static void tc_dropped(Vec v);                     /* a LZ_TAIL intermediate was overwritten unread */
+static int tc_recording_has(Vec v);
+static void tc_input_changing(Vec v, int full);    /* the right-hand side of a finished sub-cycle is about to be overwritten */
+static void tc_mat_changing(struct _p_Mat *A);
+static int tc_axpy(Vec y, double a, Vec x);        /* the three calls below and KSPSolve ask the recorder first: 1 = absorbed */
+static int tc_mult(struct _p_Mat *A, Vec x, Vec y);
+static int tc_resid(struct _p_Mat *A, Vec b, Vec x, Vec r);
+static int g_tc_off = 0;                           /* > 0: no recording (inside PCMG's own cycle, while a recording is replayed) */
 static Vec g_lz[LZ_MAX];
 static int g_nlz = 0, g_lazy = -1;
 static unsigned long g_mat_epoch = 0;      /* bumped when any matrix changes or dies and when any vector dies: speculative sweeps made before are void */
@@ -302,6 +316,7 @@ static int lazy_on(void) { if (g_lazy < 0) { const char *e = getenv("MGPETSC_LAZ
 static void lz_settle(Vec v);
 static void lz_drop(Vec v) {                       /* forget v's deferred value (it is being overwritten / has been consumed) */
     if (!v->lz) return;
+    if (v->lz == LZ_TAIL) tc_dropped(v);
     v->lz = LZ_NONE; v->lz_A = v->lz_A2 = NULL; v->lz_b = v->lz_x = NULL; v->lz_ksp = NULL;
     for (int q = 0; q < g_nlz; q++) if (g_lz[q] == v) { g_lz[q] = g_lz[--g_nlz]; break; }
 }
@@ -313,6 +328,8 @@ static void lz_register(Vec v, int kind, struct _p_Mat *A, Vec b, Vec x) {
 /* before v's value changes: compute whatever is defined in terms of the current v; full: v is overwritten entirely, its own
  * deferred value is dead, otherwise it is computed first */
 static void lz_before_write(Vec v, int full) {
+    if (v->lz == LZ_TAIL && tc_recording_has(v)) tc_settle(v);      /* a write from outside the pattern: the recording is executed first */
+    tc_input_changing(v, full);
     for (int q = 0; q < g_nlz; ) {
         Vec L = g_lz[q];
         if (L != v && (L->lz_b == v || L->lz_x == v)) { lz_settle(L); q = 0; } else q++;
@@ -322,6 +339,7 @@ static void lz_before_write(Vec v, int full) {
 }
 static void lz_before_mat_change(struct _p_Mat *A) {
     g_mat_epoch++;
+    tc_mat_changing(A);
     for (int q = 0; q < g_nlz; ) { if (g_lz[q]->lz_A == A || g_lz[q]->lz_A2 == A) { lz_settle(g_lz[q]); q = 0; } else q++; }
 }
 static double *vdev(Vec v) { if (v->lz) lz_settle(v); if (v->host_dirty) vec_upload(v); return v->dev; }
@@ -381,6 +399,7 @@ PetscErrorCode VecCopy(Vec x, Vec y) {
 PetscErrorCode VecScale(Vec v, PetscScalar a) { lz_before_write(v, 0); DEV(mgk_flat_scale(G, v->nalloc, a, vdev(v), NULL)); return 0; }
 PetscErrorCode VecAXPY(Vec y, PetscScalar a, Vec x) {       /* y = y + a x  (src/solver.c:1517,1541) */
     need_same(x, y, "VecAXPY");
+    if (tc_axpy(y, a, x)) return 0;
     if (x->lz == LZ_PROLONG && a == 1.0 && x != y && y != x->lz_x && y->padded == 1 && lazy_on()) {
         /* u += P u_c with P u_c not computed yet (src/solver.c:1540-1541): u's correction is deferred in turn -- the KSPSolve that
          * follows makes its first sweep on u + P u_c directly; anything else that touches u first runs mgk_prolong_add */
@@ -965,6 +984,7 @@ static void levelg_apply(Mat A, Vec x, Vec y, double alpha, Vec addto, const cha
 PetscErrorCode MatMult(Mat A, Vec x, Vec y) {                       /* src/solver.c:1516,1535,1540 */
     if (!A->assembled) UNSUPPORTED("MatMult on an unassembled matrix");
     if (x == y) UNSUPPORTED("MatMult with x == y");
+    if (tc_mult(A, x, y)) return 0;
     if (A->kind == MAT_RESTRICT && x->lz == LZ_RESIDUAL && x->lz_A->gf.dim == 2 && geom_eq(&x->lz_A->gf, &A->gf) && y->padded == 1 && geom_eq(&y->g, &A->gc) &&
         y != x->lz_b && y != x->lz_x) {
         /* b_c = R (b - A u) with the residual not computed yet (src/solver.c:1534-1535): one pass, r stays deferred */
@@ -1036,6 +1056,7 @@ PetscErrorCode MatMultAdd(Mat A, Vec x, Vec y, Vec z) {            /* z = y + A 
 }
 static void mat_residual_now(Mat A, Vec b, Vec x, Vec r);
 PetscErrorCode MatResidual(Mat A, Vec b, Vec x, Vec r) {           /* r = b - A x */
+    if (tc_resid(A, b, x, r)) return 0;
     if ((A->kind == MAT_STENCIL || A->kind == MAT_STENCIL_ROW) && lazy_on() && r != b && r != x && r->padded == 1 && geom_eq(&r->g, &A->gf)) {
         need_vec(x, 1, &A->gf, A->n, "MatResidual"); need_vec(b, 1, &A->gf, A->m, "MatResidual");
         (void)vdev(b); (void)vdev(x);                        /* operands concrete */
@@ -1060,6 +1081,7 @@ static void lz_settle(Vec v) {
     struct _p_Mat *A = v->lz_A; Vec b = v->lz_b, x = v->lz_x;
     struct _p_Mat *A2 = v->lz_A2;
     if (!kind) return;
+    if (kind == LZ_TAIL) { tc_settle(v); return; }
     lz_drop(v);
     if (kind == LZ_RR) { rr_now(A, A2, b, x, v, NULL, 1.0, 1.0, NULL); return; }
     g_lzstat[1 + kind]++;
@@ -1201,7 +1223,14 @@ static int pc_type_from(const char *t) {
 /* (every setter that changes what a sweep IS drops the speculative first sweep the last norm pass may have left in work[0]: it was made
  * with the old scale / preconditioner / type -- ADVICE round 2) */
 PetscErrorCode KSPSetType(KSP k, KSPType t) { k->type = ksp_type_from(t); k->type_from_user = 1; k->spec_ok = 0; return 0; }
-PetscErrorCode KSPSetOperators(KSP k, Mat A, Mat P) { (void)P; k->A = A; k->spec_ok = 0; return 0; }
+/* (the sweep's work vector is created here, not inside the first KSPSolve: a 134 MB hipMalloc takes ~2 ms, a third of the reference's whole
+ * `Solver walltime` at 4097^2 -- PETSc creates its work vectors in KSPSetUp, which the reference never calls explicitly; ksp_work replaces it
+ * if a solve comes with another layout) */
+PetscErrorCode KSPSetOperators(KSP k, Mat A, Mat P) {
+    (void)P; k->A = A; k->spec_ok = 0;
+    if (A && A->assembled && (A->kind == MAT_STENCIL || A->kind == MAT_STENCIL_ROW) && !k->work[0]) MatCreateVecs(A, &k->work[0], NULL);
+    return 0;
+}
 PetscErrorCode KSPSetNormType(KSP k, KSPNormType n) { k->normtype = n; k->spec_ok = 0; return 0; }
 PetscErrorCode KSPSetTolerances(KSP k, PetscReal rtol, PetscReal atol, PetscReal dtol, PetscInt maxits) {
     /* KSP_NORM_NONE (the smoothers): only max_it matters (src/solver.c:1473-1474); the tolerances are kept for the
@@ -1404,6 +1433,7 @@ static PetscErrorCode ksp_solve_mg(KSP k, Vec b, Vec x) {
     if (k->type != K_RICHARDSON) UNSUPPORTED("PCMG under an outer Krylov type other than richardson");
     need_same(b, x, "KSPSolve");
     mg_setup(k);
+    g_tc_off++;                                              /* (PCMG's own cycle calls MatMultAdd, not the reference loop's pattern: no recording) */
     k->b = b; k->x = x; k->its = 0;
     (void)vdev(b); (void)vdev(x);
     Vec r = ksp_work(k, 0, x), z = ksp_work(k, 1, x);
@@ -1425,6 +1455,7 @@ static PetscErrorCode ksp_solve_mg(KSP k, Vec b, Vec x) {
         k->its++;
         if (k->hist && k->its < k->nhist) k->hist[k->its] = rn;
     }
+    g_tc_off--;
     return 0;
 }
 
@@ -1436,6 +1467,7 @@ static PetscErrorCode ksp_solve_monitored(KSP k, Vec b, Vec x) {
     Mat A = k->A;
     if (k->type != K_RICHARDSON) UNSUPPORTED("a monitored (KSP_NORM_UNPRECONDITIONED) solve with a Krylov type other than richardson");
     need_same(b, x, "KSPSolve");
+    g_tc_off++;                                              /* (one sweep per inner solve with a norm in between: nothing to record) */
     const PetscInt maxits = k->maxits;
     const int guess = k->guess_nonzero;
     Vec r = ksp_work(k, 2, x);
@@ -1459,6 +1491,7 @@ static PetscErrorCode ksp_solve_monitored(KSP k, Vec b, Vec x) {
     }
     k->normtype = KSP_NORM_UNPRECONDITIONED; k->maxits = maxits; k->guess_nonzero = guess; k->its = its;
     k->b = b; k->x = x;
+    g_tc_off--;
     return 0;
 }
 
@@ -1554,6 +1587,323 @@ static int j3_on(void) {
     return v;
 }
 
+/* ---- tail capture (round 3) -------------------------------------------------------------------------------------------------------
+ * Below 63^2 a level's part of the reference's loop (src/solver.c:1533-1544) is three launches of ~5 us whose arithmetic is a rounding
+ * error; the own driver runs those levels as ONE launch of one workgroup with everything in LDS (mgk_tail_cycle_f64).  The drop-in sees
+ * the same work as a stream of PETSc calls, so it RECORDS them instead of executing them, as long as they keep to the pattern
+ *     KSPSolve(ksp[t], b[t], u[t])                                  zero guess, n <= 63: the recording starts (b[t] is made concrete)
+ *     { KSPBuildResidual / MatResidual(A[l], b[l], u[l], r[l]);  MatMult(res[l], r[l], b[l+1]);  KSPSolve(ksp[l+1], b[l+1], u[l+1]) }   l = t, t+1, ...
+ *     { MatMult(pro[l], u[l+1], rv[l]);  VecAXPY(u[l], 1.0, rv[l]);  KSPSolve(ksp[l], b[l], u[l]) }                                     ... back up to l = t
+ * (Richardson, Jacobi / none, one scale, max_it = v0 above the coarsest level; the solver's parameters are snapshot at each call, so the
+ * KSPSetInitialGuessNonzero calls in between, :1537 and :1543, need nothing).  When the last call of the pattern arrives the tail kernel
+ * runs the whole sub-cycle and u[t] is concrete; the intermediates (u, b, r, rv of the levels below) are never computed -- they stay marked
+ * LZ_TAIL with the log kept, and the next cycle overwrites them unread.  PETSc's semantics hold for everything else: the vectors a recording
+ * has written are LZ_TAIL, so ANY read of one (vdev -> lz_settle), any write to one or to b[t] (lz_before_write), any change or destruction
+ * of a matrix or solver the log names, and any of the four intercepted calls that does not continue the pattern first REPLAYS the log call
+ * by call through the ordinary paths (tc_flush); an intermediate of a finished sub-cycle that is read after all is computed by replaying
+ * the log on scratch vectors (tc_materialise: the real ones may hold newer values by then).  MGPETSC_TAIL=0 switches the recorder off. */
+#define TC_MAXLEV 8
+enum { TC_SOLVE = 1, TC_RESID, TC_RESTRICT, TC_PROLONG, TC_AXPY };
+enum { TCS_AFTER_PRE = 1, TCS_AFTER_RESID, TCS_AFTER_RESTRICT, TCS_AFTER_PROLONG, TCS_AFTER_AXPY, TCS_AFTER_POST };
+typedef struct { int op; KSP k; Mat A; Vec a, b, c; int guess, pc; PetscInt maxits; double scale; KSPNormType nt; } tc_op;
+typedef struct {
+    int complete;                                   /* 0: recording; 1: the tail kernel has run, the intermediates are unread ghosts */
+    int nops; tc_op ops[6 * TC_MAXLEV + 2];
+    int nlev, j, step;                              /* levels entered so far, current level, what the last absorbed call was */
+    KSP ksp[TC_MAXLEV]; Mat A[TC_MAXLEV], R[TC_MAXLEV], P[TC_MAXLEV];
+    Vec b[TC_MAXLEV], u[TC_MAXLEV], r[TC_MAXLEV], rv[TC_MAXLEV];
+    PetscInt its[TC_MAXLEV]; int pc[TC_MAXLEV]; double scale;
+    int nv; Vec vec[4 * TC_MAXLEV]; mgk_geom vg[4 * TC_MAXLEV]; PetscInt vn[4 * TC_MAXLEV]; char alive[4 * TC_MAXLEV];   /* the vectors the log writes */
+    double *b0_priv; long b0_n;                     /* finished log: its right-hand side, once b[0] itself has been given a new value (below) */
+    mgk_geom b0_g; PetscInt b0_len;
+} tailcap;
+static tailcap *g_tc_rec = NULL, *g_tc_done = NULL;
+/* The reference overwrites b[t] (MatMult(res), :1535) BEFORE it overwrites the intermediates of the previous cycle, and those are defined in
+ * terms of the old b[t].  Computing them at that point would double the work, copying b[t] would cost a launch per cycle: instead the log
+ * takes b[t]'s device buffer (its old value is dead for the vector: the write is a full overwrite) and the vector continues on a spare buffer
+ * of the same layout -- the buffer the previous log gave back when its last ghost was overwritten.  A partial write copies. */
+static double *g_tc_spare = NULL; static long g_tc_spare_n = 0;
+static void tc_free_log(tailcap *t) {
+    if (t->b0_priv) {
+        if (g_tc_spare && G) mgk_free(G, g_tc_spare);
+        g_tc_spare = t->b0_priv; g_tc_spare_n = t->b0_n;
+    }
+    free(t);
+}
+static void tc_input_changing(Vec v, int full) {
+    tailcap *t = g_tc_done;
+    if (!t || v != t->b[0] || t->b0_priv) return;
+    double *spare = NULL;
+    if (g_tc_spare && g_tc_spare_n == v->nalloc) { spare = g_tc_spare; g_tc_spare = NULL; g_tc_spare_n = 0; }
+    else {
+        void *q = NULL;
+        DEV(mgk_malloc(G, &q, sizeof(double) * (size_t)v->nalloc));
+        DEV(mgk_memset0(G, q, sizeof(double) * (size_t)v->nalloc, NULL));       /* (the padding of the layout is zero and stays zero) */
+        spare = (double *)q;
+    }
+    if (v->host_dirty) vec_upload(v);
+    if (full) { t->b0_priv = v->dev; v->dev = spare; }
+    else { DEV(mgk_d2d(G, spare, v->dev, sizeof(double) * (size_t)v->nalloc, NULL)); t->b0_priv = spare; }
+    t->b0_n = v->nalloc; t->b0_g = v->g; t->b0_len = v->n;
+    for (int i = 0; i < t->nv; i++) if (t->alive[i]) t->vec[i]->lz_b = NULL;        /* the ghosts no longer depend on the vector */
+}
+static int tc_on(void) {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MGPETSC_TAIL"); v = (e && *e) ? atoi(e) : 1; }
+    return v && lazy_on() == 1 && g_tc_off == 0;
+}
+static int tc_index(const tailcap *t, Vec v) { for (int i = 0; t && i < t->nv; i++) if (t->vec[i] == v) return i; return -1; }
+static int tc_recording_has(Vec v) { return g_tc_rec && tc_index(g_tc_rec, v) >= 0; }
+static void tc_unmark(Vec v) {                                      /* (lz_drop without the bookkeeping of a dropped ghost) */
+    if (v->lz != LZ_TAIL) return;
+    v->lz = LZ_NONE; v->lz_A = v->lz_A2 = NULL; v->lz_b = v->lz_x = NULL; v->lz_ksp = NULL;
+    for (int q = 0; q < g_nlz; q++) if (g_lz[q] == v) { g_lz[q] = g_lz[--g_nlz]; break; }
+}
+/* v becomes a vector the recording writes (every one of them fully, the first time) */
+static void tc_take(tailcap *t, Vec v) {
+    if (tc_index(t, v) >= 0) return;                                /* (r[l] and rv[l] are one vector in the reference) */
+    lz_before_write(v, 1);                                          /* its old value dies: dependents computed, an older deferred value / ghost dropped */
+    v->host_dirty = 0;
+    t->vec[t->nv] = v; t->vg[t->nv] = v->g; t->vn[t->nv] = v->n; t->alive[t->nv] = 1; t->nv++;
+    lz_register(v, LZ_TAIL, NULL, t->b[0], NULL);                   /* depends on the sub-cycle's right-hand side */
+}
+static void tc_log(tailcap *t, int op, KSP k, Mat A, Vec a, Vec b, Vec c) {
+    tc_op *o = &t->ops[t->nops++];
+    memset(o, 0, sizeof(*o));
+    o->op = op; o->k = k; o->A = A; o->a = a; o->b = b; o->c = c;
+    if (k) { o->guess = k->guess_nonzero; o->pc = ksp_pc(k); o->maxits = k->maxits; o->scale = k->scale; o->nt = k->normtype; }
+}
+/* one logged call through the ordinary paths, on (possibly substituted) vectors */
+static void tc_run(const tc_op *o, Vec a, Vec b, Vec c) {
+    switch (o->op) {
+    case TC_SOLVE: {
+        KSP k = o->k;
+        Mat A0 = k->A; const int g0 = k->guess_nonzero, t0 = k->type, p0 = k->pc; const PetscInt m0 = k->maxits, i0 = k->its; const double s0 = k->scale;
+        const KSPNormType n0 = k->normtype; Vec kb = k->b, kx = k->x;
+        k->A = o->A; k->guess_nonzero = o->guess; k->type = K_RICHARDSON; k->pc = o->pc; k->maxits = o->maxits; k->scale = o->scale; k->normtype = o->nt;
+        KSPSolve(k, a, b);
+        k->A = A0; k->guess_nonzero = g0; k->type = t0; k->pc = p0; k->maxits = m0; k->scale = s0; k->normtype = n0; k->its = i0;
+        if (a != o->a || b != o->b) { k->b = kb; k->x = kx; }           /* scratch vectors: the solver keeps naming the real ones */
+        break;
+    }
+    case TC_RESID: MatResidual(o->A, a, b, c); break;
+    case TC_RESTRICT: case TC_PROLONG: MatMult(o->A, a, b); break;
+    case TC_AXPY: VecAXPY(a, 1.0, b); break;
+    }
+}
+/* the recording is executed after all, call by call, on the real vectors */
+static void tc_flush(void) {
+    tailcap *t = g_tc_rec;
+    if (!t) return;
+    g_tc_rec = NULL;
+    g_lzstat[12]++;
+    for (int i = 0; i < t->nv; i++) tc_unmark(t->vec[i]);
+    g_tc_off++;
+    for (int q = 0; q < t->nops; q++) tc_run(&t->ops[q], t->ops[q].a, t->ops[q].b, t->ops[q].c);
+    g_tc_off--;
+    tc_free_log(t);
+}
+/* an intermediate of a finished sub-cycle is read after all: the log is replayed on scratch vectors (the real u[t], and any intermediate the
+ * caller has overwritten since, hold newer values) and the intermediates that are still unread ghosts receive their values */
+static void tc_materialise(void) {
+    tailcap *t = g_tc_done;
+    if (!t) return;
+    g_tc_done = NULL;
+    g_lzstat[13]++;
+    if (getenv("MGPETSC_TAIL_DEBUG")) {
+        fprintf(stderr, "[mgpetsc] tail log of %d levels from n = %d: intermediates computed after all; unread so far:", t->nlev, t->A[0]->gf.nx);
+        for (int i = 0; i < t->nv; i++) if (t->alive[i]) fprintf(stderr, " vec#%d(n=%d)", i, (int)t->vn[i]);
+        fprintf(stderr, "\n");
+    }
+    Vec tmp[4 * TC_MAXLEV], tb0 = NULL;
+    for (int i = 0; i < t->nv; i++) tmp[i] = vec_new(t->vn[i], &t->vg[i]);
+    if (t->b0_priv) {                                               /* the right-hand side as it was (b[0] itself has a newer value) */
+        tb0 = vec_new(t->b0_len, &t->b0_g);
+        DEV(mgk_d2d(G, tb0->dev, t->b0_priv, sizeof(double) * (size_t)t->b0_n, NULL));
+    }
+    g_tc_off++;
+#define TC_MAP(v) (tc_index(t, (v)) >= 0 ? tmp[tc_index(t, (v))] : ((v) == t->b[0] && tb0) ? tb0 : (v))
+    for (int q = 0; q < t->nops; q++) {
+        const tc_op *o = &t->ops[q];
+        tc_run(o, o->a ? TC_MAP(o->a) : NULL, o->b ? TC_MAP(o->b) : NULL, o->c ? TC_MAP(o->c) : NULL);
+    }
+#undef TC_MAP
+    for (int i = 0; i < t->nv; i++) {
+        if (t->alive[i]) {
+            Vec v = t->vec[i];
+            tc_unmark(v);
+            v->host_dirty = 0; v->ver++;
+            DEV(mgk_d2d(G, v->dev, vdev(tmp[i]), sizeof(double) * (size_t)v->nalloc, NULL));
+        }
+    }
+    for (int i = 0; i < t->nv; i++) VecDestroy(&tmp[i]);
+    if (tb0) VecDestroy(&tb0);
+    g_tc_off--;
+    tc_free_log(t);
+}
+static void tc_settle(Vec v) {
+    if (tc_recording_has(v)) tc_flush();
+    else if (g_tc_done && tc_index(g_tc_done, v) >= 0) tc_materialise();
+    else tc_unmark(v);                                              /* (cannot happen: a LZ_TAIL vector belongs to one of the two logs) */
+}
+static void tc_dropped(Vec v) {                                     /* a ghost overwritten unread; the log goes with the last of them */
+    tailcap *t = g_tc_done;
+    const int i = tc_index(t, v);
+    if (i < 0) return;
+    t->alive[i] = 0;
+    for (int q = 0; q < t->nv; q++) if (t->alive[q]) return;
+    g_tc_done = NULL;
+    tc_free_log(t);
+}
+static int tc_names_mat(const tailcap *t, Mat A) {
+    for (int l = 0; t && l < t->nlev; l++) if (t->A[l] == A || t->R[l] == A || t->P[l] == A) return 1;
+    return 0;
+}
+static void tc_mat_changing(struct _p_Mat *A) {
+    if (tc_names_mat(g_tc_rec, A)) tc_flush();
+    if (tc_names_mat(g_tc_done, A)) tc_materialise();
+}
+static void tc_ksp_dying(KSP k) {
+    for (int l = 0; g_tc_rec && l < g_tc_rec->nlev; l++) if (g_tc_rec->ksp[l] == k) { tc_flush(); break; }
+    for (int l = 0; g_tc_done && l < g_tc_done->nlev; l++) if (g_tc_done->ksp[l] == k) { tc_materialise(); break; }
+}
+static void tc_shutdown(void) {                                     /* PetscFinalize: nobody reads anything any more */
+    tailcap *both[2] = {g_tc_rec, g_tc_done};
+    g_tc_rec = g_tc_done = NULL;
+    for (int q = 0; q < 2; q++) if (both[q]) { for (int i = 0; i < both[q]->nv; i++) if (q == 0 || both[q]->alive[i]) tc_unmark(both[q]->vec[i]); tc_free_log(both[q]); }
+    if (g_tc_spare && G) mgk_free(G, g_tc_spare);
+    g_tc_spare = NULL; g_tc_spare_n = 0;
+}
+static int tc_level_ok(Mat A, Vec b, Vec x) {                       /* a level the tail kernel handles, on vectors in the padded layout */
+    return (A->kind == MAT_STENCIL || A->kind == MAT_STENCIL_ROW) && A->gf.dim == 2 && A->gf.nx == A->gf.ny && A->gf.nx <= mgk_tail_max_n(2) &&
+           b->padded == 1 && x->padded == 1 && geom_eq(&b->g, &A->gf) && geom_eq(&x->g, &A->gf) && b != x;
+}
+/* the last call of the pattern has arrived: ONE launch for the whole sub-cycle */
+static void tc_complete(tailcap *t) {
+    int n[TC_MAXLEV];
+    double coef7[7 * TC_MAXLEV], dinv[TC_MAXLEV];
+    const double *ctab[TC_MAXLEV], *dtab[TC_MAXLEV];
+    const int rows = t->A[0]->kind == MAT_STENCIL_ROW;
+    for (int l = 0; l < t->nlev; l++) {
+        Mat A = t->A[l];
+        n[l] = A->gf.nx;
+        if (rows) { mat_device_rowtabs(A); ctab[l] = A->d_ctab; dtab[l] = (t->pc[l] == P_JACOBI) ? A->d_dtab : A->d_ones; }
+        else {
+            for (int q = 0; q < 7; q++) coef7[7 * l + q] = q < 5 ? A->coef[q] : 0.0;
+            dinv[l] = (t->pc[l] == P_JACOBI) ? 1.0 / A->coef[2] : 1.0;
+        }
+    }
+    Vec b0 = t->b[0], u0 = t->u[0];
+    const int v0 = (int)t->its[0], v1 = (int)t->its[t->nlev - 1];
+    g_tc_rec = NULL;
+    tc_unmark(u0);                                                  /* written in full by the kernel below: concrete from here on */
+    t->alive[tc_index(t, u0)] = 0;
+    u0->host_dirty = 0; u0->ver++;
+    if (rows) DEV(mgk_tail_cycle_rowcoef_f64(G, &u0->g, t->nlev, n, ctab, dtab, t->scale, v0, v1, b0->dev, u0->dev, NULL));
+    else DEV(mgk_tail_cycle_f64(G, &u0->g, t->nlev, n, coef7, dinv, t->scale, v0, v1, b0->dev, u0->dev, NULL));
+    g_lzstat[11]++;
+    t->complete = 1;
+    if (g_tc_done) tc_materialise();                                /* (an older finished log whose ghosts this cycle did not overwrite: rare) */
+    int any = 0;
+    for (int i = 0; i < t->nv; i++) any |= t->alive[i];
+    if (any) g_tc_done = t; else tc_free_log(t);
+}
+/* KSPSolve asks here first (Richardson, KSP_NORM_NONE, max_it >= 1, operands checked): 1 = absorbed */
+static int tc_solve(KSP k, Vec b, Vec x) {
+    Mat A = k->A;
+    tailcap *t = g_tc_rec;
+    if (t) {
+        const int j = t->j;
+        if (t->step == TCS_AFTER_RESTRICT && !k->guess_nonzero && b == t->b[j + 1] && tc_index(t, x) < 0 && tc_level_ok(A, b, x) &&
+            A->kind == t->A[0]->kind && A->gf.nx == (t->A[j]->gf.nx - 1) / 2 && k->scale == t->scale && k->maxits >= 1 && j + 2 <= TC_MAXLEV) {
+            int fresh = 1;
+            for (int l = 0; l <= j; l++) if (t->ksp[l] == k) fresh = 0;
+            if (fresh) {
+                t->j = j + 1; t->nlev = j + 2;
+                t->ksp[j + 1] = k; t->A[j + 1] = A; t->u[j + 1] = x; t->its[j + 1] = k->maxits; t->pc[j + 1] = ksp_pc(k);
+                tc_take(t, x);
+                tc_log(t, TC_SOLVE, k, A, b, x, NULL);
+                t->step = TCS_AFTER_PRE;
+                k->b = b; k->x = x; k->its = k->maxits;
+                return 1;
+            }
+        }
+        if (t->step == TCS_AFTER_AXPY && k->guess_nonzero && k == t->ksp[j] && A == t->A[j] && b == t->b[j] && x == t->u[j] &&
+            k->maxits == t->its[0] && k->scale == t->scale && ksp_pc(k) == t->pc[j]) {
+            tc_log(t, TC_SOLVE, k, A, b, x, NULL);
+            k->b = b; k->x = x; k->its = k->maxits;
+            if (j == 0) tc_complete(t); else t->step = TCS_AFTER_POST;
+            return 1;
+        }
+        tc_flush();
+    }
+    /* a pre-smoothing solve from the zero guess on a level the tail kernel holds: a recording starts */
+    if (!tc_on() || k->guess_nonzero || k->maxits < 1 || !tc_level_ok(A, b, x) || A->gf.nx < 3) return 0;
+    (void)vdev(b);                                                   /* the sub-cycle's right-hand side: concrete, on the device */
+    if (x->lz == LZ_TAIL && tc_recording_has(x)) return 0;
+    t = (tailcap *)calloc(1, sizeof(*t));
+    t->nlev = 1; t->j = 0; t->step = TCS_AFTER_PRE;
+    t->ksp[0] = k; t->A[0] = A; t->b[0] = b; t->u[0] = x; t->its[0] = k->maxits; t->pc[0] = ksp_pc(k); t->scale = k->scale;
+    tc_take(t, x);
+    g_tc_rec = t;
+    tc_log(t, TC_SOLVE, k, A, b, x, NULL);
+    k->b = b; k->x = x; k->its = k->maxits;
+    return 1;
+}
+static int tc_resid(struct _p_Mat *A, Vec b, Vec x, Vec r) {
+    tailcap *t = g_tc_rec;
+    if (!t) return 0;
+    const int j = t->j;
+    if (t->step == TCS_AFTER_PRE && A == t->A[j] && b == t->b[j] && x == t->u[j] && r != b && r != x && r->padded == 1 && geom_eq(&r->g, &A->gf) &&
+        (tc_index(t, r) < 0) && j + 1 < TC_MAXLEV) {
+        t->r[j] = r;
+        tc_take(t, r);
+        tc_log(t, TC_RESID, NULL, A, b, x, r);
+        t->step = TCS_AFTER_RESID;
+        return 1;
+    }
+    tc_flush();
+    return 0;
+}
+static int tc_mult(struct _p_Mat *A, Vec x, Vec y) {
+    tailcap *t = g_tc_rec;
+    if (!t) return 0;
+    const int j = t->j;
+    if (A->kind == MAT_RESTRICT && t->step == TCS_AFTER_RESID && x == t->r[j] && geom_eq(&A->gf, &t->A[j]->gf) && A->gc.nx == (A->gf.nx - 1) / 2 &&
+        A->gc.nx >= 1 && y->padded == 1 && geom_eq(&y->g, &A->gc) && tc_index(t, y) < 0 && y != t->b[0]) {
+        t->R[j] = A; t->b[j + 1] = y;
+        tc_take(t, y);
+        tc_log(t, TC_RESTRICT, NULL, A, x, y, NULL);
+        t->step = TCS_AFTER_RESTRICT;
+        return 1;
+    }
+    if (A->kind == MAT_PROLONG && j >= 1 && (t->step == TCS_AFTER_PRE || t->step == TCS_AFTER_POST) && x == t->u[j] && geom_eq(&A->gc, &t->A[j]->gf) &&
+        geom_eq(&A->gf, &t->A[j - 1]->gf) && y->padded == 1 && geom_eq(&y->g, &A->gf) && y != t->u[j - 1] && y != t->b[j - 1]) {
+        int ok = 1;
+        if (t->step == TCS_AFTER_PRE) for (int l = 0; l < j; l++) if (t->its[l] != t->its[0]) ok = 0;       /* the turn: level j is the coarsest; v0 above it */
+        if (ok) {
+            t->P[j - 1] = A; t->rv[j - 1] = y;
+            tc_take(t, y);
+            tc_log(t, TC_PROLONG, NULL, A, x, y, NULL);
+            t->j = j - 1; t->step = TCS_AFTER_PROLONG;
+            return 1;
+        }
+    }
+    tc_flush();
+    return 0;
+}
+static int tc_axpy(Vec y, double a, Vec x) {
+    tailcap *t = g_tc_rec;
+    if (!t) return 0;
+    if (t->step == TCS_AFTER_PROLONG && a == 1.0 && y == t->u[t->j] && x == t->rv[t->j]) {
+        tc_log(t, TC_AXPY, NULL, NULL, y, x, NULL);
+        t->step = TCS_AFTER_AXPY;
+        return 1;
+    }
+    tc_flush();
+    return 0;
+}
+
 /* KSPSolve, KSP_NORM_NONE: exactly max_it iterations (src/solver.c:1531,1536,1542) */
 PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
     Mat A = k->A;
@@ -1572,6 +1922,7 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
     need_same(b, x, "KSPSolve");
     const int pc = ksp_pc(k);
     const PetscInt maxit = k->maxits;
+    if (k->type == K_RICHARDSON && (g_tc_rec || tc_on()) && tc_solve(k, b, x)) return 0;     /* recorded for the tail kernel (above) */
     k->b = b; k->x = x; k->its = 0;
     /* the first sweep was made by the pass that evaluated the last residual norm (norm_of_deferred_residual) and nothing has touched b or x since */
     const int spec = k->spec_ok && k->guess_nonzero && maxit >= k->spec_n && k->type == K_RICHARDSON && k->spec_b == b && k->spec_x == x &&
@@ -1824,6 +2175,7 @@ PetscErrorCode KSPView(KSP k, PetscViewer viewer) {               /* src/solver.
 }
 PetscErrorCode KSPDestroy(KSP *pk) {
     if (!pk || !*pk) return 0;
+    tc_ksp_dying(*pk);
     for (int q = 0; q < g_nlz; q++) if (g_lz[q]->lz_ksp == *pk) g_lz[q]->lz_ksp = NULL;      /* deferred residuals no longer name this solver */
     for (int q = 0; q < 3; q++) if ((*pk)->work[q]) VecDestroy(&(*pk)->work[q]);
     pcmg *mg = (*pk)->pcobj.mg;

@@ -311,6 +311,136 @@ def residual_left_deferred_by_the_norm_pass(L, orc):
     L.MatDestroy(C.byref(mA))
 
 
+def recorded_coarse_subcycle_keeps_petsc_semantics(L, orc):
+    """the drop-in RECORDS the reference's calls on the levels from 63^2 down and runs them as ONE tail launch when the pattern completes
+    (DESIGN.md 8b N2, round 3).  Here the pattern is completed, interrupted, broken and abused in ways the reference never does; after every
+    program each vector must hold what call-by-call execution gives (a numpy model runs the same program)."""
+    L.PetscInitialize(None, None, None, None)
+    L.PetscOptionsSetValue(None, b"-pc_type", b"jacobi")
+    L.PetscOptionsSetValue(None, b"-ksp_richardson_scale", b"0.8")
+    L.MatScale.argtypes = [C.c_void_p, C.c_double]
+    npts, nlev = 33, 3
+    A = [_dense(orc, "A", npts, l) for l in range(nlev)]
+    R = [_dense(orc, "R", npts, l) for l in range(nlev - 1)]
+    P = [_dense(orc, "P", npts, l) for l in range(nlev - 1)]
+    rng = np.random.default_rng(23)
+    b0v = rng.standard_normal(A[0].shape[0])
+
+    programs = {
+        "complete, then every intermediate read": ["cycle", "read_all"],
+        "complete, b0 overwritten, then the intermediates read": ["cycle", ("set", "b0", 1.5), "read_all"],
+        "complete, b0 scaled, then the intermediates read": ["cycle", ("scale", "b0", 2.0), "read_all"],
+        "two cycles, the second overwrites the first's intermediates unread": ["cycle", ("scale", "b0", 0.5), "cycle", "read_all"],
+        "b1 read in the middle of the descent": [("cycle", {"after_restrict0": [("read", "b1")]}), "read_all"],
+        "u0 scaled in the middle of the descent": [("cycle", {"after_restrict0": [("scale", "u0", 2.0)]}), "read_all"],
+        "u1 overwritten on the way up": [("cycle", {"after_prolong1": [("set", "u1", 0.25)]}), "read_all"],
+        "another scale on level 1": [("cycle", {"before_solve1": [("kscale", 1, 0.5)]}), "read_all"],
+        "two sweeps on level 0, three below": [("cycle", {"start": [("kits", 0, 2)]}), "read_all"],
+        "A1 scaled in the middle of the ascent": [("cycle", {"after_prolong1": [("matscale", 1, 1.25)]}), "read_all", ("matscale", 1, 0.8)],
+        "solver of level 1 destroyed after the cycle": ["cycle", ("kdestroy", 1), "read_all"],
+        "descent abandoned after the first restriction": [("cycle", {"after_restrict0": ["stop"]}), "read_all"],
+    }
+    for name, prog in programs.items():
+        mA, mR, mP = [_assemble(L, a) for a in A], [_assemble(L, r) for r in R], [_assemble(L, q) for q in P]
+        V, M = {}, {}                                        # PETSc vectors / the numpy model's values
+        for l in range(nlev):
+            for nm in ("u", "b", "rv"):
+                v = C.c_void_p()
+                L.MatCreateVecs(mA[l], C.byref(v), None)
+                V[nm + str(l)] = v
+                M[nm + str(l)] = np.zeros(A[l].shape[0])
+        _set(L, V["b0"], b0v); M["b0"] = b0v.copy()
+        K, par = [], []
+        for l in range(nlev):
+            k = C.c_void_p()
+            L.KSPCreate(1, C.byref(k))
+            L.KSPSetType(k, b"richardson"); L.KSPSetOperators(k, mA[l], mA[l]); L.KSPSetNormType(k, 0)
+            L.KSPSetTolerances(k, 1e-7, -2.0, -2.0, 3)
+            L.KSPSetFromOptions(k)
+            K.append(k); par.append({"its": 3, "scale": 0.8, "guess": 0, "A": A[l].copy(), "alive": True})
+
+        def solve(l):
+            x = M["u%d" % l] if par[l]["guess"] else np.zeros_like(M["u%d" % l])
+            d = 1.0 / np.diag(par[l]["A"])
+            for _ in range(par[l]["its"]):
+                x = x + par[l]["scale"] * (d * (M["b%d" % l] - par[l]["A"] @ x))
+            M["u%d" % l] = x
+            L.KSPSolve(K[l], V["b%d" % l], V["u%d" % l])
+
+        def extra(steps):
+            for st in steps or []:
+                if st == "stop":
+                    return True
+                if st[0] == "read":
+                    assert np.max(np.abs(_get(L, V[st[1]], M[st[1]].size) - M[st[1]])) <= tol(st[1]), (name, st)
+                elif st[0] == "scale":
+                    L.VecScale(V[st[1]], st[2]); M[st[1]] = st[2] * M[st[1]]
+                elif st[0] == "set":
+                    L.VecSet(V[st[1]], st[2]); M[st[1]] = np.full_like(M[st[1]], st[2])
+                elif st[0] == "kscale":
+                    L.KSPRichardsonSetScale(K[st[1]], st[2]); par[st[1]]["scale"] = st[2]
+                elif st[0] == "kits":
+                    L.KSPSetTolerances(K[st[1]], 1e-7, -2.0, -2.0, st[2]); par[st[1]]["its"] = st[2]
+                elif st[0] == "matscale":
+                    L.MatScale(mA[st[1]], st[2]); par[st[1]]["A"] = st[2] * par[st[1]]["A"]
+                elif st[0] == "kdestroy":
+                    L.KSPDestroy(C.byref(K[st[1]])); par[st[1]]["alive"] = False
+            return False
+
+        def tol(nm):
+            return 1e-11 * max(1.0, np.abs(M[nm]).max())
+
+        def cycle(hooks):
+            # the reference's loop on these levels (src/solver.c:1531-1544), every solver back to the zero guess first
+            for l in range(nlev):
+                L.KSPSetInitialGuessNonzero(K[l], 0); par[l]["guess"] = 0
+            if extra(hooks.get("start")):
+                return
+            solve(0)
+            L.KSPSetInitialGuessNonzero(K[0], 1); par[0]["guess"] = 1
+            for l in range(1, nlev):
+                Vp = C.c_void_p()
+                L.KSPBuildResidual(K[l - 1], None, V["rv%d" % (l - 1)], C.byref(Vp))
+                M["rv%d" % (l - 1)] = M["b%d" % (l - 1)] - par[l - 1]["A"] @ M["u%d" % (l - 1)]
+                L.MatMult(mR[l - 1], Vp, V["b%d" % l])
+                M["b%d" % l] = R[l - 1] @ M["rv%d" % (l - 1)]
+                if extra(hooks.get("after_restrict%d" % (l - 1))):
+                    return
+                if extra(hooks.get("before_solve%d" % l)):
+                    return
+                solve(l)
+                if l != nlev - 1:
+                    L.KSPSetInitialGuessNonzero(K[l], 1); par[l]["guess"] = 1
+            for l in range(nlev - 2, -1, -1):
+                L.MatMult(mP[l], V["u%d" % (l + 1)], V["rv%d" % l])
+                M["rv%d" % l] = P[l] @ M["u%d" % (l + 1)]
+                if extra(hooks.get("after_prolong%d" % l)):
+                    return
+                L.VecAXPY(V["u%d" % l], 1.0, V["rv%d" % l])
+                M["u%d" % l] = M["u%d" % l] + M["rv%d" % l]
+                solve(l)
+                if l != 0:
+                    L.KSPSetInitialGuessNonzero(K[l], 0); par[l]["guess"] = 0
+
+        for st in prog:
+            if st == "cycle":
+                cycle({})
+            elif st == "read_all":
+                for nm in sorted(M):
+                    assert np.max(np.abs(_get(L, V[nm], M[nm].size) - M[nm])) <= tol(nm), (name, nm)
+            elif st[0] == "cycle":
+                cycle(st[1])
+            else:
+                extra([st])
+        for l in range(nlev):
+            if par[l]["alive"]:
+                L.KSPDestroy(C.byref(K[l]))
+        for v in V.values():
+            L.VecDestroy(C.byref(v))
+        for m in mA + mR + mP:
+            L.MatDestroy(C.byref(m))
+
+
 def richardson_with_lu_is_damped_not_exact(L, orc):
     """-pc_type lu (the dense inverse of a small operator): preonly and richardson with scale 1 return A^-1 b whatever the guess;
     richardson with scale s != 1 makes max_it DAMPED steps x <- (1 - s) x + s A^-1 b, as PETSc would (it used to come
@@ -359,5 +489,5 @@ if __name__ == "__main__":      # python tests/shim_semantics.py <shared library
     from oracle import Oracle
     lib = type_shim(C.CDLL(sys.argv[1], mode=os.RTLD_LOCAL))
     {"lazy": lazy_temporaries_keep_petsc_semantics, "spec": speculative_sweep_is_adopted_only_when_nothing_changed,
-     "keepr": residual_left_deferred_by_the_norm_pass, "lu": richardson_with_lu_is_damped_not_exact}[sys.argv[2]](lib, Oracle())
+     "keepr": residual_left_deferred_by_the_norm_pass, "tailrec": recorded_coarse_subcycle_keeps_petsc_semantics, "lu": richardson_with_lu_is_damped_not_exact}[sys.argv[2]](lib, Oracle())
     print("SEMANTICS_OK", sys.argv[2])

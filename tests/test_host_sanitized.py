@@ -282,17 +282,28 @@ def test_lazy_temporaries_of_the_reference_loop(san, tmp_path, mesh, cycle):
     opts = (f"-npts {npts}\n-mesh {mesh}\n-iter 1000\n-grids {levels}\n-levels {levels}\n-cycle {cycle}\n-map 0\n-v 3,3\n-moreNorm 0\n"
             + (lv if cycle == 8 else "-pc_type jacobi\n-ksp_richardson_scale 0.8\n"))
     res = {}
-    for lazy in ("1", "0"):
+    # "1": the lazy temporaries alone (MGPETSC_TAIL=0: every level by its own launches), "0": every call executed at once,
+    # "tail": the default -- the levels from 31^2 down also recorded and run as ONE tail launch per cycle (round 3)
+    for lazy in ("1", "0", "tail"):
         d = tmp_path / lazy
         d.mkdir()
-        out = _refdrv(san, d, opts, {"MGPETSC_LAZY": lazy, "MGPETSC_LAZY_STATS": "1"})
+        out = _refdrv(san, d, opts, {"MGPETSC_LAZY": "1" if lazy == "tail" else lazy, "MGPETSC_TAIL": "1" if lazy == "tail" else "0", "MGPETSC_LAZY_STATS": "1"})
         it = int(re.search(r"Number of iterations:\s+(\d+)", out).group(1))
         m = re.search(r"lazy temporaries: (\d+) residual\+restriction passes, (\d+) prolongation sweeps fused; computed after all: (\d+) residuals, "
                       r"(\d+) prolongations, (\d+) corrections; (\d+) dropped unread; (\d+) zero-guess sweeps out of the restriction's pass; (\d+) norm passes that store r and make the next sweep, (\d+) of those sweeps adopted; "
                       r"(\d+) norm passes that left r deferred, (\d+) of those", out)
         assert m, out[-800:]
         st = [int(x) for x in m.groups()]
-        if lazy == "1":
+        tl = re.search(r"(\d+) coarse sub-cycles run as ONE tail launch, (\d+) recordings replayed call by call, (\d+) times their unread", out)
+        tl = [int(x) for x in tl.groups()]
+        if lazy == "tail":
+            if cycle == 0:
+                assert tl[0] == it and tl[1] == 0 and tl[2] <= 1, tl          # one launch per cycle, nothing replayed; the last cycle's unread intermediates
+                                                                              # are computed once, when the reference destroys the solvers before the vectors
+            else:
+                assert tl == [0, 0, 0], tl                                    # PCMG's own cycle is not the recorded pattern
+        elif lazy == "1":
+            assert tl == [0, 0, 0], tl
             assert st[0] == it * (levels - 1) and st[1] == it * (levels - 1), st      # every restriction and every first post-sweep fused
             assert st[3] == 0 and st[4] == 0, st                                      # rv never computed, no correction left over
             if cycle == 0:
@@ -306,6 +317,7 @@ def test_lazy_temporaries_of_the_reference_loop(san, tmp_path, mesh, cycle):
             assert st == [0] * 11
         res[lazy] = (it, (d / "rData.dat").read_text(), (d / "uData.dat").read_text())
     assert res["1"][0] == res["0"][0] and res["1"][2] == res["0"][2]                  # cycle count, solution file
+    assert res["tail"][0] == res["0"][0] and res["tail"][2] == res["0"][2] and res["tail"][1] == res["1"][1]
     r1, r0 = (np.array(res[q][1].split(), dtype=np.float64) for q in ("1", "0"))      # (the fused norm pass sums r^2 in another order)
     assert np.max(np.abs(r1 / r0 - 1)) <= 1e-12
     if cycle == 0:

@@ -588,6 +588,12 @@ def test_residual_left_deferred_by_the_norm_pass(orc):
     residual_left_deferred_by_the_norm_pass(type_shim(_shim()), orc)
 
 
+def test_recorded_coarse_subcycle_keeps_petsc_semantics(orc):
+    """the levels from 63^2 down are recorded and run as ONE tail launch; see tests/shim_semantics.py"""
+    from shim_semantics import recorded_coarse_subcycle_keeps_petsc_semantics, type_shim
+    recorded_coarse_subcycle_keeps_petsc_semantics(type_shim(_shim()), orc)
+
+
 def test_richardson_with_lu_is_damped_not_exact():
     """a process of its own (it changes -pc_type in the options database): see tests/shim_semantics.py"""
     import subprocess

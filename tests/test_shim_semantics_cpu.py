@@ -53,5 +53,9 @@ def test_residual_left_deferred_by_the_norm_pass_on_the_mock(mock_shim):
     _check(mock_shim, "keepr")
 
 
+def test_recorded_coarse_subcycle_keeps_petsc_semantics_on_the_mock(mock_shim):
+    _check(mock_shim, "tailrec")
+
+
 def test_richardson_with_lu_is_damped_on_the_mock(mock_shim):
     _check(mock_shim, "lu")

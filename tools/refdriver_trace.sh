@@ -4,5 +4,5 @@ printf -- "-npts 4097\n-mesh 0\n-iter 1000\n-grids 12\n-levels 12\n-cycle 0\n-ma
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/trr -- $GRAFT_REPO_ROOT/build/refdriver/poisson > out.txt 2>&1
 grep -E "Solver walltime|iterations" out.txt
-python3 $GRAFT_REPO_ROOT/tools/trace_cycle.py $(ls $GRAFT_REPO_ROOT/gpurun_out/trr/*/*_results.db) 6 60 > $GRAFT_REPO_ROOT/gpurun_out/trace_refdriver_4097.txt 2>&1
+python3 $GRAFT_REPO_ROOT/tools/trace_cycle.py $(ls $GRAFT_REPO_ROOT/gpurun_out/trr/*/*_results.db) 6 60 > $GRAFT_REPO_ROOT/gpurun_out/trace_refdriver_4097.txt 2>&1; python3 $GRAFT_REPO_ROOT/tools/trace_cycle_spans.py $(ls $GRAFT_REPO_ROOT/gpurun_out/trr/*/*_results.db) > $GRAFT_REPO_ROOT/gpurun_out/trace_refdriver_4097_spans.txt 2>&1
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/trr
