@@ -43,7 +43,9 @@ for n in [int(x) for x in sys.argv[1:]] or [4095, 2047, 1023, 511, 255, 127]:
         ("prolong + THREE", 25, lambda: L.mgk_prolong_jacobi3_2d_f64(m.ctx, G, GC, coef, dinv, 0.8, None, None, b, uc, u, o, None)),
         ("residual+restrict THREE", 18, lambda: L.mgk_residual_restrict_2d_f64(m.ctx, G, GC, coef, b, u, uc, None, 0.0, 0.0, None)),
     ]
-    for var, zc in ((-1, -1), (57, -1), (58, -1)):
+    # MG_J3_TUNE="var,zc;var,zc" replaces the list of (tuning variant, rows per chunk) pairs
+    tune = [tuple(int(t) for t in q.split(",")) for q in os.environ["MG_J3_TUNE"].split(";")] if os.environ.get("MG_J3_TUNE") else [(-1, -1), (57, -1), (58, -1)]
+    for var, zc in tune:
         L.mgk_set_tuning(var, zc)
         for name, byts, fn in rows:
             if (var, zc) != (-1, -1) and "THREE" not in name:
