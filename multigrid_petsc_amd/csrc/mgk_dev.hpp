@@ -27,6 +27,9 @@ struct mgk_ctx {
                            // (slab ranks: short blocks, so that the exchange kernels of the comm stream find CUs beside them)
 };
 static inline hipStream_t S(mgk_ctx *c, void *s) { return s ? (hipStream_t)s : c->compute; }
+// a double in the CONSTANT address space: data that is read-only for the life of a kernel (the row tables of the stretched meshes) read through
+// such a pointer at a wave-uniform address becomes a scalar load; through an ordinary pointer of the argument struct it stays a vector load
+typedef double __attribute__((address_space(4))) CDBL4;
 // per THREAD tuning knobs (mgk_set_tuning) and the fixed-order finish of per-block / per-wave partial sums (mgk_kernels.hip)
 extern thread_local int g_variant, g_zchunk;
 int finish_to_host(mgk_ctx *c, int nparts, int nslots, hipStream_t s, double *host_out);

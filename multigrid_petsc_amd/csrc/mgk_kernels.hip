@@ -4764,7 +4764,7 @@ struct PJ2dArgs {
 __global__ void __launch_bounds__(256) k_pj2d(const PJ2dArgs a) {
     using VT = V16<double>;
     const int lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));      // (row indices and row addresses on the scalar unit)
     const int tx = wid % a.ntx, cy = wid / a.ntx;
     const int y0 = cy * a.yc, y1 = min(y0 + a.yc, a.ny);
     if (y0 >= y1) return;                                     // whole wave
@@ -4814,7 +4814,7 @@ __global__ void __launch_bounds__(256) k_pj2d(const PJ2dArgs a) {
         const VT un = correct(ur, y + 2, cA, cB);
         const double Wv = lane_up<true>(ub.v[1]), Ev = lane_dn<true>(ub.v[0]);
         double k0 = a.a0, k2 = a.a2, k3 = a.a3, k4 = a.a4, k6 = a.a6, kd = a.dinv;
-        if (a.ctab) { const double *cr = a.ctab + 5 * (long)y; k0 = cr[0]; k2 = cr[1]; k3 = cr[2]; k4 = cr[3]; k6 = cr[4]; kd = a.dtab[y]; }
+        if (a.ctab) { const CDBL4 *cr = (const CDBL4 *)(a.ctab + 5 * (long)y); k0 = cr[0]; k2 = cr[1]; k3 = cr[2]; k4 = cr[3]; k6 = cr[4]; kd = ((const CDBL4 *)(a.dtab + y))[0]; }
         VT o;
 #pragma unroll
         for (int e = 0; e < 2; e++) {
@@ -5210,7 +5210,7 @@ __global__ void __launch_bounds__(256) k_rr2d(const RR2dArgs a) {
     constexpr int NP = PD + 3;
     using VT = V16<double>;
     const int lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));      // (row indices and row addresses on the scalar unit)
     const int tx = wid % a.ntx, cy = wid / a.ntx;
     const int ic0 = cy * a.ycc, ic1 = min(ic0 + a.ycc, a.nyc);
     if (ic0 >= ic1) return;                                   // whole wave
@@ -5249,7 +5249,7 @@ __global__ void __launch_bounds__(256) k_rr2d(const RR2dArgs a) {
                 const VT &c = U[cc];
                 const double Wv = lane_up<true>(c.v[1]), Ev = lane_dn<true>(c.v[0]);
                 double k0 = a.a0, k2 = a.a2, k3 = a.a3, k4 = a.a4, k6 = a.a6;
-                if (a.ctab) { const double *cr = a.ctab + 5 * (long)y; k0 = cr[0]; k2 = cr[1]; k3 = cr[2]; k4 = cr[3]; k6 = cr[4]; }
+                if (a.ctab) { const CDBL4 *cr = (const CDBL4 *)(a.ctab + 5 * (long)y); k0 = cr[0]; k2 = cr[1]; k3 = cr[2]; k4 = cr[3]; k6 = cr[4]; }
                 VT r;
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
@@ -5339,7 +5339,7 @@ struct SRR2dArgs {
 __global__ void __launch_bounds__(256) k_srr2d(const SRR2dArgs a) {
     using VT = V16<double>;
     const int lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));      // (row indices and row addresses on the scalar unit)
     const int tx = wid % a.ntx, cy = wid / a.ntx;
     const int ic0 = cy * a.ycc, ic1 = min(ic0 + a.ycc, a.nyc);
     if (ic0 >= ic1) return;                                   // whole wave
@@ -5378,7 +5378,7 @@ __global__ void __launch_bounds__(256) k_srr2d(const SRR2dArgs a) {
             const double Wv = lane_up<true>(ub.v[1]), Ev = lane_dn<true>(ub.v[0]);
             const bool pin = (p >= 0 && p < a.ny);
             double k0 = a.a0, k2 = a.a2, k3 = a.a3, k4 = a.a4, k6 = a.a6, kd = a.dinv;
-            if (a.ctab) { const int pr_ = min(max(p, 0), a.ny - 1); const double *cr = a.ctab + 5 * (long)pr_; k0 = cr[0]; k2 = cr[1]; k3 = cr[2]; k4 = cr[3]; k6 = cr[4]; kd = a.dtab[pr_]; }
+            if (a.ctab) { const int pr_ = min(max(p, 0), a.ny - 1); const CDBL4 *cr = (const CDBL4 *)(a.ctab + 5 * (long)pr_); k0 = cr[0]; k2 = cr[1]; k3 = cr[2]; k4 = cr[3]; k6 = cr[4]; kd = ((const CDBL4 *)(a.dtab + pr_))[0]; }
 #pragma unroll
             for (int e = 0; e < 2; e++) {
                 const double wv = (e == 0) ? Wv : ub.v[0];
@@ -5399,7 +5399,7 @@ __global__ void __launch_bounds__(256) k_srr2d(const SRR2dArgs a) {
         if (t >= y0) {
             const double Wv = lane_up<true>(wc.v[1]), Ev = lane_dn<true>(wc.v[0]);
             double k0 = a.a0, k2 = a.a2, k3 = a.a3, k4 = a.a4, k6 = a.a6;
-            if (a.ctab) { const double *cr = a.ctab + 5 * (long)t; k0 = cr[0]; k2 = cr[1]; k3 = cr[2]; k4 = cr[3]; k6 = cr[4]; }
+            if (a.ctab) { const CDBL4 *cr = (const CDBL4 *)(a.ctab + 5 * (long)t); k0 = cr[0]; k2 = cr[1]; k3 = cr[2]; k4 = cr[3]; k6 = cr[4]; }
             VT r;
 #pragma unroll
             for (int e = 0; e < 2; e++) {

@@ -46,7 +46,9 @@ __global__ void __launch_bounds__(256) k_jacobi3_2d(const J3dArgs a) {
     // neighbouring tiles share are re-read from the L2 they were first brought into (the grid is padded to a multiple of 8 blocks)
     int bid = blockIdx.x;
     if (a.xcd) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
-    const int wid = bid * 4 + (threadIdx.x >> 6);
+    // (readfirstlane: the wave number, and with it every row index and row address below, lives on the scalar unit -- the row tables of the
+    // stretched meshes are then read by scalar loads, not by 64 lanes loading one address)
+    const int wid = __builtin_amdgcn_readfirstlane(bid * 4 + (threadIdx.x >> 6));
     const int tx = wid % a.ntx, cy = wid / a.ntx;
     const int yc = YC > 0 ? YC : a.yc;
     const int y0 = cy * yc, y1 = min(y0 + yc, a.ny);
@@ -87,15 +89,30 @@ __global__ void __launch_bounds__(256) k_jacobi3_2d(const J3dArgs a) {
         }
         return fix(v, y);
     };
-    // coefficients of grid row y: the launch constants, or row y of the tables (stretched meshes; wave-uniform scalar loads)
-#define J3_COEFS(y)                                                                                                   \
-    double k0 = a.a0, k2 = a.a2, k3 = a.a3, k4 = a.a4, k6 = a.a6, kd = a.dinv;                                        \
-    if (TAB) { const int yy_ = min(max((y), 0), a.ny - 1); const double *cr_ = a.ctab + 5 * (long)yy_;                \
-                  k0 = cr_[0]; k2 = cr_[1]; k3 = cr_[2]; k4 = cr_[3]; k6 = cr_[4]; kd = a.dtab[yy_]; }
+    // coefficients of grid row y: the launch constants, or row y of the tables (stretched meshes).  The row index is wave-uniform (readfirstlane
+    // above), so these are scalar loads; a step requests the sets of its three stages at its top, before it waits for its vector loads.  (As
+    // first written -- loaded inside each stage, with a row index the compiler could not prove uniform -- they were 18 vector loads per step,
+    // each waited for where it was used: 4097^2 -mesh 1 138 / 130 us per pass against 85 / 89 us on the uniform mesh.)
+    struct K6 { double k0, k2, k3, k4, k6, kd; };
+    auto ldk = [&](int y) -> K6 {
+        K6 k = {a.a0, a.a2, a.a3, a.a4, a.a6, a.dinv};
+        if (TAB) {
+            // (the constant address space: the tables are read-only for the life of the kernel, which the compiler cannot see through the
+            // pointers of the argument struct -- without it, loads with a uniform address still go through the vector memory path)
+            const int yy_ = min(max(y, 0), a.ny - 1);
+            const CDBL4 *cr_ = (const CDBL4 *)(a.ctab + 5 * (long)yy_);
+            const CDBL4 *dr_ = (const CDBL4 *)(a.dtab + yy_);
+            k.k0 = cr_[0]; k.k2 = cr_[1]; k.k3 = cr_[2]; k.k4 = cr_[3]; k.k6 = cr_[4]; k.kd = dr_[0];
+        }
+        return k;
+    };
+#define J3_COEFS(kk)                                                                                                  \
+    const double k0 = TAB ? (kk).k0 : a.a0, k2 = TAB ? (kk).k2 : a.a2, k3 = TAB ? (kk).k3 : a.a3, k4 = TAB ? (kk).k4 : a.a4,    \
+                 k6 = TAB ? (kk).k6 : a.a6, kd = TAB ? (kk).kd : a.dinv;
     // one sweep of row y from the rows lo / c / hi of the previous iterate
     double nacc = 0.0;
-    auto sweep = [&](const VT &lo, const VT &c, const VT &hi, const VT &bb, int y, bool norm) -> VT {
-        J3_COEFS(y)
+    auto sweep = [&](const VT &lo, const VT &c, const VT &hi, const VT &bb, int y, bool norm, const K6 &kk) -> VT {
+        J3_COEFS(kk)
         const double Wv = lane_up<true>(c.v[1]), Ev = lane_dn<true>(c.v[0]);
         VT o, rr;
 #pragma unroll
@@ -116,8 +133,8 @@ __global__ void __launch_bounds__(256) k_jacobi3_2d(const J3dArgs a) {
         if (NORM && norm && a.rout && store && y >= y0 && y < y1) stv_stream(a.rout + (long)y * a.rs + x0, rr);
         return fix(o, y);
     };
-    auto sweep0 = [&](const VT &bb, int y) -> VT {            // first sweep from the zero guess (k_jacobi_zero)
-        J3_COEFS(y)
+    auto sweep0 = [&](const VT &bb, int y, const K6 &kk) -> VT {            // first sweep from the zero guess (k_jacobi_zero)
+        J3_COEFS(kk)
         (void)k0; (void)k2; (void)k3; (void)k4; (void)k6;
         VT o;
 #pragma unroll
@@ -137,17 +154,18 @@ __global__ void __launch_bounds__(256) k_jacobi3_2d(const J3dArgs a) {
     auto stepg = [&](auto revc, int t, const VT &ur, double cA, double cB, const VT &bnext) {
         constexpr bool REV = decltype(revc)::value;
         auto ph = [&](int tt) -> int { return REV ? (y0 + y1 - 1 - tt) : tt; };
+        const K6 kc2 = ldk(ph(t + 2)), kc1 = ldk(ph(t + 1)), kc0 = ldk(ph(t));
         VT p2;
-        if (ZG) p2 = sweep0(b2, ph(t + 2));
+        if (ZG) p2 = sweep0(b2, ph(t + 2), kc2);
         else {
             const VT uc = correct(ur, ph(t + 3), cA, cB);
-            p2 = REV ? sweep(uc, ub, ua, b2, ph(t + 2), true) : sweep(ua, ub, uc, b2, ph(t + 2), true);
+            p2 = REV ? sweep(uc, ub, ua, b2, ph(t + 2), true, kc2) : sweep(ua, ub, uc, b2, ph(t + 2), true, kc2);
             ua = ub; ub = uc;
         }
         if (t >= y0 - 2) {                                    // wave-uniform
-            const VT q2 = REV ? sweep(p2, p1, p0, b1, ph(t + 1), false) : sweep(p0, p1, p2, b1, ph(t + 1), false);
+            const VT q2 = REV ? sweep(p2, p1, p0, b1, ph(t + 1), false, kc1) : sweep(p0, p1, p2, b1, ph(t + 1), false, kc1);
             if (t >= y0 && t < y1) {
-                const VT o = REV ? sweep(q2, q1, q0, b0, ph(t), false) : sweep(q0, q1, q2, b0, ph(t), false);
+                const VT o = REV ? sweep(q2, q1, q0, b0, ph(t), false, kc0) : sweep(q0, q1, q2, b0, ph(t), false, kc0);
                 if (store) stv_stream(op_ + (long)ph(t) * a.rs, o);
             }
             q0 = q1; q1 = q2;

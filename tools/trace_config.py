@@ -9,7 +9,7 @@ dim, npts, prec = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3] if len(sys.arg
 levels = 0
 while (npts - 1) % (2 ** levels) == 0 and (npts - 1) // (2 ** levels) - 1 >= 1:
     levels += 1
-s = Solver(dim, npts, levels, scale=6.0 / 7.0 if dim == 3 else 0.8, maxiter=100, precision=prec, pair_min_n=int(os.environ.get("MG_PAIR_MIN_N", "0")))
+s = Solver(dim, npts, levels, scale=6.0 / 7.0 if dim == 3 else 0.8, maxiter=100, precision=prec, pair_min_n=int(os.environ.get("MG_PAIR_MIN_N", "0")), mesh=int(os.environ.get("MG_MESH", "0")))
 if os.environ.get("MG_TUNE"):          # "variant,zchunk": a tuning experiment over every launch of the cycle (mgk_set_tuning)
     from multigrid_petsc_amd.mgk import load_mgk as load
     v, z = (int(t) for t in os.environ["MG_TUNE"].split(","))
