@@ -1840,8 +1840,8 @@ static int tc_solve(KSP k, Vec b, Vec x) {
     /* a pre-smoothing solve from the zero guess on a level the tail kernel holds: a recording starts */
     if (!tc_on() || k->guess_nonzero || k->maxits < 1 || !tc_level_ok(A, b, x) || A->gf.nx < 3) return 0;
     (void)vdev(b);                                                   /* the sub-cycle's right-hand side: concrete, on the device */
-    if (x->lz == LZ_TAIL && tc_recording_has(x)) return 0;
     t = (tailcap *)calloc(1, sizeof(*t));
+    if (!t) return 0;
     t->nlev = 1; t->j = 0; t->step = TCS_AFTER_PRE;
     t->ksp[0] = k; t->A[0] = A; t->b[0] = b; t->u[0] = x; t->its[0] = k->maxits; t->pc[0] = ksp_pc(k); t->scale = k->scale;
     tc_take(t, x);
