@@ -142,25 +142,32 @@ __global__ void __launch_bounds__(256) k_jacobi3_2d(const J3dArgs a) {
         return fix(o, y);
     };
     // one marching step: first sweep of row t+2 (from the corrected u rows ua, ub and the raw row ur = row t+3 with its parents), second
-    // sweep of row t+1, third sweep of row t
-    VT ua = Z, ub = Z;
-    VT b2 = Z, b1 = Z, b0 = Z;                                // b of the rows t+2, t+1, t
-    VT p0 = Z, p1 = Z;                                        // first sweep: rows t, t+1
-    VT q0 = Z, q1 = Z;                                        // second sweep: rows t-1, t
+    // sweep of row t+1, third sweep of row t.  The rows a step hands to the next one live in rings of two (u, first sweep, second sweep) and
+    // three (b) registers whose ROLES rotate with the phase K = step mod 6 instead of their contents being copied: the marching loop is
+    // unrolled by six by hand (the compiler declines), every index below is a constant after inlining (round 3: 54 of the 171 vector
+    // instructions of a step were register copies; the 2-D passes are bound by instruction issue, not by HBM)
+    VT UU[2] = {Z, Z};                                        // phase K: ua = UU[K & 1] (row t+1), ub = UU[(K + 1) & 1] (row t+2)
+    VT BB[3] = {Z, Z, Z};                                     // b0 = BB[K % 3] (row t), b1 = BB[(K + 1) % 3], b2 = BB[(K + 2) % 3]
+    VT PP[2] = {Z, Z};                                        // first sweep: p0 = PP[K & 1] (row t), p1 = PP[(K + 1) & 1]
+    VT QQ[2] = {Z, Z};                                        // second sweep: q0 = QQ[K & 1] (row t-1), q1 = QQ[(K + 1) & 1]
     // REV: the chunk is marched DOWNWARDS (logical step t works on the physical row y0 + y1 - 1 - t): neighbouring chunks then touch the rows
     // they share at the same time (a forward chunk ends where the reversed chunk above it ends, and starts where the one below starts), so
     // that the second reader finds them in L2.  The physical row above (coefficient a0) is then the logically NEXT row: the sweeps take
     // their rows in swapped order, the per-point expression is the same
-    auto stepg = [&](auto revc, int t, const VT &ur, double cA, double cB, const VT &bnext) {
+    auto stepg = [&](auto revc, const int K, int t, const VT &ur, double cA, double cB, const VT &bnext) {
         constexpr bool REV = decltype(revc)::value;
         auto ph = [&](int tt) -> int { return REV ? (y0 + y1 - 1 - tt) : tt; };
         const K6 kc2 = ldk(ph(t + 2)), kc1 = ldk(ph(t + 1)), kc0 = ldk(ph(t));
+        VT &ua = UU[K & 1], &ub = UU[(K + 1) & 1];
+        VT &p0 = PP[K & 1], &p1 = PP[(K + 1) & 1];
+        VT &q0 = QQ[K & 1], &q1 = QQ[(K + 1) & 1];
+        VT &b0 = BB[K % 3], &b1 = BB[(K + 1) % 3], &b2 = BB[(K + 2) % 3];
         VT p2;
         if (ZG) p2 = sweep0(b2, ph(t + 2), kc2);
         else {
             const VT uc = correct(ur, ph(t + 3), cA, cB);
             p2 = REV ? sweep(uc, ub, ua, b2, ph(t + 2), true, kc2) : sweep(ua, ub, uc, b2, ph(t + 2), true, kc2);
-            ua = ub; ub = uc;
+            ua = uc;                                          // (the next phase's ub)
         }
         if (t >= y0 - 2) {                                    // wave-uniform
             const VT q2 = REV ? sweep(p2, p1, p0, b1, ph(t + 1), false, kc1) : sweep(p0, p1, p2, b1, ph(t + 1), false, kc1);
@@ -168,12 +175,11 @@ __global__ void __launch_bounds__(256) k_jacobi3_2d(const J3dArgs a) {
                 const VT o = REV ? sweep(q2, q1, q0, b0, ph(t), false, kc0) : sweep(q0, q1, q2, b0, ph(t), false, kc0);
                 if (store) stv_stream(op_ + (long)ph(t) * a.rs, o);
             }
-            q0 = q1; q1 = q2;
+            q0 = q2;                                          // (the next phase's q1; before the first second sweep both are zero)
         }
-        p0 = p1; p1 = p2;
-        b0 = b1; b1 = b2; b2 = fix(bnext, ph(t + 3));
+        p0 = p2;
+        b0 = fix(bnext, ph(t + 3));                           // (the next phase's b2)
     };
-    auto step = [&](int t, const VT &ur, double cA, double cB, const VT &bnext) { stepg(std::false_type{}, t, ur, cA, cB, bnext); };
     const int t0 = y0 - 4;
     if constexpr (YC > 0) {
         // rows t0+1 .. t0+YC+6 of u, t0+2 .. t0+YC+6 of b, and the coarse rows that are their parents: requested together
@@ -188,41 +194,43 @@ __global__ void __launch_bounds__(256) k_jacobi3_2d(const J3dArgs a) {
         // t0 = cy * YC - 4 is even, so the parents of row t0 + k are the coarse rows c0 + (k - 1) / 2 (k odd) or c0 + k / 2 - 1 and
         // c0 + k / 2 (k even) with c0 = t0 / 2: every index below is a compile-time constant once the loop is unrolled
         if (!ZG) {
-            ua = correct(U[0], t0 + 1, Cc[0], Cc[0]);
-            ub = correct(U[1], t0 + 2, Cc[0], Cc[1]);
+            UU[0] = correct(U[0], t0 + 1, Cc[0], Cc[0]);
+            UU[1] = correct(U[1], t0 + 2, Cc[0], Cc[1]);
         }
-        b2 = fix(B[1], t0 + 2);
+        BB[2] = fix(B[1], t0 + 2);
 #pragma unroll
         for (int sidx = 0; sidx < YC + 4; sidx++) {
-            constexpr int dummy = 0; (void)dummy;
             const int k = sidx + 3;                           // the raw row of this step is row t0 + k
             const int ia = (k & 1) ? (k - 1) / 2 : k / 2 - 1;
             const int ib = (k & 1) ? (k - 1) / 2 : k / 2;
-            step(t0 + sidx, ZG ? Z : U[sidx + 2], Cc[ia], Cc[ib], B[sidx + 2]);
+            stepg(std::false_type{}, sidx % 6, t0 + sidx, ZG ? Z : U[sidx + 2], Cc[ia], Cc[ib], B[sidx + 2]);
         }
     } else {
         auto march = [&](auto revc) {
             constexpr bool REV = decltype(revc)::value;
             auto ph = [&](int tt) -> int { return REV ? (y0 + y1 - 1 - tt) : tt; };
-            VT ur = Z;
-            double cA = 0.0, cB = 0.0;
+            VT UR[2] = {Z, Z}, BN[2];                         // the loads a step consumes are requested a step ahead: two sets, roles by phase
+            double CA[2] = {0.0, 0.0}, CB[2] = {0.0, 0.0};
             if (!ZG) {
-                ua = correct(ldraw(ph(t0 + 1)), ph(t0 + 1), ldc(pA(ph(t0 + 1))), ldc(pB(ph(t0 + 1))));
-                ub = correct(ldraw(ph(t0 + 2)), ph(t0 + 2), ldc(pA(ph(t0 + 2))), ldc(pB(ph(t0 + 2))));
-                ur = ldraw(ph(t0 + 3));
-                cA = ldc(pA(ph(t0 + 3))); cB = ldc(pB(ph(t0 + 3)));
+                UU[0] = correct(ldraw(ph(t0 + 1)), ph(t0 + 1), ldc(pA(ph(t0 + 1))), ldc(pB(ph(t0 + 1))));
+                UU[1] = correct(ldraw(ph(t0 + 2)), ph(t0 + 2), ldc(pA(ph(t0 + 2))), ldc(pB(ph(t0 + 2))));
+                UR[0] = ldraw(ph(t0 + 3));
+                CA[0] = ldc(pA(ph(t0 + 3))); CB[0] = ldc(pB(ph(t0 + 3)));
             }
-            b2 = fix(ldbraw(ph(t0 + 2)), ph(t0 + 2));
-            VT bn = ldbraw(ph(t0 + 3));
-            for (int t = t0; t < y1; t++) {
-                // loads consumed in the next step
-                VT ur2 = Z;
-                double cA2 = 0.0, cB2 = 0.0;
-                if (!ZG) { ur2 = ldraw(ph(t + 4)); cA2 = ldc(pA(ph(t + 4))); cB2 = ldc(pB(ph(t + 4))); }
-                const VT bn2 = ldbraw(ph(t + 4));
-                stepg(revc, t, ur, cA, cB, bn);
-                ur = ur2; cA = cA2; cB = cB2; bn = bn2;
-            }
+            BB[2] = fix(ldbraw(ph(t0 + 2)), ph(t0 + 2));
+            BN[0] = ldbraw(ph(t0 + 3));
+            auto S = [&](const int K, int t) {
+                if (!ZG) { UR[(K + 1) & 1] = ldraw(ph(t + 4)); CA[(K + 1) & 1] = ldc(pA(ph(t + 4))); CB[(K + 1) & 1] = ldc(pB(ph(t + 4))); }
+                BN[(K + 1) & 1] = ldbraw(ph(t + 4));
+                stepg(revc, K, t, UR[K & 1], CA[K & 1], CB[K & 1], BN[K & 1]);
+            };
+            int t = t0;
+            for (; t + 6 <= y1; t += 6) { S(0, t); S(1, t + 1); S(2, t + 2); S(3, t + 3); S(4, t + 4); S(5, t + 5); }
+            if (t < y1) { S(0, t); t++; }
+            if (t < y1) { S(1, t); t++; }
+            if (t < y1) { S(2, t); t++; }
+            if (t < y1) { S(3, t); t++; }
+            if (t < y1) { S(4, t); t++; }
         };
         if (a.bous && ((cy & 1) || a.bous == 2)) march(std::true_type{}); else march(std::false_type{});
     }
