@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Why does a 4095^2 pass take longer inside the cycle than alone?  One sequence per process, rocprofv3 --kernel-trace around it:
    exp_incycle_2d.py alone|fine|cycle zero|rand
- alone: the three-sweep + norm pass 30 times;  fine: the three fine-level passes of a cycle in turn;  cycle: the same with the 2047^2 passes
+ alone: the three-sweep + norm pass 30 times;  alt: the same on two sets of fields in turn (nothing of a set survives in the 256 MB Infinity Cache);  fine: the three fine-level passes of a cycle in turn;  cycle: the same with the 2047^2 passes
  and 12 small launches in between (the shape of the real cycle)."""
 import ctypes as C
 import os
@@ -31,6 +31,8 @@ def level(n):
 
 
 lv = [level(n) for n in (4095, 2047, 1023, 511)]
+if mode == "alt":                       # a second set of fine-level fields: the two sets alternate, 800 MB in turn (beyond the Infinity Cache)
+    lv.append(level(4095))
 ss = C.c_double()
 
 
@@ -60,6 +62,8 @@ def pj(k):
 for it in range(30):
     if mode == "alone":
         j3n(0)
+    elif mode == "alt":
+        j3n(0); j3n(4)
     elif mode == "fine":
         j3n(0); rr(0); pj(0)
     else:
