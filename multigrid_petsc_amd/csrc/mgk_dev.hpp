@@ -129,6 +129,14 @@ __device__ __forceinline__ V16<float> ldv_stream(const float *p, bool ok) {
     return r;
 }
 __device__ __forceinline__ void stv_stream(double *p, const V16<double> &v) { st2_stream(p, make_double2(v.v[0], v.v[1])); }
+// The store of a 2-D pass: non-temporal only when the field is larger than the 256 MB Infinity Cache.  Measured at 4095^2 (134 MB per field,
+// tools/exp_incycle_2d.py): a pass that READS what its predecessor wrote with non-temporal stores takes 83-85 us, with ordinary stores 73 us
+// (launched alone, reading fields nobody wrote: 70 / 71 us) -- and in a multigrid cycle every pass reads what the previous one wrote.  The
+// 3-D kernels keep their non-temporal stores: at 511^3 and 1023^3 they are worth 5-9 %, at 255^3 (133 MB) the two policies measured the same.
+__device__ __forceinline__ bool mgk_store_nt_2d(int ny, long rs) { return (long)ny * rs * 8 > (256L << 20); }
+__device__ __forceinline__ void stv_policy(double *p, const V16<double> &v, bool nt) {
+    if (nt) stv_stream(p, v); else *reinterpret_cast<V16<double> *>(p) = v;
+}
 __device__ __forceinline__ void stv_stream(float *p, const V16<float> &v) {
 #if MGK_NT & 2
     f4v t; t.x = v.v[0]; t.y = v.v[1]; t.z = v.v[2]; t.w = v.v[3];
@@ -192,5 +200,5 @@ template <typename T> __device__ __forceinline__ V16<T> bufld_nt(__amdgpu_buffer
     return __builtin_bit_cast(V16<T>, v);
 }
 template <typename T> __device__ __forceinline__ void bufst_nt(const V16<T> &x, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mgk_u4v, x), r, voff, soff, 2);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mgk_u4v, x), r, voff, soff, (MGK_NT & 2) ? 2 : 0);
 }

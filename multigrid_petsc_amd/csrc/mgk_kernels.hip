@@ -2967,7 +2967,7 @@ __global__ void __launch_bounds__(64 * WX) k_jacobi2_2d(const J2dArgs a) {
                 o.v[e] = wc.v[e] + a.scale * zz;
                 if (lastvec && x0 + e >= a.nx) o.v[e] = 0.0;
             }
-            if (outl) stv_stream(a.out + (long)t * a.rs + x0, o);
+            if (outl) stv_policy(a.out + (long)t * a.rs + x0, o, mgk_store_nt_2d(a.ny, a.rs));
         }
         // wave edges for the next step: u(row p+1) = uc, u'(row p) = wp
         if (lane == 0) { eUW[(p + 1) & 1][w] = uc.v[0]; ePW[p & 1][w] = wp.v[0]; }
@@ -4830,7 +4830,7 @@ __global__ void __launch_bounds__(256) k_pj2d(const PJ2dArgs a) {
             o.v[e] = ub.v[e] + a.scale * zz;
         }
         if (lastvec) o.v[1] = 0.0;
-        if (store) stv_stream(a.out + (long)y * a.rs + x0, o);
+        if (store) stv_policy(a.out + (long)y * a.rs + x0, o, mgk_store_nt_2d(a.ny, a.rs));
         ua = ub; ub = uc; uc = un; ur = ur2; cA = cA2; cB = cB2; b0 = bn;
     }
 }
@@ -5393,7 +5393,7 @@ __global__ void __launch_bounds__(256) k_srr2d(const SRR2dArgs a) {
                 wp.v[e] = ub.v[e] + a.scale * zz;
                 if (!pin || !xin || (lastvec && e == 1)) wp.v[e] = 0.0;
             }
-            if (store && p >= y0 && p < ys1) stv_stream(a.out + (long)p * a.rs + x0, wp);
+            if (store && p >= y0 && p < ys1) stv_policy(a.out + (long)p * a.rs + x0, wp, mgk_store_nt_2d(a.ny, a.rs));
         }
         // ---- residual of the swept row t, full weighting ----
         if (t >= y0) {

@@ -28,7 +28,7 @@ struct J3dArgs {
     double *out;
     int nx, ny, nxc, nyc;
     long rs, crs;
-    int ntx, yc, nwaves, xcd, bous;
+    int ntx, yc, nwaves, xcd, bous, plainst;
     double a0, a2, a3, a4, a6, dinv, scale;
     const double *ctab, *dtab;
     double *partials;               // NORM: one partial of || b - A u ||^2 per wave
@@ -64,6 +64,7 @@ __global__ void __launch_bounds__(256) k_jacobi3_2d(const J3dArgs a) {
     const double *__restrict__ cp_ = PRO ? a.uc + min(max(pidx, -1), a.nxc) : nullptr;
     double *__restrict__ op_ = a.out + x0;
     const VT Z = v16_zero<double>();
+    const bool nts = a.plainst == 2 || (a.plainst == 0 && mgk_store_nt_2d(a.ny, a.rs));       // non-temporal stores: big fields only (mgk_dev.hpp)
     // a row of a field as it counts for a sweep: zero outside the grid (rows -1 / ny and everything beyond, columns < 0 and >= nx)
     auto fix = [&](VT v, int y) -> VT {
         if (!xin || y < 0 || y >= a.ny) { v.v[0] = 0.0; v.v[1] = 0.0; }
@@ -130,7 +131,7 @@ __global__ void __launch_bounds__(256) k_jacobi3_2d(const J3dArgs a) {
             rr.v[e] = (lastvec && e == 1) ? 0.0 : res;
             if (NORM && norm) nacc += (store && y >= y0 && y < y1 && !(lastvec && e == 1)) ? res * res : 0.0;     // the points this wave owns
         }
-        if (NORM && norm && a.rout && store && y >= y0 && y < y1) stv_stream(a.rout + (long)y * a.rs + x0, rr);
+        if (NORM && norm && a.rout && store && y >= y0 && y < y1) stv_policy(a.rout + (long)y * a.rs + x0, rr, nts);
         return fix(o, y);
     };
     auto sweep0 = [&](const VT &bb, int y, const K6 &kk) -> VT {            // first sweep from the zero guess (k_jacobi_zero)
@@ -173,7 +174,7 @@ __global__ void __launch_bounds__(256) k_jacobi3_2d(const J3dArgs a) {
             const VT q2 = REV ? sweep(p2, p1, p0, b1, ph(t + 1), false, kc1) : sweep(p0, p1, p2, b1, ph(t + 1), false, kc1);
             if (t >= y0 && t < y1) {
                 const VT o = REV ? sweep(q2, q1, q0, b0, ph(t), false, kc0) : sweep(q0, q1, q2, b0, ph(t), false, kc0);
-                if (store) stv_stream(op_ + (long)ph(t) * a.rs, o);
+                if (store) stv_policy(op_ + (long)ph(t) * a.rs, o, nts);
             }
             q0 = q2;                                          // (the next phase's q1; before the first second sweep both are zero)
         }
@@ -287,6 +288,7 @@ static int jacobi3_2d(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gc, const d
     // odd chunks marched downwards (tuning variant 58 only: bit-identical, but at 4095^2 it measured 67-68 us against 64 us with every chunk
     // marching upwards -- the shared rows are served by the Infinity Cache either way)
     a.bous = (ycs == 0 && g_variant == 58) ? 1 : (ycs == 0 && g_variant == 59) ? 2 : 0;      // 59: EVERY chunk downwards
+    a.plainst = (g_variant == 60) ? 1 : (g_variant == 61) ? 2 : 0;      // tuning: 60 forces ordinary stores, 61 non-temporal ones; default by field size
     if (NORM) {
         if (!norm_parts || 4L * nblk > c->max_partials) return fail(MGK_EINVAL, "mgk_jacobi3_2d_sumsq_f64: more waves than partial slots");
         a.partials = c->partials;

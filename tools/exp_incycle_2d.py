@@ -64,6 +64,35 @@ for it in range(30):
         j3n(0)
     elif mode == "alt":
         j3n(0); j3n(4)
+    elif mode == "chain":               # every launch reads the field its predecessor wrote (u -> o, o -> u)
+        g, (u, b, o), coef, dinv = lv[0]
+        m._chk(L.mgk_jacobi3_2d_sumsq_f64(m.ctx, C.byref(g), coef, dinv, 0.8, None, None, b, u, o, C.byref(ss), None))
+        m._chk(L.mgk_jacobi3_2d_sumsq_f64(m.ctx, C.byref(g), coef, dinv, 0.8, None, None, b, o, u, C.byref(ss), None))
+    elif mode == "chain_plain":         # the same without the norm (no host round trip between the launches)
+        g, (u, b, o), coef, dinv = lv[0]
+        m._chk(L.mgk_jacobi3_2d_f64(m.ctx, C.byref(g), coef, dinv, 0.8, None, None, b, u, o, None))
+        m._chk(L.mgk_jacobi3_2d_f64(m.ctx, C.byref(g), coef, dinv, 0.8, None, None, b, o, u, None))
+    elif mode == "chain_st":            # chain_plain with ordinary (not non-temporal) stores: tuning variant 60
+        g, (u, b, o), coef, dinv = lv[0]
+        L.mgk_set_tuning(60, -1)
+        m._chk(L.mgk_jacobi3_2d_f64(m.ctx, C.byref(g), coef, dinv, 0.8, None, None, b, u, o, None))
+        m._chk(L.mgk_jacobi3_2d_f64(m.ctx, C.byref(g), coef, dinv, 0.8, None, None, b, o, u, None))
+        L.mgk_set_tuning(-1, -1)
+    elif mode == "alone_st":
+        g, (u, b, o), coef, dinv = lv[0]
+        L.mgk_set_tuning(60, -1)
+        m._chk(L.mgk_jacobi3_2d_f64(m.ctx, C.byref(g), coef, dinv, 0.8, None, None, b, u, o, None))
+        L.mgk_set_tuning(-1, -1)
+    elif mode == "rot3":                # three fields in rotation: each launch reads what its predecessor wrote and writes the field read two launches ago
+        g, (u, b, o), coef, dinv = lv[0]
+        if it == 0:
+            lv.append(level(4095))
+        x = lv[4][1][0]
+        f = [u, o, x]
+        m._chk(L.mgk_jacobi3_2d_f64(m.ctx, C.byref(g), coef, dinv, 0.8, None, None, b, f[it % 3], f[(it + 1) % 3], None))
+    elif mode == "alone_plain":
+        g, (u, b, o), coef, dinv = lv[0]
+        m._chk(L.mgk_jacobi3_2d_f64(m.ctx, C.byref(g), coef, dinv, 0.8, None, None, b, u, o, None))
     elif mode == "fine":
         j3n(0); rr(0); pj(0)
     else:
