@@ -271,6 +271,27 @@ def test_reference_driver_pcmg_exact_coarse_solve_under_sanitizers(san, tmp_path
     assert "type: lu" in out
 
 
+@pytest.mark.parametrize("npts,levels,v0,v1,mesh", [
+    (33, 4, 1, 1, 0), (33, 4, 2, 2, 0), (33, 4, 4, 4, 0), (33, 4, 3, 1, 0), (33, 4, 1, 3, 0), (33, 4, 5, 2, 0), (33, 3, 3, 3, 0), (33, 2, 3, 3, 0), (33, 1, 3, 3, 0),
+    (65, 5, 2, 4, 0), (65, 3, 4, 3, 0), (129, 6, 3, 3, 0), (129, 7, 4, 1, 0), (17, 3, 3, 3, 1), (33, 4, 2, 2, 2), (65, 5, 4, 4, 1), (65, 4, 3, 5, 2),
+])
+def test_reference_driver_sweep_counts_and_depths(san, tmp_path, npts, levels, v0, v1, mesh):
+    """the reference's -v v0,v1 and -levels in combinations it is not usually run with: the drop-in's fast paths have preconditions on the sweep
+    counts (three sweeps per pass from max_it >= 3, the norm pass without a stored r at max_it = 3, the tail recorder with one v0 above the
+    coarsest level) -- whichever of them apply, the iteration count and the solution are the oracle's"""
+    opts = (f"-npts {npts}\n-mesh {mesh}\n-iter 400\n-grids {levels}\n-levels {levels}\n-cycle 0\n-map 2\n-v {v0},{v1}\n-moreNorm 0\n"
+            "-pc_type jacobi\n-ksp_richardson_scale 0.8\n")
+    out = _refdrv(san, tmp_path, opts, {"MGPETSC_LAZY_STATS": "1"})
+    it = int(re.search(r"Number of iterations:\s+(\d+)", out).group(1))
+    ref = Oracle().vcycle(2, npts, levels, v0, v1, maxiter=400, scale=0.8, use_csr=1 if mesh else 0, mesh=mesh)
+    assert it == ref["iters"], (it, ref["iters"])
+    u = np.array((tmp_path / "uData.dat").read_text().split(), dtype=np.float64)
+    assert np.array_equal(u, ref["u"])
+    tl = re.search(r"(\d+) coarse sub-cycles run as ONE tail launch, (\d+) recordings replayed", out)
+    if levels >= 3 and (npts - 1) // 2 - 1 <= 63 and v0 >= 1:
+        assert int(tl.group(1)) >= it - 1, out[-600:]           # the recorder did take the coarse levels (every cycle, or every cycle but the first)
+
+
 @pytest.mark.parametrize("mesh,cycle", [(0, 0), (1, 0), (0, 8)])
 def test_lazy_temporaries_of_the_reference_loop(san, tmp_path, mesh, cycle):
     """KSPBuildResidual -> MatMult(res) and MatMult(pro) -> VecAXPY -> KSPSolve of the reference's loop (src/solver.c:1531-1546) run as the

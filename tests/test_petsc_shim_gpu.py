@@ -221,6 +221,21 @@ def test_unmodified_reference_driver_on_the_gpu(orc, tmp_path, npts, levels, sca
 
 
 @pytest.mark.skipif(not os.path.exists(REFDRV), reason="build/refdriver/poisson absent")
+@pytest.mark.parametrize("npts,levels,v0,v1,mesh", [
+    (33, 4, 1, 1, 0), (65, 5, 2, 4, 0), (129, 7, 4, 1, 0), (257, 8, 4, 4, 0), (513, 9, 5, 2, 0), (257, 5, 3, 3, 0), (129, 6, 2, 2, 2), (257, 8, 4, 3, 1),
+])
+def test_reference_driver_sweep_counts_and_depths_on_the_gpu(orc, tmp_path, npts, levels, v0, v1, mesh):
+    """-v and -levels in combinations the reference is not usually run with (the drop-in's fast paths have preconditions on the sweep counts;
+    the CPU tier runs a larger set of these over the mock): iteration count and solution are the oracle's"""
+    opts = (f"-npts {npts}\n-mesh {mesh}\n-iter 400\n-grids {levels}\n-levels {levels}\n-cycle 0\n-map 2\n-v {v0},{v1}\n-moreNorm 0\n"
+            "-pc_type jacobi\n-ksp_richardson_scale 0.8\n")
+    it, rdat, u, e, out = _run_reference_driver(tmp_path, opts)
+    ref = orc.vcycle(2, npts, levels, v0, v1, maxiter=400, scale=0.8, use_csr=1 if mesh else 0, mesh=mesh)
+    assert it == ref["iters"]
+    assert np.array_equal(u, ref["u"])
+
+
+@pytest.mark.skipif(not os.path.exists(REFDRV), reason="build/refdriver/poisson absent")
 def test_reference_driver_default_options_file(orc, tmp_path):
     """the reference's default run (poisson.in: npts 17, 2 grids, 2 levels, V(3,3), no -pc_type): PETSc would use ILU(0);
     the drop-in says so on stderr and smooths with Jacobi, scale 1 -> 99 cycles."""
