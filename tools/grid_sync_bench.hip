@@ -1,5 +1,5 @@
 // cost of a grid-wide barrier on MI355X (cooperative launch, cooperative_groups grid sync): N syncs inside one kernel, timed with events.
-// build: hipcc --offload-arch=gfx950 -O3 -o tools/grid_sync_bench tools/exp_src/grid_sync_bench.hip     run: tools/grid_sync_bench [blocks] [threads]
+// build: hipcc --offload-arch=gfx950 -O3 -o tools/grid_sync_bench tools/grid_sync_bench.hip     run: tools/grid_sync_bench [blocks] [threads]
 #include <hip/hip_runtime.h>
 #include <hip/hip_cooperative_groups.h>
 #include <cstdio>
