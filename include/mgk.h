@@ -256,6 +256,11 @@ int  mgk_tail_cycle_f64(mgk_ctx *ctx, const mgk_geom *g0, int nlev, const int *n
                         double scale, int v0, int v1, const double *b, double *u, void *stream);
 int  mgk_tail_cycle_f32(mgk_ctx *ctx, const mgk_geom *g0, int nlev, const int *n, const double *coef7, const double *dinv,
                         double scale, int v0, int v1, const float *b, float *u, void *stream);
+/* ... with its own damping factor on the COARSEST level (2-D fp64; either coef7 + dinv or the row tables ctab + dtab, the other pair NULL):
+ * PCMG's exact coarse solve on a 1 x 1 grid is one undamped Jacobi sweep from the zero guess (v1 = 1, coarse_scale = 1) */
+int  mgk_tail_cycle_cs_f64(mgk_ctx *ctx, const mgk_geom *g0, int nlev, const int *n, const double *coef7, const double *dinv,
+                           const double *const *ctab, const double *const *dtab, double scale, double coarse_scale, int v0, int v1,
+                           const double *b, double *u, void *stream);
 int  mgk_tail_max_n(int dim);
 /* profiling aid: the tail kernels this thread launches deposit (s_memrealtime [100 MHz], s_memtime [shader clock]) pairs at each of their
  * barriers into dev[0 .. 255] and the number of pairs into dev[256] (257 long longs of DEVICE memory; NULL switches it off) */

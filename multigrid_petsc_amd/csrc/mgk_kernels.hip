@@ -4955,7 +4955,7 @@ struct TailArgs {
     int n[MGK_TAIL_MAXLEV];
     int off[MGK_TAIL_MAXLEV];              // offset (elements) of the level's three arrays in LDS: A0, A1 (u ping-pong), B; each (n+2)^dim
     T coef[MGK_TAIL_MAXLEV][7], dinv[MGK_TAIL_MAXLEV];
-    T scale;
+    T scale, cscale;                       // the Richardson damping factor; cscale: on the COARSEST level (PCMG's exact solve of a 1 x 1 system is one undamped sweep)
     const T *b_in;
     T *u_out;                              // both at the interior origin of the first tail level's padded field
     long rs, ms;                           // its row / plane strides
@@ -5101,10 +5101,11 @@ __global__ void __launch_bounds__(1024) k_tail(const TailArgs<T> a) {
     auto smooth0 = [&](int l, int sweeps) {
         cur[l] = 0;
         if (sweeps < 1) return;                   // KSPSolve zero-fills: A0 is still all zeros
-        tail_stencil<T, DIM>(2, a.n[l], a.coef[l], a.dinv[l], a.scale, A(l, 0), Bv(l), A(l, 0), a.ctab[l], a.dtab[l]);
+        const T sc = (l == a.nlev - 1) ? a.cscale : a.scale;
+        tail_stencil<T, DIM>(2, a.n[l], a.coef[l], a.dinv[l], sc, A(l, 0), Bv(l), A(l, 0), a.ctab[l], a.dtab[l]);
         __syncthreads(); stamp();
         for (int it = 1; it < sweeps; it++) {
-            tail_stencil<T, DIM>(0, a.n[l], a.coef[l], a.dinv[l], a.scale, A(l, cur[l]), Bv(l), A(l, cur[l] ^ 1), a.ctab[l], a.dtab[l]);
+            tail_stencil<T, DIM>(0, a.n[l], a.coef[l], a.dinv[l], sc, A(l, cur[l]), Bv(l), A(l, cur[l] ^ 1), a.ctab[l], a.dtab[l]);
             __syncthreads(); stamp();
             cur[l] ^= 1;
         }
@@ -5145,14 +5146,14 @@ static thread_local long long *g_tail_stamps = nullptr;
 extern "C" void mgk_debug_tail_stamps(long long *dev) { g_tail_stamps = dev; }
 template <typename T>
 static int tail_cycle(mgk_ctx *c, const mgk_geom *g0, int nlev, const int *n, const double *coef7, const double *dinv, double scale,
-                      int v0, int v1, const T *b, T *u, void *stream, const T *const *ctab = nullptr, const T *const *dtab = nullptr) {
+                      int v0, int v1, const T *b, T *u, void *stream, const T *const *ctab = nullptr, const T *const *dtab = nullptr, const double *cscale = nullptr) {
     if (!c || !g0 || !n || (!coef7 && !ctab) || (!dinv && !dtab) || !b || !u || nlev < 1 || nlev > MGK_TAIL_MAXLEV || v0 < 0 || v1 < 0 ||
         (ctab && (!dtab || g0->dim != 2)))
         return fail(MGK_EINVAL, "mgk_tail_cycle: bad arguments");
     if (n[0] != g0->nx || g0->ny != g0->nx || (g0->dim == 3 && g0->nz != g0->nx))
         return fail(MGK_EINVAL, "mgk_tail_cycle: the first tail level must be a whole cube / square of n[0] unknowns per side");
     TailArgs<T> a; memset(&a, 0, sizeof(a));
-    a.dim = g0->dim; a.nlev = nlev; a.v0 = v0; a.v1 = v1; a.scale = (T)scale;
+    a.dim = g0->dim; a.nlev = nlev; a.v0 = v0; a.v1 = v1; a.scale = (T)scale; a.cscale = (T)(cscale ? *cscale : scale);
     long off = 0;
     for (int l = 0; l < nlev; l++) {
         if (n[l] < 1 || (l > 0 && n[l - 1] != 2 * n[l] + 1)) return fail(MGK_EINVAL, "mgk_tail_cycle: need n[l-1] = 2 n[l] + 1");
@@ -5185,6 +5186,14 @@ extern "C" int mgk_tail_cycle_rowcoef_f64(mgk_ctx *c, const mgk_geom *g0, int nl
                                           double scale, int v0, int v1, const double *b, double *u, void *stream) {
     if (!ctab || !dtab) return fail(MGK_EINVAL, "mgk_tail_cycle_rowcoef_f64: null tables");
     return tail_cycle<double>(c, g0, nlev, n, nullptr, nullptr, scale, v0, v1, b, u, stream, ctab, dtab);
+}
+// ... with another damping factor on the COARSEST level (2-D, fp64; constant coefficients or row tables: pass either coef7 + dinv or ctab + dtab):
+// PCMG's default coarse solver is exact, and on a 1 x 1 grid the exact solve IS one undamped Jacobi sweep from the zero guess (v1 = 1, coarse_scale = 1)
+extern "C" int mgk_tail_cycle_cs_f64(mgk_ctx *c, const mgk_geom *g0, int nlev, const int *n, const double *coef7, const double *dinv,
+                                     const double *const *ctab, const double *const *dtab, double scale, double coarse_scale, int v0, int v1,
+                                     const double *b, double *u, void *stream) {
+    if ((ctab == nullptr) != (dtab == nullptr)) return fail(MGK_EINVAL, "mgk_tail_cycle_cs_f64: ctab and dtab go together");
+    return tail_cycle<double>(c, g0, nlev, n, ctab ? nullptr : coef7, ctab ? nullptr : dinv, scale, v0, v1, b, u, stream, ctab, dtab, &coarse_scale);
 }
 extern "C" int mgk_tail_max_n(int dim) { return dim == 3 ? 15 : 63; }
 

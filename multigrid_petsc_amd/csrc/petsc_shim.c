@@ -1405,9 +1405,11 @@ static void mg_setup(KSP k) {
         if (i > 0) mg_vec(&mg->r[i], &mg->own_r[i], s->A, 1);
     }
 }
+static int mg_tail_try(pcmg *mg, int i, Vec b, Vec x);     /* levels 0 .. i as ONE tail launch (below, with the recorder) */
 static void mg_cycle(pcmg *mg, int i, Vec b, Vec x) {       /* PCMGMCycle_Private, one cycle per level */
     KSP s = mg->smooth[i];
     if (i == 0) { KSPSolve(s, b, x); return; }            /* coarse solve (zero initial guess) */
+    if (mg_tail_try(mg, i, b, x)) return;
     {   /* pre-smoothing: x is the zero vector on entry (the caller's x_i = 0), so the solve runs with the zero-guess flag -- the same
          * values (0 + s*((b - 0)*dinv) is the zero-guess sweep bit for bit) without the zero fill and without reading x, and the first
          * sweep can come out of the restriction's pass */
@@ -1603,9 +1605,9 @@ static int j3_on(void) {
  * by call through the ordinary paths (tc_flush); an intermediate of a finished sub-cycle that is read after all is computed by replaying
  * the log on scratch vectors (tc_materialise: the real ones may hold newer values by then).  MGPETSC_TAIL=0 switches the recorder off. */
 #define TC_MAXLEV 8
-enum { TC_SOLVE = 1, TC_RESID, TC_RESTRICT, TC_PROLONG, TC_AXPY };
+enum { TC_SOLVE = 1, TC_RESID, TC_RESTRICT, TC_PROLONG, TC_AXPY, TC_MULTADD };
 enum { TCS_AFTER_PRE = 1, TCS_AFTER_RESID, TCS_AFTER_RESTRICT, TCS_AFTER_PROLONG, TCS_AFTER_AXPY, TCS_AFTER_POST };
-typedef struct { int op; KSP k; Mat A; Vec a, b, c; int guess, pc; PetscInt maxits; double scale; KSPNormType nt; } tc_op;
+typedef struct { int op; KSP k; Mat A; Vec a, b, c; int guess, pc, type; PetscInt maxits; double scale; KSPNormType nt; } tc_op;
 typedef struct {
     int complete;                                   /* 0: recording; 1: the tail kernel has run, the intermediates are unread ghosts */
     int nops; tc_op ops[6 * TC_MAXLEV + 2];
@@ -1671,7 +1673,7 @@ static void tc_log(tailcap *t, int op, KSP k, Mat A, Vec a, Vec b, Vec c) {
     tc_op *o = &t->ops[t->nops++];
     memset(o, 0, sizeof(*o));
     o->op = op; o->k = k; o->A = A; o->a = a; o->b = b; o->c = c;
-    if (k) { o->guess = k->guess_nonzero; o->pc = ksp_pc(k); o->maxits = k->maxits; o->scale = k->scale; o->nt = k->normtype; }
+    if (k) { o->guess = k->guess_nonzero; o->pc = (k->pc == P_LU) ? P_LU : ksp_pc(k); o->type = k->type; o->maxits = k->maxits; o->scale = k->scale; o->nt = k->normtype; }
 }
 /* one logged call through the ordinary paths, on (possibly substituted) vectors */
 static void tc_run(const tc_op *o, Vec a, Vec b, Vec c) {
@@ -1680,7 +1682,7 @@ static void tc_run(const tc_op *o, Vec a, Vec b, Vec c) {
         KSP k = o->k;
         Mat A0 = k->A; const int g0 = k->guess_nonzero, t0 = k->type, p0 = k->pc; const PetscInt m0 = k->maxits, i0 = k->its; const double s0 = k->scale;
         const KSPNormType n0 = k->normtype; Vec kb = k->b, kx = k->x;
-        k->A = o->A; k->guess_nonzero = o->guess; k->type = K_RICHARDSON; k->pc = o->pc; k->maxits = o->maxits; k->scale = o->scale; k->normtype = o->nt;
+        k->A = o->A; k->guess_nonzero = o->guess; k->type = o->type; k->pc = o->pc; k->maxits = o->maxits; k->scale = o->scale; k->normtype = o->nt;
         KSPSolve(k, a, b);
         k->A = A0; k->guess_nonzero = g0; k->type = t0; k->pc = p0; k->maxits = m0; k->scale = s0; k->normtype = n0; k->its = i0;
         if (a != o->a || b != o->b) { k->b = kb; k->x = kx; }           /* scratch vectors: the solver keeps naming the real ones */
@@ -1689,6 +1691,7 @@ static void tc_run(const tc_op *o, Vec a, Vec b, Vec c) {
     case TC_RESID: MatResidual(o->A, a, b, c); break;
     case TC_RESTRICT: case TC_PROLONG: MatMult(o->A, a, b); break;
     case TC_AXPY: VecAXPY(a, 1.0, b); break;
+    case TC_MULTADD: MatMultAdd(o->A, a, b, b); break;           /* MatInterpolateAdd of PCMG's own cycle */
     }
 }
 /* the recording is executed after all, call by call, on the real vectors */
@@ -1902,6 +1905,100 @@ static int tc_axpy(Vec y, double a, Vec x) {
     }
     tc_flush();
     return 0;
+}
+
+/* PCMG's own cycle (-cycle 8) on the levels 0 .. i, x = cycle(b) from x = 0, as ONE tail launch: every level a 2-D stencil operator of
+ * n <= 63 with the canonical transfer operators; Richardson + Jacobi / none with one damping factor and one max_it on the levels above the
+ * coarsest; the coarsest solved by Richardson too, by one undamped step (preonly), or exactly -- PETSc's default, LU -- on a 1 x 1 grid, where the
+ * exact solve IS one undamped Jacobi sweep from the zero guess.  The level vectors below i (the reference hands PCMG its own through
+ * PCMGSetRhs / PCMGSetX, src/solver.c:1949-1954) are not computed: they become LZ_TAIL ghosts of a finished log that holds the calls of
+ * mg_cycle, computed on scratch vectors if anybody reads them (tc_materialise), dropped when the next cycle overwrites them. */
+static int mg_tail_try(pcmg *mg, int i, Vec b, Vec x) {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("MGPETSC_TAIL"); on = (e && *e) ? atoi(e) : 1; }
+    if (!on || lazy_on() != 1 || i < 1 || i + 1 > TC_MAXLEV) return 0;
+    KSP top = mg->smooth[i];
+    if (!top->A || (top->A->kind != MAT_STENCIL && top->A->kind != MAT_STENCIL_ROW)) return 0;
+    const int rows = top->A->kind == MAT_STENCIL_ROW;
+    const double scale = top->scale;
+    const PetscInt v0 = top->maxits;
+    int n[TC_MAXLEV], v1 = 1;
+    double coef7[7 * TC_MAXLEV], dinv[TC_MAXLEV], cscale = scale;
+    const double *ctab[TC_MAXLEV], *dtab[TC_MAXLEV];
+    if (b->padded != 1 || x->padded != 1 || b == x || !geom_eq(&b->g, &top->A->gf) || !geom_eq(&x->g, &top->A->gf)) return 0;
+    for (int l = i; l >= 0; l--) {
+        KSP s = mg->smooth[l];
+        Mat A = s->A;
+        const int t = i - l;                                         /* the tail counts from the finest level */
+        if (!A || !A->assembled || A->kind != top->A->kind || A->gf.dim != 2 || A->gf.nx != A->gf.ny || A->gf.nx > mgk_tail_max_n(2)) return 0;
+        if (t > 0 && A->gf.nx != (n[t - 1] - 1) / 2) return 0;
+        n[t] = A->gf.nx;
+        if (s->normtype == KSP_NORM_UNPRECONDITIONED || s->pc == P_MG || s->pc == P_DEFAULT) return 0;
+        int jac = (s->pc == P_JACOBI);
+        if (l > 0) {
+            Mat R = mg->restr[l], P = mg->interp[l];
+            Mat Ac = mg->smooth[l - 1]->A;
+            if (s->type != K_RICHARDSON || s->scale != scale || s->maxits != v0 || v0 < 1 || (s->pc != P_JACOBI && s->pc != P_NONE)) return 0;
+            if (!R || !P || !Ac || R->kind != MAT_RESTRICT || P->kind != MAT_PROLONG || !geom_eq(&R->gf, &A->gf) || !geom_eq(&P->gf, &A->gf) ||
+                !geom_eq(&R->gc, &Ac->gf) || !geom_eq(&P->gc, &Ac->gf)) return 0;
+            if (l < i && (!mg->x[l] || !mg->b[l] || mg->x[l]->padded != 1 || mg->b[l]->padded != 1 || !geom_eq(&mg->x[l]->g, &A->gf) ||
+                          !geom_eq(&mg->b[l]->g, &A->gf) || mg->x[l] == mg->b[l])) return 0;
+        } else {
+            if (!mg->x[0] || !mg->b[0] || mg->x[0]->padded != 1 || mg->b[0]->padded != 1 || !geom_eq(&mg->x[0]->g, &A->gf) || !geom_eq(&mg->b[0]->g, &A->gf) ||
+                mg->x[0] == mg->b[0]) return 0;
+            if (s->pc == P_LU) {                                     /* exact: only where it is one undamped sweep */
+                if (A->gf.nx != 1 || !(s->type == K_PREONLY || (s->type == K_RICHARDSON && s->scale == 1.0 && s->maxits >= 1))) return 0;
+                v1 = 1; cscale = 1.0; jac = 1;
+            } else if (s->type == K_PREONLY && (s->pc == P_JACOBI || s->pc == P_NONE)) { v1 = 1; cscale = 1.0; }
+            else if (s->type == K_RICHARDSON && (s->pc == P_JACOBI || s->pc == P_NONE) && s->maxits >= 1) { v1 = (int)s->maxits; cscale = s->scale; }
+            else return 0;
+        }
+        if (rows) { mat_device_rowtabs(A); ctab[t] = A->d_ctab; dtab[t] = jac ? A->d_dtab : A->d_ones; }
+        else { for (int q = 0; q < 7; q++) coef7[7 * t + q] = q < 5 ? A->coef[q] : 0.0; dinv[t] = jac ? 1.0 / A->coef[2] : 1.0; }
+    }
+    /* the log of what mg_cycle would have called (replayed only if a ghost is read) */
+    tailcap *t = (tailcap *)calloc(1, sizeof(*t));
+    if (!t) return 0;
+    (void)vdev(b);
+    if (g_tc_done) {                                                 /* the previous cycle's ghosts are overwritten now: its log dies with them */
+        for (int l = 0; l < i; l++) { lz_before_write(mg->x[l], 1); lz_before_write(mg->b[l], 1); }
+        if (g_tc_done) tc_materialise();                             /* (another finished log: rare) */
+    }
+    t->complete = 1; t->nlev = i + 1; t->b[0] = b; t->u[0] = x; t->scale = scale;
+    for (int l = i; l >= 0; l--) { t->ksp[i - l] = mg->smooth[l]; t->A[i - l] = mg->smooth[l]->A; if (l > 0) { t->R[i - l] = mg->restr[l]; t->P[i - l] = mg->interp[l]; } }
+    lz_before_write(x, 1);
+    x->host_dirty = 0; x->ver++;
+#define MG_LOG_SOLVE(l_, rhs_, sol_, guess_) do { tc_log(t, TC_SOLVE, mg->smooth[l_], mg->smooth[l_]->A, (rhs_), (sol_), NULL); t->ops[t->nops - 1].guess = (guess_); } while (0)
+    for (int l = i; l >= 1; l--) {                                   /* mg_cycle, level by level */
+        Vec bl = (l == i) ? b : mg->b[l], xl = (l == i) ? x : mg->x[l];
+        MG_LOG_SOLVE(l, bl, xl, 0);
+        tc_log(t, TC_RESID, NULL, mg->smooth[l]->A, bl, xl, mg->r[l]);
+        tc_log(t, TC_RESTRICT, NULL, mg->restr[l], mg->r[l], mg->b[l - 1], NULL);
+    }
+    MG_LOG_SOLVE(0, mg->b[0], mg->x[0], mg->smooth[0]->guess_nonzero);
+    for (int l = 1; l <= i; l++) {
+        Vec bl = (l == i) ? b : mg->b[l], xl = (l == i) ? x : mg->x[l];
+        tc_log(t, TC_MULTADD, NULL, mg->interp[l], mg->x[l - 1], xl, NULL);
+        MG_LOG_SOLVE(l, bl, xl, mg->smooth[l]->guess_nonzero);
+    }
+#undef MG_LOG_SOLVE
+    /* the vectors the log writes: x (concrete after the launch), r[l] (PCMG's residual work vectors: contents unspecified after a cycle,
+     * as in mg_cycle), and the ghosts x[l], b[l] below level i */
+    t->vec[t->nv] = x; t->vg[t->nv] = x->g; t->vn[t->nv] = x->n; t->alive[t->nv] = 0; t->nv++;
+    for (int l = i; l >= 1; l--) if (mg->r[l] && tc_index(t, mg->r[l]) < 0) {
+        Vec r = mg->r[l];
+        lz_before_write(r, 1);
+        t->vec[t->nv] = r; t->vg[t->nv] = r->g; t->vn[t->nv] = r->n; t->alive[t->nv] = 0; t->nv++;
+    }
+    for (int l = i - 1; l >= 0; l--) { tc_take(t, mg->b[l]); tc_take(t, mg->x[l]); }
+    if (rows) DEV(mgk_tail_cycle_cs_f64(G, &x->g, i + 1, n, NULL, NULL, ctab, dtab, scale, cscale, (int)v0, v1, b->dev, x->dev, NULL));
+    else DEV(mgk_tail_cycle_cs_f64(G, &x->g, i + 1, n, coef7, dinv, NULL, NULL, scale, cscale, (int)v0, v1, b->dev, x->dev, NULL));
+    g_lzstat[11]++;
+    for (int l = 0; l <= i; l++) { mg->smooth[l]->its = (l == 0) ? v1 : v0; }
+    mg->smooth[i]->b = b; mg->smooth[i]->x = x;
+    for (int l = 0; l < i; l++) { mg->smooth[l]->b = mg->b[l]; mg->smooth[l]->x = mg->x[l]; }
+    g_tc_done = t;
+    return 1;
 }
 
 /* KSPSolve, KSP_NORM_NONE: exactly max_it iterations (src/solver.c:1531,1536,1542) */

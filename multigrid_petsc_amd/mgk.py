@@ -133,6 +133,7 @@ def _sigs(L):
         "mgk_residual_f64_to_f32_jz": (i, [vp, G, G, c_dp, vp, vp, vp, vp, d, d, C.POINTER(d), vp]),
         "mgk_correct_residual_f64_f32_jz": (i, [vp, G, G, c_dp, vp, vp, vp, vp, vp, vp, d, d, C.POINTER(d), vp]),
         "mgk_tail_cycle_f64": (i, [vp, G, i, C.POINTER(i), c_dp, c_dp, d, i, i, vp, vp, vp]),
+        "mgk_tail_cycle_cs_f64": (i, [vp, G, i, C.POINTER(i), c_dp, c_dp, C.POINTER(vp), C.POINTER(vp), d, d, i, i, vp, vp, vp]),
         "mgk_tail_cycle_f32": (i, [vp, G, i, C.POINTER(i), c_dp, c_dp, d, i, i, vp, vp, vp]),
         "mgk_tail_max_n": (i, [i]),
         "mgk_debug_tail_stamps": (None, [vp]),

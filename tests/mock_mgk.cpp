@@ -468,8 +468,9 @@ int mgk_residual_restrict_2d_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom 
     });
 }
 }   // extern "C"
-template <class T> static int tail_api(mgk_ctx *c, const mgk_geom *g0, int nlev, const int *n, const double *coef7, const double *dinv, double scale, int v0, int v1, const T *b, T *u,
-                                       const double *const *ctab = nullptr, const double *const *dtab = nullptr) {
+template <class T> static int tail_api(mgk_ctx *c, const mgk_geom *g0, int nlev, const int *n, const double *coef7, const double *dinv, double scale_, int v0, int v1, const T *b, T *u,
+                                       const double *const *ctab = nullptr, const double *const *dtab = nullptr, const double *cscale_ = nullptr) {
+    const double cscale = cscale_ ? *cscale_ : scale_;
     if (!c || !g0 || !n || (!coef7 && !ctab) || (!dinv && !dtab) || !b || !u || nlev < 1 || nlev > 8 || n[0] != g0->nx || n[0] > mgk_tail_max_n(g0->dim)) return fail(MGK_EINVAL, "mgk_tail_cycle");
     if (ctab && (!dtab || g0->dim != 2 || sizeof(T) != 8)) return fail(MGK_EINVAL, "mgk_tail_cycle: tables are 2-D fp64");
     for (int l = 1; l < nlev; l++) if (n[l - 1] != 2 * n[l] + 1) return fail(MGK_EINVAL, "mgk_tail_cycle: hierarchy");
@@ -488,6 +489,7 @@ template <class T> static int tail_api(mgk_ctx *c, const mgk_geom *g0, int nlev,
         }
         memcpy(B[0].data(), b, sizeof(T) * (size_t)G0.total);
         auto smooth = [&](int l, int sweeps, bool zero) {
+            const double scale = (l == nlev - 1) ? cscale : scale_;        // (mgk_tail_cycle_cs_f64: another damping factor on the coarsest level)
             for (int it = 0; it < sweeps; it++) {
                 if (it == 0 && zero) { for (long q = 0; q < G[l].total; q++) W[l][q] = (T)0;
                     for (int k = 0; k < G[l].nz; k++) for (int i = 0; i < G[l].ny; i++) for (int j = 0; j < G[l].nx; j++) { const T zx = at(B[l].data(), G[l], k, i, j) * (T)(dt[l] ? dt[l][i] : di[l]); at(W[l].data(), G[l], k, i, j) = (T)scale * zx; } }
@@ -678,6 +680,11 @@ int mgk_sweep_residual_restrict_slab_f64(mgk_ctx *c, const mgk_geom *gf, const m
 }
 
 // the fused forms on a row-table operator (2-D stretched meshes)
+int mgk_tail_cycle_cs_f64(mgk_ctx *c, const mgk_geom *g0, int nl, const int *n, const double *k7, const double *di, const double *const *ctab, const double *const *dtab, double s, double cs,
+                          int v0, int v1, const double *b, double *u, void *) {
+    if ((ctab == nullptr) != (dtab == nullptr)) return fail(MGK_EINVAL, "mgk_tail_cycle_cs_f64");
+    return tail_api<double>(c, g0, nl, n, ctab ? nullptr : k7, ctab ? nullptr : di, s, v0, v1, b, u, ctab, dtab, &cs);
+}
 int mgk_tail_cycle_rowcoef_f64(mgk_ctx *c, const mgk_geom *g0, int nl, const int *n, const double *const *ctab, const double *const *dtab, double s, int v0, int v1, const double *b, double *u, void *) {
     if (!ctab || !dtab) return fail(MGK_EINVAL, "mgk_tail_cycle_rowcoef_f64");
     return tail_api<double>(c, g0, nl, n, nullptr, nullptr, s, v0, v1, b, u, ctab, dtab);

@@ -43,6 +43,13 @@ def type_shim(L):
     L.KSPBuildResidual.argtypes = [vp, vp, vp, C.POINTER(vp)]
     L.KSPDestroy.argtypes = [C.POINTER(vp)]
     L.KSPRichardsonSetScale.argtypes = [vp, d]
+    L.KSPGetPC.argtypes = [vp, C.POINTER(vp)]
+    L.PCSetType.argtypes = [vp, C.c_char_p]
+    L.PCMGSetLevels.argtypes = [vp, i, vp]
+    L.PCMGGetCoarseSolve.argtypes = [vp, C.POINTER(vp)]
+    L.PCMGGetSmoother.argtypes = [vp, i, C.POINTER(vp)]
+    for f in (L.PCMGSetInterpolation, L.PCMGSetRestriction, L.PCMGSetR, L.PCMGSetRhs, L.PCMGSetX):
+        f.argtypes = [vp, i, vp]
     return L
 
 
@@ -441,6 +448,83 @@ def recorded_coarse_subcycle_keeps_petsc_semantics(L, orc):
             L.MatDestroy(C.byref(m))
 
 
+def pcmg_level_vectors_after_the_tail_launch(L, orc):
+    """-cycle 8 set up as the reference does (src/solver.c:1918-1956: its own vectors handed to PCMG through PCMGSetRhs / PCMGSetX / PCMGSetR), full
+    depth, PETSc's default exact coarse solve: the drop-in runs PCMG's levels from 63^2 down -- here all of them -- as ONE tail launch and does
+    not compute the level vectors.  Reading them after the solve must give what the level-by-level cycle leaves there (numpy model)."""
+    L.PetscInitialize(None, None, None, None)
+    for k_, v_ in ((b"-mg_levels_ksp_type", b"richardson"), (b"-mg_levels_pc_type", b"jacobi"), (b"-mg_levels_ksp_max_it", b"3"),
+                   (b"-mg_levels_ksp_richardson_scale", b"0.8")):
+        L.PetscOptionsSetValue(None, k_, v_)
+    npts, nlev = 33, 5
+    A = [_dense(orc, "A", npts, l) for l in range(nlev)]
+    R = [_dense(orc, "R", npts, l) for l in range(nlev - 1)]
+    P = [_dense(orc, "P", npts, l) for l in range(nlev - 1)]
+    mA, mR, mP = [_assemble(L, a) for a in A], [_assemble(L, r) for r in R], [_assemble(L, q) for q in P]
+    rng = np.random.default_rng(31)
+    b0v = rng.standard_normal(A[0].shape[0])
+    u, b, r = [], [], []
+    for l in range(nlev):
+        for lst in (u, b, r):
+            v = C.c_void_p()
+            L.MatCreateVecs(mA[l], C.byref(v), None)
+            lst.append(v)
+    _set(L, b[0], b0v)
+    ksp, pc, kt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    L.KSPCreate(1, C.byref(ksp))
+    L.KSPSetType(ksp, b"richardson"); L.KSPSetOperators(ksp, mA[0], mA[0]); L.KSPSetNormType(ksp, 2)
+    L.KSPSetTolerances(ksp, 1e-30, -2.0, -2.0, 2)                       # two applications of the preconditioner
+    L.KSPGetPC(ksp, C.byref(pc))
+    L.PCSetType(pc, b"mg")
+    L.PCMGSetLevels(pc, nlev, None)
+    L.PCMGGetCoarseSolve(pc, C.byref(kt)); L.KSPSetOperators(kt, mA[nlev - 1], mA[nlev - 1])
+    for i in range(1, nlev):
+        L.PCMGGetSmoother(pc, i, C.byref(kt)); L.KSPSetOperators(kt, mA[nlev - i - 1], mA[nlev - i - 1])
+        L.PCMGSetInterpolation(pc, i, mP[nlev - i - 1]); L.PCMGSetRestriction(pc, i, mR[nlev - i - 1])
+    L.PCMGSetR(pc, nlev - 1, r[0])
+    for i in range(1, nlev - 1):
+        L.PCMGSetRhs(pc, i, b[nlev - i - 1]); L.PCMGSetX(pc, i, u[nlev - i - 1]); L.PCMGSetR(pc, i, r[nlev - i - 1])
+    L.PCMGSetRhs(pc, 0, b[nlev - 1]); L.PCMGSetX(pc, 0, u[nlev - 1])
+    L.KSPSetFromOptions(ksp)
+    L.KSPSolve(ksp, b[0], u[0])
+    # the numpy model: outer Richardson (scale 1), PCMG V-cycle with 3 + 3 damped Jacobi sweeps, exact solve on the 1 x 1 grid
+    lev = {}
+
+    def sm(l, x, rhs, m):
+        d = 1.0 / np.diag(A[l])
+        for _ in range(m):
+            x = x + 0.8 * (d * (rhs - A[l] @ x))
+        return x
+
+    def cyc(l, rhs):
+        if l == nlev - 1:
+            x = np.linalg.solve(A[l], rhs)
+        else:
+            x = sm(l, np.zeros_like(rhs), rhs, 3)
+            bc = R[l] @ (rhs - A[l] @ x)
+            x = x + P[l] @ cyc(l + 1, bc)
+            x = sm(l, x, rhs, 3)
+        if l > 0:
+            lev[l] = (rhs.copy(), x.copy())
+        return x
+
+    x = np.zeros_like(b0v)
+    for _ in range(2):
+        x = x + cyc(0, b0v - A[0] @ x)
+    tol = 1e-11 * max(1.0, np.abs(x).max())
+    assert np.max(np.abs(_get(L, u[0], x.size) - x)) <= tol
+    for l in range(nlev - 1, 0, -1):                                     # the level vectors, coarsest first, then once more in the other order
+        assert np.max(np.abs(_get(L, u[l], lev[l][1].size) - lev[l][1])) <= 1e-11 * max(1.0, np.abs(lev[l][1]).max()), ("u", l)
+        assert np.max(np.abs(_get(L, b[l], lev[l][0].size) - lev[l][0])) <= 1e-11 * max(1.0, np.abs(lev[l][0]).max()), ("b", l)
+    for l in range(1, nlev):
+        assert np.max(np.abs(_get(L, u[l], lev[l][1].size) - lev[l][1])) <= 1e-11 * max(1.0, np.abs(lev[l][1]).max()), ("u again", l)
+    L.KSPDestroy(C.byref(ksp))
+    for v in u + b + r:
+        L.VecDestroy(C.byref(v))
+    for m in mA + mR + mP:
+        L.MatDestroy(C.byref(m))
+
+
 def richardson_with_lu_is_damped_not_exact(L, orc):
     """-pc_type lu (the dense inverse of a small operator): preonly and richardson with scale 1 return A^-1 b whatever the guess;
     richardson with scale s != 1 makes max_it DAMPED steps x <- (1 - s) x + s A^-1 b, as PETSc would (it used to come
@@ -489,5 +573,5 @@ if __name__ == "__main__":      # python tests/shim_semantics.py <shared library
     from oracle import Oracle
     lib = type_shim(C.CDLL(sys.argv[1], mode=os.RTLD_LOCAL))
     {"lazy": lazy_temporaries_keep_petsc_semantics, "spec": speculative_sweep_is_adopted_only_when_nothing_changed,
-     "keepr": residual_left_deferred_by_the_norm_pass, "tailrec": recorded_coarse_subcycle_keeps_petsc_semantics, "lu": richardson_with_lu_is_damped_not_exact}[sys.argv[2]](lib, Oracle())
+     "keepr": residual_left_deferred_by_the_norm_pass, "tailrec": recorded_coarse_subcycle_keeps_petsc_semantics, "pcmgtail": pcmg_level_vectors_after_the_tail_launch, "lu": richardson_with_lu_is_damped_not_exact}[sys.argv[2]](lib, Oracle())
     print("SEMANTICS_OK", sys.argv[2])

@@ -609,6 +609,16 @@ def test_recorded_coarse_subcycle_keeps_petsc_semantics(orc):
     recorded_coarse_subcycle_keeps_petsc_semantics(type_shim(_shim()), orc)
 
 
+def test_pcmg_level_vectors_after_the_tail_launch():
+    """a process of its own (it sets -mg_levels_* in the options database): see tests/shim_semantics.py"""
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "multigrid_petsc_amd", "libmgpetsc.so")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "shim_semantics.py"), lib, "pcmgtail"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and "SEMANTICS_OK pcmgtail" in p.stdout, (p.returncode, p.stdout[-3000:])
+
+
 def test_richardson_with_lu_is_damped_not_exact():
     """a process of its own (it changes -pc_type in the options database): see tests/shim_semantics.py"""
     import subprocess

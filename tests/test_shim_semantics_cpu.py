@@ -57,5 +57,9 @@ def test_recorded_coarse_subcycle_keeps_petsc_semantics_on_the_mock(mock_shim):
     _check(mock_shim, "tailrec")
 
 
+def test_pcmg_level_vectors_after_the_tail_launch_on_the_mock(mock_shim):
+    _check(mock_shim, "pcmgtail")
+
+
 def test_richardson_with_lu_is_damped_on_the_mock(mock_shim):
     _check(mock_shim, "lu")
