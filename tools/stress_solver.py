@@ -25,11 +25,12 @@ for q in range(count):
     fuse = int(rng.choice([-1, -1, -1, 0, 63, 63 | 256 | 512, 63 | 256 | 512 | 1024 | 2048, 63 | 256 | 512 | 8192, int(rng.integers(0, 16384))]))
     pair = int(rng.choice([0, 0, 7, 15, 31]))
     graph = int(rng.choice([-1, -1, 0]))
+    prec = str(rng.choice(["fp64", "fp64", "mixed"])) if dim == 3 else "fp64"
     if v0 == 0 and levels > 1:
         v0 = 1
-    tag = f"dim={dim} npts={npts} levels={levels} v=({v0},{v1}) mesh={mesh} scale={scale:.4f} fuse={fuse} pair_min_n={pair} graph={graph}"
+    tag = f"dim={dim} npts={npts} levels={levels} v=({v0},{v1}) mesh={mesh} scale={scale:.4f} fuse={fuse} pair_min_n={pair} graph={graph} {prec}"
     try:
-        s = Solver(dim, npts, levels, v=(v0, v1), maxiter=60, scale=scale, fuse=fuse, pair_min_n=pair, mesh=mesh, graph=graph)
+        s = Solver(dim, npts, levels, v=(v0, v1), maxiter=60, scale=scale, fuse=fuse, pair_min_n=pair, mesh=mesh, graph=graph, precision=prec)
         s.set_rhs_problem()
         it = s.solve()
         u = s.solution()
@@ -38,7 +39,10 @@ for q in range(count):
     except Exception as e:                                   # a configuration the solver refuses is reported, not counted as a mismatch
         print("REFUSED", tag, str(e)[:120], flush=True)
         continue
-    ref = orc.vcycle(dim, npts, levels, v0, v1, maxiter=60, scale=scale, use_csr=1 if mesh else 0, mesh=mesh)
+    if prec == "mixed":
+        ref = orc.vcycle_mixed(npts, levels, v0, v1, maxiter=60, scale=scale)
+    else:
+        ref = orc.vcycle(dim, npts, levels, v0, v1, maxiter=60, scale=scale, use_csr=1 if mesh else 0, mesh=mesh)
     ok = it == ref["iters"] and np.array_equal(u, ref["u"]) and np.max(np.abs(rn - ref["rnorm"]) / np.maximum(ref["rnorm"], 1e-300)) <= 1e-10
     if not ok:
         bad += 1
