@@ -152,6 +152,8 @@ struct mg_solver {
     int lgraph;             /* levels >= lgraph form the launch-bound coarse part replayed as one HIP graph (0: off) */
     int ltail;              /* levels >= ltail (n <= 15 in 3-D, <= 63 in 2-D) run as ONE kernel with their fields in LDS (0: off) */
     void *coarse_graph[2];  /* one recording per precision */
+    void *graph_u[2], *graph_tmp[2];   /* u / tmp of the level that feeds the recording, as the recorded kernels know them */
+    int graph_rerecorded;   /* recordings thrown away because those pointers had changed (0 in every default configuration) */
     /* profiling */
     int prof_on, prof_n;
     void *timers[MG_MAX_TIMERS];
@@ -1341,7 +1343,17 @@ static int cycle_body(mg_solver *s, int P, int first) {
     const int lend = s->ltail ? s->ltail : levels - 1;
     for (int l = 1; l < lg && l <= lend; l++) CHK(descend(s, P, l));
     if (lg < levels && lg <= lend) {
+        mg_fset *Fe = &s->L[lg - 1].f[P];
+        if (s->coarse_graph[P] && (Fe->u != s->graph_u[P] || Fe->tmp != s->graph_tmp[P])) {
+            /* the level that feeds the recording has swapped u / tmp an odd number of times since it was made (sweep groupings that differ
+             * on the way down and on the way up, e.g. pairs without the fused prolongation and an even v0): the recorded restriction would
+             * read the stale buffer.  Never in a default configuration; correctness first -- record again on the pointers of this cycle */
+            mgk_graph_destroy(s->ctx, s->coarse_graph[P]);
+            s->coarse_graph[P] = NULL;
+            s->graph_rerecorded++;
+        }
         if (!s->coarse_graph[P]) {                                      /* record once ... */
+            s->graph_u[P] = Fe->u; s->graph_tmp[P] = Fe->tmp;
             CHK(mgk_capture_begin(s->ctx));
             int rc = coarse_part(s, P, lg);
             void *ge = NULL;

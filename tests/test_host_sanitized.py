@@ -90,6 +90,23 @@ def test_own_driver_under_sanitizers_matches_the_oracle(san, tmp_path, args, dim
     assert np.array_equal(u, ref["u"])
 
 
+@pytest.mark.parametrize("prec,v0,fuse,pair,levels", [("mixed", 2, 7533, 31, 4), ("mixed", 4, 32, 31, 4), ("fp64", 2, 32, 7, 4), ("fp64", 2, 32 | 1024, 15, 5),
+                                                      ("fp64", 4, 32 | 4 | 256, 7, 3)])
+def test_sweep_groupings_that_swap_the_graph_feeding_level_an_odd_number_of_times(san, tmp_path, prec, v0, fuse, pair, levels):
+    """Pairs of sweeps WITHOUT the fused prolongation and an even v0: the level that feeds the coarse-level recording swaps u / tmp three times per
+    cycle, so the recorded restriction would read the stale buffer in every second cycle (found by tools/stress_solver.py, seed 11: max|du| 3.4e-9
+    with equal iteration counts).  The solver now compares that level's pointers with the recorded ones and records again when they differ."""
+    args = ["-dim", "3", "-npts", "33", "-levels", str(levels), "-v", f"{v0},3", "-ksp_richardson_scale", "0.857142857142857095", "-mg_fuse", str(fuse),
+            "-mg_pair_min_n", str(pair), "-pc_type", "jacobi", "-write_fields", "1"] + (["-precision", "mixed"] if prec == "mixed" else [])
+    out = _run(san["mgpoisson"], args, tmp_path)
+    orc = Oracle()
+    ref = (orc.vcycle_mixed(33, levels, v0, 3, maxiter=100000, scale=6.0 / 7.0) if prec == "mixed"
+           else orc.vcycle(3, 33, levels, v0, 3, maxiter=100000, scale=6.0 / 7.0, use_csr=0))
+    assert int(re.search(r"Number of iterations:\s+(\d+)", out).group(1)) == ref["iters"]
+    u = np.array((tmp_path / "uData.dat").read_text().split(), dtype=np.float64)
+    assert np.array_equal(u, ref["u"].ravel())
+
+
 @pytest.mark.parametrize("mesh,npts,levels,extra", [(1, 65, 5, []), (2, 33, 4, []), (1, 257, 8, []), (2, 257, 3, []),
                                                     (1, 129, 6, ["-mg_pair_min_n", "15", "-mg_graph", "0"]), (2, 129, 7, ["-mg_pair_min_n", "15"])])
 def test_own_driver_stretched_mesh_under_sanitizers_matches_the_oracle(san, tmp_path, mesh, npts, levels, extra):
