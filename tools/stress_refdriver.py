@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """The reference's UNMODIFIED driver over the drop-in (build/refdriver/poisson) with options drawn at random -- size, depth, -v, -mesh, -map,
 damping -- against the oracle: iteration count equal, uData.dat bit-identical.  A one-off stress run (GPU box; needs the binary that
-__graft_entry__.build() links where /root/reference exists).  usage: stress_refdriver.py [count] [seed]"""
+__graft_entry__.build() links where /root/reference exists).  MG_STRESS_EXE=<binary> runs another link of the same driver instead -- on the
+CPU tests/_san/san_refdriver (the reference's objects + the drop-in's host C over tests/mock_mgk.cpp, sanitized; built by
+tests/test_host_sanitized.py), with MG_STRESS_MAXN bounding the sizes the scalar mock has to sweep.  usage: stress_refdriver.py [count] [seed]"""
 import os
 import subprocess
 import sys
@@ -13,11 +15,12 @@ from oracle import Oracle
 
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-exe = os.path.join(ROOT, "build", "refdriver", "poisson")
+exe = os.environ.get("MG_STRESS_EXE") or os.path.join(ROOT, "build", "refdriver", "poisson")
+maxn = int(os.environ.get("MG_STRESS_MAXN", "513"))
 orc = Oracle()
 bad = 0
 for q in range(count):
-    npts = int(rng.choice([17, 33, 65, 129, 257, 513]))
+    npts = int(rng.choice([n for n in (17, 33, 65, 129, 257, 513) if n <= maxn]))
     lmax = int(np.log2(npts - 1))
     levels = int(rng.integers(1, lmax + 1))
     v0, v1 = int(rng.integers(1, 6)), int(rng.integers(1, 6))

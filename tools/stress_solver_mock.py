@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""tools/stress_solver.py on the CPU: the PRODUCT's host logic (csrc/mg_solver.c, unchanged) over tests/mock_mgk.cpp (the kernel ABI in host
+memory, canonical arithmetic) with configurations drawn at random against the oracle -- sweep counts, depth, damping, fuse bits, pair
+threshold, recording on / off, precision.  What it can find is what the host decides: which pass runs when, buffer swaps, the coarse-level
+recording, deferred sweeps (the odd-swap hole of the recording, round 3, shows here exactly as on the GPU).  Small sizes only: the mock is
+scalar host code.  Test infrastructure: the mock library is injected into the package's loader cache HERE; the product has no such switch.
+usage: stress_solver_mock.py [count] [seed]"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def build_mock():
+    out = os.path.join(ROOT, "tests", "_san")
+    os.makedirs(out, exist_ok=True)
+    inc = "-I" + os.path.join(ROOT, "include")
+    objs = []
+    for cc, std, src, obj in (("g++", "-std=c++17", os.path.join(ROOT, "tests", "mock_mgk.cpp"), "stress_mock_mgk.o"),
+                              ("gcc", "-std=c99", os.path.join(ROOT, "multigrid_petsc_amd", "csrc", "mg_solver.c"), "stress_mg_solver.o"),
+                              ("gcc", "-std=c99", os.path.join(ROOT, "multigrid_petsc_amd", "csrc", "mg_comm.c"), "stress_mg_comm.o")):
+        o = os.path.join(out, obj)
+        subprocess.run([cc, std, "-O2", "-fPIC", "-ffp-contract=off", "-D_POSIX_C_SOURCE=200809L", inc, "-c", src, "-o", o], check=True)
+        objs.append(o)
+    so = os.path.join(out, "libmgsolve_stress.so")
+    subprocess.run(["g++", "-shared", "-Wl,-Bsymbolic", "-o", so] + objs + ["-lm", "-lpthread", "-ldl"], check=True)
+    return so
+
+
+def main():
+    count = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    import multigrid_petsc_amd._lib as loader
+    lib = ctypes.CDLL(build_mock(), mode=ctypes.RTLD_GLOBAL)
+    loader._cache["mgk"] = lib
+    loader._cache["mgpetsc"] = lib
+    from multigrid_petsc_amd.solver import Solver
+    from oracle import Oracle
+    orc = Oracle()
+    bad = 0
+    for q in range(count):
+        dim = int(rng.choice([2, 3, 3]))
+        npts = int(rng.choice([9, 17, 33, 65, 129] if dim == 2 else [9, 17, 33]))
+        lmax = int(np.log2(npts - 1))
+        levels = int(rng.integers(1, lmax + 1))
+        v0, v1 = int(rng.integers(0, 6)), int(rng.integers(1, 5))
+        mesh = int(rng.choice([0, 0, 1, 2])) if dim == 2 else 0
+        scale = float(rng.choice([0.8, 1.0, 6.0 / 7.0, 0.5]))
+        fuse = int(rng.choice([-1, -1, 0, 32, 63, 63 | 256 | 512, 63 | 256 | 512 | 1024 | 2048, 63 | 256 | 512 | 8192, int(rng.integers(0, 16384)),
+                               int(rng.integers(0, 16384)) | 32]))
+        pair = int(rng.choice([0, 7, 7, 15, 31]))
+        graph = int(rng.choice([-1, -1, 0]))
+        prec = str(rng.choice(["fp64", "fp64", "mixed"])) if dim == 3 else "fp64"
+        if v0 == 0 and levels > 1:
+            v0 = 1
+        tag = f"dim={dim} npts={npts} levels={levels} v=({v0},{v1}) mesh={mesh} scale={scale:.4f} fuse={fuse} pair_min_n={pair} graph={graph} {prec}"
+        try:
+            s = Solver(dim, npts, levels, v=(v0, v1), maxiter=40, scale=scale, fuse=fuse, pair_min_n=pair, mesh=mesh, graph=graph, precision=prec)
+            s.set_rhs_problem()
+            it = s.solve()
+            u = s.solution()
+            rn = s.rnorm
+            s.close()
+        except Exception as e:                               # a configuration the solver refuses is reported, not counted as a mismatch
+            print("REFUSED", tag, str(e)[:120], flush=True)
+            continue
+        if prec == "mixed":
+            ref = orc.vcycle_mixed(npts, levels, v0, v1, maxiter=40, scale=scale)
+        else:
+            ref = orc.vcycle(dim, npts, levels, v0, v1, maxiter=40, scale=scale, use_csr=1 if mesh else 0, mesh=mesh)
+        ok = it == ref["iters"] and np.array_equal(u, ref["u"]) and np.max(np.abs(rn - ref["rnorm"]) / np.maximum(ref["rnorm"], 1e-300)) <= 1e-10
+        if not ok:
+            bad += 1
+            print("MISMATCH", tag, "iters", it, ref["iters"], "max|du|", float(np.max(np.abs(u - ref["u"]))), flush=True)
+    print(f"{count} configurations, {bad} mismatches")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
