@@ -2,12 +2,18 @@
 """Randomised z-slab configurations (loopback ranks = threads sharing one GPU) against the oracle: rank count, size, depth, where the hierarchy
 stops being distributed, sweep counts, fuse bits, overlap, chunk hint, pair threshold, precision drawn at random; every rank's iteration count must
 agree with the oracle's and the concatenated slabs must be bit-identical to its u.  A one-off stress run, not part of the suite.
+MG_STRESS_MOCK=1: the same draws on the CPU -- mg_solver.c + mg_comm.c over tests/mock_mgk.cpp (tools/stress_solver_mock.py injects the library),
+sizes bounded by MG_STRESS_MAXN (the mock is scalar host code).
 usage: stress_slabs.py [count] [seed]"""
 import os
 import sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+if os.environ.get("MG_STRESS_MOCK"):
+    from stress_solver_mock import inject
+    inject()
 from multigrid_petsc_amd.solver import Solver
 from multigrid_petsc_amd.comm import LoopbackWorld
 from oracle import Oracle
@@ -17,7 +23,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 orc = Oracle()
 bad = 0
 for q in range(count):
-    npts = int(rng.choice([33, 65, 65, 129]))
+    npts = int(rng.choice([n for n in (33, 65, 65, 129) if n <= int(os.environ.get("MG_STRESS_MAXN", "129"))]))
     lmax = int(np.log2(npts - 1))
     levels = int(rng.integers(2, lmax + 1))
     P = int(rng.choice([2, 3, 4, 8]))

@@ -33,13 +33,18 @@ def build_mock():
     return so
 
 
-def main():
-    count = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+def inject():
+    """build the mock-backed library and make the package's loader hand it out (before multigrid_petsc_amd.solver / .comm are imported)"""
     import multigrid_petsc_amd._lib as loader
     lib = ctypes.CDLL(build_mock(), mode=ctypes.RTLD_GLOBAL)
     loader._cache["mgk"] = lib
     loader._cache["mgpetsc"] = lib
+
+
+def main():
+    count = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    inject()
     from multigrid_petsc_amd.solver import Solver
     from oracle import Oracle
     orc = Oracle()
