@@ -736,17 +736,18 @@ static int smooth_chebyshev(mg_solver *s, int l, int maxit) {
     double mu = 1.0 / alpha, omegaprod = 2.0 / alpha, ckm1 = 1.0, ck = mu, ckp1;
     double *pkm1 = (double *)F->u, *pk = (double *)F->tmp, *pkp1 = L->p2;
     const int mesh = s->cfg.mesh != 0;                              /* -mesh 1/2: the same steps on the level's row tables (2-D, one rank) */
+    /* the recurrence takes its first step BEFORE its loop (PETSc's cheby.c; oracle/mgo.c: smooth, mgo_chebyshev_csr): with max_it = 0 the
+     * solve still makes that one step (round 3: the product returned the guess untouched -- found by the random draws over the mock) */
     if (!F->guess_nonzero) {
         CHK(mgk_memset0(s->ctx, pkm1, bytes, NULL));
         F->u_ghost_ok = 0; F->u_ghost_pending = 0;
-        if (maxit > 0 && mesh) CHK(mgk_jacobi_zero_rowcoef_f64(s->ctx, &F->g, L->dtab, scale, (const double *)F->b, pk, NULL));
-        else if (maxit > 0) CHK(mgk_jacobi_zero_f64(s->ctx, &F->g, L->dinv, scale, (const double *)F->b, pk, NULL));
-    } else if (maxit > 0) {
+        if (mesh) CHK(mgk_jacobi_zero_rowcoef_f64(s->ctx, &F->g, L->dtab, scale, (const double *)F->b, pk, NULL));
+        else CHK(mgk_jacobi_zero_f64(s->ctx, &F->g, L->dinv, scale, (const double *)F->b, pk, NULL));
+    } else {
         CHK(ensure_u_ghosts(s, 0, L));
         if (mesh) CHK(mgk_rowcoef_f64(s->ctx, &F->g, 0, L->ctab, L->dtab, scale, (const double *)F->b, pkm1, pk, NULL));
         else CHK(mgk_jacobi_f64(s->ctx, &F->g, L->coef, L->dinv, scale, (const double *)F->b, pkm1, pk, NULL));
     }
-    if (maxit == 0) return 0;
     for (int it = 1; it < maxit; it++) {
         ckp1 = 2.0 * mu * ck - ckm1;
         double omega = omegaprod * ck / ckp1;

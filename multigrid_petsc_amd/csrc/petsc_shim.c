@@ -2082,7 +2082,8 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
         /* (the Chebyshev recurrence reads the zero guess as p_{k-1} in its second step) */
         if (maxit <= 0 || k->type == K_CHEBYSHEV || (A->kind != MAT_STENCIL && A->kind != MAT_STENCIL_ROW)) DEV(mgk_memset0(G, x->dev, sizeof(double) * (size_t)x->nalloc, NULL));
     }
-    if (maxit <= 0) return 0;
+    /* (Chebyshev on a stencil operator: the recurrence takes its first step before its loop, max_it = 0 included -- oracle/mgo.c) */
+    if (maxit <= 0 && !(k->type == K_CHEBYSHEV && (A->kind == MAT_STENCIL || A->kind == MAT_STENCIL_ROW))) return 0;
 
     if (A->kind == MAT_STENCIL) {
         need_vec(x, 1, &A->gf, A->n, "KSPSolve");
@@ -2132,7 +2133,7 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
             ckm1 = ck; ck = ckp1;
         }
         x->dev = pk; w->dev = pkm1; w2->dev = pkp1;
-        k->its = maxit;
+        k->its = maxit > 0 ? maxit : 0;
         return 0;
     }
 
@@ -2157,7 +2158,7 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
                 ckm1 = ck; ck = ckp1;
             }
             x->dev = pk; w->dev = pkm1; w2->dev = pkp1;
-            k->its = maxit;
+            k->its = maxit > 0 ? maxit : 0;
             return 0;
         }
         const int j3 = j3_on() && A->gf.dim == 2 && maxit >= 3;

@@ -566,6 +566,221 @@ def richardson_with_lu_is_damped_not_exact(L, orc):
     L.MatDestroy(C.byref(mA))
 
 
+def random_programs_keep_petsc_semantics(L, orc, seed=1, nprog=40, nops=60):
+    """Programs of PETSc calls drawn at random over a two-level set-up (fine / coarse 5-point operators, full weighting, bilinear prolongation,
+    two Richardson + Jacobi solvers, six fine and three coarse vectors) against a numpy model that executes call by call: residuals, transfers,
+    corrections, BLAS-1, norms, solves with changing max_it / scale / guess flag, reads, destroy + re-create -- with the fragments of the
+    reference's loop (src/solver.c:1531-1546) among the draws, so that the drop-in's deferred temporaries, speculative sweeps and fused passes
+    start and are then interrupted wherever the draw says.  Every value read, every norm and every vector at the end of a program must be what
+    call-by-call execution gives (tolerance: 1e-11 of a running magnitude bound of the vector; the arithmetic order differs from numpy's)."""
+    L.PetscInitialize(None, None, None, None)
+    L.PetscOptionsSetValue(None, b"-pc_type", b"jacobi")
+    rng = np.random.default_rng(seed)
+    for prog in range(nprog):
+        npts = int(rng.choice([17, 33, 33, 65]))
+        A0, A1, P, R = _dense(orc, "A", npts, 0), _dense(orc, "A", npts, 1), _dense(orc, "P", npts, 0), _dense(orc, "R", npts, 0)
+        mA0, mA1, mP, mR = _assemble(L, A0), _assemble(L, A1), _assemble(L, P), _assemble(L, R)
+        nf, nc = A0.shape[0], A1.shape[0]
+        amax = {0: 5.0 * np.abs(A0).max(), 1: 5.0 * np.abs(A1).max()}
+        dinv = {0: 1.0 / np.diag(A0), 1: 1.0 / np.diag(A1)}
+        Aop = {0: A0, 1: A1}
+        fine, coarse = ["x", "b", "r", "rv", "u", "w"], ["uc", "bc", "rc"]
+        lev = {**{v: 0 for v in fine}, **{v: 1 for v in coarse}}
+        H, M, mag = {}, {}, {}
+        first_f, first_c = C.c_void_p(), C.c_void_p()
+        L.MatCreateVecs(mA0, C.byref(first_f), None)
+        L.MatCreateVecs(mA1, C.byref(first_c), None)
+        for v in fine + coarse:
+            h = C.c_void_p()
+            L.VecDuplicate(first_f if lev[v] == 0 else first_c, C.byref(h))
+            H[v] = h
+            M[v] = rng.standard_normal(nf if lev[v] == 0 else nc)
+            mag[v] = float(np.abs(M[v]).max())
+            _set(L, h, M[v])
+        K, kst = {}, {}
+        for q, mat in ((0, mA0), (1, mA1)):
+            k = C.c_void_p()
+            L.KSPCreate(1, C.byref(k))
+            L.KSPSetType(k, b"richardson"); L.KSPSetOperators(k, mat, mat); L.KSPSetNormType(k, 0)
+            kst[q] = {"maxit": int(rng.integers(0, 5)), "scale": float(rng.choice([0.5, 0.8, 1.0])), "guess": int(rng.integers(0, 2)), "b": None, "x": None}
+            L.KSPSetTolerances(k, 1e-7, -2.0, -2.0, kst[q]["maxit"])
+            L.KSPSetFromOptions(k)
+            L.KSPRichardsonSetScale(k, kst[q]["scale"])
+            L.KSPSetInitialGuessNonzero(k, kst[q]["guess"])
+            K[q] = k
+        trace = []
+
+        def pick(level, n=1, exclude=()):
+            pool = [v for v in (fine if level == 0 else coarse) if v not in exclude]
+            return [str(t) for t in rng.choice(pool, size=n, replace=False)]
+
+        def check(v, what):
+            n = nf if lev[v] == 0 else nc
+            got = _get(L, H[v], n)
+            err = float(np.max(np.abs(got - M[v])))
+            assert err <= 1e-11 * max(mag[v], 1e-30) + 1e-300, (f"seed {seed} program {prog}: {what} of {v}: error {err:.3e} against magnitude {mag[v]:.3e}", trace)
+
+        def residual(q, bn, xn, rn_, via_ksp):
+            if via_ksp:
+                V = C.c_void_p()
+                L.KSPBuildResidual(K[q], None, H[rn_], C.byref(V))
+            else:
+                L.MatResidual(mA0 if q == 0 else mA1, H[bn], H[xn], H[rn_])
+            M[rn_] = M[bn] - Aop[q] @ M[xn]
+            mag[rn_] = mag[bn] + amax[q] * mag[xn]
+
+        def solve(q, bn, xn):
+            st = kst[q]
+            L.KSPSolve(K[q], H[bn], H[xn])
+            xm = M[xn].copy() if st["guess"] else np.zeros_like(M[xn])
+            mg = mag[xn] if st["guess"] else 0.0
+            for _ in range(st["maxit"]):
+                xm = xm + st["scale"] * (dinv[q] * (M[bn] - Aop[q] @ xm))
+                mg = mg + st["scale"] * float(dinv[q].max()) * (mag[bn] + amax[q] * mg)
+            M[xn], mag[xn] = xm, max(mg, float(np.abs(xm).max()))
+            st["b"], st["x"] = bn, xn
+
+        for step in range(nops):
+            op = str(rng.choice(["resid", "kresid", "restrict", "prolong", "apply", "axpy", "scale", "set", "copy", "norm", "solve", "solve", "param", "read",
+                                 "recreate", "frag_down", "frag_up", "frag_up", "frag_norm", "frag_norm", "frag_cycle"]))
+            q = int(rng.integers(0, 2))
+            if op == "resid":
+                bn, xn, rn_ = pick(q, 3)
+                trace.append(f"MatResidual(A{q}, {bn}, {xn}, {rn_})")
+                residual(q, bn, xn, rn_, False)
+            elif op == "kresid":
+                if kst[q]["b"] is None:
+                    continue
+                (rn_,) = pick(q, 1, exclude=(kst[q]["b"], kst[q]["x"]))
+                trace.append(f"KSPBuildResidual(k{q}, {rn_})   [b={kst[q]['b']}, x={kst[q]['x']}]")
+                residual(q, kst[q]["b"], kst[q]["x"], rn_, True)
+            elif op == "restrict":
+                (f,), (c,) = pick(0), pick(1)
+                trace.append(f"MatMult(R, {f}, {c})")
+                L.MatMult(mR, H[f], H[c]); M[c] = R @ M[f]; mag[c] = mag[f]
+            elif op == "prolong":
+                (f,), (c,) = pick(0), pick(1)
+                trace.append(f"MatMult(P, {c}, {f})")
+                L.MatMult(mP, H[c], H[f]); M[f] = P @ M[c]; mag[f] = mag[c]
+            elif op == "apply":
+                a, bb = pick(q, 2)
+                trace.append(f"MatMult(A{q}, {a}, {bb})")
+                L.MatMult(mA0 if q == 0 else mA1, H[a], H[bb]); M[bb] = Aop[q] @ M[a]; mag[bb] = amax[q] * mag[a]
+            elif op == "axpy":
+                y, xx = pick(q, 2)
+                al = float(rng.choice([1.0, -1.0, 0.5, 2.0]))
+                trace.append(f"VecAXPY({y}, {al}, {xx})")
+                L.VecAXPY(H[y], al, H[xx]); M[y] = M[y] + al * M[xx]; mag[y] = mag[y] + abs(al) * mag[xx]
+            elif op == "scale":
+                (v,) = pick(q)
+                al = float(rng.choice([0.5, -1.0, 2.0, 0.0]))
+                trace.append(f"VecScale({v}, {al})")
+                L.VecScale(H[v], al); M[v] = al * M[v]; mag[v] = abs(al) * mag[v]
+            elif op == "set":
+                (v,) = pick(q)
+                al = float(rng.choice([0.0, 1.0, -2.5]))
+                trace.append(f"VecSet({v}, {al})")
+                L.VecSet(H[v], al); M[v] = np.full_like(M[v], al); mag[v] = abs(al)
+            elif op == "copy":
+                a, bb = pick(q, 2)
+                trace.append(f"VecCopy({a}, {bb})")
+                L.VecCopy(H[a], H[bb]); M[bb] = M[a].copy(); mag[bb] = mag[a]
+            elif op == "norm":
+                (v,) = pick(q)
+                trace.append(f"VecNorm({v})")
+                val = C.c_double()
+                L.VecNorm(H[v], NORM_2, C.byref(val))
+                assert abs(val.value - np.linalg.norm(M[v])) <= 1e-11 * np.sqrt(M[v].size) * max(mag[v], 1e-30) + 1e-300, (f"seed {seed} program {prog}: norm of {v}", trace)
+            elif op == "solve":
+                bn, xn = pick(q, 2)
+                trace.append(f"KSPSolve(k{q}, {bn}, {xn})   [max_it={kst[q]['maxit']} scale={kst[q]['scale']} guess={kst[q]['guess']}]")
+                solve(q, bn, xn)
+            elif op == "param":
+                what = str(rng.choice(["maxit", "scale", "guess"]))
+                if what == "maxit":
+                    kst[q]["maxit"] = int(rng.integers(0, 5))
+                    L.KSPSetTolerances(K[q], 1e-7, -2.0, -2.0, kst[q]["maxit"])
+                elif what == "scale":
+                    kst[q]["scale"] = float(rng.choice([0.5, 0.8, 1.0]))
+                    L.KSPRichardsonSetScale(K[q], kst[q]["scale"])
+                else:
+                    kst[q]["guess"] = int(rng.integers(0, 2))
+                    L.KSPSetInitialGuessNonzero(K[q], kst[q]["guess"])
+                trace.append(f"k{q}.{what} = {kst[q][what]}")
+            elif op == "read":
+                (v,) = pick(q)
+                trace.append(f"read {v}")
+                check(v, "read")
+            elif op == "recreate":
+                (v,) = pick(q, 1, exclude=(kst[q]["b"], kst[q]["x"]))       # (the solver's vectors stay: KSPBuildResidual refers to them)
+                trace.append(f"VecDestroy({v}); VecDuplicate; VecSet(1.5)")
+                L.VecDestroy(C.byref(H[v]))
+                h = C.c_void_p()
+                L.VecDuplicate(first_f if q == 0 else first_c, C.byref(h))
+                H[v] = h
+                L.VecSet(h, 1.5); M[v] = np.full_like(M[v], 1.5); mag[v] = 1.5
+            elif op == "frag_down":          # src/solver.c:1534-1536
+                if kst[0]["b"] is None:
+                    continue
+                (rn_,) = pick(0, 1, exclude=(kst[0]["b"], kst[0]["x"]))
+                bc_, uc_ = pick(1, 2)
+                trace.append(f"down: KSPBuildResidual(k0, {rn_}); MatMult(R, {rn_}, {bc_}); KSPSolve(k1, {bc_}, {uc_})")
+                residual(0, kst[0]["b"], kst[0]["x"], rn_, True)
+                L.MatMult(mR, H[rn_], H[bc_]); M[bc_] = R @ M[rn_]; mag[bc_] = mag[rn_]
+                solve(1, bc_, uc_)
+            elif op == "frag_up":            # :1540-1542
+                (uc_,) = pick(1)
+                rv_, u_, b_ = pick(0, 3)
+                if kst[0]["x"] is not None and rng.integers(0, 2):
+                    u_, b_ = kst[0]["x"], kst[0]["b"]
+                    if rv_ in (u_, b_):
+                        (rv_,) = pick(0, 1, exclude=(u_, b_))
+                trace.append(f"up: MatMult(P, {uc_}, {rv_}); VecAXPY({u_}, 1, {rv_}); KSPSolve(k0, {b_}, {u_})")
+                L.MatMult(mP, H[uc_], H[rv_]); M[rv_] = P @ M[uc_]; mag[rv_] = mag[uc_]
+                L.VecAXPY(H[u_], 1.0, H[rv_]); M[u_] = M[u_] + M[rv_]; mag[u_] = mag[u_] + mag[rv_]
+                solve(0, b_, u_)
+            elif op == "frag_norm":          # :1545-1546 and the next :1531
+                if kst[0]["b"] is None:
+                    continue
+                (rn_,) = pick(0, 1, exclude=(kst[0]["b"], kst[0]["x"]))
+                trace.append(f"norm: KSPBuildResidual(k0, {rn_}); VecNorm({rn_})" + ("; KSPSolve(k0, same b, same x)" if step % 2 else ""))
+                residual(0, kst[0]["b"], kst[0]["x"], rn_, True)
+                val = C.c_double()
+                L.VecNorm(H[rn_], NORM_2, C.byref(val))
+                assert abs(val.value - np.linalg.norm(M[rn_])) <= 1e-11 * np.sqrt(nf) * max(mag[rn_], 1e-30) + 1e-300, (f"seed {seed} program {prog}: residual norm", trace)
+                if step % 2:
+                    solve(0, kst[0]["b"], kst[0]["x"])
+            elif op == "frag_cycle":         # one whole two-level cycle of the reference's loop on fixed vectors
+                trace.append("cycle: KSPSolve(k0,b,u); KSPBuildResidual(k0,r); MatMult(R,r,bc); KSPSolve(k1,bc,uc); MatMult(P,uc,rv); VecAXPY(u,1,rv); KSPSolve(k0,b,u); "
+                             "KSPBuildResidual(k0,r); VecNorm(r)")
+                solve(0, "b", "u")
+                residual(0, "b", "u", "r", True)
+                L.MatMult(mR, H["r"], H["bc"]); M["bc"] = R @ M["r"]; mag["bc"] = mag["r"]
+                solve(1, "bc", "uc")
+                L.MatMult(mP, H["uc"], H["rv"]); M["rv"] = P @ M["uc"]; mag["rv"] = mag["uc"]
+                L.VecAXPY(H["u"], 1.0, H["rv"]); M["u"] = M["u"] + M["rv"]; mag["u"] = mag["u"] + mag["rv"]
+                solve(0, "b", "u")
+                residual(0, "b", "u", "r", True)
+                val = C.c_double()
+                L.VecNorm(H["r"], NORM_2, C.byref(val))
+                assert abs(val.value - np.linalg.norm(M["r"])) <= 1e-11 * np.sqrt(nf) * max(mag["r"], 1e-30) + 1e-300, (f"seed {seed} program {prog}: cycle norm", trace)
+            if max(mag.values()) > 1e200:        # (a draw that keeps multiplying by A: start the next program)
+                break
+        for v in fine + coarse:
+            check(v, "final value")
+        for q in (0, 1):
+            L.KSPDestroy(C.byref(K[q]))
+        for v in fine + coarse:
+            L.VecDestroy(C.byref(H[v]))
+        L.VecDestroy(C.byref(first_f)); L.VecDestroy(C.byref(first_c))
+        for m in (mA0, mA1, mP, mR):
+            L.MatDestroy(C.byref(m))
+    import os
+    if os.environ.get("MGPETSC_LAZY_STATS"):       # which of the drop-in's fast paths the draws went through (printed by PetscFinalize)
+        L.PetscFinalize.argtypes = []
+        L.PetscFinalize()
+
+
 if __name__ == "__main__":      # python tests/shim_semantics.py <shared library> <function name>: one check in a process of its own
     import os
     import sys
@@ -573,5 +788,7 @@ if __name__ == "__main__":      # python tests/shim_semantics.py <shared library
     from oracle import Oracle
     lib = type_shim(C.CDLL(sys.argv[1], mode=os.RTLD_LOCAL))
     {"lazy": lazy_temporaries_keep_petsc_semantics, "spec": speculative_sweep_is_adopted_only_when_nothing_changed,
-     "keepr": residual_left_deferred_by_the_norm_pass, "tailrec": recorded_coarse_subcycle_keeps_petsc_semantics, "pcmgtail": pcmg_level_vectors_after_the_tail_launch, "lu": richardson_with_lu_is_damped_not_exact}[sys.argv[2]](lib, Oracle())
+     "keepr": residual_left_deferred_by_the_norm_pass, "tailrec": recorded_coarse_subcycle_keeps_petsc_semantics, "pcmgtail": pcmg_level_vectors_after_the_tail_launch, "lu": richardson_with_lu_is_damped_not_exact,
+     "random": lambda L_, o_: random_programs_keep_petsc_semantics(L_, o_, seed=int(sys.argv[3]) if len(sys.argv) > 3 else 1,
+                                                                   nprog=int(sys.argv[4]) if len(sys.argv) > 4 else 40)}[sys.argv[2]](lib, Oracle())
     print("SEMANTICS_OK", sys.argv[2])

@@ -223,13 +223,15 @@ def test_reference_driver_over_the_shim_under_sanitizers(san, tmp_path, npts, le
         assert np.array_equal(u, ref["u"])
 
 
-@pytest.mark.parametrize("mesh,npts,levels", [(0, 65, 5), (1, 65, 5), (2, 33, 3)])
-def test_reference_driver_chebyshev_under_sanitizers(san, tmp_path, mesh, npts, levels):
+@pytest.mark.parametrize("mesh,npts,levels,v0,v1", [(0, 65, 5, 3, 3), (1, 65, 5, 3, 3), (2, 33, 3, 3, 3),
+                                                     # max_it = 0: the recurrence still takes the step that precedes its loop (oracle/mgo.c; round 3)
+                                                     (0, 33, 3, 0, 2), (0, 33, 4, 2, 0), (1, 33, 3, 0, 1), (0, 17, 1, 0, 0)])
+def test_reference_driver_chebyshev_under_sanitizers(san, tmp_path, mesh, npts, levels, v0, v1):
     """-ksp_type chebyshev through the reference's own -cycle 0 driver (uniform and stretched meshes): KSPSolve restarts the recurrence
     from the zero guess on every coarse level of every cycle, so the guess must really be zero-filled (a stale x was read as p_{k-1})"""
-    out = _refdrv(san, tmp_path, f"-npts {npts}\n-mesh {mesh}\n-iter 200\n-grids {levels}\n-levels {levels}\n-cycle 0\n-map 0\n-v 3,3\n-moreNorm 0\n"
+    out = _refdrv(san, tmp_path, f"-npts {npts}\n-mesh {mesh}\n-iter 200\n-grids {levels}\n-levels {levels}\n-cycle 0\n-map 0\n-v {v0},{v1}\n-moreNorm 0\n"
                   "-pc_type jacobi\n-ksp_type chebyshev\n-ksp_chebyshev_eigenvalues 0.2,2.0\n")
-    ref = Oracle().vcycle(2, npts, levels, 3, 3, maxiter=200, ksp_type=1, emin=0.2, emax=2.0, use_csr=1, mesh=mesh)
+    ref = Oracle().vcycle(2, npts, levels, v0, v1, maxiter=200, ksp_type=1, emin=0.2, emax=2.0, use_csr=1, mesh=mesh)
     assert int(re.search(r"Number of iterations:\s+(\d+)", out).group(1)) == ref["iters"]
     u = np.array((tmp_path / "uData.dat").read_text().split(), dtype=np.float64)
     assert np.array_equal(u, ref["u"])

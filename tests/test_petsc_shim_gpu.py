@@ -627,3 +627,14 @@ def test_richardson_with_lu_is_damped_not_exact():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "shim_semantics.py"), lib, "lu"], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0 and "SEMANTICS_OK lu" in p.stdout, (p.returncode, p.stdout[-3000:])
+
+
+def test_random_programs_of_petsc_calls_keep_petsc_semantics():
+    """programs of PETSc calls drawn at random over a two-level set-up against a call-by-call numpy model -- the fragments of the reference's loop
+    started and interrupted wherever the draw says (a process of its own; see tests/shim_semantics.py: random_programs_keep_petsc_semantics)"""
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "multigrid_petsc_amd", "libmgpetsc.so")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "shim_semantics.py"), lib, "random", "1", "25"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and "SEMANTICS_OK random" in p.stdout, (p.returncode, p.stdout[-3000:])

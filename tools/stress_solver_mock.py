@@ -41,17 +41,22 @@ def inject():
     loader._cache["mgpetsc"] = lib
 
 
-def main():
+def main(mock=True):
+    """mock=False: the same draws on the GPU over the real libraries, with the larger sizes (tools/stress_solver.py)"""
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    inject()
+    if mock:
+        inject()
     from multigrid_petsc_amd.solver import Solver
     from oracle import Oracle
     orc = Oracle()
     bad = 0
     for q in range(count):
         dim = int(rng.choice([2, 3, 3]))
-        npts = int(rng.choice([9, 17, 33, 65, 129] if dim == 2 else [9, 17, 33]))
+        if mock:
+            npts = int(rng.choice([9, 17, 33, 65, 129] if dim == 2 else [9, 17, 33]))
+        else:
+            npts = int(rng.choice([9, 17, 33, 65, 129, 257, 513, 1025] if dim == 2 else [9, 17, 33, 65, 129]))
         lmax = int(np.log2(npts - 1))
         levels = int(rng.integers(1, lmax + 1))
         v0, v1 = int(rng.integers(0, 6)), int(rng.integers(1, 5))
@@ -64,25 +69,52 @@ def main():
         prec = str(rng.choice(["fp64", "fp64", "mixed"])) if dim == 3 else "fp64"
         if v0 == 0 and levels > 1:
             v0 = 1
-        tag = f"dim={dim} npts={npts} levels={levels} v=({v0},{v1}) mesh={mesh} scale={scale:.4f} fuse={fuse} pair_min_n={pair} graph={graph} {prec}"
+        # what is done with the solver: solve to the tolerance | the bench's loop (fixed count, norms deferred, in one or two calls) followed
+        # by a reset and a solve on the same handle | the same with the counts the other way round
+        mode = str(rng.choice(["solve", "solve", "cycles", "cycles+solve"]))
+        k1, k2 = int(rng.integers(1, 5)), int(rng.integers(0, 4))
+        cheb = dim == 2 and mesh == 0 and prec == "fp64" and bool(rng.integers(0, 4) == 0)
+        if v1 == 0 and cheb:
+            v1 = 1
+        kso = dict(ksp_type="chebyshev", eigenvalues=(0.2, 2.0)) if cheb else {}
+        kor = dict(ksp_type=1, emin=0.2, emax=2.0) if cheb else {}
+        tag = (f"dim={dim} npts={npts} levels={levels} v=({v0},{v1}) mesh={mesh} scale={scale:.4f} fuse={fuse} pair_min_n={pair} graph={graph} {prec} "
+               f"{'chebyshev ' if cheb else ''}{mode} {k1}+{k2}")
+
+        def oracle_run(fixed):
+            if prec == "mixed":
+                return orc.vcycle_mixed(npts, levels, v0, v1, maxiter=max(40, fixed), scale=scale, fixed_cycles=fixed)
+            return orc.vcycle(dim, npts, levels, v0, v1, maxiter=max(40, fixed), scale=scale, use_csr=1 if mesh else 0, mesh=mesh, fixed_cycles=fixed, **kor)
+
+        def same(it, u, rn, ref):
+            return (it == ref["iters"] and np.array_equal(u, ref["u"]) and
+                    np.max(np.abs(rn - ref["rnorm"]) / np.maximum(ref["rnorm"], 1e-300)) <= 1e-10)
         try:
-            s = Solver(dim, npts, levels, v=(v0, v1), maxiter=40, scale=scale, fuse=fuse, pair_min_n=pair, mesh=mesh, graph=graph, precision=prec)
+            s = Solver(dim, npts, levels, v=(v0, v1), maxiter=40, scale=scale, fuse=fuse, pair_min_n=pair, mesh=mesh, graph=graph, precision=prec, **kso)
             s.set_rhs_problem()
-            it = s.solve()
-            u = s.solution()
-            rn = s.rnorm
+            results = []
+            if mode != "solve":
+                s.cycles(k1)
+                if k2:
+                    s.cycles(k2)
+                s.sync()
+                results.append((k1 + k2, s.iterations, s.solution(), s.rnorm))
+                if mode == "cycles+solve":
+                    s.reset()
+            if mode != "cycles":
+                it = s.solve()
+                results.append((0, it, s.solution(), s.rnorm))
             s.close()
         except Exception as e:                               # a configuration the solver refuses is reported, not counted as a mismatch
             print("REFUSED", tag, str(e)[:120], flush=True)
             continue
-        if prec == "mixed":
-            ref = orc.vcycle_mixed(npts, levels, v0, v1, maxiter=40, scale=scale)
-        else:
-            ref = orc.vcycle(dim, npts, levels, v0, v1, maxiter=40, scale=scale, use_csr=1 if mesh else 0, mesh=mesh)
-        ok = it == ref["iters"] and np.array_equal(u, ref["u"]) and np.max(np.abs(rn - ref["rnorm"]) / np.maximum(ref["rnorm"], 1e-300)) <= 1e-10
-        if not ok:
-            bad += 1
-            print("MISMATCH", tag, "iters", it, ref["iters"], "max|du|", float(np.max(np.abs(u - ref["u"]))), flush=True)
+        for fixed, it, u, rn in results:
+            ref = oracle_run(fixed)
+            if not same(it, u, rn, ref):
+                bad += 1
+                print("MISMATCH", tag, f"(leg: {'fixed ' + str(fixed) if fixed else 'solve'})", "iters", it, ref["iters"], "max|du|", float(np.max(np.abs(u - ref["u"]))),
+                      flush=True)
+                break
     print(f"{count} configurations, {bad} mismatches")
     sys.exit(1 if bad else 0)
 
