@@ -38,11 +38,22 @@ for q in range(count):
     tag = f"P={P} npts={npts} levels={levels} dist_min_n={dist} v=({v0},{v1}) {kw}"
     world = LoopbackWorld(P)
 
+    # solve to the tolerance | the bench's loop: a fixed number of cycles in two calls, norms deferred to the end (what the N-GPU run executes)
+    k1, k2 = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    fixed = (k1 + k2) if rng.integers(0, 3) == 0 else 0
+    tag += f" {'cycles ' + str(k1) + '+' + str(k2) if fixed else 'solve'}"
+
     def fn(rank, comm):
         s = Solver(3, npts, levels, v=(v0, v1), scale=scale, maxiter=40, rank=rank, nranks=P, comm=comm, dist_min_n=dist, **kw)
         s.set_rhs_problem()
-        it = s.solve()
-        res = (it, s.solution())
+        if fixed:
+            s.cycles(k1)
+            s.cycles(k2)
+            s.sync()
+            it = s.iterations
+        else:
+            it = s.solve()
+        res = (it, s.solution(), s.rnorm)
         s.close()
         return res
 
@@ -54,11 +65,12 @@ for q in range(count):
     finally:
         world.close()
     if kw["precision"] == "mixed":
-        ref = orc.vcycle_mixed(npts, levels, v0, v1, maxiter=40, scale=scale)
+        ref = orc.vcycle_mixed(npts, levels, v0, v1, maxiter=40, scale=scale, fixed_cycles=fixed)
     else:
-        ref = orc.vcycle(3, npts, levels, v0, v1, maxiter=40, scale=scale)
+        ref = orc.vcycle(3, npts, levels, v0, v1, maxiter=40, scale=scale, fixed_cycles=fixed)
     u = np.concatenate([r[1] for r in res])
-    ok = all(r[0] == ref["iters"] for r in res) and np.array_equal(u, ref["u"])
+    ok = (all(r[0] == ref["iters"] for r in res) and np.array_equal(u, ref["u"]) and
+          all(np.max(np.abs(r[2] - ref["rnorm"]) / np.maximum(ref["rnorm"], 1e-300)) <= 1e-10 for r in res))
     if not ok:
         bad += 1
         print("MISMATCH", tag, "iters", [r[0] for r in res], ref["iters"], "max|du|", float(np.max(np.abs(u - ref["u"]))), flush=True)
