@@ -362,6 +362,18 @@ int  mgk_sweep_residual_restrict_2d_f64(mgk_ctx *ctx, const mgk_geom *gf, const 
 int  mgk_jacobi2_sumsq_slab_f64(mgk_ctx *ctx, const mgk_geom *g, const mgk_geom *gfar, const double *coef, double dinv, double scale,
                                 const double *b, const double *u, double *unew, const double *far, int has_lo, int has_hi,
                                 int zbeg, int zend, int part_off, int *nparts, void *stream);
+/* (round 3, second session) the 91-byte fine level on z-slabs: mgk_jacobi2_sumsq_mid_f64 and mgk_prolong_jacobi2_f64 on the planes [zbeg, zend) of
+ * a slab.  The prolongation pass also reads uc's ghost planes (the neighbours' coarse boundary planes) and, from `cfar` (geometry gcfar = (nxc, nyc, 2)),
+ * the rank below's coarse plane nzc-2 (its lo ghost plane); u's ghost planes and `far` hold the neighbours' planes BEFORE the correction -- every rank
+ * corrects and sweeps the planes -2 .. nz+1 it needs itself (same operands, same arithmetic as their owner: same bits).  zbeg must be even.
+ * Replaces the same reference calls as the whole-grid forms (src/solver.c:1540-1542, :1545-1546 + :1531). */
+int  mgk_jacobi2_sumsq_mid_slab_f64(mgk_ctx *ctx, const mgk_geom *g, const mgk_geom *gfar, const double *coef, double dinv, double scale,
+                                    const double *b, const double *u, double *unew, const double *far, int has_lo, int has_hi,
+                                    int zbeg, int zend, int part_off, int *nparts, void *stream);
+int  mgk_prolong_jacobi2_slab_ok_f64(const mgk_geom *gf, const mgk_geom *gc, int has_hi);
+int  mgk_prolong_jacobi2_slab_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const mgk_geom *gfar, const mgk_geom *gcfar, const double *coef,
+                                  double dinv, double scale, const double *b, const double *uc, const double *u, double *unew,
+                                  const double *far, const double *cfar, int has_lo, int has_hi, int zbeg, int zend, void *stream);
 int  mgk_sweep_residual_restrict_slab_ok_f64(const mgk_geom *gf, const mgk_geom *gc);
 int  mgk_sweep_residual_restrict_slab_f64(mgk_ctx *ctx, const mgk_geom *gf, const mgk_geom *gc, const mgk_geom *gfar, const double *coef,
                                           double dinv, double scale, const double *b, const double *u, double *unew,

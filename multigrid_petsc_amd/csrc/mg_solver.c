@@ -1046,13 +1046,25 @@ static int pjp_ok(const mg_solver *s, int P) {
     const mg_level *L = &s->L[0];
     const int need = 4096 | 1024 | 32 | 8 | 2 | 1;
     if ((s->cfg.fuse & need) != need || P != 0 || s->cfg.dim != 3 || s->cfg.mesh || s->cfg.ksp_type != MG_KSP_RICHARDSON) return 0;
-    if (s->cfg.v[0] != 3 || s->levels < 2 || L->distributed || s->lgraph == 1 || L->n < s->cfg.pair_min_n || s->last_cycle) return 0;
+    if (s->cfg.v[0] != 3 || s->levels < 2 || s->lgraph == 1 || L->n < s->cfg.pair_min_n || s->last_cycle) return 0;
+    if (L->distributed) {
+        /* (round 3, second session; fuse bit 14) the same three passes on z-slabs: the prolongation pass needs the neighbours' boundary AND second
+         * planes of u (before the correction) and of the coarse u -- the far fields of the two-sweep passes of both levels carry them */
+        const mg_level *Lc = &s->L[1];
+        const int hi = s->cfg.rank < s->cfg.nranks - 1;
+        if (!(s->cfg.fuse & 16384) || !Lc->distributed || !L->f[0].far || !Lc->f[0].far || L->nz_min < 8 || Lc->nz_min < 4) return 0;
+        return mgk_prolong_jacobi2_slab_ok_f64(&L->f[0].g, &Lc->f[0].g, hi) && mgk_jacobi2_sumsq_ok_f64(&L->f[0].g);
+    }
     return mgk_prolong_jacobi2_ok_f64(&L->f[0].g, &s->L[1].f[0].g) && mgk_jacobi2_sumsq_ok_f64(&L->f[0].g);
 }
 static int finalize_iterate(mg_solver *s) {
     if (!s->iterate_behind) return 0;
     mg_level *L = &s->L[0];
     mg_fset *F = &L->f[0];
+    if (L->distributed) {
+        CHK(ensure_u_ghosts(s, 0, L));
+        CHK(mgk_jacobi_range_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u, (double *)F->tmp, 0, F->g.nz, NULL));
+    } else
     CHK(mgk_jacobi_f64(s->ctx, &F->g, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u, (double *)F->tmp, NULL));
     swap_ptr(&F->u, &F->tmp);
     F->u_ghost_ok = 0; F->u_ghost_pending = 0;
@@ -1078,6 +1090,33 @@ static int prolong_smooth(mg_solver *s, int P, int l) {
         swap_ptr(&F->u, &F->tmp);
         F->u_ghost_ok = 0; F->u_ghost_pending = 0;
         return v0 > 3 ? smooth(s, P, l, v0 - 3, 0) : 0;
+    }
+    if (l == 0 && pjp_ok(s, P) && Lf->distributed) {
+        /* ... on a z-slab: TWO grouped exchanges on the comm stream (the coarse u's ghost planes + the neighbours' second coarse planes; u's ghost planes,
+         * the neighbours' second planes of u, b's ghost planes once per cycle) travel while the output planes that read none of it are produced:
+         * plane z reads u on z-2 .. z+2 and their parents -- with a rank below from z = 4 on (plane 2's parents are the own coarse planes 0, 1),
+         * with a rank above up to nz-3 (plane nz-1's parent is the own coarse plane nzc-1) */
+        const int nz = F->g.nz, lo = s->cfg.rank > 0, hi = s->cfg.rank < s->cfg.nranks - 1;
+        void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
+        CHK(group_exchange(s, P, Cq, 0));
+        CHK(group_exchange(s, P, F, 0));
+        const int zi0 = lo ? 4 : 0, zi1 = hi ? nz - 2 : nz;
+        const int split = s->cfg.overlap && zi1 - zi0 >= 2;
+#define PJ2S(z0, z1) mgk_prolong_jacobi2_slab_f64(s->ctx, &F->g, &Cq->g, &F->gfar, &Cq->gfar, Lf->coef, Lf->dinv, s->cfg.scale, (const double *)F->b, \
+                        (const double *)Cq->u, (const double *)F->u, (double *)F->tmp, (const double *)F->far, (const double *)Cq->far, lo, hi, z0, z1, cs)
+        if (split) CHK(PJ2S(zi0, zi1));
+        CHK(mgk_stream_wait(s->ctx, cs, ms));
+        Cq->u_ghost_pending = 0; Cq->u_ghost_ok = 1; Cq->b_ghost_ok = 1;
+        F->u_ghost_pending = 0; F->u_ghost_ok = 1; F->b_ghost_ok = 1;
+        if (split) {
+            if (lo) CHK(PJ2S(0, 4));
+            if (hi) CHK(PJ2S(nz - 2, nz));
+        } else CHK(PJ2S(0, nz));
+#undef PJ2S
+        swap_ptr(&F->u, &F->tmp);
+        F->u_ghost_ok = 0; F->u_ghost_pending = 0;
+        s->sweep_owed = 1;
+        return 0;
     }
     if (l == 0 && pjp_ok(s, P)) {
         /* the prolongation and the first TWO post-smoothing sweeps in one pass; the third one is made by the pass that evaluates the
@@ -1407,6 +1446,33 @@ static int vcycle_once(mg_solver *s) {
         CHK(cycle_body(s, 0, s->iter == 0));
         /* :1545-1546  r0 = b0 - A0 u0 ; ||r0|| */
         const int jnorm = (s->cfg.fuse & 8) && (s->cfg.fuse & 1) && s->cfg.ksp_type == MG_KSP_RICHARDSON && s->cfg.v[0] >= 1 && !s->last_cycle;
+        if (s->sweep_owed && L->distributed) {
+            /* ... on a z-slab: the planes 2 .. nz-3 while the grouped exchange (u's ghosts, the far planes; b's are valid) travels, one reduction
+             * over the block partials of the three launches */
+            const int nz = F->g.nz, lo = s->cfg.rank > 0, hi = s->cfg.rank < s->cfg.nranks - 1;
+            void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
+            int n1 = 0, n2 = 0, n3 = 0;
+            CHK(group_exchange(s, 0, F, 0));
+#define J2M(z0, z1, off, np) mgk_jacobi2_sumsq_mid_slab_f64(s->ctx, &F->g, &F->gfar, L->coef, L->dinv, s->cfg.scale, (const double *)F->b, (const double *)F->u, \
+                                (double *)F->tmp, (const double *)F->far, lo, hi, z0, z1, off, np, cs)
+            const int split = s->cfg.overlap && nz >= 6;
+            if (split) {
+                s->prof_kind = 1;
+                void *t = prof_begin(s, 0);
+                s->prof_kind = 0;
+                int rc2 = J2M(2, nz - 2, 0, &n1);
+                prof_end(s, t);
+                CHK(rc2);
+            }
+            CHK(mgk_stream_wait(s->ctx, cs, ms));
+            F->u_ghost_pending = 0; F->u_ghost_ok = 1; F->b_ghost_ok = 1;
+            if (split) { CHK(J2M(0, 2, n1, &n2)); CHK(J2M(nz - 2, nz, n1 + n2, &n3)); }
+            else CHK(J2M(0, nz, 0, &n1));
+#undef J2M
+            CHK(mgk_partials_finish(s->ctx, n1 + n2 + n3, &ss, NULL));
+            s->sweep_owed = 0; s->iterate_behind = 1; s->spec_valid = 1;
+            goto norm_done;
+        }
         if (s->sweep_owed) {
             /* the third post-smoothing sweep, the norm of ITS result and the first pre-smoothing sweep of the next cycle in one pass;
              * u stays one sweep behind the iterate, tmp is one sweep ahead of it */

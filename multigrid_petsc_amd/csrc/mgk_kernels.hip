@@ -1656,6 +1656,11 @@ struct PJ2Args {
     long rs, ms, crs, cms;
     int nty, zc;
     double a0, a1, a2, a3, a4, a5, a6, dinv, scale;
+    // z-slab of a multi-GPU run (k_pj2r3<WX, true>): planes -1 / nz of u and b and planes -1 / nzc of uc are the fields' ghost planes (the
+    // neighbours' boundary planes, u BEFORE the correction); plane -2 of u (far_lo), plane nz+1 of u (far_hi) and plane -2 of uc (cfar_lo)
+    // come in separate plane buffers (pointers at their interior origin); [zbeg, zend): the output planes of this launch, zbeg even
+    const double *far_lo, *far_hi, *cfar_lo;
+    int has_lo, has_hi, zbeg, zend;
 };
 typedef unsigned int mgk_u2v __attribute__((ext_vector_type(2)));
 template <int WX>
@@ -1862,7 +1867,7 @@ __global__ void __launch_bounds__(64 * WX) k_pj2r(const PJ2Args a) {
         for (int rr = 0; rr < R1; rr++) { VT tmpv = ua[rr]; ua[rr] = ub[rr]; ub[rr] = uc[rr]; uc[rr] = tmpv; }
     }
 }
-template <int WX>
+template <int WX, bool SLAB>
 __global__ void __launch_bounds__(64 * WX) k_pj2r3(const PJ2Args a) {
     typedef double T;
     constexpr int VX = 2, TY = 4, R1 = TY + 4, R2 = TY + 2, TX = 64 * VX * WX, LW = TX + 2 * VX, NCR = 5, LC = 64 * WX + 4;
@@ -1877,7 +1882,10 @@ __global__ void __launch_bounds__(64 * WX) k_pj2r3(const PJ2Args a) {
     if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
     const int ty = bid % a.nty, tz = bid / a.nty;
     const int yb = TY * ty;
-    const int z0 = tz * a.zc, z1 = min(z0 + a.zc, a.nz);          // zc is even: z0 is even
+    const int z0 = (SLAB ? a.zbeg : 0) + tz * a.zc, z1 = min(z0 + a.zc, SLAB ? a.zend : a.nz);          // zc (and zbeg) even: z0 is even
+    const int pmin = (SLAB && a.has_lo) ? -2 : -1, pmax = (SLAB && a.has_hi) ? a.nz + 1 : a.nz;     // u planes that exist
+    const int smin = (SLAB && a.has_lo) ? -1 : 0, smax = (SLAB && a.has_hi) ? a.nz : a.nz - 1;      // planes on which the first sweep is real
+    const int cmin = (SLAB && a.has_lo) ? -2 : -1;                                                  // coarse planes that exist: cmin .. nzc
     if (z0 >= z1) return;
     const int xl = VX * tid;
     const bool lastlane = (tid == 64 * WX - 1);
@@ -1892,9 +1900,17 @@ __global__ void __launch_bounds__(64 * WX) k_pj2r3(const PJ2Args a) {
     for (int q = 0; q < R2; q++) brb[q] = (unsigned)(max(0, min(yb - 1 + q, a.ny)) + 1) * rowb;
 #pragma unroll
     for (int j = 0; j < NCR; j++) crb[j] = (unsigned)(max(-1, min(2 * ty - 2 + j, a.nyc)) + 1) * crowb;
-    auto URS = [&](int p) { return __builtin_amdgcn_make_buffer_rsrc((void *)(a.u - a.rs + (long)max(-1, min(p, a.nz)) * a.ms), 0, (int)plane_bytes, 0x00020000); };
-    auto BRS = [&](int p) { return __builtin_amdgcn_make_buffer_rsrc((void *)(a.b - a.rs + (long)max(0, min(p, a.nz - 1)) * a.ms), 0, (int)plane_bytes, 0x00020000); };
-    auto CRS = [&](int k) { return __builtin_amdgcn_make_buffer_rsrc((void *)(a.uc - a.crs + (long)max(-1, min(k, a.nzc)) * a.cms), 0, (int)cplane_bytes, 0x00020000); };
+    auto URS = [&](int p) {
+        const int pp = max(pmin, min(p, pmax));
+        const double *pl = (SLAB && pp == -2) ? a.far_lo : (SLAB && pp == a.nz + 1) ? a.far_hi : a.u + (long)pp * a.ms;
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(pl - a.rs), 0, (int)plane_bytes, 0x00020000);
+    };
+    auto BRS = [&](int p) { return __builtin_amdgcn_make_buffer_rsrc((void *)(a.b - a.rs + (long)max(smin, min(p, smax)) * a.ms), 0, (int)plane_bytes, 0x00020000); };
+    auto CRS = [&](int k) {
+        const int kk = max(cmin, min(k, a.nzc));
+        const double *pl = (SLAB && kk == -2) ? a.cfar_lo : a.uc + (long)kk * a.cms;
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(pl - a.crs), 0, (int)cplane_bytes, 0x00020000);
+    };
     const unsigned clb = (unsigned)(min(tid, a.nxc) * (int)sizeof(T));      // coarse column tid (columns beyond the ghost column alias it: zero)
     auto ldc = [&](T (&cl)[NCR], int k) {
         const auto r = CRS(k);
@@ -1980,7 +1996,7 @@ __global__ void __launch_bounds__(64 * WX) k_pj2r3(const PJ2Args a) {
         if (t > t0) correct(uc, t + 2);                           // the plane requested in the last step (its edges below come after this)
         // ---- first sweep of plane p on rows yb-1 .. yb+TY ----
         {
-            const bool pin = (p >= 0 && p < a.nz);
+            const bool pin = (p >= smin && p <= smax);
             const int eb = p & 1, cb = p & 1;
             const int qlo_t = pin ? qlo : R2;
             const unsigned span_t = (unsigned)(qhi - qlo_t);
@@ -2094,12 +2110,62 @@ extern "C" int mgk_prolong_jacobi2_f64(mgk_ctx *c, const mgk_geom *gf, const mgk
     if (zc < 8) zc = 8;
     a.zc = zc;
     const unsigned nblk = (unsigned)(a.nty * ((gf->nz + zc - 1) / zc));
-    if ((gf->nx + 1) / 128 == 4 && g_variant != 46) hipLaunchKernelGGL((k_pj2r3<4>), dim3(nblk), dim3(256), 0, S(c, stream), a);   // round 3: the unrolled form on rows of
+    if ((gf->nx + 1) / 128 == 4 && g_variant != 46) hipLaunchKernelGGL((k_pj2r3<4, false>), dim3(nblk), dim3(256), 0, S(c, stream), a);   // round 3: the unrolled form on rows of
                                                                                                         // 512 too: 511^3 0.651 -> 0.601 ms (253 VGPRs, two blocks per CU)
     else if ((gf->nx + 1) / 128 == 4) hipLaunchKernelGGL((k_pj2r<4>), dim3(nblk), dim3(256), 0, S(c, stream), a);
-    else if (g_variant != 46) hipLaunchKernelGGL((k_pj2r3<8>), dim3(nblk), dim3(512), 0, S(c, stream), a);      // marching loop unrolled by three, the plane roles
+    else if (g_variant != 46) hipLaunchKernelGGL((k_pj2r3<8, false>), dim3(nblk), dim3(512), 0, S(c, stream), a);      // marching loop unrolled by three, the plane roles
                                                                                                         // permuted instead of copied: 4.80 against 4.90 ms (46: the copying form)
     else hipLaunchKernelGGL((k_pj2r<8>), dim3(nblk), dim3(512), 0, S(c, stream), a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// The same on a z-slab of a multi-GPU run, output planes [zbeg, zend) (zbeg even).  u's and b's ghost planes hold the neighbours' boundary planes
+// (u BEFORE the correction), uc's ghost planes the neighbours' coarse boundary planes; `far` / `cfar`: fields of geometry gfar = (nx, ny, 2) /
+// gcfar = (nxc, nyc, 2) whose ghost planes hold the neighbours' SECOND planes (lo ghost: plane nz-2 / nzc-2 of the rank below, hi ghost: plane 1
+// of the rank above; of cfar only the lo ghost is read).  With them every rank corrects and sweeps the planes -2 .. nz+1 it needs itself -- same
+// operands, same arithmetic as their owner: same bits.  An inner slab (has_hi) owns nz = 2 nzc planes, the last one 2 nzc + 1.
+extern "C" int mgk_prolong_jacobi2_slab_ok_f64(const mgk_geom *gf, const mgk_geom *gc, int has_hi) {
+    if (!gf || !gc || gf->dim != 3 || gc->dim != 3 || gf->nx != 2 * gc->nx + 1 || gf->ny != 2 * gc->ny + 1) return 0;
+    if (gf->nz != (has_hi ? 2 * gc->nz : 2 * gc->nz + 1) || gf->nz < 4 || gc->nz < 2) return 0;
+    if ((gf->nx + 1) % 128 != 0 || (gf->ny + 1) % 4 != 0) return 0;
+    const int w = (gf->nx + 1) / 128;
+    return (w == 4 || w == 8) ? 1 : 0;
+}
+extern "C" int mgk_prolong_jacobi2_slab_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const mgk_geom *gfar, const mgk_geom *gcfar, const double *coef,
+                                            double dinv, double scale, const double *b, const double *uc, const double *u, double *unew,
+                                            const double *far, const double *cfar, int has_lo, int has_hi, int zbeg, int zend, void *stream) {
+    if (!c || !coef || !b || !uc || !u || !unew || u == unew || !mgk_prolong_jacobi2_slab_ok_f64(gf, gc, has_hi))
+        return fail(MGK_EINVAL, "mgk_prolong_jacobi2_slab_f64: bad arguments / shape not built");
+    if ((has_lo || has_hi) && (!far || !gfar || gfar->dim != 3 || gfar->nz != 2 || gfar->nx != gf->nx || gfar->ny != gf->ny || gfar->pitch != gf->pitch))
+        return fail(MGK_EINVAL, "mgk_prolong_jacobi2_slab_f64: the far-plane field must have the geometry (nx, ny, 2) of the slab");
+    if (has_lo && (!cfar || !gcfar || gcfar->dim != 3 || gcfar->nz != 2 || gcfar->nx != gc->nx || gcfar->ny != gc->ny || gcfar->pitch != gc->pitch))
+        return fail(MGK_EINVAL, "mgk_prolong_jacobi2_slab_f64: the coarse far-plane field must have the geometry (nxc, nyc, 2) of the coarse slab");
+    if (zbeg < 0 || (zbeg & 1) || zend > gf->nz || zbeg >= zend) return fail(MGK_EINVAL, "mgk_prolong_jacobi2_slab_f64: empty, odd or out-of-range plane range");
+    PJ2Args a; memset(&a, 0, sizeof(a));
+    a.u = u + gf->org; a.b = b + gf->org; a.uc = uc + gc->org; a.out = unew + gf->org;
+    a.nx = gf->nx; a.ny = gf->ny; a.nz = gf->nz; a.nxc = gc->nx; a.nyc = gc->ny; a.nzc = gc->nz;
+    a.rs = gf->pitch; a.ms = gf->plane; a.crs = gc->pitch; a.cms = gc->plane;
+    a.a0 = coef[0]; a.a1 = coef[1]; a.a2 = coef[2]; a.a3 = coef[3]; a.a4 = coef[4]; a.a5 = coef[5]; a.a6 = coef[6];
+    a.dinv = dinv; a.scale = scale;
+    a.has_lo = has_lo ? 1 : 0; a.has_hi = has_hi ? 1 : 0;
+    a.far_lo = has_lo ? far + gfar->org - gfar->plane : nullptr;
+    a.far_hi = has_hi ? far + gfar->org + 2 * gfar->plane : nullptr;
+    a.cfar_lo = has_lo ? cfar + gcfar->org - gcfar->plane : nullptr;
+    a.zbeg = zbeg; a.zend = zend;
+    const int nzr = zend - zbeg;
+    a.nty = (gf->ny + 3) / 4;
+    const long target = ((gf->nx + 1) / 128 > 4) ? 256 : 512;
+    long nch = (a.nty >= target) ? 1 : (target + a.nty - 1) / a.nty;
+    if (g_zchunk > 0) nch = (nzr + g_zchunk - 1) / g_zchunk;
+    else if (c->chunk_planes > 0 && nch < (nzr + c->chunk_planes - 1) / c->chunk_planes) nch = (nzr + c->chunk_planes - 1) / c->chunk_planes;
+    int zc = (int)((nzr + nch - 1) / nch);
+    zc = (zc + 1) & ~1;                                          // even: every chunk starts on an even plane
+    if (zc < 8) zc = 8;
+    a.zc = zc;
+    const unsigned nblk = (unsigned)(a.nty * ((nzr + zc - 1) / zc));
+    if ((gf->nx + 1) / 128 == 4) hipLaunchKernelGGL((k_pj2r3<4, true>), dim3(nblk), dim3(256), 0, S(c, stream), a);
+    else hipLaunchKernelGGL((k_pj2r3<8, true>), dim3(nblk), dim3(512), 0, S(c, stream), a);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -2282,6 +2348,17 @@ extern "C" int mgk_jacobi2_sumsq_slab_f64(mgk_ctx *c, const mgk_geom *g, const m
     const double *lo = has_lo ? far + gfar->org - gfar->plane : nullptr;
     const double *hi = has_hi ? far + gfar->org + 2 * gfar->plane : nullptr;
     return jacobi2<double>(c, g, coef, dinv, scale, b, u, unew, lo, hi, zbeg, zend, stream, nparts, part_off);
+}
+// ... the mid-iterate form (mgk_jacobi2_sumsq_mid_f64) on the planes [zbeg, zend) of a z-slab: unew = J(J(u)), partials of || b - A J(u) ||^2
+extern "C" int mgk_jacobi2_sumsq_mid_slab_f64(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gfar, const double *coef, double dinv, double scale,
+                                              const double *b, const double *u, double *unew, const double *far, int has_lo, int has_hi,
+                                              int zbeg, int zend, int part_off, int *nparts, void *stream) {
+    if (!g || !nparts) return fail(MGK_EINVAL, "mgk_jacobi2_sumsq_mid_slab_f64: bad arguments");
+    if ((has_lo || has_hi) && (!gfar || !far || gfar->dim != 3 || gfar->nz != 2 || gfar->nx != g->nx || gfar->ny != g->ny || gfar->pitch != g->pitch || g->nz < 2))
+        return fail(MGK_EINVAL, "mgk_jacobi2_sumsq_mid_slab_f64: the far-plane field must have the geometry (nx, ny, 2) of the slab");
+    const double *lo = has_lo ? far + gfar->org - gfar->plane : nullptr;
+    const double *hi = has_hi ? far + gfar->org + 2 * gfar->plane : nullptr;
+    return jacobi2<double>(c, g, coef, dinv, scale, b, u, unew, lo, hi, zbeg, zend, stream, nparts, part_off, false, 2);
 }
 // The same on a z-slab.  `far` is a field of geometry (nx, ny, nz = 2) whose ghost planes hold the neighbours' second plane
 // (lo ghost: plane nz-2 of the rank below, hi ghost: plane 1 of the rank above; mgk_geom of it in gfar); u's own ghost

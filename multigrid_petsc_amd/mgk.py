@@ -127,6 +127,9 @@ def _sigs(L):
         "mgk_prolong_jacobi3_2d_f64": (i, [vp, G, G, c_dp, d, d, vp, vp, vp, vp, vp, vp, vp]),
         "mgk_sweep_residual_restrict_2d_f64": (i, [vp, G, G, c_dp, d, d, vp, vp, vp, vp, vp, d, d, vp]),
         "mgk_jacobi2_sumsq_slab_f64": (i, [vp, G, G, c_dp, d, d, vp, vp, vp, vp, i, i, i, i, i, C.POINTER(i), vp]),
+        "mgk_jacobi2_sumsq_mid_slab_f64": (i, [vp, G, G, c_dp, d, d, vp, vp, vp, vp, i, i, i, i, i, C.POINTER(i), vp]),
+        "mgk_prolong_jacobi2_slab_ok_f64": (i, [G, G, i]),
+        "mgk_prolong_jacobi2_slab_f64": (i, [vp, G, G, G, G, c_dp, d, d, vp, vp, vp, vp, vp, vp, i, i, i, i, vp]),
         "mgk_sweep_residual_restrict_slab_ok_f64": (i, [G, G]),
         "mgk_sweep_residual_restrict_slab_f64": (i, [vp, G, G, G, c_dp, d, d, vp, vp, vp, vp, vp, vp, i, i, vp, i, i, vp]),
         "mgk_ctx_set_chunk_planes": (i, [vp, i]),

@@ -631,9 +631,64 @@ int mgk_jacobi2_sumsq_mid_f64(mgk_ctx *c, const mgk_geom *g, const double *coef,
     deliver(c, sumsq_field<double>(*g, r.data(), 0, g->nz), out);
     return 0;
 }
+// (round 3, second session) the same two on a z-slab
+static int g_calls_pj2_slab = 0, g_calls_mid_slab = 0;
+int mgk_prolong_jacobi2_slab_ok_f64(const mgk_geom *gf, const mgk_geom *gc, int has_hi) {
+    return (gf && gc && gf->dim == 3 && gc->dim == 3 && gf->nx == 2 * gc->nx + 1 && gf->ny == 2 * gc->ny + 1 && gf->nz == (has_hi ? 2 * gc->nz : 2 * gc->nz + 1) &&
+            gf->nx >= 7 && gf->nz >= 4 && gc->nz >= 2) ? 1 : 0;
+}
+int mgk_prolong_jacobi2_slab_f64(mgk_ctx *c, const mgk_geom *gf, const mgk_geom *gc, const mgk_geom *gfar, const mgk_geom *gcfar, const double *coef, double dinv, double scale,
+                                 const double *b, const double *uc, const double *u, double *o, const double *far, const double *cfar, int has_lo, int has_hi, int z0, int z1, void *) {
+    if (!c || !coef || !b || !uc || !u || !o || u == o || !mgk_prolong_jacobi2_slab_ok_f64(gf, gc, has_hi)) return fail(MGK_EINVAL, "mgk_prolong_jacobi2_slab_f64");
+    if ((has_lo || has_hi) && (!far || !far_ok(gf, gfar))) return fail(MGK_EINVAL, "mgk_prolong_jacobi2_slab_f64: far field");
+    if (has_lo && (!cfar || !far_ok(gc, gcfar))) return fail(MGK_EINVAL, "mgk_prolong_jacobi2_slab_f64: coarse far field");
+    if (z0 < 0 || (z0 & 1) || z1 > gf->nz || z0 >= z1) return fail(MGK_EINVAL, "mgk_prolong_jacobi2_slab_f64: range");
+    __atomic_fetch_add(&g_calls_pj2_slab, 1, __ATOMIC_RELAXED);
+    const mgk_geom F = *gf, Cg = *gc; std::vector<double> k(coef, coef + 7);
+    return run(c, [=] {
+        // extended slab: fine planes -2 .. nz+1 as interior planes 0 .. nz+3 of E (shift 2: parities kept), coarse planes -2 .. nzc as planes -1 .. nzc+1 of Ec
+        // (shift 1: fine plane 2 c + 1 stays centred on coarse plane c)
+        mgk_geom E, Ec; geom3<double>(&E, F.nx, F.ny, F.nz + 4); geom3<double>(&Ec, Cg.nx, Cg.ny, Cg.nz + 1);
+        std::vector<double> ue(E.total, 0.0), be(E.total, 0.0), ce(Ec.total, 0.0), w(E.total, 0.0), o2(E.total, 0.0);
+        for (int kk = -1; kk <= F.nz; kk++) memcpy(&ue[(size_t)((kk + 3) * E.plane)], u + (size_t)((kk + 1) * F.plane), sizeof(double) * (size_t)F.plane);
+        if (has_lo) memcpy(&ue[(size_t)E.plane], far, sizeof(double) * (size_t)F.plane);                                            // far's lo ghost plane = plane -2
+        if (has_hi) memcpy(&ue[(size_t)((F.nz + 4) * E.plane)], far + (size_t)(3 * F.plane), sizeof(double) * (size_t)F.plane);     // far's hi ghost plane = plane nz+1
+        for (int kk = (has_lo ? -1 : 0); kk <= (has_hi ? F.nz : F.nz - 1); kk++)
+            memcpy(&be[(size_t)((kk + 3) * E.plane)], b + (size_t)((kk + 1) * F.plane), sizeof(double) * (size_t)F.plane);
+        for (int kc = -1; kc <= Cg.nz; kc++) memcpy(&ce[(size_t)((kc + 2) * Ec.plane)], uc + (size_t)((kc + 1) * Cg.plane), sizeof(double) * (size_t)Cg.plane);
+        if (has_lo) memcpy(&ce[0], cfar, sizeof(double) * (size_t)Cg.plane);                                                        // coarse plane -2 = Ec's lo ghost plane
+        const int p0 = has_lo ? 0 : 1, p1 = has_hi ? F.nz + 4 : F.nz + 3;      // planes of E that are real (fine -2 / -1 .. nz / nz+1)
+        for (int e = p0; e < p1; e++)
+            for (int i = -1; i <= E.ny; i++)
+                for (int j = 0; j < E.nx; j++) at(ue.data(), E, e, i, j) = at(ue.data(), E, e, i, j) + prolong_at(E, Ec, ce.data(), e, i, j);
+        st_op<double>(M_JACOBI, E, k.data(), dinv, scale, 0, 0, 0, be.data(), ue.data(), (const double *)nullptr, w.data(), has_lo ? 1 : 2, has_hi ? F.nz + 3 : F.nz + 2);
+        st_op<double>(M_JACOBI, E, k.data(), dinv, scale, 0, 0, 0, be.data(), w.data(), (const double *)nullptr, o2.data(), z0 + 2, z1 + 2);
+        for (int kk = z0; kk < z1; kk++) for (int i = 0; i < F.ny; i++) memcpy(&at(o, F, kk, i, 0), &at(o2.data(), E, kk + 2, i, 0), sizeof(double) * (size_t)F.nx);
+    });
+}
+int mgk_jacobi2_sumsq_mid_slab_f64(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gf, const double *coef, double dinv, double scale, const double *b, const double *u, double *o,
+                                   const double *far, int lo, int hi, int z0, int z1, int part_off, int *nparts, void *) {
+    if (!c || !g || g->dim != 3 || !coef || !b || !u || !o || u == o || !nparts || part_off < 0 || part_off >= (int)c->partials.size()) return fail(MGK_EINVAL, "mgk_jacobi2_sumsq_mid_slab_f64");
+    if (z0 < 0 || z1 > g->nz || z0 >= z1) return fail(MGK_EINVAL, "mgk_jacobi2_sumsq_mid_slab_f64: range");
+    __atomic_fetch_add(&g_calls_mid_slab, 1, __ATOMIC_RELAXED);
+    int rc = jacobi2_api<double>(c, g, gf, coef, dinv, scale, b, u, o, far, lo, hi, z0, z1);
+    if (rc) return rc;
+    // the residual of the FIRST sweep's output on the planes [z0, z1): that sweep on the planes z0-1 .. z1 (u's ghost planes are valid), then b - A w
+    mgk_geom E; geom3<double>(&E, g->nx, g->ny, g->nz + 2);
+    std::vector<double> ue(E.total, 0.0), be(E.total, 0.0), w(E.total, 0.0), r(E.total, 0.0);
+    for (int kk = -1; kk <= g->nz; kk++) memcpy(&ue[(size_t)((kk + 2) * E.plane)], u + (size_t)((kk + 1) * g->plane), sizeof(double) * (size_t)g->plane);
+    if (lo) memcpy(&ue[0], far, sizeof(double) * (size_t)g->plane);
+    if (hi) memcpy(&ue[(size_t)((g->nz + 3) * E.plane)], far + (size_t)(3 * g->plane), sizeof(double) * (size_t)g->plane);
+    for (int kk = (lo ? -1 : 0); kk <= (hi ? g->nz : g->nz - 1); kk++) memcpy(&be[(size_t)((kk + 2) * E.plane)], b + (size_t)((kk + 1) * g->plane), sizeof(double) * (size_t)g->plane);
+    st_op<double>(M_JACOBI, E, coef, dinv, scale, 0, 0, 0, be.data(), ue.data(), (const double *)nullptr, w.data(), lo ? 0 : 1, hi ? g->nz + 2 : g->nz + 1);
+    st_op<double>(M_RESIDUAL, E, coef, 1, 1, 0, 0, 0, be.data(), w.data(), (const double *)nullptr, r.data(), z0 + 1, z1 + 1);
+    c->partials[part_off] = sumsq_field<double>(E, r.data(), z0 + 1, z1 + 1);
+    *nparts = 1;
+    return 0;
+}
 // the two on a z-slab (far planes as the halo exchange delivers them; see include/mgk.h)
 static int g_calls_j2n_slab = 0, g_calls_srr_slab = 0, g_calls_srr = 0, g_calls_j2n = 0;
-static void print_stats() { if (getenv("MOCK_MGK_STATS")) fprintf(stderr, "MOCK_MGK_STATS j2n=%d srr=%d j2n_slab=%d srr_slab=%d pj2=%d mid=%d\n", g_calls_j2n, g_calls_srr, g_calls_j2n_slab, g_calls_srr_slab, g_calls_pj2, g_calls_mid); }
+static void print_stats() { if (getenv("MOCK_MGK_STATS")) fprintf(stderr, "MOCK_MGK_STATS j2n=%d srr=%d j2n_slab=%d srr_slab=%d pj2=%d mid=%d pj2_slab=%d mid_slab=%d\n", g_calls_j2n, g_calls_srr, g_calls_j2n_slab, g_calls_srr_slab, g_calls_pj2, g_calls_mid, g_calls_pj2_slab, g_calls_mid_slab); }
 static struct StatsAtExit { StatsAtExit() { atexit(print_stats); } } g_stats_at_exit;
 int mgk_jacobi2_sumsq_slab_f64(mgk_ctx *c, const mgk_geom *g, const mgk_geom *gf, const double *coef, double dinv, double scale, const double *b, const double *u, double *o,
                                const double *far, int lo, int hi, int z0, int z1, int part_off, int *nparts, void *) {

@@ -992,3 +992,81 @@ def test_norm_pass_that_stores_the_residual_and_makes_the_next_sweep(mgk, orc, n
     assert abs(ss.value - float((rr * rr).sum())) <= 1e-12 * float((rr * rr).sum())
     for p in (du, db, dout, dr, dct, ddt):
         mgk.free(p)
+
+
+def _thin_slab_field(mgk, g, W, z0):
+    """padded fp64 field of the z-slab [z0, z0 + g.nz) of a whole (nzw, ny, nx) array, ghost planes taken from the neighbours"""
+    nzw, ny, nx = W.shape
+    pad = np.zeros(g.total)
+    for k in range(-1, g.nz + 1):
+        kz = z0 + k
+        if 0 <= kz < nzw:
+            for i in range(ny):
+                o = g.org + k * g.plane + i * g.pitch
+                pad[o:o + nx] = W[kz, i]
+    return mgk.upload(pad)
+
+
+@pytest.mark.parametrize("n,nzcw,cuts", [(511, 15, (0, 4, 9, 15)), (511, 11, (0, 2, 11)), (1023, 13, (0, 5, 7, 13)), (511, 9, (0, 9))])
+def test_ninety_one_byte_passes_on_slabs_bit_exact(mgk, orc, n, nzcw, cuts):
+    """mgk_prolong_jacobi2_slab_f64 and mgk_jacobi2_sumsq_mid_slab_f64 (round 3: the 91-byte fine level on z-slabs) on thin grids n x n x (2 nzcw + 1)
+    cut at the coarse planes `cuts`: every slab, given its neighbours' planes the way the grouped exchanges deliver them (ghost planes of u, b and of the
+    coarse u; far: the neighbours' second planes of u; cfar: the lower neighbour's second-last coarse plane), reproduces its part of the whole-grid
+    results of mgk_prolong_jacobi2_f64 / mgk_jacobi2_sumsq_mid_f64 (themselves pinned to the oracle: tests/test_headline_width_gpu.py) bit for bit, in
+    the plane ranges the solver launches (interior first, boundaries after); the slabs' norm partials sum to the whole-grid norm"""
+    rng = np.random.default_rng(9100 + n + nzcw)
+    nc, nzw = (n - 1) // 2, 2 * nzcw + 1
+    As = _stencil(orc, 3, n)
+    dinv = 1.0 / As[3]
+    L, coef = mgk.L, mgk.coef(As)
+    g, gc = mgk.geom(3, n, n, nzw), mgk.geom(3, nc, nc, nzcw)
+    U, B, UC = rng.uniform(-1, 1, (nzw, n, n)), rng.uniform(-1, 1, (nzw, n, n)), rng.uniform(-1, 1, (nzcw, nc, nc))
+    du, db, duc = _thin_slab_field(mgk, g, U, 0), _thin_slab_field(mgk, g, B, 0), _thin_slab_field(mgk, gc, UC, 0)
+    dpj, dj2 = mgk.field(g), mgk.field(g)
+    assert L.mgk_prolong_jacobi2_ok_f64(C.byref(g), C.byref(gc)) == 1
+    mgk._chk(L.mgk_prolong_jacobi2_f64(mgk.ctx, C.byref(g), C.byref(gc), coef, dinv, 0.8, db, duc, du, dpj, None))
+    ss = C.c_double(0.0)
+    mgk._chk(L.mgk_jacobi2_sumsq_mid_f64(mgk.ctx, C.byref(g), coef, dinv, 0.8, db, du, dj2, C.byref(ss), None))
+    pj_ref = mgk.from_field(g, dpj).reshape(nzw, n, n)
+    j2_ref = mgk.from_field(g, dj2).reshape(nzw, n, n)
+    norm_ref = ss.value
+    for p in (du, db, duc, dpj, dj2):
+        mgk.free(p)
+    total = 0.0
+    for s in range(len(cuts) - 1):
+        kc0, kc1 = cuts[s], cuts[s + 1]
+        last = (s == len(cuts) - 2)
+        z0, z1 = 2 * kc0, (nzw if last else 2 * kc1)
+        nz, nzc = z1 - z0, kc1 - kc0
+        has_lo, has_hi = int(s > 0), int(not last)
+        gs, gcs, gfar, gcfar = mgk.geom(3, n, n, nz), mgk.geom(3, nc, nc, nzc), mgk.geom(3, n, n, 2), mgk.geom(3, nc, nc, 2)
+        assert L.mgk_prolong_jacobi2_slab_ok_f64(C.byref(gs), C.byref(gcs), has_hi) == 1
+        us, bs, ucs = _thin_slab_field(mgk, gs, U, z0), _thin_slab_field(mgk, gs, B, z0), _thin_slab_field(mgk, gcs, UC, kc0)
+        far = _far_field(mgk, gfar, n, U[z0 - 2] if has_lo else None, U[z1 + 1] if has_hi else None)
+        cfar = _far_field(mgk, gcfar, nc, UC[kc0 - 2] if has_lo and kc0 >= 2 else None, None)
+        out = mgk.field(gs)
+        zi0, zi1 = (4 if has_lo else 0), (nz - 2 if has_hi else nz)
+        ranges = [(zi0, zi1)] + ([(0, 4)] if has_lo else []) + ([(nz - 2, nz)] if has_hi else []) if zi1 - zi0 >= 2 else [(0, nz)]
+        for zc in (-1, 8):
+            L.mgk_set_tuning(-1, zc)
+            mgk._chk(L.mgk_memset0(mgk.ctx, out, 8 * gs.total, None))
+            for a0, a1 in ranges:
+                mgk._chk(L.mgk_prolong_jacobi2_slab_f64(mgk.ctx, C.byref(gs), C.byref(gcs), C.byref(gfar), C.byref(gcfar), coef, dinv, 0.8, bs, ucs, us, out,
+                                                        far, cfar, has_lo, has_hi, a0, a1, None))
+            got = mgk.from_field(gs, out).reshape(nz, n, n)
+            assert np.array_equal(got, pj_ref[z0:z1]), f"slab {s} zc={zc}: prolongation + two sweeps, planes {np.unique(np.nonzero(got != pj_ref[z0:z1])[0])}"
+        L.mgk_set_tuning(-1, -1)
+        mgk._chk(L.mgk_memset0(mgk.ctx, out, 8 * gs.total, None))
+        n1, off = C.c_int(0), 0
+        zr = ((2, nz - 2), (0, 2), (nz - 2, nz)) if nz >= 6 else ((0, nz),)
+        for a0, a1 in zr:
+            mgk._chk(L.mgk_jacobi2_sumsq_mid_slab_f64(mgk.ctx, C.byref(gs), C.byref(gfar), coef, dinv, 0.8, bs, us, out, far, has_lo, has_hi,
+                                                      a0, a1, off, C.byref(n1), None))
+            off += n1.value
+        sp = C.c_double(0.0)
+        mgk._chk(L.mgk_partials_finish(mgk.ctx, off, C.byref(sp), None))
+        total += sp.value
+        assert np.array_equal(mgk.from_field(gs, out).reshape(nz, n, n), j2_ref[z0:z1]), f"slab {s}: two sweeps of the mid-norm pass"
+        for p in (us, bs, ucs, far, cfar, out):
+            mgk.free(p)
+    assert abs(total - norm_ref) <= 1e-13 * norm_ref

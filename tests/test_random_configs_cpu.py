@@ -32,3 +32,14 @@ def test_random_reference_driver_options_on_the_host_mock_equal_the_oracle(tmp_p
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_refdriver.py"), "60", "21"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=800, cwd=ROOT, env=env)
     assert p.returncode == 0 and "60 configurations, 0 mismatches" in p.stdout, p.stdout[-3000:]
+
+
+@pytest.mark.timeout(900)
+def test_ninety_one_byte_fine_level_on_slab_ranks_over_the_host_mock():
+    """fuse bit 14 (round 3, second session): prolongation + two sweeps, the mid-iterate norm pass and the owed final sweep on z-slabs -- 2 / 3 / 4 / 8 loopback
+    ranks over the mock, solve and the bench's fixed-count loop, overlap on / off: iteration counts, histories and the concatenated slabs equal the oracle's"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_slab91.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=800, cwd=ROOT,
+                       env=dict(os.environ, MOCK="1", MOCK_MGK_STATS="1"))
+    assert p.returncode == 0 and "bad 0" in p.stdout, p.stdout[-3000:]
+    m = __import__("re").search(r"pj2_slab=(\d+) mid_slab=(\d+)", p.stdout)
+    assert m and int(m.group(1)) > 0 and int(m.group(2)) > 0, p.stdout[-500:]          # the new passes did run

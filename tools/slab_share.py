@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--overlap", default="1,0")
     ap.add_argument("--pair-min-n", type=int, default=0)
     ap.add_argument("--dist-min-n", type=int, default=0)
+    ap.add_argument("--fuse", type=int, default=-1, help="mg_config.fuse (-1: the default bits)")
     ap.add_argument("--slab-chunks", default="-1", help="comma list of mg_config.slab_chunk values (-1: default 32, 0: long streams)")
     a = ap.parse_args()
     res = {"workload": f"3-D npts={a.npts}, {a.levels} levels, V(3,3), one rank of {a.nranks} z-slabs, phantom neighbours",
@@ -69,7 +70,7 @@ def main():
                                   "slab_chunk_planes": 32 if chunk < 0 else chunk, "ranks": {}}
             for r in [int(x) for x in a.ranks.split(",")]:
                 ms, planes = run(r, a.nranks, a.npts, a.levels, lat, gbs, a.cycles, a.warmup, overlap, a.precision,
-                                 pair_min_n=a.pair_min_n, dist_min_n=a.dist_min_n, slab_chunk=chunk)
+                                 pair_min_n=a.pair_min_n, dist_min_n=a.dist_min_n, slab_chunk=chunk, fuse=a.fuse)
                 res["models"][key]["ranks"][str(r)] = {"ms_per_cycle": ms, "local_planes_per_level": planes}
                 print(f"[slab_share] {key:24s} rank {r}: {ms:.3f} ms/cycle", file=sys.stderr, flush=True)
             worst = max(v["ms_per_cycle"] for v in res["models"][key]["ranks"].values())

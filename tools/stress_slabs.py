@@ -31,7 +31,7 @@ for q in range(count):
     while (npts - 2) // P < 4 or dist > npts - 2:
         P = int(rng.choice([2, 3, 4])); dist = int(rng.choice([7, 15, 31]))
     v0, v1 = int(rng.integers(1, 5)), int(rng.integers(1, 5))
-    fuse = int(rng.choice([-1, -1, -1, 0, 63, 63 | 256 | 512, 63 | 256 | 512 | 1024 | 2048, int(rng.integers(0, 16384))]))
+    fuse = int(rng.choice([-1, -1, -1, 0, 63, 63 | 256 | 512, 63 | 256 | 512 | 1024 | 2048, int(rng.integers(0, 16384)), 32767, 32767, int(rng.integers(0, 32768)) | 16384]))   # bit 14: the 91-byte fine level on slabs
     kw = dict(fuse=fuse, overlap=int(rng.choice([-1, 0, 1])), pair_min_n=int(rng.choice([0, 0, 7, 15])), slab_chunk=int(rng.choice([-1, 0, 4, 8])),
               precision=str(rng.choice(["fp64", "fp64", "mixed"])))
     scale = 6.0 / 7.0
