@@ -59,12 +59,17 @@ typedef struct mg_config {
                          * bit 13 (2-D, fp64, Richardson, uniform and stretched meshes): THREE sweeps per pass (mgk_jacobi3_2d_*): pre-smoothing
                          * from the zero guess in one pass over b, post-smoothing in one pass with the prolongation, and the norm pass of
                          * bit 3 makes all three pre-smoothing sweeps of the next cycle: three passes over a level per V(3,3) cycle;
-                         * default (-1): bits 0-5 and 8-13 on */
+                         * bit 14 (round 3; nranks > 1): bit 12's three passes on z-slabs -- mgk_prolong_jacobi2_slab_f64 (the neighbours' boundary and
+                         * second planes of u and of the coarse u arrive in two grouped exchanges hidden behind the interior planes),
+                         * mgk_jacobi2_sumsq_mid_slab_f64, the plain fused residual + restriction: every rank moves 91 instead of 99 B per fine
+                         * unknown and cycle;
+                         * default (-1): bits 0-5 and 8-14 on */
     int overlap;        /* nranks > 1: halo of sweep k on the comm stream while sweep k's interior runs; default on (-1) */
     int graph;          /* replay the launch-bound coarse levels as one captured HIP graph; default on (-1) */
     int pair_min_n;     /* levels with n >= pair_min_n run their sweeps two per pass (fuse bit 5); <=0: default 255 (3-D), 2047 (2-D) */
     int slab_chunk;     /* nranks > 1: planes per workgroup of the marching kernels (short blocks let the exchange kernels in beside the
-                         * interior launches); <0: default 32, 0: the long streams of a single GPU */
+                         * interior launches); <0: default = a quarter of the rank's fine planes, at least 32 (MG_SLAB_CHUNK overrides); 0: the long
+                         * streams of a single GPU */
     int mesh;           /* -mesh: 0 uniform; 1 / 2: the reference's meshes stretched in y (src/mesh.c:45-107,165-169), 2-D, one GPU,
                          * Richardson + Jacobi: the operator rows then depend on the grid row (per-row coefficient tables); the same
                          * fused cycle on the row-table forms of its kernels (mgk_*_rowcoef_f64) */

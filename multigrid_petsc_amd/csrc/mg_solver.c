@@ -380,7 +380,7 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
         const int n0 = mg_grid_n(cfg->npts, 0);
         s->cfg.dist_min_n = n0 < 255 ? n0 : 255;
     }
-    if (s->cfg.fuse < 0) s->cfg.fuse = 63 | 256 | 512 | 1024 | 2048 | 4096 | 8192;
+    if (s->cfg.fuse < 0) s->cfg.fuse = 63 | 256 | 512 | 1024 | 2048 | 4096 | 8192 | 16384;
     if (s->cfg.pair_min_n <= 0) s->cfg.pair_min_n = (cfg->dim == 3) ? 255 : 2047;   /* where a two-sweep pass beats two sweeps
                                                                                       * (255^3: 0.107 ms against 2 x 0.063) */
     if (s->cfg.mesh) s->cfg.fuse &= ~(16 | 128);   /* row-dependent coefficients (2-D, fp64): the same fused cycle on the row-table forms of the kernels */
@@ -393,7 +393,10 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
     if (rc) { free(s); return mgfail(rc, "mg_solver_create: mgk_ctx_create"); }
     if (s->cfg.slab_chunk < 0) {                /* default 32 planes; MG_SLAB_CHUNK overrides (0: the long streams of a single GPU) */
         const char *e = getenv("MG_SLAB_CHUNK");
-        s->cfg.slab_chunk = (e && *e && atoi(e) >= 0) ? atoi(e) : 32;
+        /* (round 3, second session) a quarter of the rank's fine planes, at least 32: the interior of a pass then frees a CU four times -- enough for an
+         * exchange kernel that needs one (8 ranks at 1023^3: 32 planes as before; 2 ranks: 128 -- one rank's share 12.16 -> 11.8 ms, long streams 11.45) */
+        const int quarter = (mg_grid_n(cfg->npts, 0) / (s->cfg.nranks > 0 ? s->cfg.nranks : 1)) / 4;
+        s->cfg.slab_chunk = (e && *e && atoi(e) >= 0) ? atoi(e) : (quarter > 32 ? quarter : 32);
     }
     if (s->cfg.nranks > 1 && s->cfg.dim == 3) mgk_ctx_set_chunk_planes(s->ctx, s->cfg.slab_chunk);
 
