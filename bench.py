@@ -428,7 +428,10 @@ def main():
     scale = 6.0 / 7.0 if args.dim == 3 else 0.8
     s = Solver(args.dim, args.npts, levels, v=(3, 3), maxiter=args.steps + args.warmup + 1, scale=scale,
                device=local_rank, rank=rank, nranks=world, comm=comm.handle if comm else None,
-               precision=args.precision)
+               precision=args.precision,
+               # the peer transport moves planes with the copy engines and one-wave flag kernels: nothing waits for a free CU, so the marching kernels keep
+               # the long streams of a single GPU (MG_SLAB_CHUNK still overrides); RCCL's send / recv kernel gets the chunked interiors
+               slab_chunk=(0 if (transport == "peer" and not os.environ.get("MG_SLAB_CHUNK")) else -1))
     s.set_rhs_problem()
 
     def barrier():

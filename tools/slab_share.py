@@ -67,7 +67,7 @@ def main():
         if True:
             key = f"{name}{'' if overlap else '_no_overlap'}{'' if chunk < 0 else '_chunk%d' % chunk}"
             res["models"][key] = {"latency_us": lat, "link_GBs": gbs or None, "overlap": bool(overlap),
-                                  "slab_chunk_planes": 32 if chunk < 0 else chunk, "ranks": {}}
+                                  "slab_chunk_planes": max(32, ((a.npts - 2) // a.nranks) // 4) if chunk < 0 else chunk, "ranks": {}}     # (< 0: the solver's default, a quarter of the slab, >= 32)
             for r in [int(x) for x in a.ranks.split(",")]:
                 ms, planes = run(r, a.nranks, a.npts, a.levels, lat, gbs, a.cycles, a.warmup, overlap, a.precision,
                                  pair_min_n=a.pair_min_n, dist_min_n=a.dist_min_n, slab_chunk=chunk, fuse=a.fuse)
