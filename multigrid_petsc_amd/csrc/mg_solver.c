@@ -1101,7 +1101,13 @@ static int prolong_smooth(mg_solver *s, int P, int l) {
          * with a rank above up to nz-3 (plane nz-1's parent is the own coarse plane nzc-1) */
         const int nz = F->g.nz, lo = s->cfg.rank > 0, hi = s->cfg.rank < s->cfg.nranks - 1;
         void *cs = mgk_stream_compute(s->ctx), *ms = mgk_stream_comm(s->ctx);
-        CHK(group_exchange(s, P, Cq, 0));
+        {   /* (the coarse b is done with for this cycle: its ghost planes stay as they are -- two planes less on the wire) */
+            const int cb = Cq->b_ghost_ok;
+            Cq->b_ghost_ok = 1;
+            int rcx = group_exchange(s, P, Cq, 0);
+            Cq->b_ghost_ok = cb;
+            CHK(rcx);
+        }
         CHK(group_exchange(s, P, F, 0));
         const int zi0 = lo ? 4 : 0, zi1 = hi ? nz - 2 : nz;
         const int split = s->cfg.overlap && zi1 - zi0 >= 2;
@@ -1109,7 +1115,7 @@ static int prolong_smooth(mg_solver *s, int P, int l) {
                         (const double *)Cq->u, (const double *)F->u, (double *)F->tmp, (const double *)F->far, (const double *)Cq->far, lo, hi, z0, z1, cs)
         if (split) CHK(PJ2S(zi0, zi1));
         CHK(mgk_stream_wait(s->ctx, cs, ms));
-        Cq->u_ghost_pending = 0; Cq->u_ghost_ok = 1; Cq->b_ghost_ok = 1;
+        Cq->u_ghost_pending = 0; Cq->u_ghost_ok = 1;
         F->u_ghost_pending = 0; F->u_ghost_ok = 1; F->b_ghost_ok = 1;
         if (split) {
             if (lo) CHK(PJ2S(0, 4));
