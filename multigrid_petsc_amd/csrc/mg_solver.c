@@ -394,7 +394,7 @@ int mg_solver_create(mg_solver **out, const mg_config *cfg, mg_comm *comm) {
     if (s->cfg.slab_chunk < 0) {                /* default 32 planes; MG_SLAB_CHUNK overrides (0: the long streams of a single GPU) */
         const char *e = getenv("MG_SLAB_CHUNK");
         /* (round 3, second session) a quarter of the rank's fine planes, at least 32: the interior of a pass then frees a CU four times -- enough for an
-         * exchange kernel that needs one (8 ranks at 1023^3: 32 planes as before; 2 ranks: 128 -- one rank's share 12.16 -> 11.8 ms, long streams 11.45) */
+         * exchange kernel that needs one (8 ranks at 1023^3: 32 planes as before; 2 ranks: 127 -- one rank's share 12.16 -> 11.60 ms, long streams 11.45) */
         const int quarter = (mg_grid_n(cfg->npts, 0) / (s->cfg.nranks > 0 ? s->cfg.nranks : 1)) / 4;
         s->cfg.slab_chunk = (e && *e && atoi(e) >= 0) ? atoi(e) : (quarter > 32 ? quarter : 32);
     }
