@@ -1397,6 +1397,7 @@ static int cycle_body(mg_solver *s, int P, int first) {
             /* the level that feeds the recording has swapped u / tmp an odd number of times since it was made (sweep groupings that differ
              * on the way down and on the way up, e.g. pairs without the fused prolongation and an even v0): the recorded restriction would
              * read the stale buffer.  Never in a default configuration; correctness first -- record again on the pointers of this cycle */
+            CHK(mgk_sync(s->ctx, NULL));                   /* (the last replay may still be running: nothing is destroyed under it) */
             mgk_graph_destroy(s->ctx, s->coarse_graph[P]);
             s->coarse_graph[P] = NULL;
             s->graph_rerecorded++;
